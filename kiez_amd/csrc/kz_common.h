@@ -1,0 +1,89 @@
+// Internal definitions shared by the HIP translation units of libkiez_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/kiez_amd.h"
+
+#define KZ_TILE 128   // rows per packed tile (= MFMA block tile edge)
+#define KZ_KSLICE 16  // k elements staged per LDS slice (4 k-groups of 4)
+
+struct kz_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    hipEvent_t ev[6];
+    double eps_scale;
+    int force_splits;
+    // scratch (grown on demand, reused across calls)
+    void* scratch;
+    size_t scratch_bytes;
+    int* d_counters;  // small device int array (fail counter, flags)
+    int* h_counters;  // pinned host mirror
+};
+
+struct kz_matrix {
+    kz_ctx* ctx;
+    int64_t n, d;
+    int dtype, metric;
+    int64_t n_tiles;  // ceil(n / 128)
+    int kg;           // d_pad / 4 (number of 4-wide k-groups), d_pad = round_up(d, 16)
+    void* raw;        // [n, d] dtype, row-major (exact data, used by the float64 re-rank)
+    float* packed;    // [n_tiles][kg][128][4] float32 MFMA operand image
+    float* bias;      // [n_tiles*128] accumulator init: -|y|^2/2 (euclidean family), 0 (cosine), -inf (pad rows)
+    double* sqn;      // [n] float64: squared norms (euclidean family) or norms with 0 -> 1 (cosine)
+    double max_norm;  // max_j |y_j|  (host copy)
+};
+
+void kz_set_error(const char* fmt, ...);
+
+#define KZ_HIP(call)                                                                             \
+    do {                                                                                         \
+        hipError_t _e = (call);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            kz_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return KZ_ERR_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+
+#define KZ_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            kz_set_error(__VA_ARGS__); \
+            return KZ_ERR_INVALID;     \
+        }                              \
+    } while (0)
+
+int kz_scratch(kz_ctx* ctx, size_t bytes, void** out);
+
+// ---------------------------------------------------------------------------------------------------
+// Canonical wave-cooperative float64 dot product.  Every exact distance in the library (row norms, the
+// re-rank, the exact fallback) goes through this routine so that |x|^2 + |y|^2 - 2 x.y is EXACTLY 0 for
+// x == y and the same pair gives bit-identical values in the forward and the reverse pass.
+// All 64 lanes must be active; every lane returns the same value.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double kz_wave_sum(double acc) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    return acc;
+}
+
+template <typename T>
+__device__ __forceinline__ double kz_wave_dot(const T* __restrict__ a, const T* __restrict__ b, int d, int lane) {
+    double acc = 0.0;
+    for (int k = lane; k < d; k += 64) acc = fma((double)a[k], (double)b[k], acc);
+    return kz_wave_sum(acc);
+}
+
+// cosine: sum_k (a_k / na) * (b_k / nb) with the per-element divisions scikit-learn's normalize() performs
+template <typename T>
+__device__ __forceinline__ double kz_wave_dot_normalized(const T* __restrict__ a, double na, const T* __restrict__ b,
+                                                         double nb, int d, int lane) {
+    double acc = 0.0;
+    for (int k = lane; k < d; k += 64) acc = fma((double)a[k] / na, (double)b[k] / nb, acc);
+    return kz_wave_sum(acc);
+}

@@ -1,0 +1,476 @@
+// Hubness-reduction rescaling kernels (gather / reduce over the [n, K] candidate arrays) and the final
+// candidate sort.  Compiled with -ffp-contract=off: the reference evaluates these formulas with separate
+// numpy operations in float64, so no fused multiply-add may be formed here.
+//
+//   CSLS            kiez/hubness_reduction/csls.py:85-96
+//   LocalScaling    kiez/hubness_reduction/local_scaling.py:129-151
+//   MutualProximity kiez/hubness_reduction/mutual_proximity.py:166-212
+//   DisSimLocal     kiez/hubness_reduction/dis_sim.py:96-107, 139-181
+//   _sort           kiez/hubness_reduction/base.py:72-87
+#include "kz_common.h"
+
+// numpy's pairwise summation of a contiguous float64 run (numpy/_core/src/umath/loops_utils.h.src,
+// DOUBLE_pairwise_sum): < 8 elements sequential, <= 128 eight interleaved accumulators, else split.
+__device__ double kz_np_pairwise_sum(const double* a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) {
+            r0 += a[i + 0];
+            r1 += a[i + 1];
+            r2 += a[i + 2];
+            r3 += a[i + 3];
+            r4 += a[i + 4];
+            r5 += a[i + 5];
+            r6 += a[i + 6];
+            r7 += a[i + 7];
+        }
+        double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return kz_np_pairwise_sum(a, n2) + kz_np_pairwise_sum(a + n2, n - n2);
+}
+
+// same summation applied to (a[i] - c)^2 (np.nanstd: subtract mean, square, sum; numpy/lib/_nanfunctions_impl.py)
+__device__ double kz_np_pairwise_sumsq_dev(const double* a, int n, double c) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double t = a[i] - c;
+            res += t * t;
+        }
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int u = 0; u < 8; ++u) {
+            const double t = a[u] - c;
+            r[u] = t * t;
+        }
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) {
+            for (int u = 0; u < 8; ++u) {
+                const double t = a[i + u] - c;
+                r[u] += t * t;
+            }
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) {
+            const double t = a[i] - c;
+            res += t * t;
+        }
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return kz_np_pairwise_sumsq_dev(a, n2, c) + kz_np_pairwise_sumsq_dev(a + n2, n - n2, c);
+}
+
+__global__ void kz_row_stats_kernel(const double* __restrict__ dist, int64_t n, int K, double* __restrict__ mean,
+                                    double* __restrict__ sd, double* __restrict__ last) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double* a = dist + r * (int64_t)K;
+    if (last) last[r] = a[K - 1];
+    if (mean || sd) {
+        const double m = kz_np_pairwise_sum(a, K) / (double)K;
+        if (mean) mean[r] = m;
+        if (sd) sd[r] = sqrt(kz_np_pairwise_sumsq_dev(a, K, m) / (double)K);
+    }
+}
+
+// CSLS: out = 2*d - mean_K(d[i,:]) - r_train[ind]      (csls.py:90-93)
+__global__ void kz_csls_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind, int64_t n, int K,
+                               const double* __restrict__ r_train, double* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double* a = dist + r * (int64_t)K;
+    const int64_t* id = ind + r * (int64_t)K;
+    const double r_test = kz_np_pairwise_sum(a, K) / (double)K;
+    for (int c = 0; c < K; ++c) {
+        double v = 2.0 * a[c];
+        v = v - r_test;
+        v = v - r_train[id[c]];
+        out[r * (int64_t)K + c] = v;
+    }
+}
+
+// LocalScaling (local_scaling.py:135-147)
+__global__ void kz_ls_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind, int64_t n, int K,
+                             const double* __restrict__ r_t, int nicdm, double* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double* a = dist + r * (int64_t)K;
+    const int64_t* id = ind + r * (int64_t)K;
+    if (nicdm) {
+        const double r_s = kz_np_pairwise_sum(a, K) / (double)K;
+        for (int c = 0; c < K; ++c) out[r * (int64_t)K + c] = a[c] / sqrt(r_s * r_t[id[c]]);
+    } else {
+        const double r_s = a[K - 1];
+        for (int c = 0; c < K; ++c) {
+            const double d = a[c];
+            const double inner = (-1.0 * (d * d)) / (r_s * r_t[id[c]]);
+            out[r * (int64_t)K + c] = 1.0 - exp(inner);
+        }
+    }
+}
+
+// scipy.stats.norm.sf(x, loc, scale) = ndtr(-(x-loc)/scale), cephes ndtr (scipy/special/xsf/cephes/ndtr.h)
+__device__ __forceinline__ double kz_ndtr(double a) {
+    const double SQRT1_2 = 0.70710678118654752440;
+    if (isnan(a)) return a;
+    const double x = a * SQRT1_2;
+    const double z = fabs(x);
+    if (z < SQRT1_2) return 0.5 + 0.5 * erf(x);
+    double y = 0.5 * erfc(z);
+    if (x > 0) y = 1.0 - y;
+    return y;
+}
+
+__global__ void kz_mp_normal_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind, int64_t n, int K,
+                                    const double* __restrict__ mu_t, const double* __restrict__ sd_t,
+                                    double* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double* a = dist + r * (int64_t)K;
+    const int64_t* id = ind + r * (int64_t)K;
+    const double mu = kz_np_pairwise_sum(a, K) / (double)K;
+    const double sd = sqrt(kz_np_pairwise_sumsq_dev(a, K, mu) / (double)K);
+    for (int c = 0; c < K; ++c) {
+        const double d = a[c];
+        const double p1 = kz_ndtr(-((d - mu) / sd));
+        const int64_t t = id[c];
+        const double p2 = kz_ndtr(-((d - mu_t[t]) / sd_t[t]));
+        out[r * (int64_t)K + c] = 1.0 - p1 * p2;
+    }
+}
+
+// MutualProximity empiric (mutual_proximity.py:185-212); one wave per query row.
+//   out[i,j] = 1 - #{m : d[i,m] > d[i,j] and T_j[m] > d[i,j]} / K
+//   T_j[m]   = dist_t2s[c_j, p] if ind_t2s[c_j, p] == c_m (c_m is a TARGET id matched against SOURCE ids: the
+//              reference's behaviour) else dist_t2s[c_j, Kt-1] + 1e-6
+__global__ __launch_bounds__(256) void kz_mp_empiric_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind,
+                                                            int64_t n, int K, const double* __restrict__ dist_t2s,
+                                                            const int64_t* __restrict__ ind_t2s, int64_t n_t, int Kt,
+                                                            double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    const double* d_i = dist + i * (int64_t)K;
+    const int64_t* c_i = ind + i * (int64_t)K;
+    for (int j = 0; j < K; ++j) {
+        const double dj = d_i[j];
+        const int64_t cj = c_i[j];
+        const double* rd = dist_t2s + cj * (int64_t)Kt;
+        const int64_t* ri = ind_t2s + cj * (int64_t)Kt;
+        const double fill = rd[Kt - 1] + 1e-6;
+        int cnt = 0;
+        for (int m = lane; m < K; m += 64) {
+            const double dm = d_i[m];
+            if (dm > dj) {
+                const int64_t cm = c_i[m];
+                double T = fill;
+                for (int pp = 0; pp < Kt; ++pp)
+                    if (ri[pp] == cm) T = rd[pp];
+                cnt += (T > dj) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (lane == 0) out[i * (int64_t)K + j] = 1.0 - (double)cnt / (double)K;
+    }
+}
+
+// DisSimLocal fit (dis_sim.py:96-102): t2c[j] = | target[t_begin+j] - mean_m source[ind_t2s[j,m]] |^2 ; wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void kz_dsl_fit_kernel(const int64_t* __restrict__ ind_t2s, int64_t n_rows, int Kt,
+                                                         const T* __restrict__ source, const T* __restrict__ target,
+                                                         int64_t t_begin, int d, double* __restrict__ t2c) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= n_rows) return;
+    const int64_t* id = ind_t2s + r * (int64_t)Kt;
+    const T* t = target + (t_begin + r) * (int64_t)d;
+    double acc = 0.0;
+    for (int k = lane; k < d; k += 64) {
+        double c = 0.0;
+        for (int m = 0; m < Kt; ++m) c += (double)source[id[m] * (int64_t)d + k];
+        c = c / (double)Kt;
+        const double df = (double)t[k] - c;
+        acc += df * df;
+    }
+    acc = kz_wave_sum(acc);
+    if (lane == 0) t2c[r] = acc;
+}
+
+__device__ __forceinline__ void kz_atomic_min_double(double* addr, double v) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+    unsigned long long old = *a;
+    while (v < __longlong_as_double((long long)old)) {
+        const unsigned long long assumed = old;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+        if (old == assumed) break;
+    }
+}
+
+// DisSimLocal transform (dis_sim.py:153-166): out[i,m] = |q_i - t[c_m]|^2 - |q_i - mean_m t[c_m]|^2 - t2c[c_m]
+template <typename T>
+__global__ __launch_bounds__(256) void kz_dsl_transform_kernel(const int64_t* __restrict__ ind, int64_t n, int K,
+                                                               const T* __restrict__ query, int64_t q_begin,
+                                                               const T* __restrict__ target, int d,
+                                                               const double* __restrict__ t2c, double* __restrict__ out,
+                                                               double* __restrict__ gmin) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    const int64_t* id = ind + i * (int64_t)K;
+    const T* q = query + (q_begin + i) * (int64_t)d;
+    double s2c = 0.0;
+    for (int k = lane; k < d; k += 64) {
+        double c = 0.0;
+        for (int m = 0; m < K; ++m) c += (double)target[id[m] * (int64_t)d + k];
+        c = c / (double)K;
+        const double df = (double)q[k] - c;
+        s2c += df * df;
+    }
+    s2c = kz_wave_sum(s2c);
+    double wmin = INFINITY;
+    for (int m = 0; m < K; ++m) {
+        const T* t = target + id[m] * (int64_t)d;
+        double acc = 0.0;
+        for (int k = lane; k < d; k += 64) {
+            const double df = (double)q[k] - (double)t[k];
+            acc += df * df;
+        }
+        acc = kz_wave_sum(acc);
+        double v = acc - s2c;
+        v = v - t2c[id[m]];
+        if (lane == 0) out[i * (int64_t)K + m] = v;
+        wmin = fmin(wmin, v);
+    }
+    if (lane == 0) kz_atomic_min_double(gmin, wmin);
+}
+
+__global__ void kz_dsl_finalize_kernel(double* __restrict__ out, int64_t count, double shift, int squared) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    double v = out[e] + shift;
+    if (!squared) v = sqrt(v);  // numpy `**= 1/2` on float64 is sqrt-accurate for the tolerance we state
+    out[e] = v;
+}
+
+// HubnessReduction._sort (base.py:81-86): selection sort with swaps of the first k positions; wave per row.
+// Position p lives in lane p & 63, slot p >> 6 (K <= 128 -> 2 slots).
+__global__ __launch_bounds__(256) void kz_select_topk_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind,
+                                                             int64_t n, int K, int k, double* __restrict__ odist,
+                                                             int64_t* __restrict__ oind) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= n) return;
+    const double* a = dist + r * (int64_t)K;
+    const int64_t* id = ind + r * (int64_t)K;
+    double v0 = INFINITY, v1 = INFINITY;
+    int64_t i0 = -1, i1 = -1;
+    if (lane < K) {
+        v0 = a[lane];
+        i0 = id[lane];
+    }
+    if (lane + 64 < K) {
+        v1 = a[lane + 64];
+        i1 = id[lane + 64];
+    }
+    for (int i = 0; i < k; ++i) {
+        // first strict minimum among positions [i, K)
+        double bv = INFINITY;
+        int bp = 0x7fffffff;
+        if (lane >= i && lane < K) {
+            bv = v0;
+            bp = lane;
+        }
+        if (lane + 64 >= i && lane + 64 < K) {
+            if (bp == 0x7fffffff || v1 < bv) {
+                bv = v1;
+                bp = lane + 64;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int op = __shfl_xor(bp, off, 64);
+            if (op != 0x7fffffff && (bp == 0x7fffffff || ov < bv || (ov == bv && op < bp))) {
+                bv = ov;
+                bp = op;
+            }
+        }
+        // fetch entry at position i and at position bp, swap
+        const int li = i & 63, lb = bp & 63;
+        const double vi = __shfl((i >> 6) ? v1 : v0, li, 64);
+        const int64_t ii = __shfl((i >> 6) ? i1 : i0, li, 64);
+        const double vb = __shfl((bp >> 6) ? v1 : v0, lb, 64);
+        const int64_t ib = __shfl((bp >> 6) ? i1 : i0, lb, 64);
+        if (lane == lb) {
+            if (bp >> 6) {
+                v1 = vi;
+                i1 = ii;
+            } else {
+                v0 = vi;
+                i0 = ii;
+            }
+        }
+        if (lane == li) {
+            if (i >> 6) {
+                v1 = vb;
+                i1 = ib;
+            } else {
+                v0 = vb;
+                i0 = ib;
+            }
+        }
+    }
+    if (lane < k) {
+        odist[r * (int64_t)k + lane] = v0;
+        oind[r * (int64_t)k + lane] = i0;
+    }
+    if (lane + 64 < k) {
+        odist[r * (int64_t)k + lane + 64] = v1;
+        oind[r * (int64_t)k + lane + 64] = i1;
+    }
+}
+
+__global__ void kz_cast_f64_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t count) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) out[e] = (float)in[e];
+}
+
+// ---------------------------------------------------------------------------------------------------
+static inline dim3 kz_grid1d(int64_t n, int per_block) { return dim3((unsigned)((n + per_block - 1) / per_block)); }
+
+#define KZ_CHECK_NK(fn)                                                                       \
+    KZ_REQUIRE(ctx != nullptr, fn ": null context");                                           \
+    KZ_REQUIRE(n >= 0 && K >= 1 && K <= 128, fn ": bad shape n=%lld K=%d (K must be in [1,128])", (long long)n, K); \
+    KZ_HIP(hipSetDevice(ctx->device));                                                         \
+    if (n == 0) return KZ_OK;
+
+extern "C" {
+
+int kz_row_stats(kz_ctx* ctx, const double* d_dist, int64_t n, int K, double* d_mean, double* d_std, double* d_last) {
+    KZ_CHECK_NK("kz_row_stats");
+    KZ_REQUIRE(d_dist != nullptr, "kz_row_stats: null input");
+    hipLaunchKernelGGL(kz_row_stats_kernel, kz_grid1d(n, 256), dim3(256), 0, ctx->stream, d_dist, n, K, d_mean, d_std, d_last);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_csls(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K, const double* d_r_train, double* d_out) {
+    KZ_CHECK_NK("kz_csls");
+    KZ_REQUIRE(d_dist && d_ind && d_r_train && d_out, "kz_csls: null argument");
+    hipLaunchKernelGGL(kz_csls_kernel, kz_grid1d(n, 256), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K, d_r_train, d_out);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_local_scaling(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K, const double* d_r_t, int nicdm,
+                     double* d_out) {
+    KZ_CHECK_NK("kz_local_scaling");
+    KZ_REQUIRE(d_dist && d_ind && d_r_t && d_out, "kz_local_scaling: null argument");
+    hipLaunchKernelGGL(kz_ls_kernel, kz_grid1d(n, 256), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K, d_r_t, nicdm, d_out);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_mp_normal(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K, const double* d_mu_t,
+                 const double* d_sd_t, double* d_out) {
+    KZ_CHECK_NK("kz_mp_normal");
+    KZ_REQUIRE(d_dist && d_ind && d_mu_t && d_sd_t && d_out, "kz_mp_normal: null argument");
+    hipLaunchKernelGGL(kz_mp_normal_kernel, kz_grid1d(n, 256), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K, d_mu_t, d_sd_t,
+                       d_out);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_mp_empiric(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K, const double* d_dist_t2s,
+                  const int64_t* d_ind_t2s, int64_t n_t, int Kt, double* d_out) {
+    KZ_CHECK_NK("kz_mp_empiric");
+    KZ_REQUIRE(d_dist && d_ind && d_dist_t2s && d_ind_t2s && d_out, "kz_mp_empiric: null argument");
+    KZ_REQUIRE(Kt >= 1 && n_t >= 1, "kz_mp_empiric: bad reverse list shape");
+    hipLaunchKernelGGL(kz_mp_empiric_kernel, kz_grid1d(n, 4), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K, d_dist_t2s,
+                       d_ind_t2s, n_t, Kt, d_out);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_dsl_fit(kz_ctx* ctx, const int64_t* d_ind_t2s, int64_t n_rows, int Kt, const kz_matrix* source, const kz_matrix* target,
+               int64_t t_begin, double* d_t2c) {
+    KZ_REQUIRE(ctx && d_ind_t2s && source && target && d_t2c, "kz_dsl_fit: null argument");
+    KZ_REQUIRE(source->d == target->d && source->dtype == target->dtype, "kz_dsl_fit: source/target mismatch");
+    KZ_REQUIRE(n_rows >= 0 && t_begin >= 0 && t_begin + n_rows <= target->n && Kt >= 1, "kz_dsl_fit: bad row range");
+    KZ_HIP(hipSetDevice(ctx->device));
+    if (n_rows == 0) return KZ_OK;
+    if (source->dtype == KZ_F32)
+        hipLaunchKernelGGL(kz_dsl_fit_kernel<float>, kz_grid1d(n_rows, 4), dim3(256), 0, ctx->stream, d_ind_t2s, n_rows, Kt,
+                           (const float*)source->raw, (const float*)target->raw, t_begin, (int)source->d, d_t2c);
+    else
+        hipLaunchKernelGGL(kz_dsl_fit_kernel<double>, kz_grid1d(n_rows, 4), dim3(256), 0, ctx->stream, d_ind_t2s, n_rows, Kt,
+                           (const double*)source->raw, (const double*)target->raw, t_begin, (int)source->d, d_t2c);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_dsl_transform(kz_ctx* ctx, const int64_t* d_ind, int64_t n, int K, const kz_matrix* query, int64_t q_begin,
+                     const kz_matrix* target, const double* d_t2c, double* d_out, double* d_min) {
+    KZ_CHECK_NK("kz_dsl_transform");
+    KZ_REQUIRE(d_ind && query && target && d_t2c && d_out && d_min, "kz_dsl_transform: null argument");
+    KZ_REQUIRE(query->d == target->d && query->dtype == target->dtype, "kz_dsl_transform: query/target mismatch");
+    KZ_REQUIRE(q_begin >= 0 && q_begin + n <= query->n, "kz_dsl_transform: bad row range");
+    if (query->dtype == KZ_F32)
+        hipLaunchKernelGGL(kz_dsl_transform_kernel<float>, kz_grid1d(n, 4), dim3(256), 0, ctx->stream, d_ind, n, K,
+                           (const float*)query->raw, q_begin, (const float*)target->raw, (int)query->d, d_t2c, d_out, d_min);
+    else
+        hipLaunchKernelGGL(kz_dsl_transform_kernel<double>, kz_grid1d(n, 4), dim3(256), 0, ctx->stream, d_ind, n, K,
+                           (const double*)query->raw, q_begin, (const double*)target->raw, (int)query->d, d_t2c, d_out, d_min);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_dsl_finalize(kz_ctx* ctx, double* d_out, int64_t count, double min_value, int squared) {
+    KZ_REQUIRE(ctx && d_out && count >= 0, "kz_dsl_finalize: bad argument");
+    KZ_HIP(hipSetDevice(ctx->device));
+    if (count == 0) return KZ_OK;
+    const double shift = (min_value < 0.0) ? -min_value : 0.0;  // dis_sim.py:171-173, _MINIMUM_DIST = 0.0
+    hipLaunchKernelGGL(kz_dsl_finalize_kernel, kz_grid1d(count, 256), dim3(256), 0, ctx->stream, d_out, count, shift, squared);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_select_topk(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K, int k, double* d_odist,
+                   int64_t* d_oind) {
+    KZ_CHECK_NK("kz_select_topk");
+    KZ_REQUIRE(d_dist && d_ind && d_odist && d_oind, "kz_select_topk: null argument");
+    KZ_REQUIRE(k >= 1 && k <= K, "kz_select_topk: k=%d must be in [1, K=%d]", k, K);
+    hipLaunchKernelGGL(kz_select_topk_kernel, kz_grid1d(n, 4), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K, k, d_odist, d_oind);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_cast_f64_f32(kz_ctx* ctx, const double* d_in, float* d_out, int64_t count) {
+    KZ_REQUIRE(ctx && d_in && d_out && count >= 0, "kz_cast_f64_f32: bad argument");
+    KZ_HIP(hipSetDevice(ctx->device));
+    if (count == 0) return KZ_OK;
+    hipLaunchKernelGGL(kz_cast_f64_f32_kernel, kz_grid1d(count, 256), dim3(256), 0, ctx->stream, d_in, d_out, count);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,708 @@
+// Exact k-nearest-neighbour search on MI355X (gfx950):  replaces SklearnNN._kneighbors
+// (kiez/neighbors/exact/sklearn_nearest_neighbors.py:96-101 -> sklearn brute-force ArgKmin,
+//  sklearn/metrics/_pairwise_distances_reduction/_argkmin.pyx.tp:311-510).
+//
+// Three stages (DESIGN.md "Kernels"):
+//   1. kz_knn_cand_kernel   fused  X.Y^T (float32 MFMA 32x32x2)  +  per-query top-K' candidate lists.
+//                           The n_q x n_i similarity matrix never leaves registers.
+//   2. kz_knn_finalize      merge the lists, CERTIFY that the true top-k is inside the candidate set using a
+//                           rigorous float32 rounding bound, re-rank the K' candidates with exact float64
+//                           distances, sort, strip the query itself (single-source mode), write [q, k].
+//   3. kz_exact_*           exact float64 brute force for the (rare) rows that could not be certified.
+// Result: neighbour order == order of the float64 distances the reference computes; no approximation.
+#include "kz_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+// Stage 1: fused similarity + candidate selection
+// ---------------------------------------------------------------------------------------------------
+// similarity key(q, y) = q.y + bias(y)     bias = -|y|^2/2 (euclidean: argmax key == argmin |q-y|^2), 0 (cosine)
+//
+// Workgroup = 256 threads = 4 waves, tile = 128 index rows (MFMA M) x 128 queries (MFMA N).
+// Wave w owns queries [32w, 32w+32) and all 128 index rows of the tile: 4 accumulators of 32x32.
+// With the query on the MFMA column (= lane & 31), the 64 keys a lane holds after a tile all belong to ONE
+// query, so each lane keeps a PRIVATE candidate list (query, lane-half) and needs no atomics or barriers:
+//   list(q, h) sees index rows with (row & 4) == 4h; union of the two halves' top-K' contains the top-K'.
+// Index operand: streamed HBM/L2 -> registers -> LDS (double buffered 8 KiB slices, one barrier per slice).
+// Query operand: per-lane fragments straight from L2 (no reuse across waves, so no LDS round trip).
+struct KnnCandParams {
+    const float* qpack;   // packed query matrix
+    const float* ypack;   // packed index matrix
+    const float* ybias;   // accumulator init per index row
+    int qt0;              // first query tile of this launch
+    int n_qtiles;         // query tiles in this launch
+    int n_ytiles;         // index tiles
+    int tiles_per_split;  // index tiles per split
+    int n_splits;
+    int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
+    float* out_key;       // [n_qtiles*128][n_splits][2][KP]
+    int* out_idx;
+};
+
+constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows
+
+template <int KP, bool LDS_LISTS>
+__global__ __launch_bounds__(256, 2) void kz_knn_cand_kernel(KnnCandParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ybuf = reinterpret_cast<float*>(smem);  // 2 x 2048 floats (+ 2 x 128 bias floats behind them)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+
+    // XCD-aware, bijective work mapping: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+    // range of work items so that co-resident blocks stream the SAME index split.
+    const int W = p.n_qtiles * p.n_splits;
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int q8 = W >> 3, r8 = W & 7;
+    const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int s = w / p.n_qtiles;
+    const int qt = w - s * p.n_qtiles;
+    const int t_begin = s * p.tiles_per_split;
+    const int t_end = min(p.n_ytiles, t_begin + p.tiles_per_split);
+    const int NS = p.kg >> 2;
+    const int total = (t_end - t_begin) * NS;
+
+    // candidate list of this lane
+    constexpr int LSTRIDE = LDS_LISTS ? 256 : 1;
+    const int64_t listoff = ((((int64_t)qt * KZ_TILE + 32 * wave + j) * p.n_splits + s) * 2 + h) * KP;
+    float* lk;
+    int* li;
+    if (LDS_LISTS) {
+        lk = reinterpret_cast<float*>(smem + KZ_CAND_LDS_BASE) + tid;
+        li = reinterpret_cast<int*>(smem + KZ_CAND_LDS_BASE + KP * 256 * 4) + tid;
+    } else {
+        lk = p.out_key + listoff;
+        li = p.out_idx + listoff;
+    }
+#pragma unroll 4
+    for (int e = 0; e < KP; ++e) {
+        lk[e * LSTRIDE] = -INFINITY;
+        li[e * LSTRIDE] = -1;
+    }
+    float tau = -INFINITY;  // current K'-th best key of this list (its minimum)
+    int minpos = 0;
+
+    if (total > 0) {
+        const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * NS) * 2048);
+        const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg) * 512 + (32 * wave + j) * 4;
+        float* bbuf = ybuf + 4096;  // 2 x 128 floats: accumulator-init (bias) rows of the current / next tile
+        // prologue: slice 0 and the bias rows of the first tile
+        {
+            float4* nb = reinterpret_cast<float4*>(ybuf);
+            nb[tid] = ysrc[tid];
+            nb[tid + 256] = ysrc[256 + tid];
+            bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
+        }
+        float4 qb0 = *reinterpret_cast<const float4*>(qbase + (0 + h) * 512);
+        float4 qb1 = *reinterpret_cast<const float4*>(qbase + (2 + h) * 512);
+        __syncthreads();
+
+        int g = 0;
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            f32x16 acc[4];
+            __builtin_amdgcn_sched_barrier(0);  // do not hoist the next tile's init above the epilogue (64 VGPRs)
+            {
+                const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
+                        acc[mt][4 * g4 + 0] = v.x;
+                        acc[mt][4 * g4 + 1] = v.y;
+                        acc[mt][4 * g4 + 2] = v.z;
+                        acc[mt][4 * g4 + 3] = v.w;
+                    }
+                }
+            }
+            const int tile_n = min(tile + 1, p.n_ytiles - 1);
+            const float* bias_n = p.ybias + (int64_t)tile_n * KZ_TILE + (tid & 127);
+            int sl = 0;
+            do {  // NS >= 1 always; the do-while spares the compiler a zero-trip path (64 VGPRs of phi copies)
+                // Prefetch the next slice: index rows HBM/L2 -> registers, query fragments L2 -> registers, and
+                // (redundantly every slice, 512 B) the bias rows of the next tile.  All loads are UNCONDITIONAL so
+                // that the compiler's s_waitcnt placement keeps them in flight behind the 32 MFMAs below; at the
+                // very last slice the clamp re-reads the last slice, which is harmless.
+                const int gn = min(g + 1, total - 1);
+                const float4* src = ysrc + (int64_t)gn * 512;
+                const float4 ya0 = src[tid];
+                const float4 ya1 = src[256 + tid];
+                const int sln = (sl + 1 == NS) ? 0 : sl + 1;
+                const float4 qn0 = *reinterpret_cast<const float4*>(qbase + (4 * sln + h) * 512);
+                const float4 qn1 = *reinterpret_cast<const float4*>(qbase + (4 * sln + 2 + h) * 512);
+                const float bn = *bias_n;
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ABOVE the MFMA block (hipcc sinks them)
+                // 32 MFMAs on the current slice.  Lane (j, h) feeds k = 4*(2t+h)+jj for jj = 0..3: the k order
+                // inside a slice is permuted identically for A and B, which leaves the dot product unchanged.
+                const float* buf = ybuf + (g & 1) * 2048;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float4 a[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        a[mt] = *reinterpret_cast<const float4*>(buf + ((2 * t + h) * KZ_TILE + 32 * mt + j) * 4);
+                    const float4 bq = t ? qb1 : qb0;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // ... and the LDS refill BELOW it
+                {
+                    float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 1) & 1) * 2048);
+                    nb[tid] = ya0;
+                    nb[tid + 256] = ya1;
+                    bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+                    qb0 = qn0;
+                    qb1 = qn1;
+                }
+                __syncthreads();
+                ++g;
+            } while (++sl < NS);
+            // epilogue: C layout of 32x32 MFMA: col = lane & 31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            const int rowbase = tile * KZ_TILE + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float m = acc[mt][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mt][r]);
+                if (m > tau) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[mt][r];
+                        if (v > tau) {
+                            // replace the list minimum, then rescan for the new minimum
+                            lk[minpos * LSTRIDE] = v;
+                            li[minpos * LSTRIDE] = rowbase + 32 * mt + (r & 3) + 8 * (r >> 2);
+                            float mn = lk[0];
+                            int mp = 0;
+                            for (int e = 1; e < KP; ++e) {
+                                const float x = lk[e * LSTRIDE];
+                                if (x < mn) {
+                                    mn = x;
+                                    mp = e;
+                                }
+                            }
+                            tau = mn;
+                            minpos = mp;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (LDS_LISTS) {
+        float* ok = p.out_key + listoff;
+        int* oi = p.out_idx + listoff;
+        for (int e = 0; e < KP; ++e) {
+            ok[e] = lk[e * LSTRIDE];
+            oi[e] = li[e * LSTRIDE];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stage 2: merge + certify + float64 re-rank
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void kz_wave_sync() {
+    // cross-lane exchange through LDS inside ONE wave: LDS ops of a wave execute in order, the fences only stop
+    // the compiler from reordering the accesses.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct KnnFinParams {
+    const float* in_key;  // [rows][M]
+    const int* in_idx;
+    int M;                // n_splits * 2 * KP
+    int KP;
+    int64_t list_row0;    // list row of local query 0  (= q_begin - qt0*128)
+    int64_t q_begin;      // global query row of local query 0
+    int64_t q_count;
+    const void* qraw;     // raw query rows (global row indexing)
+    const void* yraw;     // raw index rows
+    const double* qsqn;
+    const double* ysqn;
+    int64_t n_i;
+    int d;
+    int metric;
+    int k;                // neighbours to return
+    int exclude_self;
+    double gamma;         // rounding-bound factor (already multiplied by eps_scale)
+    double ymax;          // max index-row norm
+    double* out_dist;     // [q_count][k]
+    int64_t* out_ind;
+    int* fail_count;
+    int* fail_list;
+};
+
+template <typename T>
+__device__ __forceinline__ double kz_exact_value(const T* q, const T* y, double qs, double ys, int d, int metric, int lane) {
+    if (metric == KZ_COSINE) {
+        const double sim = kz_wave_dot_normalized(q, qs, y, ys, d, lane);
+        double v = 1.0 - sim;  // sklearn cosine_distances: S *= -1; S += 1; clip(0, 2)
+        v = fmin(fmax(v, 0.0), 2.0);
+        return v;
+    }
+    const double dot = kz_wave_dot(q, y, d, lane);
+    const double d2 = (qs + ys) - 2.0 * dot;  // |x|^2 - 2 x.y + |y|^2 (_argkmin.pyx.tp:494-499)
+    return fmax(d2, 0.0);                     // _argkmin.pyx.tp:502
+}
+
+template <typename T>
+__device__ __forceinline__ double kz_output_distance(double v, int metric) {
+    if (metric == KZ_EUCLIDEAN) {
+        // ArgKmin32 converts the surrogate with the float32 metric object: (double)sqrtf((float)d2)
+        // (_argkmin.pyx.tp:285-295 with INPUT_DTYPE_t = float32); ArgKmin64 uses sqrt in float64.
+        if (sizeof(T) == 4) return (double)__fsqrt_rn((float)v);
+        return sqrt(v);
+    }
+    return v;
+}
+
+// Writes the final k entries of one query from its (value, idx)-sorted prefix.  sorted arrays live in LDS.
+// sklearn self removal (neighbors/_base.py:947-965): among the first k+1, drop the entry whose index is the
+// query row; if it is absent drop the first one.
+template <typename T>
+__device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* sidx, int n_sorted, int k, int exclude_self,
+                                               int64_t self_row, int metric, double* od, int64_t* oi, int lane) {
+    int self_rank = -1;
+    if (exclude_self) {
+        self_rank = 0;
+        const int lim = min(n_sorted, k + 1);
+        for (int c = 0; c < lim; ++c)
+            if ((int64_t)sidx[c] == self_row) {
+                self_rank = c;
+                break;
+            }
+    }
+    for (int c = lane; c < n_sorted; c += 64) {
+        if (c == self_rank) continue;
+        const int o = (self_rank >= 0 && c > self_rank) ? c - 1 : c;
+        if (o < k) {
+            od[o] = kz_output_distance<T>(sval[c], metric);
+            oi[o] = (int64_t)sidx[c];
+        }
+    }
+}
+
+constexpr int KZ_FIN_MAXM = 1024;
+constexpr int KZ_FIN_MAXKP = 128;
+
+template <typename T>
+__global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
+    __shared__ float s_ekey[4][KZ_FIN_MAXM];
+    __shared__ int s_eidx[4][KZ_FIN_MAXM];
+    __shared__ float s_ck[4][KZ_FIN_MAXKP];
+    __shared__ int s_ci[4][KZ_FIN_MAXKP];
+    __shared__ double s_cv[4][KZ_FIN_MAXKP];
+    __shared__ double s_sv[4][KZ_FIN_MAXKP];
+    __shared__ int s_si[4][KZ_FIN_MAXKP];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= p.q_count) return;  // whole wave exits; only wave-level sync below
+    float* ekey = s_ekey[wave];
+    int* eidx = s_eidx[wave];
+    float* ck = s_ck[wave];
+    int* ci = s_ci[wave];
+    double* cv = s_cv[wave];
+    double* sv = s_sv[wave];
+    int* si = s_si[wave];
+    const int M = p.M, KP = p.KP;
+    const int k_eff = p.k + (p.exclude_self ? 1 : 0);
+
+    const float* gk = p.in_key + (p.list_row0 + q) * (int64_t)M;
+    const int* gi = p.in_idx + (p.list_row0 + q) * (int64_t)M;
+    for (int e = lane; e < M; e += 64) {
+        ekey[e] = gk[e];
+        eidx[e] = gi[e];
+    }
+    kz_wave_sync();
+
+    // top-KP of the M entries by (key desc, idx asc)
+    int V = 0;
+    for (int r = 0; r < KP; ++r) {
+        float bk = -INFINITY;
+        int bi = 0x7fffffff, be = -1;
+        for (int e = lane; e < M; e += 64) {
+            const float x = ekey[e];
+            const int xi = eidx[e];
+            if (xi >= 0 && (x > bk || (x == bk && xi < bi))) {
+                bk = x;
+                bi = xi;
+                be = e;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ok = __shfl_xor(bk, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            const int oe = __shfl_xor(be, off, 64);
+            if (oe >= 0 && (be < 0 || ok > bk || (ok == bk && oi < bi))) {
+                bk = ok;
+                bi = oi;
+                be = oe;
+            }
+        }
+        if (be < 0) break;  // uniform: every lane holds the same winner
+        if (lane == 0) {
+            ck[r] = bk;
+            ci[r] = bi;
+            eidx[be] = -1;  // consumed
+        }
+        V = r + 1;
+        kz_wave_sync();
+    }
+    kz_wave_sync();
+
+    const int64_t qrow = p.q_begin + q;
+    const T* qptr = reinterpret_cast<const T*>(p.qraw) + qrow * (int64_t)p.d;
+    const double qs = p.qsqn[qrow];
+
+    // Certification.  |key~ - key| <= eps for every index row (float32 fma-chain bound, DESIGN.md "Certified
+    // candidate sets").  If the K'-th candidate key is more than 2*eps below the k-th, no row outside the list
+    // can belong to the exact top-k.  V < KP means no list ever evicted anything: the set is complete.
+    bool certified;
+    if (V < KP) {
+        certified = (V >= min((int64_t)k_eff, p.n_i));
+    } else {
+        double eps;
+        if (p.metric == KZ_COSINE)
+            eps = p.gamma * 1.001;
+        else
+            eps = p.gamma * (0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax);
+        certified = (double)ck[KP - 1] < (double)ck[k_eff - 1] - 2.0 * eps;
+    }
+    if (!certified) {
+        if (lane == 0) {
+            const int pos = atomicAdd(p.fail_count, 1);
+            p.fail_list[pos] = (int)q;
+        }
+        return;
+    }
+
+    // exact float64 re-rank of the V candidates
+    for (int c = 0; c < V; ++c) {
+        const int yi = ci[c];
+        const T* yptr = reinterpret_cast<const T*>(p.yraw) + (int64_t)yi * p.d;
+        const double v = kz_exact_value<T>(qptr, yptr, qs, p.ysqn[yi], p.d, p.metric, lane);
+        if (lane == 0) cv[c] = v;
+    }
+    kz_wave_sync();
+    // rank by (value asc, idx asc) and scatter into sorted order
+    for (int c = lane; c < V; c += 64) {
+        const double v = cv[c];
+        const int id = ci[c];
+        int rank = 0;
+        for (int o = 0; o < V; ++o) {
+            const double ov = cv[o];
+            const int oid = ci[o];
+            rank += (ov < v || (ov == v && oid < id)) ? 1 : 0;
+        }
+        sv[rank] = v;
+        si[rank] = id;
+    }
+    kz_wave_sync();
+    kz_emit_sorted<T>(sv, si, V, p.k, p.exclude_self, qrow, p.metric, p.out_dist + q * (int64_t)p.k,
+                      p.out_ind + q * (int64_t)p.k, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stage 3: exact float64 brute force for uncertified rows (rare; correctness backstop)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void kz_exact_dist_kernel(const int* __restrict__ fail_list, int batch0, int64_t q_begin,
+                                                            const T* __restrict__ qraw, const T* __restrict__ yraw,
+                                                            const double* __restrict__ qsqn, const double* __restrict__ ysqn,
+                                                            int64_t n_i, int d, int metric, double* __restrict__ vals) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= n_i) return;
+    const int b = blockIdx.y;
+    const int64_t qrow = q_begin + fail_list[batch0 + b];
+    const double v = kz_exact_value<T>(qraw + qrow * (int64_t)d, yraw + i * (int64_t)d, qsqn[qrow], ysqn[i], d, metric, lane);
+    if (lane == 0) vals[(int64_t)b * n_i + i] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restrict__ fail_list, int batch0, int64_t q_begin,
+                                                              const double* __restrict__ vals, int64_t n_i, int k,
+                                                              int exclude_self, int metric, double* __restrict__ out_dist,
+                                                              int64_t* __restrict__ out_ind) {
+    __shared__ double s_v[4];
+    __shared__ int s_i[4];
+    __shared__ double s_sv[KZ_FIN_MAXKP];
+    __shared__ int s_si[KZ_FIN_MAXKP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int q = fail_list[batch0 + b];
+    const double* v = vals + (int64_t)b * n_i;
+    const int k_eff = (int)min((int64_t)(k + (exclude_self ? 1 : 0)), n_i);
+    double pv = -1.0;  // values are >= 0
+    int pi = -1;
+    for (int r = 0; r < k_eff; ++r) {
+        double bv = INFINITY;
+        int bi = 0x7fffffff;
+        for (int64_t i = tid; i < n_i; i += 256) {
+            const double x = v[i];
+            const bool after = (x > pv) || (x == pv && (int)i > pi);
+            if (after && (x < bv || (x == bv && (int)i < bi))) {
+                bv = x;
+                bi = (int)i;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov < bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_v[wave] = bv;
+            s_i[wave] = bi;
+        }
+        __syncthreads();
+        bv = s_v[0];
+        bi = s_i[0];
+        for (int ww = 1; ww < 4; ++ww) {
+            if (s_v[ww] < bv || (s_v[ww] == bv && s_i[ww] < bi)) {
+                bv = s_v[ww];
+                bi = s_i[ww];
+            }
+        }
+        if (tid == 0) {
+            s_sv[r] = bv;
+            s_si[r] = bi;
+        }
+        pv = bv;
+        pi = bi;
+        __syncthreads();
+    }
+    if (wave == 0)
+        kz_emit_sorted<T>(s_sv, s_si, k_eff, k, exclude_self, q_begin + q, metric, out_dist + (int64_t)q * k,
+                          out_ind + (int64_t)q * k, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------------------
+static int kz_pick_list_len(int k_eff) {
+    if (k_eff <= 12) return 16;
+    if (k_eff <= 26) return 32;
+    if (k_eff <= 54) return 64;
+    if (k_eff <= 110) return 128;
+    return 0;
+}
+
+template <int KP, bool LDS_LISTS>
+static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p) {
+    const size_t lds = KZ_CAND_LDS_BASE + (LDS_LISTS ? (size_t)KP * 256 * 8 : 0);
+    auto kern = kz_knn_cand_kernel<KP, LDS_LISTS>;
+    if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(p.n_qtiles * p.n_splits), dim3(256), lds, ctx->stream, p);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index, int k,
+                      int exclude_self, double* d_dist, int64_t* d_ind, kz_knn_stats* stats) {
+    KZ_REQUIRE(ctx && query && index && d_dist && d_ind, "kz_knn: null argument");
+    KZ_REQUIRE(query->ctx == ctx && index->ctx == ctx, "kz_knn: matrices belong to a different context");
+    KZ_REQUIRE(query->d == index->d, "kz_knn: feature dimensions differ (%lld vs %lld)", (long long)query->d,
+               (long long)index->d);
+    KZ_REQUIRE(query->dtype == index->dtype, "kz_knn: query and index must have the same dtype");
+    KZ_REQUIRE(query->metric == index->metric, "kz_knn: query and index were packed for different metrics");
+    KZ_REQUIRE(q_begin >= 0 && q_count >= 0 && q_begin + q_count <= query->n, "kz_knn: query row range out of bounds");
+    KZ_REQUIRE(k >= 1, "kz_knn: Expected k > 0. Got %d", k);
+    const int k_eff = k + (exclude_self ? 1 : 0);
+    KZ_REQUIRE((int64_t)k_eff <= index->n, "kz_knn: Expected n_neighbors %s n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld",
+               exclude_self ? "<" : "<=", k, (long long)index->n);
+    if (exclude_self) KZ_REQUIRE(query->n == index->n, "kz_knn: exclude_self needs query and index of equal length");
+    const int KP = kz_pick_list_len(k_eff);
+    if (KP == 0) {
+        kz_set_error("kz_knn: k=%d exceeds the supported maximum of 110 neighbours per query", k_eff);
+        return KZ_ERR_UNSUPPORTED;
+    }
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (q_count == 0) return KZ_OK;
+    KZ_HIP(hipSetDevice(ctx->device));
+
+    const int metric = index->metric;
+    const int n_ytiles = (int)index->n_tiles;
+    const int max_splits_m = KZ_FIN_MAXM / (2 * KP);
+    // rounding bound factor: (d_pad + 16) * 2^-24 covers the d+1 step fma chain, the float32 rounding of the bias
+    // and (float64 inputs) of the operands; 1e-12 covers the float64 re-rank's own rounding.
+    const double gamma = ((double)(index->kg * 4 + 16) * 5.9604644775390625e-08 + 1e-12) * ctx->eps_scale;
+
+    // query rows are processed in chunks so that the candidate lists stay below ~1 GiB
+    const int64_t max_rows_per_chunk = 128 * 4096;
+    double main_ms = 0, fin_ms = 0, fb_ms = 0;
+    int64_t n_fail_total = 0;
+    int last_splits = 1, last_blocks = 0;
+    for (int64_t c0 = 0; c0 < q_count; c0 += max_rows_per_chunk) {
+        const int64_t cq_begin = q_begin + c0;
+        const int64_t cq_count = (q_count - c0 < max_rows_per_chunk) ? (q_count - c0) : max_rows_per_chunk;
+        const int qt0 = (int)(cq_begin / KZ_TILE);
+        const int qt1 = (int)((cq_begin + cq_count - 1) / KZ_TILE);
+        const int n_qtiles = qt1 - qt0 + 1;
+        int n_splits;
+        if (ctx->force_splits > 0) {
+            n_splits = ctx->force_splits;
+        } else {
+            const int target_blocks = 256 * 2 * 6;
+            n_splits = (target_blocks + n_qtiles - 1) / n_qtiles;
+            const int by_len = n_ytiles / 8 > 1 ? n_ytiles / 8 : 1;  // keep >= 8 tiles (1024 rows) per split
+            if (n_splits > by_len) n_splits = by_len;
+        }
+        if (n_splits > max_splits_m) n_splits = max_splits_m;
+        if (n_splits > n_ytiles) n_splits = n_ytiles;
+        if (n_splits < 1) n_splits = 1;
+        const int tiles_per_split = (n_ytiles + n_splits - 1) / n_splits;
+        n_splits = (n_ytiles + tiles_per_split - 1) / tiles_per_split;
+        const int M = n_splits * 2 * KP;
+        const size_t list_elems = (size_t)n_qtiles * KZ_TILE * (size_t)M;
+        const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
+        const size_t fail_bytes = ((size_t)cq_count * 4 + 255) & ~(size_t)255;
+        void* scratch = nullptr;
+        int rc = kz_scratch(ctx, key_bytes * 2 + fail_bytes, &scratch);
+        if (rc != KZ_OK) return rc;
+        float* out_key = (float*)scratch;
+        int* out_idx = (int*)((char*)scratch + key_bytes);
+        int* fail_list = (int*)((char*)scratch + 2 * key_bytes);
+        int* fail_count = ctx->d_counters + 8;
+        KZ_HIP(hipMemsetAsync(fail_count, 0, sizeof(int), ctx->stream));
+
+        KnnCandParams cp;
+        cp.qpack = query->packed;
+        cp.ypack = index->packed;
+        cp.ybias = index->bias;
+        cp.qt0 = qt0;
+        cp.n_qtiles = n_qtiles;
+        cp.n_ytiles = n_ytiles;
+        cp.tiles_per_split = tiles_per_split;
+        cp.n_splits = n_splits;
+        cp.kg = index->kg;
+        cp.out_key = out_key;
+        cp.out_idx = out_idx;
+        KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+        switch (KP) {
+            case 16: rc = kz_launch_cand<16, true>(ctx, cp); break;
+            case 32: rc = kz_launch_cand<32, true>(ctx, cp); break;
+            case 64: rc = kz_launch_cand<64, false>(ctx, cp); break;
+            default: rc = kz_launch_cand<128, false>(ctx, cp); break;
+        }
+        if (rc != KZ_OK) return rc;
+        KZ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+
+        KnnFinParams fp;
+        fp.in_key = out_key;
+        fp.in_idx = out_idx;
+        fp.M = M;
+        fp.KP = KP;
+        fp.list_row0 = cq_begin - (int64_t)qt0 * KZ_TILE;
+        fp.q_begin = cq_begin;
+        fp.q_count = cq_count;
+        fp.qraw = query->raw;
+        fp.yraw = index->raw;
+        fp.qsqn = query->sqn;
+        fp.ysqn = index->sqn;
+        fp.n_i = index->n;
+        fp.d = (int)index->d;
+        fp.metric = metric;
+        fp.k = k;
+        fp.exclude_self = exclude_self ? 1 : 0;
+        fp.gamma = gamma;
+        fp.ymax = index->max_norm;
+        fp.out_dist = d_dist + c0 * (int64_t)k;
+        fp.out_ind = d_ind + c0 * (int64_t)k;
+        fp.fail_count = fail_count;
+        fp.fail_list = fail_list;
+        const int fin_blocks = (int)((cq_count + 3) / 4);
+        if (index->dtype == KZ_F32)
+            hipLaunchKernelGGL(kz_knn_finalize_kernel<float>, dim3(fin_blocks), dim3(256), 0, ctx->stream, fp);
+        else
+            hipLaunchKernelGGL(kz_knn_finalize_kernel<double>, dim3(fin_blocks), dim3(256), 0, ctx->stream, fp);
+        KZ_HIP(hipGetLastError());
+        KZ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        KZ_HIP(hipStreamSynchronize(ctx->stream));
+        const int n_fail = ctx->h_counters[8];
+        float ms = 0;
+        KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        main_ms += ms;
+        KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+        fin_ms += ms;
+        last_splits = n_splits;
+        last_blocks = n_qtiles * n_splits;
+        n_fail_total += n_fail;
+
+        if (n_fail > 0) {
+            // exact brute force in batches; the fail list lives at the end of the scratch block, the value matrix
+            // goes to a separate allocation so that the list is not overwritten by a scratch regrow.
+            KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+            int* fl = nullptr;
+            KZ_HIP(hipMalloc((void**)&fl, (size_t)n_fail * sizeof(int)));
+            KZ_HIP(hipMemcpyAsync(fl, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+            int64_t batch = ((int64_t)256 << 20) / (index->n * 8);
+            if (batch < 1) batch = 1;
+            if (batch > n_fail) batch = n_fail;
+            if (batch > 65535) batch = 65535;
+            void* vals = nullptr;
+            rc = kz_scratch(ctx, (size_t)batch * (size_t)index->n * 8, &vals);
+            if (rc != KZ_OK) {
+                (void)hipFree(fl);
+                return rc;
+            }
+            const int dist_blocks = (int)((index->n + 3) / 4);
+            for (int b0 = 0; b0 < n_fail; b0 += (int)batch) {
+                const int nb = (n_fail - b0 < batch) ? (n_fail - b0) : (int)batch;
+                if (index->dtype == KZ_F32) {
+                    hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
+                                       cq_begin, (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn,
+                                       index->n, (int)index->d, metric, (double*)vals);
+                    hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(nb), dim3(256), 0, ctx->stream, fl, b0, cq_begin,
+                                       (const double*)vals, index->n, k, exclude_self ? 1 : 0, metric, fp.out_dist, fp.out_ind);
+                } else {
+                    hipLaunchKernelGGL(kz_exact_dist_kernel<double>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
+                                       cq_begin, (const double*)query->raw, (const double*)index->raw, query->sqn, index->sqn,
+                                       index->n, (int)index->d, metric, (double*)vals);
+                    hipLaunchKernelGGL(kz_exact_select_kernel<double>, dim3(nb), dim3(256), 0, ctx->stream, fl, b0, cq_begin,
+                                       (const double*)vals, index->n, k, exclude_self ? 1 : 0, metric, fp.out_dist, fp.out_ind);
+                }
+            }
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(ctx->ev[4], ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(fl);
+            if (e != hipSuccess) {
+                kz_set_error("kz_knn: exact fallback failed: %s", hipGetErrorString(e));
+                return KZ_ERR_HIP;
+            }
+            KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+            fb_ms += ms;
+        }
+    }
+    if (stats) {
+        stats->main_kernel_ms = main_ms;
+        stats->finalize_ms = fin_ms;
+        stats->fallback_ms = fb_ms;
+        stats->n_fallback_rows = n_fail_total;
+        stats->list_len = KP;
+        stats->n_splits = last_splits;
+        stats->n_blocks = last_blocks;
+    }
+    return KZ_OK;
+}

@@ -1,0 +1,159 @@
+// Context, memory and error plumbing of libkiez_amd.so.
+#include "kz_common.h"
+
+static thread_local char g_err[512] = "";
+
+void kz_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int kz_abi_version(void) { return KZ_ABI_VERSION; }
+
+const char* kz_last_error(void) { return g_err; }
+
+int kz_device_count(int* n) {
+    KZ_REQUIRE(n != nullptr, "kz_device_count: null output");
+    KZ_HIP(hipGetDeviceCount(n));
+    return KZ_OK;
+}
+
+int kz_ctx_create(int device, void* stream, kz_ctx** out) {
+    KZ_REQUIRE(out != nullptr, "kz_ctx_create: null output");
+    int n = 0;
+    KZ_HIP(hipGetDeviceCount(&n));
+    KZ_REQUIRE(device >= 0 && device < n, "kz_ctx_create: device %d out of range (%d visible)", device, n);
+    KZ_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    KZ_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        kz_set_error("kz_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                     prop.gcnArchName);
+        return KZ_ERR_UNSUPPORTED;
+    }
+    kz_ctx* c = new kz_ctx();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->eps_scale = 1.0;
+    c->force_splits = 0;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        KZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    for (int i = 0; i < 6; ++i) KZ_HIP(hipEventCreate(&c->ev[i]));
+    KZ_HIP(hipMalloc((void**)&c->d_counters, 64 * sizeof(int)));
+    KZ_HIP(hipHostMalloc((void**)&c->h_counters, 64 * sizeof(int), hipHostMallocDefault));
+    KZ_HIP(hipMemsetAsync(c->d_counters, 0, 64 * sizeof(int), c->stream));
+    KZ_HIP(hipStreamSynchronize(c->stream));
+    *out = c;
+    return KZ_OK;
+}
+
+int kz_ctx_destroy(kz_ctx* c) {
+    if (!c) return KZ_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return KZ_OK;
+}
+
+int kz_ctx_sync(kz_ctx* c) {
+    KZ_REQUIRE(c != nullptr, "kz_ctx_sync: null context");
+    KZ_HIP(hipStreamSynchronize(c->stream));
+    return KZ_OK;
+}
+
+int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
+    KZ_REQUIRE(c && name, "kz_ctx_set_option: null argument");
+    if (strcmp(name, "eps_scale") == 0) {
+        KZ_REQUIRE(value > 0, "eps_scale must be > 0");
+        c->eps_scale = value;
+    } else if (strcmp(name, "force_splits") == 0) {
+        KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
+        c->force_splits = (int)value;
+    } else {
+        kz_set_error("kz_ctx_set_option: unknown option '%s'", name);
+        return KZ_ERR_INVALID;
+    }
+    return KZ_OK;
+}
+
+int kz_malloc(kz_ctx* c, size_t bytes, void** d_ptr) {
+    KZ_REQUIRE(c && d_ptr, "kz_malloc: null argument");
+    KZ_HIP(hipSetDevice(c->device));
+    *d_ptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(d_ptr, bytes);
+    if (e != hipSuccess) {
+        kz_set_error("kz_malloc: hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return KZ_ERR_NOMEM;
+    }
+    return KZ_OK;
+}
+
+int kz_free(kz_ctx* c, void* d_ptr) {
+    KZ_REQUIRE(c != nullptr, "kz_free: null context");
+    if (!d_ptr) return KZ_OK;
+    KZ_HIP(hipSetDevice(c->device));
+    KZ_HIP(hipStreamSynchronize(c->stream));
+    KZ_HIP(hipFree(d_ptr));
+    return KZ_OK;
+}
+
+int kz_memcpy_h2d(kz_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+    KZ_REQUIRE(c && (bytes == 0 || (d_dst && h_src)), "kz_memcpy_h2d: null argument");
+    if (bytes == 0) return KZ_OK;
+    KZ_HIP(hipSetDevice(c->device));
+    KZ_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    KZ_HIP(hipStreamSynchronize(c->stream));
+    return KZ_OK;
+}
+
+int kz_memcpy_d2h(kz_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+    KZ_REQUIRE(c && (bytes == 0 || (h_dst && d_src)), "kz_memcpy_d2h: null argument");
+    if (bytes == 0) return KZ_OK;
+    KZ_HIP(hipSetDevice(c->device));
+    KZ_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    KZ_HIP(hipStreamSynchronize(c->stream));
+    return KZ_OK;
+}
+
+int kz_memcpy_d2d(kz_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
+    KZ_REQUIRE(c && (bytes == 0 || (d_dst && d_src)), "kz_memcpy_d2d: null argument");
+    if (bytes == 0) return KZ_OK;
+    KZ_HIP(hipSetDevice(c->device));
+    KZ_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return KZ_OK;
+}
+
+}  // extern "C"
+
+int kz_scratch(kz_ctx* c, size_t bytes, void** out) {
+    if (bytes > c->scratch_bytes) {
+        KZ_HIP(hipStreamSynchronize(c->stream));
+        if (c->scratch) KZ_HIP(hipFree(c->scratch));
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+        size_t want = bytes + (bytes >> 3) + (1 << 20);
+        hipError_t e = hipMalloc(&c->scratch, want);
+        if (e != hipSuccess) {
+            kz_set_error("scratch allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+            return KZ_ERR_NOMEM;
+        }
+        c->scratch_bytes = want;
+    }
+    *out = c->scratch;
+    return KZ_OK;
+}

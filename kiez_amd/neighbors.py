@@ -1,0 +1,252 @@
+"""NN backends: the reference's `NNAlgorithm` plugin interface and the MI355X exact backend behind it.
+
+`NNAlgorithm` mirrors kiez/neighbors/neighbor_algorithm_base.py:13-136 (same method names, argument
+meaning, errors and warnings).  `SklearnNN` keeps the reference class's name and constructor
+(kiez/neighbors/exact/sklearn_nearest_neighbors.py:51-65) so that `Kiez(algorithm="SklearnNN", ...)`
+configurations keep working, but `_fit` / `_kneighbors` run on the GPU through the C ABI
+(include/kiez_amd.h): brute-force exact search, identical neighbours.
+"""
+from __future__ import annotations
+
+import warnings
+from abc import ABC, abstractmethod
+from typing import Any, Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+
+class NotFittedError(ValueError, AttributeError):
+    """Same bases as sklearn.exceptions.NotFittedError (raised by the reference through check_is_fitted)."""
+
+
+def check_is_fitted(obj, attributes, all_or_any=all):
+    if isinstance(attributes, str):
+        attributes = [attributes]
+    if not all_or_any([hasattr(obj, a) for a in attributes]):
+        raise NotFittedError(
+            f"This {type(obj).__name__} instance is not fitted yet. Call 'fit' with appropriate arguments before "
+            "using this estimator.")
+
+
+class NNAlgorithm(ABC):
+    """Base class for nearest neighbor algorithms (kiez/neighbors/neighbor_algorithm_base.py:13-136)."""
+
+    _ALLOWED_INPUT_TYPES: Tuple[Any, ...] = (np.ndarray,)
+
+    def __init__(self, n_candidates, metric, n_jobs):
+        self.n_candidates = n_candidates
+        self.metric = metric
+        self.n_jobs = n_jobs
+
+    def _describe_source_target_fitted(self):
+        if hasattr(self, "source_"):
+            return f" is fitted with: source.shape={self.source_.shape} and target.shape={self.target_.shape}"
+        return " is unfitted"
+
+    @property
+    @abstractmethod
+    def valid_metrics(self):
+        pass  # pragma: no cover
+
+    @abstractmethod
+    def _fit(self, data, is_source: bool) -> Any:
+        pass  # pragma: no cover
+
+    def _check_input_types(self, value):
+        if not isinstance(value, tuple):
+            value = (value,)
+        if not all(isinstance(x, self.__class__._ALLOWED_INPUT_TYPES) for x in value if x is not None):
+            found_types = [type(x) for x in value]
+            raise ValueError(
+                f"Not implemented for input type(s) {found_types}! Only {self.__class__._ALLOWED_INPUT_TYPES} allowed!")
+
+    def fit(self, source, target=None, only_fit_target: bool = False):
+        """Index the data (neighbor_algorithm_base.py:53-96)."""
+        self._check_input_types((source, target))
+        self.source_equals_target = target is None
+        if self.source_equals_target:
+            self.source_index = self._fit(source, True)
+            self.target_index = self.source_index
+            target = source
+        else:
+            if target is not None and source.shape[1] != target.shape[1]:
+                raise ValueError(
+                    "Expected source and target to have the same number of features,"
+                    f" but got source.shape: {source.shape} and target.shape: {target.shape}")
+            if only_fit_target:
+                self.target_index = self._fit(target, True)
+            else:
+                self.source_index = self._fit(source, True)
+                self.target_index = self._fit(target, False)
+        self.source_ = source
+        self.target_ = target
+
+    def _check_k_value(self, k: int, needed_space) -> int:
+        if not np.issubdtype(type(k), np.integer):
+            raise TypeError(f"k does not take {type(k)} value, enter integer value")
+        if k <= 0:
+            raise ValueError(f"Expected k > 0. Got {k}")
+        if k > needed_space:
+            warnings.warn(
+                f"k={k} is larger than number of samples in indexed space.\n" + f"Setting to k={needed_space}",
+                stacklevel=2)
+            return needed_space
+        return k
+
+    @abstractmethod
+    def _kneighbors(self, k, query, index, return_distance, is_self_querying):
+        pass  # pragma: no cover
+
+    def _select_direction(self, k, query, s_to_t):
+        check_is_fitted(self, ["source_index", "target_index"], all_or_any=any)
+        k = self.n_candidates if k is None else k
+        is_self_querying = query is None and self.source_equals_target
+        if s_to_t:
+            query = self.source_ if query is None else query
+            index = self.target_index
+            needed_space = self.target_.shape[0]
+        else:
+            query = self.target_ if query is None else query
+            index = self.source_index
+            needed_space = self.source_.shape[0]
+        k = self._check_k_value(k, needed_space)
+        return k, query, index, is_self_querying
+
+    def kneighbors(self, k=None, query=None, s_to_t=True, return_distance=True):
+        """neighbor_algorithm_base.py:116-136."""
+        k, query, index, is_self_querying = self._select_direction(k, query, s_to_t)
+        return self._kneighbors(k=k, query=query, index=index, return_distance=return_distance,
+                                is_self_querying=is_self_querying)
+
+
+def canonical_metric(metric: str, p=2) -> str:
+    """Map the reference's metric spelling to one the HIP kernels implement; anything else fails loudly."""
+    if metric == "minkowski":
+        if p != 2:
+            raise ValueError(
+                f"metric='minkowski' with p={p} is not implemented by the MI355X exact backend (only p=2, i.e. euclidean)")
+        return "euclidean"
+    if metric in ("l2", "euclidean"):
+        return "euclidean"
+    if metric in ("sqeuclidean", "cosine"):
+        return metric
+    raise ValueError(
+        f"metric='{metric}' is not implemented by the MI355X exact backend; valid metrics: {SklearnNN.valid_metrics}")
+
+
+class SklearnNN(NNAlgorithm):
+    """Exact brute-force nearest neighbours on MI355X, under the reference class's name and signature
+    (kiez/neighbors/exact/sklearn_nearest_neighbors.py:7-101).
+
+    `algorithm`, `leaf_size` and `n_jobs` are accepted for configuration compatibility; every sklearn
+    algorithm choice is exact, so the neighbours are the same and the search always runs as one fused
+    distance + top-k pass on the GPU.
+    """
+
+    valid_metrics = ["cosine", "euclidean", "l2", "minkowski", "sqeuclidean"]
+
+    def __init__(self, n_candidates=5, algorithm="auto", leaf_size=30, metric="minkowski", p=2, metric_params=None,
+                 n_jobs=None, device=None):
+        super().__init__(n_candidates=n_candidates, metric=metric, n_jobs=n_jobs)
+        self.algorithm = algorithm
+        self.leaf_size = leaf_size
+        self.p = p
+        self.metric_params = metric_params
+        self.device = device
+        self._metric_c = canonical_metric(metric, p)
+        self._ctx = None
+        self._aux = {}  # id(array) -> (array, DeviceMatrix) for query matrices that are not an index
+        self.last_stats = None
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(n_candidates={self.n_candidates},algorithm={self.algorithm},"
+                f"leaf_size={self.leaf_size},metric={self.metric},n_jobs={self.n_jobs} )")
+
+    # ---- device plumbing ---------------------------------------------------------------------------
+    @property
+    def ctx(self) -> N.Context:
+        if self._ctx is None:
+            self._ctx = N.Context.get(self.device)
+        return self._ctx
+
+    @staticmethod
+    def _prepare(data) -> np.ndarray:
+        arr = np.asarray(data)
+        if arr.ndim != 2:
+            raise ValueError(f"Expected 2D array, got {arr.ndim}D array instead")
+        if arr.dtype not in (np.float32, np.float64):
+            arr = arr.astype(np.float64)
+        return np.ascontiguousarray(arr)
+
+    def _fit(self, data, is_source: bool):
+        """Replaces SklearnNN._fit (sklearn_nearest_neighbors.py:83-94): upload + norms + MFMA tile packing."""
+        if is_source:
+            self._aux = {}
+        return N.DeviceMatrix(self.ctx, self._prepare(data), self._metric_c)
+
+    def fit(self, source, target=None, only_fit_target: bool = False):
+        self._check_input_types((source, target))
+        if (target is not None and np.ndim(source) == 2 and np.ndim(target) == 2
+                and source.shape[1] == target.shape[1] and np.asarray(source).dtype != np.asarray(target).dtype):
+            # one dtype for both sides (sklearn dispatches on X.dtype == Y.dtype, _dispatcher.py:292): use float64
+            super().fit(np.asarray(source, dtype=np.float64), np.asarray(target, dtype=np.float64), only_fit_target)
+            self.source_, self.target_ = source, target  # keep the caller's arrays, as the reference does
+            return
+        super().fit(source, target, only_fit_target)
+
+    def _matrix_for(self, array) -> N.DeviceMatrix:
+        """Device matrix of a query array: an existing index if it is the fitted source/target, else a cached upload."""
+        if hasattr(self, "source_index") and array is self.source_:
+            return self.source_index
+        if hasattr(self, "target_index") and array is self.target_:
+            return self.target_index
+        hit = self._aux.get(id(array))
+        if hit is not None and hit[0] is array:
+            return hit[1]
+        self._check_input_types(array)
+        ref = self.target_index if hasattr(self, "target_index") else self.source_index
+        arr = self._prepare(array)
+        if arr.dtype != ref.dtype:
+            arr = arr.astype(ref.dtype)
+        m = N.DeviceMatrix(self.ctx, arr, self._metric_c)
+        self._aux[id(array)] = (array, m)
+        return m
+
+    def _out_dtype(self, index: N.DeviceMatrix):
+        # sklearn: euclidean family -> float64 always (ArgKmin); cosine -> dtype of the input
+        return np.float32 if (self._metric_c == "cosine" and index.dtype == np.float32) else np.float64
+
+    def kneighbors_device(self, k=None, query=None, s_to_t=True, q_begin=0, q_count=None):
+        """`kneighbors` that leaves (dist float64, ind int64) in HBM; used by the GPU hubness reductions."""
+        k, query, index, is_self_querying = self._select_direction(k, query, s_to_t)
+        if k > N.MAX_NEIGHBORS - (1 if is_self_querying else 0):
+            raise NotImplementedError(
+                f"k={k} exceeds the {N.MAX_NEIGHBORS} neighbours per query the MI355X exact backend supports")
+        qm = self._matrix_for(query)
+        dist, ind, stats = N.knn(self.ctx, qm, index, k, exclude_self=is_self_querying, q_begin=q_begin, q_count=q_count)
+        self.last_stats = stats
+        return dist, ind
+
+    def _kneighbors(self, k, query, index, return_distance, is_self_querying):
+        """Replaces SklearnNN._kneighbors (sklearn_nearest_neighbors.py:96-101)."""
+        if k > N.MAX_NEIGHBORS - (1 if is_self_querying else 0):
+            raise NotImplementedError(
+                f"k={k} exceeds the {N.MAX_NEIGHBORS} neighbours per query the MI355X exact backend supports")
+        qm = self._matrix_for(query)
+        dist, ind, stats = N.knn(self.ctx, qm, index, k, exclude_self=is_self_querying)
+        self.last_stats = stats
+        ind_h = ind.numpy()
+        if not return_distance:
+            return ind_h
+        dist_h = dist.numpy()
+        out_dtype = self._out_dtype(index)
+        if out_dtype != np.float64:
+            dist_h = dist_h.astype(out_dtype)
+        return dist_h, ind_h
+
+
+def available_nn_algorithms(as_string: bool = False):
+    """kiez/neighbors/util.py:18-39 (only the exact backend exists here)."""
+    return ["SklearnNN"] if as_string else [SklearnNN]

@@ -1,0 +1,228 @@
+"""Parity of the HIP path (through the C ABI) with the golden vectors of the real reference and with the
+oracle on seeded inputs.  Needs an MI355X: `pytest -m gpu`."""
+import warnings
+
+import numpy as np
+import pytest
+
+from tests.golden_util import GOLDEN, HUB, case_params, ktag, load_case
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5   # north-star tolerance for rescaled distances
+ATOL = 1e-6   # self distances of a single-source reverse pass: exact 0 here vs sqrt(1e-14) in sklearn
+
+
+def _kiez(K, metric, p, hname, kw, **algo_kw):
+    from kiez_amd import Kiez
+    return Kiez(n_candidates=K, algorithm="SklearnNN", algorithm_kwargs=dict(metric=metric, p=p, **algo_kw),
+                hubness=hname, hubness_kwargs=dict(kw))
+
+
+def _knife_edge_rows(ind):
+    """MP-empiric compares d(s_i, t_c) with the reverse-pass value of the same pair when a candidate id equals the
+    query id; the outcome depends on last-bit rounding inside the reference (DESIGN.md 'MP-empiric knife edge')."""
+    n = ind.shape[0]
+    return (ind == np.arange(n)[:, None]).any(axis=1)
+
+
+@pytest.mark.parametrize("case,tag,k", case_params())
+def test_golden_pipeline(case, tag, k):
+    g = load_case(case)
+    hname, kw = HUB[tag]
+    src, tgt = g["source"], g["_target"]
+    if g["_metric"] == "cosine":
+        pass  # goldens were generated from float64 casts of float32 data; we feed the same float64 arrays
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = _kiez(g["_K"], g["_metric"], g["_p"], hname, kw)
+        kz.fit(src, tgt)
+        d, i = kz.kneighbors(k)
+    ref_d, ref_i = g[f"{tag}__k{ktag(k)}__dist"], g[f"{tag}__k{ktag(k)}__ind"]
+    assert i.dtype == np.int64 and i.shape == ref_i.shape and d.shape == ref_d.shape
+    keep = np.ones(len(i), dtype=bool)
+    if tag == "mp_empiric":
+        keep &= ~_knife_edge_rows(g["mp_empiric__ind_s2t"])
+    np.testing.assert_array_equal(i[keep], ref_i[keep])
+    rtol, atol = RTOL, ATOL
+    if tag == "dsl":
+        atol = 5e-6
+    np.testing.assert_allclose(d[keep], ref_d[keep], rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("case", ["c0_two_source", "f32_euclidean", "cosine_k50", "conftest_single_source"])
+def test_golden_intermediates(case):
+    """Stage-by-stage: reverse kNN, forward kNN and the unsorted transform output."""
+    from kiez_amd import hubness_reduction as H
+    g = load_case(case)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag in g["_tags"]:
+            if tag == "none":
+                continue
+            hname, kw = HUB[tag]
+            kz = _kiez(g["_K"], g["_metric"], g["_p"], hname, kw)
+            kz.fit(g["source"], g["_target"])
+            nn = kz.algorithm
+            tgt = g["source"] if g["_target"] is None else g["_target"]
+            d_t2s, i_t2s = nn.kneighbors(k=g["_K"], query=tgt, s_to_t=False)
+            d_s2t, i_s2t = nn.kneighbors(k=g["_K"])
+            np.testing.assert_array_equal(i_t2s, g[f"{tag}__ind_t2s"])
+            np.testing.assert_array_equal(i_s2t, g[f"{tag}__ind_s2t"])
+            np.testing.assert_allclose(d_t2s, g[f"{tag}__dist_t2s"], rtol=1e-9, atol=ATOL)
+            np.testing.assert_allclose(d_s2t, g[f"{tag}__dist_s2t"], rtol=1e-9, atol=ATOL)
+            tr, _ = kz.hubness.transform(g[f"{tag}__dist_s2t"], g[f"{tag}__ind_s2t"], g["source"])
+            keep = np.ones(len(tr), dtype=bool)
+            if tag == "mp_empiric":
+                keep &= ~_knife_edge_rows(g["mp_empiric__ind_s2t"])
+            np.testing.assert_allclose(tr[keep], g[f"{tag}__transformed"][keep], rtol=RTOL,
+                                       atol=5e-6 if tag == "dsl" else ATOL)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 10])
+def test_golden_sort(k):
+    from kiez_amd.hubness_reduction import HubnessReduction
+    z = np.load(GOLDEN / "sort.npz")
+    d, i = HubnessReduction._sort(z["dist0"], z["ind0"], k)
+    np.testing.assert_array_equal(i, z[f"sorted0_k{k}_ind"])
+    np.testing.assert_array_equal(d, z[f"sorted0_k{k}_dist"])
+    d, i = HubnessReduction._sort(z["tie_d"], z["tie_i"], k)
+    np.testing.assert_array_equal(d, z[f"tie_k{k}_dist"])
+    np.testing.assert_array_equal(i, z[f"tie_k{k}_ind"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# seeded inputs against the oracle
+# ---------------------------------------------------------------------------------------------------
+def _data(n_s, n_t, d, dtype, seed=0, gauss=False):
+    rng = np.random.RandomState(seed)
+    gen = rng.randn if gauss else rng.rand
+    return gen(n_s, d).astype(dtype), gen(n_t, d).astype(dtype)
+
+
+@pytest.mark.parametrize("n_s,n_t,d,dtype,metric,K", [
+    (1000, 1300, 64, np.float32, "euclidean", 10),
+    (777, 513, 50, np.float64, "minkowski", 10),
+    (2000, 3000, 200, np.float32, "cosine", 50),
+    (1500, 1500, 128, np.float32, "sqeuclidean", 5),
+    (300, 5000, 300, np.float32, "euclidean", 10),
+    (4100, 130, 17, np.float64, "euclidean", 25),
+])
+@pytest.mark.parametrize("tag", ["none", "csls", "ls", "nicdm", "mp_normal", "mp_empiric", "dsl"])
+def test_oracle_parity(n_s, n_t, d, dtype, metric, K, tag):
+    from oracle import kiez_oracle as O
+    if tag == "dsl" and metric == "cosine":
+        pytest.skip("DSL rejects cosine (dis_sim.py:47-61)")
+    if tag == "mp_empiric" and n_s * K * K > 4e6:
+        pytest.skip("oracle MP-empiric loop too slow at this size")
+    hname, kw = HUB[tag]
+    s, t = _data(n_s, n_t, d, dtype, seed=n_s + d)
+    if metric == "cosine":
+        s, t = s.astype(np.float64), t.astype(np.float64)
+    k = max(1, K // 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = _kiez(K, metric, 2, hname, kw)
+        kz.fit(s, t)
+        dist, ind = kz.kneighbors(k)
+    od, oi = O.kiez_pipeline(s, t, K, k, metric, 2, hname, kw)
+    bad = (ind != oi).any(axis=1)
+    if tag == "mp_empiric":
+        bad &= ~_knife_edge_rows(O.knn_exact(s, t, K, O.canonical_metric(metric))[1])
+    assert not bad.any(), f"{bad.sum()} rows differ"
+    np.testing.assert_allclose(dist, od, rtol=RTOL, atol=5e-6 if tag == "dsl" else ATOL)
+
+
+def test_single_source_self_is_stripped_forward_but_kept_reverse():
+    from oracle import kiez_oracle as O
+    s, _ = _data(1500, 1, 40, np.float32, seed=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = _kiez(10, "euclidean", 2, "CSLS", {})
+        kz.fit(s)
+        d, i = kz.kneighbors(10)
+        fwd_d, fwd_i = kz.algorithm.kneighbors(k=10)
+        rev_d, rev_i = kz.algorithm.kneighbors(k=10, query=s, s_to_t=False)
+    assert not (fwd_i == np.arange(len(s))[:, None]).any()
+    assert (rev_i[:, 0] == np.arange(len(s))).all() and (rev_d[:, 0] == 0).all()
+    od, oi = O.kiez_pipeline(s, None, 10, 10, "euclidean", 2, "CSLS", {})
+    np.testing.assert_array_equal(i, oi)
+    np.testing.assert_allclose(d, od, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("splits", [1, 2, 5])
+def test_split_counts_give_identical_results(splits):
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    s, t = _data(700, 5000, 48, np.float32, seed=9)
+    ctx = N.Context.get()
+    ctx.set_option("force_splits", splits)
+    try:
+        qm, ym = N.DeviceMatrix(ctx, s, "euclidean"), N.DeviceMatrix(ctx, t, "euclidean")
+        d, i, st = N.knn(ctx, qm, ym, 10)
+        assert st["n_splits"] == splits
+        od, oi = O.knn_exact(s, t, 10, "euclidean")
+        np.testing.assert_array_equal(i.numpy(), oi)
+        np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=1e-9)
+    finally:
+        ctx.set_option("force_splits", 0)
+
+
+def test_exact_fallback_path_is_exact():
+    """eps_scale = 1e9 makes every row fail certification: the float64 brute-force backstop must agree too."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    ctx = N.Context.get()
+    for metric, dtype in (("euclidean", np.float32), ("cosine", np.float64), ("sqeuclidean", np.float64)):
+        s, t = _data(150, 900, 33, dtype, seed=21)
+        ctx.set_option("eps_scale", 1e9)
+        try:
+            qm, ym = N.DeviceMatrix(ctx, s, metric), N.DeviceMatrix(ctx, t, metric)
+            d, i, st = N.knn(ctx, qm, ym, 7)
+            assert st["n_fallback_rows"] == 150
+        finally:
+            ctx.set_option("eps_scale", 1.0)
+        od, oi = O.knn_exact(s, t, 7, metric)
+        np.testing.assert_array_equal(i.numpy(), oi)
+        np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=1e-9)
+        # self-stripping through the fallback
+        ctx.set_option("eps_scale", 1e9)
+        try:
+            d, i, st = N.knn(ctx, ym, ym, 7, exclude_self=True)
+        finally:
+            ctx.set_option("eps_scale", 1.0)
+        od, oi = O.knn_exact(t, t, 7, metric, exclude_self=True)
+        np.testing.assert_array_equal(i.numpy(), oi)
+
+
+def test_near_duplicates_trigger_certification_failure_but_stay_exact():
+    """Index rows that differ by ~1e-7 relative cannot be separated in float32: those queries must take the exact
+    path and still return the float64 order."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.RandomState(3)
+    base = rng.rand(40, 32)
+    t = np.repeat(base, 30, axis=0) + 1e-9 * rng.rand(1200, 32)   # 30 near-copies of each of 40 points, float64
+    s = rng.rand(64, 32)
+    ctx = N.Context.get()
+    qm, ym = N.DeviceMatrix(ctx, s, "euclidean"), N.DeviceMatrix(ctx, t, "euclidean")
+    d, i, st = N.knn(ctx, qm, ym, 10)
+    assert st["n_fallback_rows"] > 0
+    od, oi = O.knn_exact(s, t, 10, "euclidean")
+    # float64 expanded-form distances of near-copies agree to ~1e-16 relative: compare as sets per tie group
+    dd = d.numpy()
+    np.testing.assert_allclose(dd, od, rtol=1e-7, atol=1e-9)
+    assert (np.sort(i.numpy() // 30, axis=1) == np.sort(oi // 30, axis=1)).all()
+
+
+def test_medium_size_all_rows_bit_identical():
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    s, t = _data(20000, 20000, 128, np.float32, seed=0)
+    ctx = N.Context.get()
+    qm, ym = N.DeviceMatrix(ctx, s, "euclidean"), N.DeviceMatrix(ctx, t, "euclidean")
+    d, i, st = N.knn(ctx, qm, ym, 10)
+    od, oi = O.knn_exact(s, t, 10, "euclidean")
+    assert np.array_equal(i.numpy(), oi)
+    np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=0)
+    assert st["n_fallback_rows"] < 20
