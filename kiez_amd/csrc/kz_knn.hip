@@ -262,7 +262,8 @@ __device__ __forceinline__ double kz_output_distance(double v, int metric) {
     if (metric == KZ_EUCLIDEAN) {
         // ArgKmin32 converts the surrogate with the float32 metric object: (double)sqrtf((float)d2)
         // (_argkmin.pyx.tp:285-295 with INPUT_DTYPE_t = float32); ArgKmin64 uses sqrt in float64.
-        if (sizeof(T) == 4) return (double)__fsqrt_rn((float)v);
+        // exactly what sklearn executes: float32 argument, double sqrt, result rounded back to float32
+        if (sizeof(T) == 4) return (double)(float)sqrt((double)(float)v);
         return sqrt(v);
     }
     return v;
