@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: source queries/s over fit + kneighbors (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c2_mp|c3s]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one full `fit(source, target)` + `kneighbors(k)` over synthetic embeddings that are already resident in
+HBM (the reference's `rng.rand` data, float32).  Default workload = BASELINE.json configs[1]:
+100k x 100k, d=128, euclidean, k=10, hubness=None.  With N > 1 every rank owns a 100k-row source shard (weak
+scaling); the target lives on rank 0 and is RCCL-broadcast inside `fit`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("KIEZ_AMD_WITH_TORCH", "1")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (before the HIP library: one HIP runtime per process)
+
+WORKLOADS = {
+    # name: (n_source_per_gpu, n_target, d, metric, K, k, hubness, hubness_kwargs, description)
+    "c1": (100_000, 100_000, 128, "euclidean", 10, 10, None, {},
+           "C1: 100k x 100k, d=128, euclidean, k=10, hubness=None"),
+    "c2": (100_000, 100_000, 128, "euclidean", 10, 10, "CSLS", {},
+           "C2: 100k x 100k, d=128, euclidean, k=10, hubness=CSLS"),
+    "c3s": (100_000, 100_000, 200, "cosine", 50, 50, "MutualProximity", {"method": "empiric"},
+            "C3 (scaled to 100k x 100k): d=200, cosine, k=50, MutualProximity empiric"),
+    "c4s": (250_000, 1_000_000, 300, "euclidean", 10, 10, "CSLS", {},
+            "C4 per-GPU share: 250k source rows x 1M target, d=300, k=10, CSLS"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
+
+
+def cpu_baseline(source, target, metric, k, budget_rows=10_000):
+    """CPU leg, timed on this host's cores on a bounded query-row sample against the FULL index:
+    value       = scikit-learn's brute-force kNN, i.e. the third-party routine the reference's SklearnNN._kneighbors
+                  delegates to (kiez/neighbors/exact/sklearn_nearest_neighbors.py:98-101) — the reference's real CPU path;
+    port_value  = the oracle's numpy restatement of the same algorithm (oracle/kiez_oracle.py: knn_exact)."""
+    from oracle import kiez_oracle as O
+    rows = min(budget_rows, len(source))
+    q = source[:rows]
+    t0 = time.perf_counter()
+    O.knn_exact(q, target, k, metric)
+    t_oracle = time.perf_counter() - t0
+    out = {"value": rows / t_oracle, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"hubness=None forward pass: first {rows} source rows x all {len(target)} target rows, d={source.shape[1]}, "
+                     f"{metric}, k={k}",
+           "port_value": rows / t_oracle, "port_seconds": t_oracle}
+    try:
+        from sklearn.neighbors import NearestNeighbors
+        nn = NearestNeighbors(n_neighbors=k, algorithm="brute", metric=metric).fit(target)
+        nn.kneighbors(q[:256])  # thread-pool warm-up
+        t0 = time.perf_counter()
+        nn.kneighbors(q)
+        t_sk = time.perf_counter() - t0
+        out.update(value=rows / t_sk, kind="reference", seconds=t_sk,
+                   note="value = sklearn.neighbors.NearestNeighbors(algorithm='brute').kneighbors (what kiez's SklearnNN calls); "
+                        "port_value = oracle/kiez_oracle.py knn_exact (numpy, mostly single-threaded selection)")
+    except Exception as e:  # pragma: no cover
+        out["note"] = f"sklearn timing failed ({e}); value = oracle port"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify a row sample of the result against the oracle")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from kiez_amd.distributed import Comm, HipEngine, ShardedKiez
+    n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[args.workload]
+    eng = HipEngine(local_rank)
+    comm = Comm()
+
+    # synthetic data in the reference's style (kiez/kiez.py:50-52): rng.rand, source first, then target
+    rng = np.random.RandomState(0 if rank == 0 else 1000 + rank)
+    source_h = rng.rand(n_s, d).astype(np.float32)
+    target_h = rng.rand(n_t, d).astype(np.float32) if rank == 0 else None
+    source = eng.to_engine(source_h)
+    target = eng.to_engine(target_h) if rank == 0 else None
+    eng.sync()
+
+    sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": metric}, hubness=hub, hubness_kwargs=hub_kw,
+                     engine=eng, comm=comm)
+    knn_log = []
+    orig_knn = eng.knn
+
+    def logged_knn(qm, q_begin, q_count, im, kk, exclude_self):
+        out = orig_knn(qm, q_begin, q_count, im, kk, exclude_self)
+        knn_log.append((q_count, im.shape[0], dict(eng.last_stats)))
+        return out
+
+    eng.knn = logged_knn
+
+    def step():
+        sk.fit(source, target)
+        return sk.kneighbors(k)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    knn_log.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.cpu()[0])
+
+    # roofline of the dominant kernel (fused distance + top-k): algorithmic flops 2*n_q*n_i*d per launch
+    flops = sum(2.0 * q * n * d for q, n, _ in knn_log)
+    kernel_s = sum(st["main_kernel_ms"] for _, _, st in knn_log) * 1e-3
+    n_launch = len(knn_log)
+    achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
+    fallback_rows = sum(st["n_fallback_rows"] for _, _, st in knn_log)
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    check = None
+    if args.check and rank == 0:
+        from oracle import kiez_oracle as O
+        rows = 2000
+        dd, ii = res
+        od, oi = O.kiez_pipeline(source_h, target_h, K, k, metric, 2, hub, hub_kw) if (hub and n_s <= 20000) else \
+            O.knn_exact(source_h[:rows], target_h, k, metric)
+        got_i = ii[:len(oi)].cpu().numpy()
+        check = {"rows": int(len(oi)), "index_rows_identical": int((got_i == oi).all(axis=1).sum()),
+                 "max_rel_dist_err": float(np.max(np.abs(dd[:len(od)].cpu().numpy() - od) / np.maximum(np.abs(od), 1e-12)))}
+
+    if rank == 0:
+        total_queries = n_s * world * args.steps
+        line = {
+            "metric": "source queries/sec (fit+kneighbors)",
+            "value": total_queries / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "n_source_per_gpu": n_s, "n_target": n_t, "d": d, "metric": metric,
+                       "n_candidates": K, "k": k, "hubness": hub, "hubness_kwargs": hub_kw,
+                       "inputs": "float32 rng.rand, resident in HBM; results left in HBM",
+                       "parallelism": f"source row-sharded x{world}, target replicated (RCCL broadcast)"},
+            "roofline": {"bound": "mfma", "kernel": "kz_knn_cand_kernel (fp32 MFMA 32x32x2 fused distance+top-k)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "launches": n_launch, "avg_launch_ms": kernel_s / max(n_launch, 1) * 1e3,
+                         "algorithmic_flop_per_launch": flops / max(n_launch, 1)},
+            "certification_fallback_rows": int(fallback_rows),
+        }
+        if check is not None:
+            line["check"] = check
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(source_h, target_h, metric, k)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,358 @@
+"""Multi-GPU execution of the hot path: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI).
+
+Partitioning (DESIGN.md "Multi-GPU"):
+  * every rank owns a ROW SHARD of the source; the target is replicated (RCCL broadcast from rank 0);
+  * hubness=None: nothing else moves — each rank searches its shard against the replicated target;
+  * hubness != None: `fit` needs the reverse kNN of every target row against ALL source rows, so the source
+    shards are all-gathered once (both matrices are small next to 288 GB of HBM), each rank runs the reverse
+    pass for ITS slice of target rows, and only the per-target-row fit state is all-gathered:
+      CSLS / NICDM: mean reverse distance, LS: K-th reverse distance, MP normal: mean + std (8-16 B per row),
+      DSL: distance to the local centroid (8 B per row), MP empiric: the full reverse lists;
+    DSL additionally all-reduces ONE scalar (MIN) before its global shift (kiez/hubness_reduction/dis_sim.py:171-173).
+  * `kneighbors` returns the rows of the local shard (global target ids).
+
+The arithmetic is delegated to an *engine*.  `HipEngine` (the product) drives the C ABI on torch CUDA tensors;
+tests inject a CPU engine so the sharding / exchange logic runs under gloo with world_size 2.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+
+from .neighbors import canonical_metric
+
+_P = C.c_void_p
+
+
+def _torch():
+    import torch
+    return torch
+
+
+# ---------------------------------------------------------------------------------------------------
+# engine: the per-rank compute backend
+# ---------------------------------------------------------------------------------------------------
+class HipEngine:
+    """C-ABI calls on torch CUDA tensors (`tensor.data_ptr()` is a plain HBM pointer)."""
+
+    def __init__(self, device: Optional[int] = None):
+        os.environ.setdefault("KIEZ_AMD_WITH_TORCH", "1")
+        torch = _torch()  # torch first: one HIP runtime per process (kiez_amd/_native.py)
+        from . import _native as N
+        self.N = N
+        self.torch = torch
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(device)
+        self.device = torch.device("cuda", device)
+        # ONE stream for torch ops, RCCL collectives (they order against the current stream) and our kernels
+        self.stream = torch.cuda.Stream(self.device)
+        torch.cuda.synchronize(self.device)
+        torch.cuda.set_stream(self.stream)
+        self.ctx = N.Context.get(device, self.stream.cuda_stream)
+        self.lib = self.ctx.lib
+        self.last_stats: Dict[str, Any] = {}
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def _ptr(self, t):
+        assert t.is_cuda and t.is_contiguous()
+        return _P(t.data_ptr())
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+    def to_engine(self, array):
+        """numpy / torch (any device) -> contiguous tensor on this engine's device."""
+        torch = self.torch
+        t = array if isinstance(array, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(array))
+        return t.to(self.device).contiguous()
+
+    def to_numpy(self, t):
+        return t.cpu().numpy()
+
+    # -- compute ----------------------------------------------------------------------------------
+    def matrix(self, rows, metric: str):
+        N = self.N
+        assert rows.dtype in (self.torch.float32, self.torch.float64)
+        dt = np.float32 if rows.dtype == self.torch.float32 else np.float64
+        return N.DeviceMatrix(self.ctx, None, metric, device_ptr=rows.data_ptr(), shape=tuple(rows.shape), dtype=dt)
+
+    def knn(self, qm, q_begin: int, q_count: int, im, k: int, exclude_self: bool):
+        torch, N = self.torch, self.N
+        dist = self.empty((q_count, k), torch.float64)
+        ind = self.empty((q_count, k), torch.int64)
+        st = N.KnnStats()
+        N._check(self.lib.kz_knn(self.ctx.handle, qm.handle, q_begin, q_count, im.handle, int(k), int(bool(exclude_self)),
+                                 self._ptr(dist), self._ptr(ind), C.byref(st)), "kz_knn")
+        self.last_stats = st.as_dict()
+        return dist, ind
+
+    def row_stats(self, dist, mean=False, std=False, last=False):
+        torch = self.torch
+        n, K = dist.shape
+        m = self.empty((n,), torch.float64) if mean else None
+        s = self.empty((n,), torch.float64) if std else None
+        l_ = self.empty((n,), torch.float64) if last else None
+        self.N._check(self.lib.kz_row_stats(self.ctx.handle, self._ptr(dist), n, K, self._ptr(m) if mean else None,
+                                            self._ptr(s) if std else None, self._ptr(l_) if last else None), "kz_row_stats")
+        return m, s, l_
+
+    def csls(self, dist, ind, r_train):
+        out = self.empty(tuple(dist.shape), self.torch.float64)
+        self.N._check(self.lib.kz_csls(self.ctx.handle, self._ptr(dist), self._ptr(ind), dist.shape[0], dist.shape[1],
+                                       self._ptr(r_train), self._ptr(out)), "kz_csls")
+        return out
+
+    def local_scaling(self, dist, ind, r_t, nicdm: bool):
+        out = self.empty(tuple(dist.shape), self.torch.float64)
+        self.N._check(self.lib.kz_local_scaling(self.ctx.handle, self._ptr(dist), self._ptr(ind), dist.shape[0], dist.shape[1],
+                                                self._ptr(r_t), int(nicdm), self._ptr(out)), "kz_local_scaling")
+        return out
+
+    def mp_normal(self, dist, ind, mu_t, sd_t):
+        out = self.empty(tuple(dist.shape), self.torch.float64)
+        self.N._check(self.lib.kz_mp_normal(self.ctx.handle, self._ptr(dist), self._ptr(ind), dist.shape[0], dist.shape[1],
+                                            self._ptr(mu_t), self._ptr(sd_t), self._ptr(out)), "kz_mp_normal")
+        return out
+
+    def mp_empiric(self, dist, ind, dist_t2s, ind_t2s):
+        out = self.empty(tuple(dist.shape), self.torch.float64)
+        self.N._check(self.lib.kz_mp_empiric(self.ctx.handle, self._ptr(dist), self._ptr(ind), dist.shape[0], dist.shape[1],
+                                             self._ptr(dist_t2s), self._ptr(ind_t2s), dist_t2s.shape[0], dist_t2s.shape[1],
+                                             self._ptr(out)), "kz_mp_empiric")
+        return out
+
+    def dsl_fit(self, ind_t2s, sm, tm, t_begin: int):
+        out = self.empty((ind_t2s.shape[0],), self.torch.float64)
+        self.N._check(self.lib.kz_dsl_fit(self.ctx.handle, self._ptr(ind_t2s), ind_t2s.shape[0], ind_t2s.shape[1], sm.handle,
+                                          tm.handle, t_begin, self._ptr(out)), "kz_dsl_fit")
+        return out
+
+    def dsl_transform(self, ind, qm, q_begin: int, tm, t2c):
+        torch = self.torch
+        out = self.empty(tuple(ind.shape), torch.float64)
+        gmin = torch.full((1,), float("inf"), dtype=torch.float64, device=self.device)
+        self.N._check(self.lib.kz_dsl_transform(self.ctx.handle, self._ptr(ind), ind.shape[0], ind.shape[1], qm.handle, q_begin,
+                                                tm.handle, self._ptr(t2c), self._ptr(out), self._ptr(gmin)), "kz_dsl_transform")
+        return out, gmin
+
+    def dsl_finalize(self, out, min_value: float, squared: bool):
+        self.N._check(self.lib.kz_dsl_finalize(self.ctx.handle, self._ptr(out), out.numel(), float(min_value), int(squared)),
+                      "kz_dsl_finalize")
+        return out
+
+    def select_topk(self, dist, ind, k: int):
+        torch = self.torch
+        od = self.empty((dist.shape[0], k), torch.float64)
+        oi = self.empty((dist.shape[0], k), torch.int64)
+        self.N._check(self.lib.kz_select_topk(self.ctx.handle, self._ptr(dist), self._ptr(ind), dist.shape[0], dist.shape[1], k,
+                                              self._ptr(od), self._ptr(oi)), "kz_select_topk")
+        return od, oi
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+# ---------------------------------------------------------------------------------------------------
+# communicator: thin wrapper over torch.distributed (RCCL on GPUs, gloo in CPU tests)
+# ---------------------------------------------------------------------------------------------------
+class Comm:
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def broadcast(self, t, src=0):
+        if self.world > 1:
+            self.dist.broadcast(t, src=src, group=self.group)
+        return t
+
+    def broadcast_shape(self, shape_or_none, device, src=0):
+        torch = _torch()
+        buf = torch.zeros(4, dtype=torch.int64, device=device)
+        if self.rank == src:
+            buf[0], buf[1], buf[2] = shape_or_none[0], shape_or_none[1], shape_or_none[2]
+        self.broadcast(buf, src)
+        return int(buf[0]), int(buf[1]), int(buf[2])
+
+    def all_gather_rows(self, t, counts):
+        """Concatenate ragged row blocks [n_r, ...] of all ranks in rank order (padded all_gather)."""
+        torch = _torch()
+        if self.world == 1:
+            return t
+        mx = max(counts)
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        if t.is_cuda:
+            out = torch.empty((self.world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(out, pad, group=self.group)
+            if all(c == mx for c in counts):
+                return out
+            return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(self.world)], dim=0)
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(parts, pad, group=self.group)
+        return torch.cat([parts[r][: counts[r]] for r in range(self.world)], dim=0)
+
+    def all_gather_ints(self, value: int, device):
+        torch = _torch()
+        if self.world == 1:
+            return [int(value)]
+        mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        return [int(x.cpu()[0]) for x in parts]
+
+    def all_reduce_min(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return t
+
+
+def row_slice(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous balanced partition of n rows: (begin, count) of `rank`."""
+    base, rem = divmod(n, world)
+    begin = rank * base + min(rank, rem)
+    return begin, base + (1 if rank < rem else 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the sharded pipeline
+# ---------------------------------------------------------------------------------------------------
+_HUB = {None: "none", "no": "none", "nohubnessreduction": "none", "csls": "csls", "localscaling": "ls", "ls": "ls",
+        "mutualproximity": "mp", "mp": "mp", "dissimlocal": "dsl", "dsl": "dsl"}
+
+
+class ShardedKiez:
+    """`Kiez` over a row-sharded source (one instance per rank).
+
+    fit(source_shard, target): `target` is needed on rank 0 only (other ranks may pass None when `target_from_rank0`);
+    pass `single_source=True` for the reference's `fit(source)` mode (target == full source).
+    kneighbors(k) -> (dist, ind) of the local shard rows as engine tensors.
+    """
+
+    def __init__(self, n_candidates: int = 10, algorithm_kwargs: Optional[Dict[str, Any]] = None, hubness=None,
+                 hubness_kwargs: Optional[Dict[str, Any]] = None, engine=None, comm: Optional[Comm] = None):
+        if not np.issubdtype(type(n_candidates), np.integer):
+            raise TypeError(f"n_neighbors does not take {type(n_candidates)} value, enter integer value")
+        if n_candidates <= 0:
+            raise ValueError(f"Expected n_candidates > 0. Got {n_candidates}")
+        if n_candidates == 1:
+            raise ValueError("Cannot perform hubness reduction with a single candidate per query!")
+        akw = dict(algorithm_kwargs or {})
+        self.K = int(akw.get("n_candidates", n_candidates))
+        self.metric = canonical_metric(akw.get("metric", "minkowski"), akw.get("p", 2))
+        key = hubness.lower() if isinstance(hubness, str) else hubness
+        if key not in _HUB:
+            raise KeyError(f"Invalid hubness reduction: {hubness}")
+        self.hub = _HUB[key]
+        hkw = dict(hubness_kwargs or {})
+        self.method = str(hkw.get("method", "standard" if self.hub == "ls" else "normal")).lower()
+        if self.hub == "ls" and self.method not in ("ls", "standard", "nicdm"):
+            raise ValueError(f"Internal: Invalid method {self.method}. Try 'ls' or 'nicdm'.")
+        if self.hub == "mp":
+            if self.method not in ("exact", "empiric", "normal", "gaussi"):
+                raise ValueError(f'Mutual proximity method "{self.method}" not recognized. Try "normal" or "empiric".')
+            self.method = "empiric" if self.method in ("exact", "empiric") else "normal"
+        if self.hub == "dsl" and self.metric == "cosine":
+            raise ValueError("DisSimLocal only supports squared Euclidean distances, not metric=cosine.")
+        self.engine = engine if engine is not None else HipEngine()
+        self.comm = comm if comm is not None else Comm()
+        self.state: Dict[str, Any] = {}
+
+    # -- fit -----------------------------------------------------------------------------------------
+    def fit(self, source_shard, target=None, single_source: bool = False, target_from_rank0: bool = True):
+        eng, comm = self.engine, self.comm
+        src = eng.to_engine(source_shard)
+        if src.dim() != 2:
+            raise ValueError("Expected 2D array")
+        counts = comm.all_gather_ints(src.shape[0], src.device)
+        self.counts = counts
+        self.s_begin = sum(counts[: comm.rank])
+        self.n_local = counts[comm.rank]
+        n_s = sum(counts)
+        self.single = bool(single_source)
+        need_full_source = self.single or self.hub != "none"
+        src_full = comm.all_gather_rows(src, counts) if need_full_source else None
+        if self.single:
+            tgt = src_full
+        else:
+            if target_from_rank0 and comm.world > 1:
+                torch = _torch()
+                shape = None
+                if comm.rank == 0:
+                    tgt = eng.to_engine(target)
+                    shape = (tgt.shape[0], tgt.shape[1], 0 if tgt.dtype == torch.float32 else 1)
+                n_t, d, code = comm.broadcast_shape(shape, src.device)
+                if comm.rank != 0:
+                    tgt = eng.empty((n_t, d), torch.float32 if code == 0 else torch.float64)
+                comm.broadcast(tgt, 0)  # RCCL broadcast of the replicated target over xGMI
+            else:
+                tgt = eng.to_engine(target)
+            if tgt.shape[1] != src.shape[1]:
+                raise ValueError("Expected source and target to have the same number of features,"
+                                 f" but got source.shape: {tuple(src.shape)} and target.shape: {tuple(tgt.shape)}")
+            if tgt.dtype != src.dtype:
+                raise ValueError("source and target must have the same dtype")
+        self._keep = (src, src_full, tgt)  # the engine matrices borrow nothing, but keep inputs alive for clarity
+        self.n_s, self.n_t = n_s, tgt.shape[0]
+        self.T = eng.matrix(tgt, self.metric)
+        if need_full_source:
+            self.S = self.T if self.single else eng.matrix(src_full, self.metric)
+            self.q_begin = self.s_begin   # forward queries are a row range of the full source matrix
+        else:
+            self.S = eng.matrix(src, self.metric)
+            self.q_begin = 0
+        if self.hub == "none":
+            return self
+        # reverse pass, sharded over target rows (explicit query: self is NOT stripped, base.py:37-42)
+        Kr = min(self.K, n_s)
+        t_begin, t_count = row_slice(self.n_t, comm.rank, comm.world)
+        t_counts = [row_slice(self.n_t, r, comm.world)[1] for r in range(comm.world)]
+        d_t2s, i_t2s = eng.knn(self.T, t_begin, t_count, self.S, Kr, False)
+        st = self.state
+        if self.hub == "csls" or (self.hub == "ls" and self.method == "nicdm"):
+            m, _, _ = eng.row_stats(d_t2s, mean=True)
+            st["r_t"] = comm.all_gather_rows(m, t_counts)
+        elif self.hub == "ls":
+            _, _, last = eng.row_stats(d_t2s, last=True)
+            st["r_t"] = comm.all_gather_rows(last, t_counts)
+        elif self.hub == "mp" and self.method == "normal":
+            m, s, _ = eng.row_stats(d_t2s, mean=True, std=True)
+            st["mu_t"] = comm.all_gather_rows(m, t_counts)
+            st["sd_t"] = comm.all_gather_rows(s, t_counts)
+        elif self.hub == "mp":
+            st["dist_t2s"] = comm.all_gather_rows(d_t2s, t_counts)
+            st["ind_t2s"] = comm.all_gather_rows(i_t2s, t_counts)
+        elif self.hub == "dsl":
+            t2c = eng.dsl_fit(i_t2s, self.S, self.T, t_begin)
+            st["t2c"] = comm.all_gather_rows(t2c, t_counts)
+        return self
+
+    # -- kneighbors ------------------------------------------------------------------------------------
+    def kneighbors(self, k: Optional[int] = None):
+        eng, comm, st = self.engine, self.comm, self.state
+        if k is None or k > self.K:
+            k = self.K
+        if self.hub == "none":
+            kk = min(k, self.n_t)
+            return eng.knn(self.S, self.q_begin, self.n_local, self.T, kk, self.single)
+        Kf = min(self.K, self.n_t)
+        dist, ind = eng.knn(self.S, self.q_begin, self.n_local, self.T, Kf, self.single)
+        if self.hub == "csls":
+            out = eng.csls(dist, ind, st["r_t"])
+        elif self.hub == "ls":
+            out = eng.local_scaling(dist, ind, st["r_t"], self.method == "nicdm")
+        elif self.hub == "mp" and self.method == "normal":
+            out = eng.mp_normal(dist, ind, st["mu_t"], st["sd_t"])
+        elif self.hub == "mp":
+            out = eng.mp_empiric(dist, ind, st["dist_t2s"], st["ind_t2s"])
+        else:
+            out, gmin = eng.dsl_transform(ind, self.S, self.q_begin, self.T, st["t2c"])
+            comm.all_reduce_min(gmin)  # the shift uses the GLOBAL minimum (dis_sim.py:171-173)
+            out = eng.dsl_finalize(out, float(gmin.cpu()[0]), self.metric == "sqeuclidean")
+        return eng.select_topk(out, ind, min(k, Kf))

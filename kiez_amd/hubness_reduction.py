@@ -102,18 +102,25 @@ class HubnessReduction(ABC):
             od_h = od_h.astype(np.float32)
         return od_h, oi.numpy()
 
+    def kneighbors_device(self, k: Optional[int] = None):
+        """`kneighbors` with the result left in HBM (MI355X NN backend only): (dist, ind) DeviceArrays."""
+        if not self._gpu_nn:
+            raise TypeError("kneighbors_device needs the MI355X SklearnNN backend")
+        n_neighbors = self._set_k_if_needed(k)
+        nn = self.nn_algo
+        query_dist, query_ind = nn.kneighbors_device(query=None, k=nn.n_candidates)
+        hub_dist, query_ind = self.transform(query_dist, query_ind, nn.source_)
+        od, oi = HubnessReduction._sort(hub_dist, query_ind, n_neighbors, ctx=self.ctx)
+        if nn._out_dtype(nn.target_index) == np.float32:
+            od = N.cast_f32(self.ctx, od)
+        return od, oi
+
     def kneighbors(self, k: Optional[int] = None):
         """base.py:89-105: forward candidates, rescale, final top-k."""
-        n_neighbors = self._set_k_if_needed(k)
         if self._gpu_nn:
-            nn = self.nn_algo
-            query_dist, query_ind = nn.kneighbors_device(query=None, k=nn.n_candidates)
-            hub_dist, query_ind = self.transform(query_dist, query_ind, nn.source_)
-            od, oi = HubnessReduction._sort(hub_dist, query_ind, n_neighbors, ctx=self.ctx)
-            out_dtype = nn._out_dtype(nn.target_index)
-            if out_dtype == np.float32:
-                od = N.cast_f32(self.ctx, od)
+            od, oi = self.kneighbors_device(k)
             return od.numpy(), oi.numpy()
+        n_neighbors = self._set_k_if_needed(k)
         query_dist, query_ind = self.nn_algo.kneighbors(query=None, k=self.nn_algo.n_candidates, return_distance=True)
         hub_dist, query_ind = self.transform(query_dist, query_ind, self.nn_algo.source_)
         return HubnessReduction._sort(hub_dist, query_ind, n_neighbors, ctx=self.ctx)
@@ -145,6 +152,14 @@ class NoHubnessReduction(HubnessReduction):
 
     def transform(self, neigh_dist, neigh_ind, query):
         return neigh_dist, neigh_ind
+
+    def kneighbors_device(self, k: Optional[int] = None):
+        n_neighbors = self._set_k_if_needed(k)
+        nn = self.nn_algo
+        od, oi = nn.kneighbors_device(query=None, k=n_neighbors)
+        if nn._out_dtype(nn.target_index) == np.float32:
+            od = N.cast_f32(self.ctx, od)
+        return od, oi
 
     def kneighbors(self, k: Optional[int] = None):
         n_neighbors = self._set_k_if_needed(k)

@@ -80,6 +80,10 @@ class Kiez:
         self.hubness.fit(source, target)
         return self
 
+    def kneighbors_device(self, k: Optional[int] = None):
+        """Like `kneighbors` but the (dist, ind) result stays in HBM as DeviceArrays (no PCIe copy)."""
+        return self.hubness.kneighbors_device(k)
+
     def kneighbors(self, k: Optional[int] = None, return_distance: bool = True):
         hubness_reduced_query_dist, query_ind = self.hubness.kneighbors(k)
         if return_distance:

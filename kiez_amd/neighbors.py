@@ -146,6 +146,8 @@ class SklearnNN(NNAlgorithm):
     """
 
     valid_metrics = ["cosine", "euclidean", "l2", "minkowski", "sqeuclidean"]
+    # numpy arrays as in the reference; additionally arrays already resident in HBM (zero-copy fit)
+    _ALLOWED_INPUT_TYPES = (np.ndarray, N.DeviceArray)
 
     def __init__(self, n_candidates=5, algorithm="auto", leaf_size=30, metric="minkowski", p=2, metric_params=None,
                  n_jobs=None, device=None):
@@ -180,16 +182,29 @@ class SklearnNN(NNAlgorithm):
             arr = arr.astype(np.float64)
         return np.ascontiguousarray(arr)
 
+    def _make_matrix(self, data, dtype=None) -> N.DeviceMatrix:
+        if isinstance(data, N.DeviceArray):
+            if len(data.shape) != 2 or data.dtype not in (np.float32, np.float64):
+                raise ValueError("device inputs must be 2D float32/float64 arrays")
+            if dtype is not None and data.dtype != dtype:
+                raise ValueError(f"device input has dtype {data.dtype}, the index has {dtype}")
+            return N.DeviceMatrix(self.ctx, None, self._metric_c, device_ptr=data.ptr.value, shape=data.shape,
+                                  dtype=data.dtype)
+        arr = self._prepare(data)
+        if dtype is not None and arr.dtype != dtype:
+            arr = arr.astype(dtype)
+        return N.DeviceMatrix(self.ctx, arr, self._metric_c)
+
     def _fit(self, data, is_source: bool):
         """Replaces SklearnNN._fit (sklearn_nearest_neighbors.py:83-94): upload + norms + MFMA tile packing."""
         if is_source:
             self._aux = {}
-        return N.DeviceMatrix(self.ctx, self._prepare(data), self._metric_c)
+        return self._make_matrix(data)
 
     def fit(self, source, target=None, only_fit_target: bool = False):
         self._check_input_types((source, target))
-        if (target is not None and np.ndim(source) == 2 and np.ndim(target) == 2
-                and source.shape[1] == target.shape[1] and np.asarray(source).dtype != np.asarray(target).dtype):
+        if (isinstance(source, np.ndarray) and isinstance(target, np.ndarray) and source.ndim == 2 and target.ndim == 2
+                and source.shape[1] == target.shape[1] and source.dtype != target.dtype):
             # one dtype for both sides (sklearn dispatches on X.dtype == Y.dtype, _dispatcher.py:292): use float64
             super().fit(np.asarray(source, dtype=np.float64), np.asarray(target, dtype=np.float64), only_fit_target)
             self.source_, self.target_ = source, target  # keep the caller's arrays, as the reference does
@@ -207,10 +222,7 @@ class SklearnNN(NNAlgorithm):
             return hit[1]
         self._check_input_types(array)
         ref = self.target_index if hasattr(self, "target_index") else self.source_index
-        arr = self._prepare(array)
-        if arr.dtype != ref.dtype:
-            arr = arr.astype(ref.dtype)
-        m = N.DeviceMatrix(self.ctx, arr, self._metric_c)
+        m = self._make_matrix(array, dtype=ref.dtype)
         self._aux[id(array)] = (array, m)
         return m
 

@@ -1,0 +1,90 @@
+"""World-size-2 gloo tests of the multi-GPU sharding logic (kiez_amd.distributed.ShardedKiez) with the CPU engine.
+The sharded run must equal the single-process oracle pipeline on the concatenated source."""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+
+CASES = [
+    ("none", None, {}, "euclidean", False),
+    ("csls", "CSLS", {}, "euclidean", False),
+    ("ls", "LocalScaling", {"method": "standard"}, "euclidean", False),
+    ("nicdm", "LocalScaling", {"method": "nicdm"}, "minkowski", False),
+    ("mp_normal", "MutualProximity", {"method": "normal"}, "cosine", False),
+    ("mp_empiric", "MutualProximity", {"method": "empiric"}, "euclidean", False),
+    ("dsl", "DisSimLocal", {}, "sqeuclidean", False),
+    ("csls_single", "CSLS", {}, "euclidean", True),
+    ("none_single", None, {}, "euclidean", True),
+    ("dsl_single", "DisSimLocal", {}, "euclidean", True),
+]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import torch.distributed as dist
+        from kiez_amd.distributed import Comm, ShardedKiez, row_slice
+        from oracle import kiez_oracle as O
+        from tests.cpu_engine import OracleEngine
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        rng = np.random.RandomState(17)
+        source = rng.rand(203, 12)
+        target = rng.rand(157, 12)
+        b, c = row_slice(len(source), rank, world)
+        results = {}
+        for name, hub, kw, metric, single in CASES:
+            sk = ShardedKiez(n_candidates=7, algorithm_kwargs={"metric": metric}, hubness=hub, hubness_kwargs=kw,
+                             engine=OracleEngine(), comm=Comm())
+            sk.fit(source[b:b + c], None if single else (target if rank == 0 else None), single_source=single)
+            d, i = sk.kneighbors(4)
+            od, oi = O.kiez_pipeline(source, None if single else target, 7, 4, metric, 2, hub, kw)
+            results[name] = (bool(np.array_equal(i.numpy(), oi[b:b + c])),
+                             bool(np.allclose(d.numpy(), od[b:b + c], rtol=1e-9, atol=1e-9)), tuple(i.shape))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, results, None))
+    except Exception:  # pragma: no cover
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_sharded_pipeline_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, results, err in out:
+        assert err is None, f"rank {rank} failed:\n{err}"
+        for name, (idx_ok, dist_ok, shape) in results.items():
+            assert idx_ok, f"rank {rank} case {name}: indices differ from the single-process oracle"
+            assert dist_ok, f"rank {rank} case {name}: distances differ"
+            assert shape[1] == 4
+
+
+def test_row_slice_partitions_everything():
+    from kiez_amd.distributed import row_slice
+    for n in (0, 1, 7, 100, 101):
+        for w in (1, 2, 3, 8):
+            parts = [row_slice(n, r, w) for r in range(w)]
+            assert sum(c for _, c in parts) == n
+            pos = 0
+            for b, c in parts:
+                assert b == pos
+                pos += c
