@@ -24,6 +24,9 @@ struct kz_ctx {
     size_t scratch_bytes;
     int* d_counters;  // small device int array (fail counter, flags)
     int* h_counters;  // pinned host mirror
+    int n_cus;        // compute units of the device
+    void* h_stage;    // pinned host staging for the per-call work table
+    size_t h_stage_bytes;
 };
 
 struct kz_matrix {

@@ -30,15 +30,40 @@ struct KnnCandParams {
     const float* qpack;   // packed query matrix
     const float* ypack;   // packed index matrix
     const float* ybias;   // accumulator init per index row
-    int qt0;              // first query tile of this launch
-    int n_qtiles;         // query tiles in this launch
+    const int4* work;     // one descriptor per workgroup: {query tile (local), first index tile, end index tile, list slot}
+    int qt0;              // first query tile of this launch (global tile index into qpack)
     int n_ytiles;         // index tiles
-    int tiles_per_split;  // index tiles per split
-    int n_splits;
+    int s_max;            // list slots per query in the output layout
     int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
-    float* out_key;       // [n_qtiles*128][n_splits][2][KP]
+    float* out_key;       // [n_qtiles*128][s_max][2][KP]
     int* out_idx;
 };
+
+// Replace the minimum of an unsorted K'-entry list by (v, idx) and find the new minimum.  All keys are fetched
+// before the compare chain starts so that the LDS latency is paid once, not per element.
+template <int KP, int LSTRIDE>
+__device__ __forceinline__ void kz_list_replace_min(float* lk, int* li, float v, int idx, float& tau, int& minpos) {
+    lk[minpos * LSTRIDE] = v;
+    li[minpos * LSTRIDE] = idx;
+    float mn = INFINITY;
+    int mp = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < KP; c0 += 16) {
+        float kk[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) kk[e] = lk[(c0 + e) * LSTRIDE];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (kk[e] < mn) {
+                mn = kk[e];
+                mp = c0 + e;
+            }
+        }
+    }
+    tau = mn;
+    minpos = mp;
+}
 
 constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows
 
@@ -52,22 +77,19 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_kernel(KnnCandParams p) {
     const int j = lane & 31;
     const int h = lane >> 5;
 
-    // XCD-aware, bijective work mapping: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
-    // range of work items so that co-resident blocks stream the SAME index split.
-    const int W = p.n_qtiles * p.n_splits;
-    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-    const int q8 = W >> 3, r8 = W & 7;
-    const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    const int s = w / p.n_qtiles;
-    const int qt = w - s * p.n_qtiles;
-    const int t_begin = s * p.tiles_per_split;
-    const int t_end = min(p.n_ytiles, t_begin + p.tiles_per_split);
+    // The host schedules the work (kz_build_work): large items first, small items to fill the tail, and an XCD-aware
+    // order (blocks b and b+8 share an XCD and its L2: co-resident blocks stream the SAME index range).
+    const int4 wd = p.work[blockIdx.x];
+    const int qt = wd.x;
+    const int t_begin = wd.y;
+    const int t_end = wd.z;
+    const int s = wd.w;
     const int NS = p.kg >> 2;
     const int total = (t_end - t_begin) * NS;
 
     // candidate list of this lane
     constexpr int LSTRIDE = LDS_LISTS ? 256 : 1;
-    const int64_t listoff = ((((int64_t)qt * KZ_TILE + 32 * wave + j) * p.n_splits + s) * 2 + h) * KP;
+    const int64_t listoff = ((((int64_t)qt * KZ_TILE + 32 * wave + j) * p.s_max + s) * 2 + h) * KP;
     float* lk;
     int* li;
     if (LDS_LISTS) {
@@ -167,31 +189,22 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_kernel(KnnCandParams p) {
                 ++g;
             } while (++sl < NS);
             // epilogue: C layout of 32x32 MFMA: col = lane & 31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            // Lanes l and l+32 hold the two half-lists of ONE query: a key below the OTHER half's K'-th best cannot be
+            // in the merged top-K' either, so both halves prune with the larger of the two thresholds.
+            float tau_eff = fmaxf(tau, __shfl_xor(tau, 32, 64));
             const int rowbase = tile * KZ_TILE + 4 * h;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 float m = acc[mt][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mt][r]);
-                if (m > tau) {
+                if (m > tau_eff) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[mt][r];
-                        if (v > tau) {
-                            // replace the list minimum, then rescan for the new minimum
-                            lk[minpos * LSTRIDE] = v;
-                            li[minpos * LSTRIDE] = rowbase + 32 * mt + (r & 3) + 8 * (r >> 2);
-                            float mn = lk[0];
-                            int mp = 0;
-                            for (int e = 1; e < KP; ++e) {
-                                const float x = lk[e * LSTRIDE];
-                                if (x < mn) {
-                                    mn = x;
-                                    mp = e;
-                                }
-                            }
-                            tau = mn;
-                            minpos = mp;
+                        if (v > tau_eff) {
+                            kz_list_replace_min<KP, LSTRIDE>(lk, li, v, rowbase + 32 * mt + (r & 3) + 8 * (r >> 2), tau, minpos);
+                            tau_eff = fmaxf(tau_eff, tau);
                         }
                     }
                 }
@@ -222,7 +235,8 @@ __device__ __forceinline__ void kz_wave_sync() {
 struct KnnFinParams {
     const float* in_key;  // [rows][M]
     const int* in_idx;
-    int M;                // n_splits * 2 * KP
+    int M;                // s_max * 2 * KP: list entries stored per query
+    const int* nslots;    // per local query tile: slots actually written (entries beyond nslots*2*KP are garbage)
     int KP;
     int64_t list_row0;    // list row of local query 0  (= q_begin - qt0*128)
     int64_t q_begin;      // global query row of local query 0
@@ -318,11 +332,12 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
     double* cv = s_cv[wave];
     double* sv = s_sv[wave];
     int* si = s_si[wave];
-    const int M = p.M, KP = p.KP;
+    const int KP = p.KP;
     const int k_eff = p.k + (p.exclude_self ? 1 : 0);
 
-    const float* gk = p.in_key + (p.list_row0 + q) * (int64_t)M;
-    const int* gi = p.in_idx + (p.list_row0 + q) * (int64_t)M;
+    const float* gk = p.in_key + (p.list_row0 + q) * (int64_t)p.M;
+    const int* gi = p.in_idx + (p.list_row0 + q) * (int64_t)p.M;
+    const int M = p.nslots[(p.list_row0 + q) >> 7] * 2 * KP;
     for (int e = lane; e < M; e += 64) {
         ekey[e] = gk[e];
         eidx[e] = gi[e];
@@ -509,11 +524,22 @@ static int kz_pick_list_len(int k_eff) {
 }
 
 template <int KP, bool LDS_LISTS>
-static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p) {
+static int kz_cand_occupancy(int* blocks_per_cu) {
     const size_t lds = KZ_CAND_LDS_BASE + (LDS_LISTS ? (size_t)KP * 256 * 8 : 0);
     auto kern = kz_knn_cand_kernel<KP, LDS_LISTS>;
     if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(p.n_qtiles * p.n_splits), dim3(256), lds, ctx->stream, p);
+    int nb = 0;
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds));
+    *blocks_per_cu = nb < 1 ? 1 : nb;
+    return KZ_OK;
+}
+
+template <int KP, bool LDS_LISTS>
+static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
+    const size_t lds = KZ_CAND_LDS_BASE + (LDS_LISTS ? (size_t)KP * 256 * 8 : 0);
+    auto kern = kz_knn_cand_kernel<KP, LDS_LISTS>;
+    if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, ctx->stream, p);
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }
@@ -548,6 +574,18 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     // and (float64 inputs) of the operands; 1e-12 covers the float64 re-rank's own rounding.
     const double gamma = ((double)(index->kg * 4 + 16) * 5.9604644775390625e-08 + 1e-12) * ctx->eps_scale;
 
+    int blocks_per_cu = 1;
+    {
+        int rc0;
+        switch (KP) {
+            case 16: rc0 = kz_cand_occupancy<16, true>(&blocks_per_cu); break;
+            case 32: rc0 = kz_cand_occupancy<32, true>(&blocks_per_cu); break;
+            case 64: rc0 = kz_cand_occupancy<64, false>(&blocks_per_cu); break;
+            default: rc0 = kz_cand_occupancy<128, false>(&blocks_per_cu); break;
+        }
+        if (rc0 != KZ_OK) return rc0;
+    }
+    const int slots = blocks_per_cu * ctx->n_cus;
     // query rows are processed in chunks so that the candidate lists stay below ~1 GiB
     const int64_t max_rows_per_chunk = 128 * 4096;
     double main_ms = 0, fin_ms = 0, fb_ms = 0;
@@ -559,51 +597,118 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         const int qt0 = (int)(cq_begin / KZ_TILE);
         const int qt1 = (int)((cq_begin + cq_count - 1) / KZ_TILE);
         const int n_qtiles = qt1 - qt0 + 1;
-        int n_splits;
+        // ---- schedule: which workgroup sweeps which (query tile, index-tile range) ------------------------------
+        // Region 1: as many FULL rounds of equal, large items as fit (slots = resident workgroups on the chip);
+        // region 2: the remaining query tiles cut into small items that fill the tail round (dispatch is in block-id
+        // order, so large items go first).  force_splits (test knob) = one region with exactly that many splits.
+        int s1, A, s2;
+        const int by_len = n_ytiles / 8 > 1 ? n_ytiles / 8 : 1;  // keep >= 8 tiles (1024 rows) per item
+        auto clamp_s = [&](int v) {
+            if (v > max_splits_m) v = max_splits_m;
+            if (v > by_len) v = by_len;
+            if (v < 1) v = 1;
+            return v;
+        };
         if (ctx->force_splits > 0) {
-            n_splits = ctx->force_splits;
+            s1 = ctx->force_splits < n_ytiles ? ctx->force_splits : n_ytiles;
+            if (s1 > max_splits_m) s1 = max_splits_m;
+            A = n_qtiles;
+            s2 = s1;
         } else {
-            const int target_blocks = 256 * 2 * 6;
-            n_splits = (target_blocks + n_qtiles - 1) / n_qtiles;
-            const int by_len = n_ytiles / 8 > 1 ? n_ytiles / 8 : 1;  // keep >= 8 tiles (1024 rows) per split
-            if (n_splits > by_len) n_splits = by_len;
+            s1 = clamp_s((slots + n_qtiles - 1) / n_qtiles);  // long sweeps: list warm-up is paid once per item
+            const int rounds = (int)(((int64_t)n_qtiles * s1) / slots);
+            if (rounds == 0) {
+                s1 = clamp_s((slots + n_qtiles - 1) / n_qtiles);  // fewer items than slots: maximise parallelism
+                A = n_qtiles;
+                s2 = s1;
+            } else {
+                A = (int)(((int64_t)rounds * slots) / s1);
+                if (A > n_qtiles) A = n_qtiles;
+                s2 = clamp_s(max_splits_m);
+                if (s2 < s1) s2 = s1;
+            }
         }
-        if (n_splits > max_splits_m) n_splits = max_splits_m;
-        if (n_splits > n_ytiles) n_splits = n_ytiles;
-        if (n_splits < 1) n_splits = 1;
-        const int tiles_per_split = (n_ytiles + n_splits - 1) / n_splits;
-        n_splits = (n_ytiles + tiles_per_split - 1) / tiles_per_split;
-        const int M = n_splits * 2 * KP;
+        auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
+        auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
+        const int c1 = split_cnt(s1), c2 = split_cnt(s2);
+        const int s_max = (A < n_qtiles && c2 > c1) ? c2 : c1;
+        const int W1 = A * c1, W2 = (n_qtiles - A) * c2;
+        const int W = W1 + W2;
+        const int M = s_max * 2 * KP;
         const size_t list_elems = (size_t)n_qtiles * KZ_TILE * (size_t)M;
         const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
         const size_t fail_bytes = ((size_t)cq_count * 4 + 255) & ~(size_t)255;
+        const size_t work_bytes = ((size_t)W * sizeof(int4) + 255) & ~(size_t)255;
+        const size_t nslot_bytes = ((size_t)n_qtiles * 4 + 255) & ~(size_t)255;
         void* scratch = nullptr;
-        int rc = kz_scratch(ctx, key_bytes * 2 + fail_bytes, &scratch);
+        int rc = kz_scratch(ctx, key_bytes * 2 + fail_bytes + work_bytes + nslot_bytes, &scratch);
         if (rc != KZ_OK) return rc;
         float* out_key = (float*)scratch;
         int* out_idx = (int*)((char*)scratch + key_bytes);
         int* fail_list = (int*)((char*)scratch + 2 * key_bytes);
+        int4* d_work = (int4*)((char*)scratch + 2 * key_bytes + fail_bytes);
+        int* d_nslots = (int*)((char*)scratch + 2 * key_bytes + fail_bytes + work_bytes);
         int* fail_count = ctx->d_counters + 8;
         KZ_HIP(hipMemsetAsync(fail_count, 0, sizeof(int), ctx->stream));
+        {
+            // host-side table (pinned staging grows on demand)
+            const size_t need = work_bytes + nslot_bytes;
+            if (need > ctx->h_stage_bytes) {
+                KZ_HIP(hipStreamSynchronize(ctx->stream));
+                if (ctx->h_stage) KZ_HIP(hipHostFree(ctx->h_stage));
+                ctx->h_stage = nullptr;
+                ctx->h_stage_bytes = 0;
+                KZ_HIP(hipHostMalloc(&ctx->h_stage, need * 2, hipHostMallocDefault));
+                ctx->h_stage_bytes = need * 2;
+            } else {
+                KZ_HIP(hipStreamSynchronize(ctx->stream));  // previous call's async copy must have drained
+            }
+            int4* hw = (int4*)ctx->h_stage;
+            int* hn = (int*)((char*)ctx->h_stage + work_bytes);
+            // logical order inside a region: split-major (consecutive items share the index range), then
+            // spread over block ids so that blocks with equal (id % 8) -- one XCD -- take consecutive items
+            auto fill_region = [&](int off, int cnt, int q0, int nq, int sp) {
+                if (cnt == 0) return;
+                const int len = split_len(sp);
+                int next = 0;
+                for (int label = 0; label < 8; ++label) {
+                    for (int i = 0; i < cnt; ++i) {
+                        if (((off + i) & 7) != label) continue;
+                        const int sidx = next / nq, qt = q0 + next % nq;
+                        ++next;
+                        int4 w4;
+                        w4.x = qt;
+                        w4.y = sidx * len;
+                        w4.z = (sidx + 1) * len < n_ytiles ? (sidx + 1) * len : n_ytiles;
+                        w4.w = sidx;
+                        hw[off + i] = w4;
+                    }
+                }
+            };
+            fill_region(0, W1, 0, A, s1);
+            fill_region(W1, W2, A, n_qtiles - A, s2);
+            for (int t = 0; t < n_qtiles; ++t) hn[t] = t < A ? c1 : c2;
+            KZ_HIP(hipMemcpyAsync(d_work, hw, (size_t)W * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+            KZ_HIP(hipMemcpyAsync(d_nslots, hn, (size_t)n_qtiles * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
 
         KnnCandParams cp;
         cp.qpack = query->packed;
         cp.ypack = index->packed;
         cp.ybias = index->bias;
+        cp.work = d_work;
         cp.qt0 = qt0;
-        cp.n_qtiles = n_qtiles;
         cp.n_ytiles = n_ytiles;
-        cp.tiles_per_split = tiles_per_split;
-        cp.n_splits = n_splits;
+        cp.s_max = s_max;
         cp.kg = index->kg;
         cp.out_key = out_key;
         cp.out_idx = out_idx;
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         switch (KP) {
-            case 16: rc = kz_launch_cand<16, true>(ctx, cp); break;
-            case 32: rc = kz_launch_cand<32, true>(ctx, cp); break;
-            case 64: rc = kz_launch_cand<64, false>(ctx, cp); break;
-            default: rc = kz_launch_cand<128, false>(ctx, cp); break;
+            case 16: rc = kz_launch_cand<16, true>(ctx, cp, W); break;
+            case 32: rc = kz_launch_cand<32, true>(ctx, cp, W); break;
+            case 64: rc = kz_launch_cand<64, false>(ctx, cp, W); break;
+            default: rc = kz_launch_cand<128, false>(ctx, cp, W); break;
         }
         if (rc != KZ_OK) return rc;
         KZ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -612,6 +717,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         fp.in_key = out_key;
         fp.in_idx = out_idx;
         fp.M = M;
+        fp.nslots = d_nslots;
         fp.KP = KP;
         fp.list_row0 = cq_begin - (int64_t)qt0 * KZ_TILE;
         fp.q_begin = cq_begin;
@@ -646,8 +752,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         main_ms += ms;
         KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
         fin_ms += ms;
-        last_splits = n_splits;
-        last_blocks = n_qtiles * n_splits;
+        last_splits = c1;
+        last_blocks = W;
         n_fail_total += n_fail;
 
         if (n_fail > 0) {

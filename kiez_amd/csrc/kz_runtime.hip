@@ -40,6 +40,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->device = device;
     c->eps_scale = 1.0;
     c->force_splits = 0;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
@@ -63,6 +64,7 @@ int kz_ctx_destroy(kz_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
