@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify a row sample of the result against the oracle")
+    ap.add_argument("--opt", action="append", default=[], help="context option name=value (tuning experiments)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,6 +97,9 @@ def main():
     n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[args.workload]
     eng = HipEngine(local_rank)
     comm = Comm()
+    for o in args.opt:
+        name, val = o.split("=")
+        eng.ctx.set_option(name, float(val))
 
     # synthetic data in the reference's style (kiez/kiez.py:50-52): rng.rand, source first, then target
     rng = np.random.RandomState(0 if rank == 0 else 1000 + rank)

@@ -81,7 +81,8 @@ SYMBOLS = [
 
 
 def library_path() -> Path:
-    return Path(__file__).resolve().parent / _LIB_NAME
+    override = os.environ.get("KIEZ_AMD_LIB")  # diagnostic builds (tools/ablate.sh)
+    return Path(override) if override else Path(__file__).resolve().parent / _LIB_NAME
 
 
 def load():

@@ -19,6 +19,8 @@ struct kz_ctx {
     hipEvent_t ev[6];
     double eps_scale;
     int force_splits;
+    int force_nres;   // test knob: resident query slices (-1 = automatic)
+    int min_splits;   // tuning knob: minimum index splits per query tile in the large-item region
     // scratch (grown on demand, reused across calls)
     void* scratch;
     size_t scratch_bytes;

@@ -14,6 +14,19 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Diagnostic builds only (tools/ablate.sh): -DKZ_ABLATE=n removes parts of the fused kernel to price them
+// (1: no list inserts, 2: + no epilogue max, 3: + no LDS refill / barrier, 4: + no global prefetch).  Results are
+// wrong in those builds; the shipped library is built with KZ_ABLATE undefined (= 0).
+#ifndef KZ_ABLATE
+#define KZ_ABLATE 0
+#endif
+// -DKZ_STAMP: in-kernel s_memtime stamps per section, summed into p.dbg (diagnostic build, never shipped/timed).
+#ifdef KZ_STAMP
+#define KZ_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define KZ_T(var)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // Stage 1: fused similarity + candidate selection
 // ---------------------------------------------------------------------------------------------------
@@ -26,6 +39,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   list(q, h) sees index rows with (row & 4) == 4h; union of the two halves' top-K' contains the top-K'.
 // Index operand: streamed HBM/L2 -> registers -> LDS (double buffered 8 KiB slices, one barrier per slice).
 // Query operand: per-lane fragments straight from L2 (no reuse across waves, so no LDS round trip).
+// Candidate-list storage: queries of region-1 tiles own c1 slots of 2*KP entries, queries of region-2 tiles c2 slots.
+__host__ __device__ __forceinline__ int64_t kz_list_base(int64_t list_row, int reg_a, int c1, int c2, int KP) {
+    const int64_t a_rows = (int64_t)reg_a * KZ_TILE;
+    if (list_row < a_rows) return list_row * (int64_t)(c1 * 2 * KP);
+    return a_rows * (int64_t)(c1 * 2 * KP) + (list_row - a_rows) * (int64_t)(c2 * 2 * KP);
+}
+
 struct KnnCandParams {
     const float* qpack;   // packed query matrix
     const float* ypack;   // packed index matrix
@@ -33,10 +53,13 @@ struct KnnCandParams {
     const int4* work;     // one descriptor per workgroup: {query tile (local), first index tile, end index tile, list slot}
     int qt0;              // first query tile of this launch (global tile index into qpack)
     int n_ytiles;         // index tiles
-    int s_max;            // list slots per query in the output layout
+    int reg_a;            // query tiles [0, reg_a) keep reg_c1 list slots per query, the rest reg_c2 (kz_list_base)
+    int reg_c1;
+    int reg_c2;
     int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
-    float* out_key;       // [n_qtiles*128][s_max][2][KP]
+    float* out_key;       // region 1: [reg_a*128][reg_c1][2][KP], then region 2: [(n_qtiles-reg_a)*128][reg_c2][2][KP]
     int* out_idx;
+    unsigned long long* dbg;  // diagnostic stamp build only (-DKZ_STAMP): cycle sums {slices, epilogue, init, waves}
 };
 
 // Replace the minimum of an unsorted K'-entry list by (v, idx) and find the new minimum.  All keys are fetched
@@ -66,9 +89,16 @@ __device__ __forceinline__ void kz_list_replace_min(float* lk, int* li, float v,
 }
 
 constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows
+constexpr int KZ_QGROUP = 24;                   // query tiles sharing an XCD at a time (x splits ~= resident workgroups)
+constexpr int KZ_LOG_CAP = 16;                  // per-lane candidate log entries (keys + rows: 32 KiB per workgroup)
+constexpr int KZ_CAND_LDS = KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 8;
 
-template <int KP, bool LDS_LISTS>
-__global__ __launch_bounds__(256, 2) void kz_knn_cand_kernel(KnnCandParams p) {
+// NRES = number of leading 16-k slices whose QUERY fragments stay resident in registers for the whole sweep
+// (8 slices = d 128 = 64 VGPRs).  The query tile is the stationary operand: re-fetching it for every index tile
+// doubled the L2 traffic and evicted the shared index stream (profiles/r01_b_c1_pmc_lpt_schedule.json: 23 GB
+// fetched per launch, 57 % L2 miss).  Slices beyond NRES are streamed from L2 as before.
+template <int KP, int NRES>
+__global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(KnnCandParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);  // 2 x 2048 floats (+ 2 x 128 bias floats behind them)
     const int tid = threadIdx.x;
@@ -77,35 +107,36 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_kernel(KnnCandParams p) {
     const int j = lane & 31;
     const int h = lane >> 5;
 
-    // The host schedules the work (kz_build_work): large items first, small items to fill the tail, and an XCD-aware
+    // The host schedules the work (kz_knn): large items first, small items to fill the tail, and an XCD-aware
     // order (blocks b and b+8 share an XCD and its L2: co-resident blocks stream the SAME index range).
     const int4 wd = p.work[blockIdx.x];
     const int qt = wd.x;
     const int t_begin = wd.y;
     const int t_end = wd.z;
     const int s = wd.w;
-    const int NS = p.kg >> 2;
+    const int NS = p.kg >> 2;  // >= NRES (host picks NRES)
     const int total = (t_end - t_begin) * NS;
 
-    // candidate list of this lane
-    constexpr int LSTRIDE = LDS_LISTS ? 256 : 1;
-    const int64_t listoff = ((((int64_t)qt * KZ_TILE + 32 * wave + j) * p.s_max + s) * 2 + h) * KP;
-    float* lk;
-    int* li;
-    if (LDS_LISTS) {
-        lk = reinterpret_cast<float*>(smem + KZ_CAND_LDS_BASE) + tid;
-        li = reinterpret_cast<int*>(smem + KZ_CAND_LDS_BASE + KP * 256 * 4) + tid;
-    } else {
-        lk = p.out_key + listoff;
-        li = p.out_idx + listoff;
-    }
+    // Candidate state of this lane = one (query, lane-half) pair:
+    //   list  K' best (key, row) so far, UNSORTED, living directly in the output arrays (global memory, L2-resident);
+    //         touched only at merges;
+    //   log   up to KZ_LOG_CAP keys that beat the pruning threshold since the last merge (LDS, append-only).
+    // The threshold is only refreshed at merges, which follow a geometric schedule in the number of tiles seen
+    // (identical for every lane, so merges run with all 64 lanes busy); a full log forces an early merge.
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    float* lk = p.out_key + listoff;
+    int* li = p.out_idx + listoff;
+    float* sk = reinterpret_cast<float*>(smem + KZ_CAND_LDS_BASE) + tid;
+    int* si = reinterpret_cast<int*>(smem + KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
-        lk[e * LSTRIDE] = -INFINITY;
-        li[e * LSTRIDE] = -1;
+        lk[e] = -INFINITY;
+        li[e] = -1;
     }
-    float tau = -INFINITY;  // current K'-th best key of this list (its minimum)
+    float tau = -INFINITY;  // K'-th best key of this list (its minimum) as of the last merge
     int minpos = 0;
+    int cnt = 0;            // log entries
+    int tiles_done = 0, next_merge = 1;
 
     if (total > 0) {
         const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * NS) * 2048);
@@ -118,14 +149,145 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_kernel(KnnCandParams p) {
             nb[tid + 256] = ysrc[256 + tid];
             bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
         }
-        float4 qb0 = *reinterpret_cast<const float4*>(qbase + (0 + h) * 512);
-        float4 qb1 = *reinterpret_cast<const float4*>(qbase + (2 + h) * 512);
+        // resident query fragments: lane (j, h) needs k-groups 4*sl + 2*t + h of its query row
+        float4 qres[NRES > 0 ? NRES : 1][2];
+#pragma unroll
+        for (int u = 0; u < NRES; ++u) {
+            qres[u][0] = *reinterpret_cast<const float4*>(qbase + (4 * u + h) * 512);
+            qres[u][1] = *reinterpret_cast<const float4*>(qbase + (4 * u + 2 + h) * 512);
+        }
+        // streamed query fragments (slices >= NRES), current slice in qb
+        float4 qb0 = make_float4(0.f, 0.f, 0.f, 0.f), qb1 = qb0;
+        if (NRES == 0 || NS > NRES) {
+            qb0 = *reinterpret_cast<const float4*>(qbase + (4 * NRES + h) * 512);
+            qb1 = *reinterpret_cast<const float4*>(qbase + (4 * NRES + 2 + h) * 512);
+        }
         __syncthreads();
 
         int g = 0;
-        for (int tile = t_begin; tile < t_end; ++tile) {
-            f32x16 acc[4];
+#ifdef KZ_STAMP
+        unsigned long long c_qwait = 0, c_ywait = 0, c_bar = 0;
+#endif
+        f32x16 acc[4];
+        const float* bias_n = p.ybias + (tid & 127);
+        int tile = t_begin;
+
+        // One 16-k slice: prefetch the next index slice (HBM/L2 -> registers) and the next tile's bias rows, run the
+        // 32 MFMAs of the current slice out of LDS, then refill the other LDS buffer.  All loads are UNCONDITIONAL so
+        // that hipcc's s_waitcnt placement keeps them in flight behind the MFMAs (a clamp re-reads the last slice at
+        // the very end, harmless); sched_barriers pin loads above and the LDS refill below the MFMA block.
+        // Lane (j, h) feeds k = 4*(2t+h)+jj for jj = 0..3: the k order inside a slice is permuted identically for
+        // A and B, which leaves the dot product unchanged.
+        auto slice_step = [&](const float4& bq0, const float4& bq1, const bool stream_q, const int sl_next) {
+#ifdef KZ_STAMP
+            {   // how long does the wave wait for the query fragments issued one slice ago?
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                c_qwait += __builtin_amdgcn_s_memtime() - w0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+#if KZ_ABLATE >= 4
+            const float4 ya0 = make_float4(0.f, 0.f, 0.f, 0.f), ya1 = ya0;
+            const float bn = 0.f;
+#else
+            const int gn = min(g + 1, total - 1);
+            const float4* src = ysrc + (int64_t)gn * 512;
+            const float4 ya0 = src[tid];
+            const float4 ya1 = src[256 + tid];
+            const int tile_n = min(tile + 1, p.n_ytiles - 1);
+            const float bn = bias_n[(int64_t)tile_n * KZ_TILE];
+#endif
+            float4 qn0, qn1;
+            if (stream_q) {
+#if KZ_ABLATE == 5
+                qn0 = bq1;  // diagnostic: no query-fragment loads
+                qn1 = bq0;
+#else
+                qn0 = *reinterpret_cast<const float4*>(qbase + (4 * sl_next + h) * 512);
+                qn1 = *reinterpret_cast<const float4*>(qbase + (4 * sl_next + 2 + h) * 512);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* buf = ybuf + (g & 1) * 2048;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float4 a[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    a[mt] = *reinterpret_cast<const float4*>(buf + ((2 * t + h) * KZ_TILE + 32 * mt + j) * 4);
+                const float4 bq = t ? bq1 : bq0;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#if KZ_ABLATE == 6
+            // diagnostic: query-fragment loads are issued and waited for HERE (with the index loads), MFMAs keep using
+            // the loop-invariant first fragments: prices the traffic without the top-of-slice wait
+            if (stream_q) asm volatile("" ::"v"(qn0.x), "v"(qn1.x));
+            {
+                float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 1) & 1) * 2048);
+                nb[tid] = ya0;
+                nb[tid + 256] = ya1;
+                bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+            }
+            __syncthreads();
+#elif KZ_ABLATE >= 3
+            asm volatile("" ::"v"(ya0.x), "v"(ya1.x), "v"(bn));
+            if (stream_q) {
+                qb0 = qn0;
+                qb1 = qn1;
+            }
+#else
+#ifdef KZ_STAMP
+            {   // ... and for the index slice issued at the top of this slice (2 younger query loads may stay in flight)
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+                if (stream_q) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                c_ywait += __builtin_amdgcn_s_memtime() - w0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+            {
+#ifdef KZ_VARIANT_QWAIT_END
+                if (stream_q) asm volatile("" ::"v"(qn0.x), "v"(qn1.x));  // retire the query-fragment loads before the barrier
+#endif
+                float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 1) & 1) * 2048);
+                nb[tid] = ya0;
+                nb[tid + 256] = ya1;
+                bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+                if (stream_q) {
+                    qb0 = qn0;
+                    qb1 = qn1;
+                }
+            }
+#ifdef KZ_STAMP
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+                __syncthreads();
+                c_bar += __builtin_amdgcn_s_memtime() - w0;
+            }
+#else
+            __syncthreads();
+#endif
+#endif
+            ++g;
+        };
+
+#ifdef KZ_STAMP
+        unsigned long long c_slices = 0, c_epi = 0, c_init = 0, c_e1 = 0, c_e2 = 0;
+#endif
+        for (; tile < t_end; ++tile) {
             __builtin_amdgcn_sched_barrier(0);  // do not hoist the next tile's init above the epilogue (64 VGPRs)
+            KZ_T(t0);
             {
                 const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
 #pragma unroll
@@ -140,84 +302,123 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_kernel(KnnCandParams p) {
                     }
                 }
             }
-            const int tile_n = min(tile + 1, p.n_ytiles - 1);
-            const float* bias_n = p.ybias + (int64_t)tile_n * KZ_TILE + (tid & 127);
-            int sl = 0;
-            do {  // NS >= 1 always; the do-while spares the compiler a zero-trip path (64 VGPRs of phi copies)
-                // Prefetch the next slice: index rows HBM/L2 -> registers, query fragments L2 -> registers, and
-                // (redundantly every slice, 512 B) the bias rows of the next tile.  All loads are UNCONDITIONAL so
-                // that the compiler's s_waitcnt placement keeps them in flight behind the 32 MFMAs below; at the
-                // very last slice the clamp re-reads the last slice, which is harmless.
-                const int gn = min(g + 1, total - 1);
-                const float4* src = ysrc + (int64_t)gn * 512;
-                const float4 ya0 = src[tid];
-                const float4 ya1 = src[256 + tid];
-                const int sln = (sl + 1 == NS) ? 0 : sl + 1;
-                const float4 qn0 = *reinterpret_cast<const float4*>(qbase + (4 * sln + h) * 512);
-                const float4 qn1 = *reinterpret_cast<const float4*>(qbase + (4 * sln + 2 + h) * 512);
-                const float bn = *bias_n;
-                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ABOVE the MFMA block (hipcc sinks them)
-                // 32 MFMAs on the current slice.  Lane (j, h) feeds k = 4*(2t+h)+jj for jj = 0..3: the k order
-                // inside a slice is permuted identically for A and B, which leaves the dot product unchanged.
-                const float* buf = ybuf + (g & 1) * 2048;
+            __builtin_amdgcn_sched_barrier(0);
+            KZ_T(t1);
+            // resident slices: fully unrolled, fragments by static register index
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float4 a[4];
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        a[mt] = *reinterpret_cast<const float4*>(buf + ((2 * t + h) * KZ_TILE + 32 * mt + j) * 4);
-                    const float4 bq = t ? qb1 : qb0;
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // ... and the LDS refill BELOW it
-                {
-                    float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 1) & 1) * 2048);
-                    nb[tid] = ya0;
-                    nb[tid + 256] = ya1;
-                    bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
-                    qb0 = qn0;
-                    qb1 = qn1;
-                }
-                __syncthreads();
-                ++g;
-            } while (++sl < NS);
+            for (int u = 0; u < NRES; ++u) {
+                // the last resident slice prefetches the first streamed one (if any)
+                slice_step(qres[u][0], qres[u][1], (u == NRES - 1) && (NS > NRES), NRES);
+            }
+            // streamed slices
+            if (NRES == 0 || NS > NRES) {
+                int sl = NRES;
+                do {  // the do-while spares the compiler a zero-trip path
+                    const int sln = (sl + 1 == NS) ? NRES : sl + 1;
+                    const float4 c0 = qb0, c1 = qb1;
+                    slice_step(c0, c1, true, sln);
+                } while (++sl < NS);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            KZ_T(t2);
             // epilogue: C layout of 32x32 MFMA: col = lane & 31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
             // Lanes l and l+32 hold the two half-lists of ONE query: a key below the OTHER half's K'-th best cannot be
             // in the merged top-K' either, so both halves prune with the larger of the two thresholds.
             float tau_eff = fmaxf(tau, __shfl_xor(tau, 32, 64));
+#ifdef KZ_STAMP
+            asm volatile("" ::"v"(tau_eff));
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t2a = __builtin_amdgcn_s_memtime();
+            c_e1 += t2a - t2;
+#endif
             const int rowbase = tile * KZ_TILE + 4 * h;
+            ++tiles_done;
+            const bool sched = (tiles_done == next_merge) || (tile == t_end - 1);  // block-uniform
+            unsigned long long done = 0ull;  // elements of this tile already logged (bit 16*mt + r)
+            for (;;) {
+                bool ovf = false;
+                KZ_T(tg0);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                float m = acc[mt][0];
+                for (int mt = 0; mt < 4; ++mt) {
+#if KZ_ABLATE >= 2
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mt][r]);
-                if (m > tau_eff) {
+                    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[mt][r]));
+                    float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#else
+                    float m4[4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[mt][r];
-                        if (v > tau_eff) {
-                            kz_list_replace_min<KP, LSTRIDE>(lk, li, v, rowbase + 32 * mt + (r & 3) + 8 * (r >> 2), tau, minpos);
-                            tau_eff = fmaxf(tau_eff, tau);
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        m4[g4] = fmaxf(fmaxf(acc[mt][4 * g4], acc[mt][4 * g4 + 1]), fmaxf(acc[mt][4 * g4 + 2], acc[mt][4 * g4 + 3]));
+#endif
+                    const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+#if KZ_ABLATE >= 1
+                    if (m > tau_eff + 1e30f * (float)p.kg) {  // runtime-impossible: keeps the max tree, drops the logging
+#else
+                    if (m > tau_eff) {
+#endif
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            if (m4[g4] > tau_eff) {
+#pragma unroll
+                                for (int r4 = 0; r4 < 4; ++r4) {
+                                    const int r = 4 * g4 + r4;
+                                    const float v = acc[mt][r];
+                                    const unsigned long long bit = 1ull << (16 * mt + r);
+                                    if (v > tau_eff && !(done & bit)) {
+                                        if (cnt < KZ_LOG_CAP) {
+                                            sk[cnt * 256] = v;
+                                            si[cnt * 256] = rowbase + 32 * mt + (r & 3) + 8 * (r >> 2);
+                                            ++cnt;
+                                            done |= bit;
+                                        } else {
+                                            ovf = true;
+                                        }
+                                    }
+                                }
+                            }
                         }
                     }
                 }
+#ifdef KZ_STAMP
+                __builtin_amdgcn_sched_barrier(0);
+                c_e2 += __builtin_amdgcn_s_memtime() - tg0;
+#endif
+                const bool any_ovf = __any(ovf);
+                if (!any_ovf && !sched) break;
+                // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
+                for (int e = 0; e < cnt; ++e) {
+                    const float v = sk[e * 256];
+                    if (v > tau) kz_list_replace_min<KP, 1>(lk, li, v, si[e * 256], tau, minpos);
+                }
+                cnt = 0;
+                tau_eff = fmaxf(tau, __shfl_xor(tau, 32, 64));
+                if (!any_ovf) break;  // (a scheduled merge after an overflow round happens on the next pass)
             }
+            if (tiles_done == next_merge) {
+                const int step = tiles_done * KZ_LOG_CAP / KP;
+                next_merge = tiles_done + (step > 0 ? step : 1);
+            }
+#ifdef KZ_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            c_init += t1 - t0;
+            c_slices += t2 - t1;
+            c_epi += t3 - t2;
+#endif
         }
-    }
-    if (LDS_LISTS) {
-        float* ok = p.out_key + listoff;
-        int* oi = p.out_idx + listoff;
-        for (int e = 0; e < KP; ++e) {
-            ok[e] = lk[e * LSTRIDE];
-            oi[e] = li[e * LSTRIDE];
+#ifdef KZ_STAMP
+        if (lane == 0 && p.dbg) {
+            atomicAdd(p.dbg + 0, c_slices);
+            atomicAdd(p.dbg + 1, c_epi);
+            atomicAdd(p.dbg + 2, c_init);
+            atomicAdd(p.dbg + 3, (unsigned long long)(t_end - t_begin));
+            atomicAdd(p.dbg + 4, c_e1);
+            atomicAdd(p.dbg + 5, c_e2);
+            atomicAdd(p.dbg + 6, c_qwait);
+            atomicAdd(p.dbg + 7, c_ywait);
+            atomicAdd(p.dbg + 8, c_bar);
         }
+#endif
     }
 }
 
@@ -235,8 +436,7 @@ __device__ __forceinline__ void kz_wave_sync() {
 struct KnnFinParams {
     const float* in_key;  // [rows][M]
     const int* in_idx;
-    int M;                // s_max * 2 * KP: list entries stored per query
-    const int* nslots;    // per local query tile: slots actually written (entries beyond nslots*2*KP are garbage)
+    int reg_a, reg_c1, reg_c2;  // list layout (kz_list_base)
     int KP;
     int64_t list_row0;    // list row of local query 0  (= q_begin - qt0*128)
     int64_t q_begin;      // global query row of local query 0
@@ -335,9 +535,11 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
     const int KP = p.KP;
     const int k_eff = p.k + (p.exclude_self ? 1 : 0);
 
-    const float* gk = p.in_key + (p.list_row0 + q) * (int64_t)p.M;
-    const int* gi = p.in_idx + (p.list_row0 + q) * (int64_t)p.M;
-    const int M = p.nslots[(p.list_row0 + q) >> 7] * 2 * KP;
+    const int64_t lrow = p.list_row0 + q;
+    const int64_t lbase = kz_list_base(lrow, p.reg_a, p.reg_c1, p.reg_c2, KP);
+    const float* gk = p.in_key + lbase;
+    const int* gi = p.in_idx + lbase;
+    const int M = (lrow < (int64_t)p.reg_a * KZ_TILE ? p.reg_c1 : p.reg_c2) * 2 * KP;
     for (int e = lane; e < M; e += 64) {
         ekey[e] = gk[e];
         eidx[e] = gi[e];
@@ -523,10 +725,10 @@ static int kz_pick_list_len(int k_eff) {
     return 0;
 }
 
-template <int KP, bool LDS_LISTS>
+template <int KP, int NRES>
 static int kz_cand_occupancy(int* blocks_per_cu) {
-    const size_t lds = KZ_CAND_LDS_BASE + (LDS_LISTS ? (size_t)KP * 256 * 8 : 0);
-    auto kern = kz_knn_cand_kernel<KP, LDS_LISTS>;
+    const size_t lds = KZ_CAND_LDS;
+    auto kern = kz_knn_cand_kernel<KP, NRES>;
     if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int nb = 0;
     KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds));
@@ -534,15 +736,32 @@ static int kz_cand_occupancy(int* blocks_per_cu) {
     return KZ_OK;
 }
 
-template <int KP, bool LDS_LISTS>
+template <int KP, int NRES>
 static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    const size_t lds = KZ_CAND_LDS_BASE + (LDS_LISTS ? (size_t)KP * 256 * 8 : 0);
-    auto kern = kz_knn_cand_kernel<KP, LDS_LISTS>;
+    const size_t lds = KZ_CAND_LDS;
+    auto kern = kz_knn_cand_kernel<KP, NRES>;
     if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, ctx->stream, p);
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }
+
+// (list length, resident query slices) -> kernel instantiation
+#define KZ_DISPATCH_NRES(rc, fn, args, KPV)           \
+    do {                                              \
+        if (nres == 8) rc = fn<KPV, 8> args;          \
+        else if (nres == 4) rc = fn<KPV, 4> args;     \
+        else rc = fn<KPV, 0> args;                    \
+    } while (0)
+#define KZ_DISPATCH_CAND(rc, fn, args)                        \
+    do {                                                      \
+        switch (KP) {                                         \
+            case 16: KZ_DISPATCH_NRES(rc, fn, args, 16); break;   \
+            case 32: KZ_DISPATCH_NRES(rc, fn, args, 32); break;   \
+            case 64: KZ_DISPATCH_NRES(rc, fn, args, 64); break;   \
+            default: KZ_DISPATCH_NRES(rc, fn, args, 128); break;  \
+        }                                                     \
+    } while (0)
 
 extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index, int k,
                       int exclude_self, double* d_dist, int64_t* d_ind, kz_knn_stats* stats) {
@@ -574,15 +793,16 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     // and (float64 inputs) of the operands; 1e-12 covers the float64 re-rank's own rounding.
     const double gamma = ((double)(index->kg * 4 + 16) * 5.9604644775390625e-08 + 1e-12) * ctx->eps_scale;
 
+    const int n_slices = index->kg / 4;
+    // Resident query slices (registers).  Measured on C1 (d=128): 0 resident slices at 3 workgroups/CU beat 8 resident
+    // slices at 2 workgroups/CU (118 vs 101 TF), so residency is opt-in (force_nres) until the register budget allows both.
+    const int nres_max = n_slices >= 8 ? 8 : (n_slices >= 4 ? 4 : 0);
+    int nres = 0;
+    if (ctx->force_nres > 0 && ctx->force_nres <= nres_max) nres = ctx->force_nres;
     int blocks_per_cu = 1;
     {
         int rc0;
-        switch (KP) {
-            case 16: rc0 = kz_cand_occupancy<16, true>(&blocks_per_cu); break;
-            case 32: rc0 = kz_cand_occupancy<32, true>(&blocks_per_cu); break;
-            case 64: rc0 = kz_cand_occupancy<64, false>(&blocks_per_cu); break;
-            default: rc0 = kz_cand_occupancy<128, false>(&blocks_per_cu); break;
-        }
+        KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
         if (rc0 != KZ_OK) return rc0;
     }
     const int slots = blocks_per_cu * ctx->n_cus;
@@ -615,7 +835,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             A = n_qtiles;
             s2 = s1;
         } else {
-            s1 = clamp_s((slots + n_qtiles - 1) / n_qtiles);  // long sweeps: list warm-up is paid once per item
+            s1 = clamp_s((slots + n_qtiles - 1) / n_qtiles);
+            if (s1 < ctx->min_splits) s1 = clamp_s(ctx->min_splits);  // splits per query tile: L2 grouping (KZ_QGROUP)
             const int rounds = (int)(((int64_t)n_qtiles * s1) / slots);
             if (rounds == 0) {
                 s1 = clamp_s((slots + n_qtiles - 1) / n_qtiles);  // fewer items than slots: maximise parallelism
@@ -631,28 +852,24 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
         auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
         const int c1 = split_cnt(s1), c2 = split_cnt(s2);
-        const int s_max = (A < n_qtiles && c2 > c1) ? c2 : c1;
         const int W1 = A * c1, W2 = (n_qtiles - A) * c2;
         const int W = W1 + W2;
-        const int M = s_max * 2 * KP;
-        const size_t list_elems = (size_t)n_qtiles * KZ_TILE * (size_t)M;
+        const size_t list_elems = (size_t)kz_list_base((int64_t)n_qtiles * KZ_TILE, A, c1, c2, KP);
         const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
         const size_t fail_bytes = ((size_t)cq_count * 4 + 255) & ~(size_t)255;
         const size_t work_bytes = ((size_t)W * sizeof(int4) + 255) & ~(size_t)255;
-        const size_t nslot_bytes = ((size_t)n_qtiles * 4 + 255) & ~(size_t)255;
         void* scratch = nullptr;
-        int rc = kz_scratch(ctx, key_bytes * 2 + fail_bytes + work_bytes + nslot_bytes, &scratch);
+        int rc = kz_scratch(ctx, key_bytes * 2 + fail_bytes + work_bytes, &scratch);
         if (rc != KZ_OK) return rc;
         float* out_key = (float*)scratch;
         int* out_idx = (int*)((char*)scratch + key_bytes);
         int* fail_list = (int*)((char*)scratch + 2 * key_bytes);
         int4* d_work = (int4*)((char*)scratch + 2 * key_bytes + fail_bytes);
-        int* d_nslots = (int*)((char*)scratch + 2 * key_bytes + fail_bytes + work_bytes);
         int* fail_count = ctx->d_counters + 8;
         KZ_HIP(hipMemsetAsync(fail_count, 0, sizeof(int), ctx->stream));
         {
             // host-side table (pinned staging grows on demand)
-            const size_t need = work_bytes + nslot_bytes;
+            const size_t need = work_bytes;
             if (need > ctx->h_stage_bytes) {
                 KZ_HIP(hipStreamSynchronize(ctx->stream));
                 if (ctx->h_stage) KZ_HIP(hipHostFree(ctx->h_stage));
@@ -664,17 +881,25 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
                 KZ_HIP(hipStreamSynchronize(ctx->stream));  // previous call's async copy must have drained
             }
             int4* hw = (int4*)ctx->h_stage;
-            int* hn = (int*)((char*)ctx->h_stage + work_bytes);
             // logical order inside a region: split-major (consecutive items share the index range), then
             // spread over block ids so that blocks with equal (id % 8) -- one XCD -- take consecutive items
+            // Logical order inside a region: groups of KZ_QGROUP query tiles, inside a group split-major.  The ~96
+            // workgroups resident on one XCD then cover few query tiles (their fragments stay in the 4 MiB L2) times a
+            // few index ranges (each index tile is fetched once and hit by the whole group).
             auto fill_region = [&](int off, int cnt, int q0, int nq, int sp) {
                 if (cnt == 0) return;
                 const int len = split_len(sp);
+                const int nsp = split_cnt(sp);
+                const int G = KZ_QGROUP < nq ? KZ_QGROUP : nq;
                 int next = 0;
                 for (int label = 0; label < 8; ++label) {
                     for (int i = 0; i < cnt; ++i) {
                         if (((off + i) & 7) != label) continue;
-                        const int sidx = next / nq, qt = q0 + next % nq;
+                        const int grp = next / (G * nsp);
+                        const int gq0 = grp * G;
+                        const int gsz = (nq - gq0) < G ? (nq - gq0) : G;  // last group may be smaller
+                        const int within = next - grp * G * nsp;
+                        const int sidx = within / gsz, qt = q0 + gq0 + within % gsz;
                         ++next;
                         int4 w4;
                         w4.x = qt;
@@ -687,9 +912,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             };
             fill_region(0, W1, 0, A, s1);
             fill_region(W1, W2, A, n_qtiles - A, s2);
-            for (int t = 0; t < n_qtiles; ++t) hn[t] = t < A ? c1 : c2;
             KZ_HIP(hipMemcpyAsync(d_work, hw, (size_t)W * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-            KZ_HIP(hipMemcpyAsync(d_nslots, hn, (size_t)n_qtiles * 4, hipMemcpyHostToDevice, ctx->stream));
         }
 
         KnnCandParams cp;
@@ -699,25 +922,28 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         cp.work = d_work;
         cp.qt0 = qt0;
         cp.n_ytiles = n_ytiles;
-        cp.s_max = s_max;
+        cp.reg_a = A;
+        cp.reg_c1 = c1;
+        cp.reg_c2 = c2;
         cp.kg = index->kg;
         cp.out_key = out_key;
         cp.out_idx = out_idx;
+        cp.dbg = nullptr;
+#ifdef KZ_STAMP
+        cp.dbg = (unsigned long long*)(ctx->d_counters + 16);
+        KZ_HIP(hipMemsetAsync(cp.dbg, 0, 10 * sizeof(unsigned long long), ctx->stream));
+#endif
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-        switch (KP) {
-            case 16: rc = kz_launch_cand<16, true>(ctx, cp, W); break;
-            case 32: rc = kz_launch_cand<32, true>(ctx, cp, W); break;
-            case 64: rc = kz_launch_cand<64, false>(ctx, cp, W); break;
-            default: rc = kz_launch_cand<128, false>(ctx, cp, W); break;
-        }
+        KZ_DISPATCH_CAND(rc, kz_launch_cand, (ctx, cp, W));
         if (rc != KZ_OK) return rc;
         KZ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
 
         KnnFinParams fp;
         fp.in_key = out_key;
         fp.in_idx = out_idx;
-        fp.M = M;
-        fp.nslots = d_nslots;
+        fp.reg_a = A;
+        fp.reg_c1 = c1;
+        fp.reg_c2 = c2;
         fp.KP = KP;
         fp.list_row0 = cq_begin - (int64_t)qt0 * KZ_TILE;
         fp.q_begin = cq_begin;
@@ -747,6 +973,17 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         KZ_HIP(hipStreamSynchronize(ctx->stream));
         const int n_fail = ctx->h_counters[8];
+#ifdef KZ_STAMP
+        {
+            unsigned long long hd[10];
+            KZ_HIP(hipMemcpy(hd, ctx->d_counters + 16, sizeof(hd), hipMemcpyDeviceToHost));
+            const double wt = (double)(hd[3] ? hd[3] : 1);  // wave-tiles
+            fprintf(stderr, "[kz stamp] per wave-tile cycles: slices %.0f  epilogue %.0f (shfl %.0f, groups %.0f)  init %.0f  (wave-tiles %llu)\n",
+                    hd[0] / wt, hd[1] / wt, hd[4] / wt, hd[5] / wt, hd[2] / wt, hd[3]);
+            fprintf(stderr, "[kz stamp]   inside slices, per wave-tile: query-frag wait %.0f  index-slice wait %.0f  barrier %.0f\n",
+                    hd[6] / wt, hd[7] / wt, hd[8] / wt);
+        }
+#endif
         float ms = 0;
         KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         main_ms += ms;

@@ -40,6 +40,8 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->device = device;
     c->eps_scale = 1.0;
     c->force_splits = 0;
+    c->force_nres = -1;
+    c->min_splits = 1;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -85,6 +87,12 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "force_splits") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
         c->force_splits = (int)value;
+    } else if (strcmp(name, "min_splits") == 0) {
+        KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
+        c->min_splits = (int)value;
+    } else if (strcmp(name, "force_nres") == 0) {
+        KZ_REQUIRE(value == -1 || value == 0 || value == 4 || value == 8, "force_nres must be -1, 0, 4 or 8");
+        c->force_nres = (int)value;
     } else {
         kz_set_error("kz_ctx_set_option: unknown option '%s'", name);
         return KZ_ERR_INVALID;
