@@ -20,6 +20,7 @@ struct kz_ctx {
     double eps_scale;
     int force_splits;
     int force_nres;   // test knob: resident query slices (-1 = automatic)
+    int stagger;      // tuning knob: start-up phase shift in cycles (-1 = one tile of MFMA time, 0 = off)
     int min_splits;   // tuning knob: minimum index splits per query tile in the large-item region
     // scratch (grown on demand, reused across calls)
     void* scratch;
@@ -27,6 +28,7 @@ struct kz_ctx {
     int* d_counters;  // small device int array (fail counter, flags)
     int* h_counters;  // pinned host mirror
     int n_cus;        // compute units of the device
+    int* d_tickets;   // [4096] per-CU workgroup tickets (start-up phase shift)
     void* h_stage;    // pinned host staging for the per-call work table
     size_t h_stage_bytes;
 };

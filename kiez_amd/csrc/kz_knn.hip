@@ -59,6 +59,9 @@ struct KnnCandParams {
     int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
     float* out_key;       // region 1: [reg_a*128][reg_c1][2][KP], then region 2: [(n_qtiles-reg_a)*128][reg_c2][2][KP]
     int* out_idx;
+    int stagger_cycles;   // start-up delay unit: workgroup b sleeps ((b / n_cus) % 3) * stagger_cycles (phase-shifts co-resident groups)
+    int n_cus;
+    int* cu_tickets;      // [16*256] zeroed per launch
     unsigned long long* dbg;  // diagnostic stamp build only (-DKZ_STAMP): cycle sums {slices, epilogue, init, waves}
 };
 
@@ -138,6 +141,24 @@ __global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(Knn
     int cnt = 0;            // log entries
     int tiles_done = 0, next_merge = 1;
 
+    // The ~3 workgroups resident on one CU start together and run identical work, so without help their epilogues
+    // (no MFMA issued) coincide on every SIMD.  A start-up phase shift lets one group's epilogue hide under the others'
+    // MFMAs.  Dispatch fills the CUs breadth-first, so groups b, b + n_cus, b + 2 n_cus share a CU (speed only).
+    if (p.stagger_cycles > 0) {
+        // identify the CU from hardware registers (HW_REG_HW_ID[15:8] = se/sh/cu, HW_REG_XCC_ID[3:0]) and take a ticket
+        int phase = 0;
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+            phase = atomicAdd(p.cu_tickets + ((xcc & 15) * 256 + (hw & 255)), 1) % 3;
+        }
+        phase = __builtin_amdgcn_readfirstlane(phase);
+        if (wave == 0) {
+            const int loops = phase * p.stagger_cycles / (127 * 64);
+            for (int i = 0; i < loops; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+        __syncthreads();
+    }
     if (total > 0) {
         const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * NS) * 2048);
         const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg) * 512 + (32 * wave + j) * 4;
@@ -928,6 +949,10 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         cp.kg = index->kg;
         cp.out_key = out_key;
         cp.out_idx = out_idx;
+        cp.stagger_cycles = ctx->stagger >= 0 ? ctx->stagger : (index->kg / 4) * 2048;  // default: one tile of MFMA time
+        cp.n_cus = ctx->n_cus;
+        cp.cu_tickets = ctx->d_tickets;
+        if (cp.stagger_cycles > 0) KZ_HIP(hipMemsetAsync(ctx->d_tickets, 0, 4096 * sizeof(int), ctx->stream));
         cp.dbg = nullptr;
 #ifdef KZ_STAMP
         cp.dbg = (unsigned long long*)(ctx->d_counters + 16);

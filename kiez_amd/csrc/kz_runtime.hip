@@ -42,6 +42,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->force_splits = 0;
     c->force_nres = -1;
     c->min_splits = 1;
+    c->stagger = -1;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -53,6 +54,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     for (int i = 0; i < 6; ++i) KZ_HIP(hipEventCreate(&c->ev[i]));
     KZ_HIP(hipMalloc((void**)&c->d_counters, 64 * sizeof(int)));
     KZ_HIP(hipHostMalloc((void**)&c->h_counters, 64 * sizeof(int), hipHostMallocDefault));
+    KZ_HIP(hipMalloc((void**)&c->d_tickets, 4096 * sizeof(int)));
     KZ_HIP(hipMemsetAsync(c->d_counters, 0, 64 * sizeof(int), c->stream));
     KZ_HIP(hipStreamSynchronize(c->stream));
     *out = c;
@@ -65,6 +67,7 @@ int kz_ctx_destroy(kz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_tickets) (void)hipFree(c->d_tickets);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -87,6 +90,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "force_splits") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
         c->force_splits = (int)value;
+    } else if (strcmp(name, "stagger") == 0) {
+        KZ_REQUIRE(value >= -1 && value <= 1e7, "stagger must be in [-1, 1e7] cycles");
+        c->stagger = (int)value;
     } else if (strcmp(name, "min_splits") == 0) {
         KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
         c->min_splits = (int)value;
