@@ -42,7 +42,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->force_splits = 0;
     c->force_nres = -1;
     c->min_splits = 1;
-    c->stagger = -1;
+    c->stagger = 0;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         c->stream = (hipStream_t)stream;

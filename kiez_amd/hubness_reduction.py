@@ -35,10 +35,14 @@ class HubnessReduction(ABC):
         if nn_algo.n_candidates == 1:
             raise ValueError("Cannot perform hubness reduction with a single candidate per query!")
 
+    # Subclasses shipped here consume device arrays; a user-written subclass (docs/source/using_your_own.rst:11-19)
+    # gets numpy arrays exactly as in the reference.
+    _device_native = False
+
     # ---- device helpers ---------------------------------------------------------------------------
     @property
     def _gpu_nn(self) -> bool:
-        return isinstance(self.nn_algo, SklearnNN)
+        return self._device_native and isinstance(self.nn_algo, SklearnNN)
 
     @property
     def ctx(self) -> N.Context:
@@ -144,6 +148,8 @@ class HubnessReduction(ABC):
 class NoHubnessReduction(HubnessReduction):
     """kiez/hubness_reduction/base.py:108-122: no reverse pass, the NN result is returned directly."""
 
+    _device_native = True
+
     def _fit(self, neigh_dist, neigh_ind, source, target):
         pass  # pragma: no cover
 
@@ -172,6 +178,8 @@ class NoHubnessReduction(HubnessReduction):
 class CSLS(HubnessReduction):
     """Cross-domain similarity local scaling (kiez/hubness_reduction/csls.py)."""
 
+    _device_native = True
+
     def __repr__(self):
         return f"{self.__class__.__name__}(verbose = {self.verbose})"
 
@@ -193,6 +201,8 @@ class CSLS(HubnessReduction):
 
 class LocalScaling(HubnessReduction):
     """Local scaling / NICDM (kiez/hubness_reduction/local_scaling.py)."""
+
+    _device_native = True
 
     def __init__(self, method: str = "standard", **kwargs):
         super().__init__(**kwargs)
@@ -225,6 +235,8 @@ class LocalScaling(HubnessReduction):
 
 class MutualProximity(HubnessReduction):
     """Mutual proximity, 'normal' and 'empiric' (kiez/hubness_reduction/mutual_proximity.py)."""
+
+    _device_native = True
 
     def __init__(self, method: str = "normal", **kwargs):
         super().__init__(**kwargs)
@@ -273,6 +285,8 @@ _DESIRED_P_VALUE = 2
 
 class DisSimLocal(HubnessReduction):
     """DisSimLocal (kiez/hubness_reduction/dis_sim.py)."""
+
+    _device_native = True
 
     def __init__(self, squared: bool = True, **kwargs):
         super().__init__(**kwargs)

@@ -260,5 +260,5 @@ class SklearnNN(NNAlgorithm):
 
 
 def available_nn_algorithms(as_string: bool = False):
-    """kiez/neighbors/util.py:18-39 (only the exact backend exists here)."""
-    return ["SklearnNN"] if as_string else [SklearnNN]
+    """kiez/neighbors/util.py:18-39 (only the exact backend exists here; names are lower-cased as in the reference)."""
+    return ["sklearnnn"] if as_string else [SklearnNN]

@@ -261,8 +261,11 @@ def dsl_transform(dist, ind, query, target, t2c, squared: bool):
 #              kiez/neighbors/neighbor_algorithm_base.py:53-136)
 # --------------------------------------------------------------------------------------------
 def kiez_pipeline(source, target=None, n_candidates=10, k=None, metric="euclidean", p=2,
-                  hubness=None, hubness_kwargs=None, return_intermediates=False):
-    """Oracle for `Kiez(n_candidates, 'SklearnNN', {'metric':..}, hubness, hubness_kwargs).fit(s, t).kneighbors(k)`."""
+                  hubness=None, hubness_kwargs=None, return_intermediates=False, query_rows=None):
+    """Oracle for `Kiez(n_candidates, 'SklearnNN', {'metric':..}, hubness, hubness_kwargs).fit(s, t).kneighbors(k)`.
+
+    query_rows=n (two-source mode, not DSL): evaluate the forward pass / transform for the first n source rows only
+    (the fit state still uses ALL source rows) — used to spot-check full-size runs."""
     hubness_kwargs = dict(hubness_kwargs or {})
     metric_c = canonical_metric(metric, p)
     single = target is None
@@ -273,14 +276,20 @@ def kiez_pipeline(source, target=None, n_candidates=10, k=None, metric="euclidea
     hub = None if hubness is None else str(hubness).lower()
     if hub in (None, "no", "nohubnessreduction"):
         kk = min(k, tgt.shape[0])
-        d, i = knn_exact(source, tgt, kk, metric_c, exclude_self=single)   # base.py:120-122
+        d, i = knn_exact(source if query_rows is None else source[:query_rows], tgt, kk, metric_c,
+                         exclude_self=single)   # base.py:120-122
         return (d, i) if not return_intermediates else (d, i, {})
     # reverse pass: explicit query=target, so self is NOT stripped even for a single source
     # (neighbor_algorithm_base.py:119; base.py:37-42)
     Kr = min(K, source.shape[0])
     dist_t2s, ind_t2s = knn_exact(tgt, source, Kr, metric_c, exclude_self=False)
     Kf = min(K, tgt.shape[0])
-    dist_s2t, ind_s2t = knn_exact(source, tgt, Kf, metric_c, exclude_self=single)   # base.py:92-94
+    fwd_src = source
+    if query_rows is not None:
+        if single or hub in ("dissimlocal", "dsl"):
+            raise ValueError("query_rows needs two-source mode and a row-local transform")
+        fwd_src = source[:query_rows]
+    dist_s2t, ind_s2t = knn_exact(fwd_src, tgt, Kf, metric_c, exclude_self=single)   # base.py:92-94
     if hub == "csls":
         hr = csls_transform(dist_s2t, ind_s2t, dist_t2s)
     elif hub in ("localscaling", "ls"):

@@ -1,0 +1,69 @@
+"""The C-ABI shared library: it loads, it exports every symbol include/kiez_amd.h declares, the ctypes
+prototypes cover them all, and without a GPU the product path fails loudly (no CPU fallback)."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "kiez_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kz_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from kiez_amd import _native as N
+    lib = N.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"libkiez_amd.so does not export {name}"
+    bound = {s[0] for s in N.SYMBOLS}
+    assert set(declared) == bound, f"ctypes prototypes out of sync with the header: {set(declared) ^ bound}"
+    assert lib.kz_abi_version() == 1
+
+
+def test_code_object_is_gfx950_only():
+    so = (ROOT / "kiez_amd" / "libkiez_amd.so").read_bytes()
+    assert b"gfx950" in so
+    for other in (b"gfx90a", b"gfx942", b"sm_90"):
+        assert other not in so
+
+
+def test_no_gpu_means_loud_failure(have_gpu):
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    from kiez_amd import Kiez
+    with pytest.raises(RuntimeError, match="no MI355X"):
+        Kiez().fit(np.zeros((4, 3)), np.zeros((4, 3)))
+
+
+def test_product_package_never_imports_the_oracle_or_a_cpu_math_library():
+    """The oracle is test infrastructure; the product path must not route through it or any CPU fallback."""
+    for f in (ROOT / "kiez_amd").glob("*.py"):
+        for line in f.read_text().splitlines():
+            s = line.strip()
+            if s.startswith("import ") or s.startswith("from "):
+                assert "oracle" not in s, f"{f}: product code imports the oracle ({s})"
+                assert "sklearn" not in s and "scipy" not in s, f"{f}: product path must not compute on the CPU ({s})"
+
+
+@pytest.mark.gpu
+def test_context_and_error_reporting():
+    from kiez_amd import _native as N
+    ctx = N.Context.get()
+    with pytest.raises(ValueError, match="unknown option"):
+        ctx.set_option("nope", 1)
+    a = ctx.to_device(np.arange(12, dtype=np.float64).reshape(3, 4))
+    np.testing.assert_array_equal(a.numpy(), np.arange(12, dtype=np.float64).reshape(3, 4))
+    m = N.DeviceMatrix(ctx, np.random.rand(10, 4), "euclidean")
+    with pytest.raises(ValueError, match="Expected n_neighbors"):
+        N.knn(ctx, m, m, 10, exclude_self=True)
+    with pytest.raises(NotImplementedError, match="maximum"):
+        big = N.DeviceMatrix(ctx, np.random.rand(300, 4), "euclidean")
+        N.knn(ctx, big, big, 200)
