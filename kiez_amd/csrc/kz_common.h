@@ -11,6 +11,7 @@
 
 #define KZ_TILE 128   // rows per packed tile (= MFMA block tile edge)
 #define KZ_KSLICE 16  // k elements staged per LDS slice (4 k-groups of 4)
+#define KZ_LIVE_MAX 1024
 
 struct kz_ctx {
     int device;
@@ -31,7 +32,17 @@ struct kz_ctx {
     int* d_tickets;   // [4096] per-CU workgroup tickets (start-up phase shift)
     void* h_stage;    // pinned host staging for the per-call work table
     size_t h_stage_bytes;
+    // stream-ordered free list: buffers released by kz_free / kz_matrix_destroy are reused by later allocations of a
+    // similar size instead of going through hipFree (device-wide sync) + hipMalloc on every fit()
+    struct { void* ptr; size_t bytes; } pool[64];
+    int pool_n;
+    size_t pool_bytes;
+    void* live_ptr[KZ_LIVE_MAX];   // capacity of every buffer handed out (so kz_free needs no size)
+    size_t live_bytes[KZ_LIVE_MAX];
 };
+
+int kz_pool_alloc(kz_ctx* ctx, size_t bytes, void** out);   // returns KZ_OK / KZ_ERR_NOMEM
+void kz_pool_free(kz_ctx* ctx, void* ptr, size_t bytes);
 
 struct kz_matrix {
     kz_ctx* ctx;
@@ -44,6 +55,7 @@ struct kz_matrix {
     float* bias;      // [n_tiles*128] accumulator init: -|y|^2/2 (euclidean family), 0 (cosine), -inf (pad rows)
     double* sqn;      // [n] float64: squared norms (euclidean family) or norms with 0 -> 1 (cosine)
     double max_norm;  // max_j |y_j|  (host copy)
+    size_t raw_bytes, packed_bytes, bias_bytes, sqn_bytes;
 };
 
 void kz_set_error(const char* fmt, ...);

@@ -458,6 +458,8 @@ struct KnnFinParams {
     const float* in_key;  // [rows][M]
     const int* in_idx;
     int reg_a, reg_c1, reg_c2;  // list layout (kz_list_base)
+    int max_m;            // largest entry count of a query in this launch (sizes the dynamic LDS)
+    int64_t q_first, q_last;  // local query range [q_first, q_last) handled by this launch
     int KP;
     int64_t list_row0;    // list row of local query 0  (= q_begin - qt0*128)
     int64_t q_begin;      // global query row of local query 0
@@ -530,29 +532,29 @@ __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* si
     }
 }
 
-constexpr int KZ_FIN_MAXM = 1024;
+constexpr int KZ_FIN_MAXM = 1024;  // list entries per query: 4 waves x (1024*8 + 128*28) B = 47 KiB of LDS at most
 constexpr int KZ_FIN_MAXKP = 128;
+
+// Per-wave LDS of the finalize kernel for a launch whose queries hold at most max_m list entries.
+__host__ __device__ __forceinline__ int kz_fin_wave_bytes(int max_m, int KP) {
+    return ((max_m * 8 + KP * 28) + 15) & ~15;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
-    __shared__ float s_ekey[4][KZ_FIN_MAXM];
-    __shared__ int s_eidx[4][KZ_FIN_MAXM];
-    __shared__ float s_ck[4][KZ_FIN_MAXKP];
-    __shared__ int s_ci[4][KZ_FIN_MAXKP];
-    __shared__ double s_cv[4][KZ_FIN_MAXKP];
-    __shared__ double s_sv[4][KZ_FIN_MAXKP];
-    __shared__ int s_si[4][KZ_FIN_MAXKP];
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
-    if (q >= p.q_count) return;  // whole wave exits; only wave-level sync below
-    float* ekey = s_ekey[wave];
-    int* eidx = s_eidx[wave];
-    float* ck = s_ck[wave];
-    int* ci = s_ci[wave];
-    double* cv = s_cv[wave];
-    double* sv = s_sv[wave];
-    int* si = s_si[wave];
+    const int64_t q = p.q_first + (int64_t)blockIdx.x * 4 + wave;
+    if (q >= p.q_last) return;  // whole wave exits; only wave-level sync below
+    char* wbase = fsm + (size_t)wave * kz_fin_wave_bytes(p.max_m, p.KP);
+    double* cv = reinterpret_cast<double*>(wbase);
+    double* sv = cv + p.KP;
+    float* ekey = reinterpret_cast<float*>(sv + p.KP);
+    int* eidx = reinterpret_cast<int*>(ekey + p.max_m);
+    float* ck = reinterpret_cast<float*>(eidx + p.max_m);
+    int* ci = reinterpret_cast<int*>(ck + p.KP);
+    int* si = ci + p.KP;
     const int KP = p.KP;
     const int k_eff = p.k + (p.exclude_self ? 1 : 0);
 
@@ -629,12 +631,43 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
         return;
     }
 
-    // exact float64 re-rank of the V candidates
-    for (int c = 0; c < V; ++c) {
-        const int yi = ci[c];
-        const T* yptr = reinterpret_cast<const T*>(p.yraw) + (int64_t)yi * p.d;
-        const double v = kz_exact_value<T>(qptr, yptr, qs, p.ysqn[yi], p.d, p.metric, lane);
-        if (lane == 0) cv[c] = v;
+    // exact float64 re-rank of the V candidates, four rows in flight per pass (the per-candidate arithmetic is exactly
+    // kz_wave_dot: per-lane fma chain over k = lane, lane+64, ... then the butterfly sum)
+    const T* yraw = reinterpret_cast<const T*>(p.yraw);
+    for (int c0 = 0; c0 < V; c0 += 4) {
+        const T* yp[4];
+        double ys[4], acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int yi = ci[min(c0 + u, V - 1)];
+            yp[u] = yraw + (int64_t)yi * p.d;
+            ys[u] = p.ysqn[yi];
+            acc[u] = 0.0;
+        }
+        if (p.metric == KZ_COSINE) {
+            for (int k = lane; k < p.d; k += 64) {
+                const double qk = (double)qptr[k] / qs;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = fma(qk, (double)yp[u][k] / ys[u], acc[u]);
+            }
+        } else {
+            for (int k = lane; k < p.d; k += 64) {
+                const double qk = (double)qptr[k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = fma(qk, (double)yp[u][k], acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double dot = kz_wave_sum(acc[u]);
+            double v;
+            if (p.metric == KZ_COSINE) {
+                v = fmin(fmax(1.0 - dot, 0.0), 2.0);  // sklearn cosine_distances: S *= -1; S += 1; clip(0, 2)
+            } else {
+                v = fmax((qs + ys[u]) - 2.0 * dot, 0.0);  // |x|^2 - 2 x.y + |y|^2, clamped (_argkmin.pyx.tp:494-502)
+            }
+            if (lane == 0 && c0 + u < V) cv[c0 + u] = v;
+        }
     }
     kz_wave_sync();
     // rank by (value asc, idx asc) and scatter into sorted order
@@ -988,11 +1021,24 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         fp.out_ind = d_ind + c0 * (int64_t)k;
         fp.fail_count = fail_count;
         fp.fail_list = fail_list;
-        const int fin_blocks = (int)((cq_count + 3) / 4);
-        if (index->dtype == KZ_F32)
-            hipLaunchKernelGGL(kz_knn_finalize_kernel<float>, dim3(fin_blocks), dim3(256), 0, ctx->stream, fp);
-        else
-            hipLaunchKernelGGL(kz_knn_finalize_kernel<double>, dim3(fin_blocks), dim3(256), 0, ctx->stream, fp);
+        {
+            // one launch per list region: the dynamic LDS follows the region's entry count (occupancy of the gather)
+            const int64_t split_q = (int64_t)A * KZ_TILE - fp.list_row0;  // first local query of region 2
+            const int64_t bounds[3] = {0, split_q < 0 ? 0 : (split_q > cq_count ? cq_count : split_q), cq_count};
+            const int ms[2] = {c1 * 2 * KP, c2 * 2 * KP};
+            for (int rg = 0; rg < 2; ++rg) {
+                if (bounds[rg + 1] <= bounds[rg]) continue;
+                fp.q_first = bounds[rg];
+                fp.q_last = bounds[rg + 1];
+                fp.max_m = ms[rg];
+                const int fin_blocks = (int)((fp.q_last - fp.q_first + 3) / 4);
+                const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, KP);
+                if (index->dtype == KZ_F32)
+                    hipLaunchKernelGGL(kz_knn_finalize_kernel<float>, dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
+                else
+                    hipLaunchKernelGGL(kz_knn_finalize_kernel<double>, dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
+            }
+        }
         KZ_HIP(hipGetLastError());
         KZ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
         KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

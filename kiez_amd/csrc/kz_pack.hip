@@ -93,9 +93,9 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
         kz_matrix_destroy(m);
         return code;
     };
-    if (hipMalloc(&m->raw, raw_bytes) != hipSuccess || hipMalloc((void**)&m->packed, packed_bytes) != hipSuccess ||
-        hipMalloc((void**)&m->bias, (size_t)n_pad * 4) != hipSuccess ||
-        hipMalloc((void**)&m->sqn, (size_t)n * 8) != hipSuccess) {
+    if (kz_pool_alloc(ctx, raw_bytes, &m->raw) != KZ_OK || kz_pool_alloc(ctx, packed_bytes, (void**)&m->packed) != KZ_OK ||
+        kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&m->bias) != KZ_OK ||
+        kz_pool_alloc(ctx, (size_t)n * 8, (void**)&m->sqn) != KZ_OK) {
         kz_set_error("kz_matrix_create: out of device memory (raw %zu B + packed %zu B)", raw_bytes, packed_bytes);
         return fail(KZ_ERR_NOMEM);
     }
@@ -144,12 +144,11 @@ int kz_matrix_destroy(kz_matrix* m) {
     if (!m) return KZ_OK;
     if (m->ctx) {
         (void)hipSetDevice(m->ctx->device);
-        (void)hipStreamSynchronize(m->ctx->stream);
+        kz_pool_free(m->ctx, m->raw, 0);
+        kz_pool_free(m->ctx, m->packed, 0);
+        kz_pool_free(m->ctx, m->bias, 0);
+        kz_pool_free(m->ctx, m->sqn, 0);
     }
-    if (m->raw) (void)hipFree(m->raw);
-    if (m->packed) (void)hipFree(m->packed);
-    if (m->bias) (void)hipFree(m->bias);
-    if (m->sqn) (void)hipFree(m->sqn);
     delete m;
     return KZ_OK;
 }

@@ -66,6 +66,7 @@ int kz_ctx_destroy(kz_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
+    for (int i = 0; i < c->pool_n; ++i) (void)hipFree(c->pool[i].ptr);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_tickets) (void)hipFree(c->d_tickets);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -109,22 +110,14 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
 int kz_malloc(kz_ctx* c, size_t bytes, void** d_ptr) {
     KZ_REQUIRE(c && d_ptr, "kz_malloc: null argument");
     KZ_HIP(hipSetDevice(c->device));
-    *d_ptr = nullptr;
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(d_ptr, bytes);
-    if (e != hipSuccess) {
-        kz_set_error("kz_malloc: hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        return KZ_ERR_NOMEM;
-    }
-    return KZ_OK;
+    return kz_pool_alloc(c, bytes, d_ptr);
 }
 
 int kz_free(kz_ctx* c, void* d_ptr) {
     KZ_REQUIRE(c != nullptr, "kz_free: null context");
     if (!d_ptr) return KZ_OK;
     KZ_HIP(hipSetDevice(c->device));
-    KZ_HIP(hipStreamSynchronize(c->stream));
-    KZ_HIP(hipFree(d_ptr));
+    kz_pool_free(c, d_ptr, 0);
     return KZ_OK;
 }
 
@@ -155,6 +148,78 @@ int kz_memcpy_d2d(kz_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
 }
 
 }  // extern "C"
+
+// ---- stream-ordered buffer pool ---------------------------------------------------------------------
+// All work of a context runs on ONE stream, so handing a released buffer to the next allocation of a similar size is
+// ordered behind its last use; this avoids hipFree (device-wide sync) + hipMalloc on every fit().
+static const size_t KZ_POOL_MAX_BYTES = (size_t)24 << 30;
+
+static void kz_live_add(kz_ctx* c, void* ptr, size_t bytes) {
+    for (int i = 0; i < KZ_LIVE_MAX; ++i)
+        if (!c->live_ptr[i]) {
+            c->live_ptr[i] = ptr;
+            c->live_bytes[i] = bytes;
+            return;
+        }
+}
+
+static size_t kz_live_take(kz_ctx* c, void* ptr) {
+    for (int i = 0; i < KZ_LIVE_MAX; ++i)
+        if (c->live_ptr[i] == ptr) {
+            c->live_ptr[i] = nullptr;
+            return c->live_bytes[i];
+        }
+    return 0;  // untracked (table was full): plain hipFree
+}
+
+int kz_pool_alloc(kz_ctx* c, size_t bytes, void** out) {
+    *out = nullptr;
+    if (bytes == 0) bytes = 16;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (int i = 0; i < c->pool_n; ++i) {
+        if (c->pool[i].bytes >= need && c->pool[i].bytes <= need + (need >> 3) &&
+            (best < 0 || c->pool[i].bytes < c->pool[best].bytes))
+            best = i;
+    }
+    if (best >= 0) {
+        *out = c->pool[best].ptr;
+        kz_live_add(c, c->pool[best].ptr, c->pool[best].bytes);
+        c->pool_bytes -= c->pool[best].bytes;
+        c->pool[best] = c->pool[--c->pool_n];
+        return KZ_OK;
+    }
+    void* base = nullptr;
+    hipError_t e = hipMalloc(&base, need);
+    if (e != hipSuccess) {  // release the cache and retry once
+        (void)hipStreamSynchronize(c->stream);
+        for (int i = 0; i < c->pool_n; ++i) (void)hipFree(c->pool[i].ptr);
+        c->pool_n = 0;
+        c->pool_bytes = 0;
+        e = hipMalloc(&base, need);
+    }
+    if (e != hipSuccess) {
+        kz_set_error("device allocation of %zu bytes failed: %s", need, hipGetErrorString(e));
+        return KZ_ERR_NOMEM;
+    }
+    kz_live_add(c, base, need);
+    *out = base;
+    return KZ_OK;
+}
+
+void kz_pool_free(kz_ctx* c, void* ptr, size_t /*bytes*/) {
+    if (!ptr) return;
+    const size_t cap = kz_live_take(c, ptr);
+    if (cap > 0 && c->pool_n < 64 && c->pool_bytes + cap <= KZ_POOL_MAX_BYTES) {
+        c->pool[c->pool_n].ptr = ptr;
+        c->pool[c->pool_n].bytes = cap;
+        ++c->pool_n;
+        c->pool_bytes += cap;
+        return;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(ptr);
+}
 
 int kz_scratch(kz_ctx* c, size_t bytes, void** out) {
     if (bytes > c->scratch_bytes) {
