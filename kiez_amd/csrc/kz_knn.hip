@@ -101,6 +101,99 @@ constexpr int KZ_QGROUP = 24;                   // query tiles sharing an XCD at
 constexpr int KZ_LOG_CAP = 16;                  // per-lane candidate log entries (keys + rows: 32 KiB per workgroup)
 constexpr int KZ_CAND_LDS = KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 8;
 
+__device__ __forceinline__ void kz_wave_sync() {
+    // cross-lane exchange through LDS inside ONE wave: LDS ops of a wave execute in order, the fences only stop
+    // the compiler from reordering the accesses.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Per-lane candidate state of one (query, lane-half) pair (see kz_knn_cand_kernel).
+struct KzCandState {
+    float* lk;   // list keys  (global, K' entries, unsorted)
+    int* li;     // list rows
+    float* sk;   // log keys   (LDS, stride 256)
+    int* si;     // log rows
+    float tau;   // K'-th best key of the list as of the last merge
+    int minpos;
+    int cnt;     // log entries
+    int tiles_done, next_merge;
+};
+
+// Tile epilogue shared by both fused kernels.  C layout of the 32x32 MFMA: col = lane & 31 (query),
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Lanes l and l+32 hold the two half-lists of ONE query: a key below the OTHER
+// half's K'-th best cannot be in the merged top-K' either, so both halves prune with the larger of the two thresholds.
+template <int KP>
+__device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
+                                                 const int h, const float never) {
+    float tau_eff = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
+    const int rowbase = tile * KZ_TILE + 4 * h;
+    ++st.tiles_done;
+    const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
+    unsigned long long done = 0ull;  // elements of this tile already logged (bit 16*mt + r)
+    for (;;) {
+        bool ovf = false;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#if KZ_ABLATE >= 2 && KZ_ABLATE <= 4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[mt][r]));
+            float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#else
+            float m4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                m4[g4] = fmaxf(fmaxf(acc[mt][4 * g4], acc[mt][4 * g4 + 1]), fmaxf(acc[mt][4 * g4 + 2], acc[mt][4 * g4 + 3]));
+#endif
+            const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+#if KZ_ABLATE >= 1 && KZ_ABLATE <= 4
+            if (m > tau_eff + 1e30f * never) {  // runtime-impossible: keeps the max tree, drops the logging
+#else
+            if (m > tau_eff) {
+#endif
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if (m4[g4] > tau_eff) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int r = 4 * g4 + r4;
+                            const float v = acc[mt][r];
+                            const unsigned long long bit = 1ull << (16 * mt + r);
+                            if (v > tau_eff && !(done & bit)) {
+                                if (st.cnt < KZ_LOG_CAP) {
+                                    int rb = rowbase;
+                                    asm volatile("" : "+v"(rb));  // keep the 64 row ids out of registers: computed on demand
+                                    st.sk[st.cnt * 256] = v;
+                                    st.si[st.cnt * 256] = rb + 32 * mt + (r & 3) + 8 * (r >> 2);
+                                    ++st.cnt;
+                                    done |= bit;
+                                } else {
+                                    ovf = true;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const bool any_ovf = __any(ovf);
+        if (!any_ovf && !sched) break;
+        // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
+        for (int e = 0; e < st.cnt; ++e) {
+            const float v = st.sk[e * 256];
+            if (v > st.tau) kz_list_replace_min<KP, 1>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+        }
+        st.cnt = 0;
+        tau_eff = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
+        if (!any_ovf) break;  // (a scheduled merge after an overflow round happens on the next pass)
+    }
+    if (st.tiles_done == st.next_merge) {
+        const int step = st.tiles_done * KZ_LOG_CAP / KP;
+        st.next_merge = st.tiles_done + (step > 0 ? step : 1);
+    }
+}
+
 // NRES = number of leading 16-k slices whose QUERY fragments stay resident in registers for the whole sweep
 // (8 slices = d 128 = 64 VGPRs).  The query tile is the stationary operand: re-fetching it for every index tile
 // doubled the L2 traffic and evicted the shared index stream (profiles/r01_b_c1_pmc_lpt_schedule.json: 23 GB
@@ -132,19 +225,21 @@ __global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(Knn
     // The threshold is only refreshed at merges, which follow a geometric schedule in the number of tiles seen
     // (identical for every lane, so merges run with all 64 lanes busy); a full log forces an early merge.
     const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
-    float* lk = p.out_key + listoff;
-    int* li = p.out_idx + listoff;
-    float* sk = reinterpret_cast<float*>(smem + KZ_CAND_LDS_BASE) + tid;
-    int* si = reinterpret_cast<int*>(smem + KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
+    KzCandState st;
+    st.lk = p.out_key + listoff;
+    st.li = p.out_idx + listoff;
+    st.sk = reinterpret_cast<float*>(smem + KZ_CAND_LDS_BASE) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
-        lk[e] = -INFINITY;
-        li[e] = -1;
+        st.lk[e] = -INFINITY;
+        st.li[e] = -1;
     }
-    float tau = -INFINITY;  // K'-th best key of this list (its minimum) as of the last merge
-    int minpos = 0;
-    int cnt = 0;            // log entries
-    int tiles_done = 0, next_merge = 1;
+    st.tau = -INFINITY;
+    st.minpos = 0;
+    st.cnt = 0;
+    st.tiles_done = 0;
+    st.next_merge = 1;
 
     // The ~3 workgroups resident on one CU start together and run identical work, so without help their epilogues
     // (no MFMA issued) coincide on every SIMD.  A start-up phase shift lets one group's epilogue hide under the others'
@@ -359,83 +454,7 @@ __global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(Knn
             }
             __builtin_amdgcn_sched_barrier(0);
             KZ_T(t2);
-            // epilogue: C layout of 32x32 MFMA: col = lane & 31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-            // Lanes l and l+32 hold the two half-lists of ONE query: a key below the OTHER half's K'-th best cannot be
-            // in the merged top-K' either, so both halves prune with the larger of the two thresholds.
-            float tau_eff = fmaxf(tau, __shfl_xor(tau, 32, 64));
-#ifdef KZ_STAMP
-            asm volatile("" ::"v"(tau_eff));
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long t2a = __builtin_amdgcn_s_memtime();
-            c_e1 += t2a - t2;
-#endif
-            const int rowbase = tile * KZ_TILE + 4 * h;
-            ++tiles_done;
-            const bool sched = (tiles_done == next_merge) || (tile == t_end - 1);  // block-uniform
-            unsigned long long done = 0ull;  // elements of this tile already logged (bit 16*mt + r)
-            for (;;) {
-                bool ovf = false;
-                KZ_T(tg0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-#if KZ_ABLATE >= 2
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[mt][r]));
-                    float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#else
-                    float m4[4];
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4)
-                        m4[g4] = fmaxf(fmaxf(acc[mt][4 * g4], acc[mt][4 * g4 + 1]), fmaxf(acc[mt][4 * g4 + 2], acc[mt][4 * g4 + 3]));
-#endif
-                    const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-#if KZ_ABLATE >= 1
-                    if (m > tau_eff + 1e30f * (float)p.kg) {  // runtime-impossible: keeps the max tree, drops the logging
-#else
-                    if (m > tau_eff) {
-#endif
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            if (m4[g4] > tau_eff) {
-#pragma unroll
-                                for (int r4 = 0; r4 < 4; ++r4) {
-                                    const int r = 4 * g4 + r4;
-                                    const float v = acc[mt][r];
-                                    const unsigned long long bit = 1ull << (16 * mt + r);
-                                    if (v > tau_eff && !(done & bit)) {
-                                        if (cnt < KZ_LOG_CAP) {
-                                            sk[cnt * 256] = v;
-                                            si[cnt * 256] = rowbase + 32 * mt + (r & 3) + 8 * (r >> 2);
-                                            ++cnt;
-                                            done |= bit;
-                                        } else {
-                                            ovf = true;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-#ifdef KZ_STAMP
-                __builtin_amdgcn_sched_barrier(0);
-                c_e2 += __builtin_amdgcn_s_memtime() - tg0;
-#endif
-                const bool any_ovf = __any(ovf);
-                if (!any_ovf && !sched) break;
-                // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
-                for (int e = 0; e < cnt; ++e) {
-                    const float v = sk[e * 256];
-                    if (v > tau) kz_list_replace_min<KP, 1>(lk, li, v, si[e * 256], tau, minpos);
-                }
-                cnt = 0;
-                tau_eff = fmaxf(tau, __shfl_xor(tau, 32, 64));
-                if (!any_ovf) break;  // (a scheduled merge after an overflow round happens on the next pass)
-            }
-            if (tiles_done == next_merge) {
-                const int step = tiles_done * KZ_LOG_CAP / KP;
-                next_merge = tiles_done + (step > 0 ? step : 1);
-            }
+            kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
 #ifdef KZ_STAMP
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -461,15 +480,133 @@ __global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(Knn
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Barrier-free variant: every wave feeds its MFMAs straight from L1/L2.
+// The LDS-staged kernel above shares one index slice among its 4 waves and pays one workgroup barrier per slice;
+// removing only those barriers (diagnostic build) raised C1 from 119 to 139 TF, i.e. the waves of a workgroup drift
+// on their SIMDs and the barrier stalls cost ~16 %.  Here each lane loads its own A fragments from the packed image
+// (512-B coalesced segments, the 4 waves of a workgroup and the co-resident workgroups hit the same lines in L1/L2),
+// double-buffered one half-slice (16 MFMAs) ahead, so waves never wait for each other.  LDS only holds the
+// candidate logs and a per-wave copy of the tile's bias rows.
+// ---------------------------------------------------------------------------------------------------
+constexpr int KZ_DIRECT_LDS = KZ_LOG_CAP * 256 * 8 + 4 * 2 * 128 * 4;
+
+template <int KP>
+__global__ __launch_bounds__(256, 3) void kz_knn_cand_direct_kernel(KnnCandParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int4 wd = p.work[blockIdx.x];
+    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
+    const int HS = p.kg >> 1;  // half-slices (8 k each side of the lane halves = 16 MFMAs) per tile
+    const int total = (t_end - t_begin) * HS;
+
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    KzCandState st;
+    st.lk = p.out_key + listoff;
+    st.li = p.out_idx + listoff;
+    st.sk = reinterpret_cast<float*>(smem) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_LOG_CAP * 256 * 4) + tid;
+#pragma unroll 4
+    for (int e = 0; e < KP; ++e) {
+        st.lk[e] = -INFINITY;
+        st.li[e] = -1;
+    }
+    st.tau = -INFINITY;
+    st.minpos = 0;
+    st.cnt = 0;
+    st.tiles_done = 0;
+    st.next_merge = 1;
+    if (total <= 0) return;
+
+    float* bbuf = reinterpret_cast<float*>(smem + KZ_LOG_CAP * 256 * 8) + wave * 256;  // this wave's 2 x 128 bias floats
+    // Linear stream of half-slices: G = (tile - t_begin) * HS + hs; lane (j, h) reads k-group 2*hs + h of rows 32*mt + j:
+    //   address(G, mt) = ybase + G*1024 + h*512 + (32*mt + j)*4   (floats)
+    const float* ybase = p.ypack + ((int64_t)t_begin * p.kg) * 512 + h * 512 + j * 4;
+    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg + h) * 512 + (32 * wave + j) * 4;
+    auto load_a = [&](float4 (&a)[4], int G) {
+        const float* src = ybase + (int64_t)G * 1024;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const float4*>(src + mt * 128);
+    };
+    auto load_q = [&](int hs) { return kz_nt_load4(reinterpret_cast<const float4*>(qbase + (int64_t)hs * 1024)); };
+    auto mfma16 = [&](f32x16 (&acc)[4], const float4 (&a)[4], const float4& bq) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
+    };
+
+    // prologue: fragments of half-slice 0, bias rows of the first tile (each wave keeps its own copy: no barriers)
+    float4 a0[4], a1[4];
+    load_a(a0, 0);
+    float4 q0 = load_q(0), q1;
+    {
+        const float* bsrc = p.ybias + (int64_t)t_begin * KZ_TILE;
+        bbuf[(t_begin & 1) * 128 + lane] = bsrc[lane];
+        bbuf[(t_begin & 1) * 128 + 64 + lane] = bsrc[64 + lane];
+    }
+    kz_wave_sync();
+
+    int G = 0;
+    f32x16 acc[4];
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
+                    acc[mt][4 * g4 + 0] = v.x;
+                    acc[mt][4 * g4 + 1] = v.y;
+                    acc[mt][4 * g4 + 2] = v.z;
+                    acc[mt][4 * g4 + 3] = v.w;
+                }
+            }
+        }
+        // bias rows of the next tile: loaded now, parked in LDS after the slices
+        const int tile_n = min(tile + 1, p.n_ytiles - 1);
+        const float bn0 = p.ybias[(int64_t)tile_n * KZ_TILE + lane];
+        const float bn1 = p.ybias[(int64_t)tile_n * KZ_TILE + 64 + lane];
+        int hs = 0;
+        do {  // two half-slices per trip so that the fragment buffers alternate without register moves (HS is even)
+            {
+                const int Gn = min(G + 1, total - 1);
+                load_a(a1, Gn);
+                q1 = load_q(hs + 1);  // hs + 1 < HS always (hs even)
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(acc, a0, q0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                const int Gn = min(G + 2, total - 1);
+                load_a(a0, Gn);
+                q0 = load_q(hs + 2 == HS ? 0 : hs + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(acc, a1, q1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            G += 2;
+            hs += 2;
+        } while (hs < HS);
+        bbuf[((tile + 1) & 1) * 128 + lane] = bn0;
+        bbuf[((tile + 1) & 1) * 128 + 64 + lane] = bn1;
+        kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
+        kz_wave_sync();  // bias rows visible to this wave's own lanes before the next tile's init
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Stage 2: merge + certify + float64 re-rank
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void kz_wave_sync() {
-    // cross-lane exchange through LDS inside ONE wave: LDS ops of a wave execute in order, the fences only stop
-    // the compiler from reordering the accesses.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 struct KnnFinParams {
     const float* in_key;  // [rows][M]
@@ -807,6 +944,32 @@ static int kz_cand_occupancy(int* blocks_per_cu) {
     return KZ_OK;
 }
 
+template <int KP>
+static int kz_direct_occupancy(int* blocks_per_cu) {
+    auto kern = kz_knn_cand_direct_kernel<KP>;
+    int nb = 0;
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_DIRECT_LDS));
+    *blocks_per_cu = nb < 1 ? 1 : nb;
+    return KZ_OK;
+}
+
+template <int KP>
+static int kz_launch_direct(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
+    hipLaunchKernelGGL(kz_knn_cand_direct_kernel<KP>, dim3(n_blocks), dim3(256), KZ_DIRECT_LDS, ctx->stream, p);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+#define KZ_DISPATCH_DIRECT(rc, fn, args)        \
+    do {                                        \
+        switch (KP) {                           \
+            case 16: rc = fn<16> args; break;   \
+            case 32: rc = fn<32> args; break;   \
+            case 64: rc = fn<64> args; break;   \
+            default: rc = fn<128> args; break;  \
+        }                                       \
+    } while (0)
+
 template <int KP, int NRES>
 static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
     const size_t lds = KZ_CAND_LDS;
@@ -870,10 +1033,14 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     const int nres_max = n_slices >= 8 ? 8 : (n_slices >= 4 ? 4 : 0);
     int nres = 0;
     if (ctx->force_nres > 0 && ctx->force_nres <= nres_max) nres = ctx->force_nres;
+    const bool direct = ctx->kernel_variant == 1;  // 1: barrier-free direct-load kernel, 0: LDS-staged kernel
     int blocks_per_cu = 1;
     {
         int rc0;
-        KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
+        if (direct)
+            KZ_DISPATCH_DIRECT(rc0, kz_direct_occupancy, (&blocks_per_cu));
+        else
+            KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
         if (rc0 != KZ_OK) return rc0;
     }
     const int slots = blocks_per_cu * ctx->n_cus;
@@ -1009,7 +1176,10 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         KZ_HIP(hipMemsetAsync(cp.dbg, 0, 10 * sizeof(unsigned long long), ctx->stream));
 #endif
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-        KZ_DISPATCH_CAND(rc, kz_launch_cand, (ctx, cp, W));
+        if (direct)
+            KZ_DISPATCH_DIRECT(rc, kz_launch_direct, (ctx, cp, W));
+        else
+            KZ_DISPATCH_CAND(rc, kz_launch_cand, (ctx, cp, W));
         if (rc != KZ_OK) return rc;
         KZ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
 

@@ -1,6 +1,8 @@
 // Context, memory and error plumbing of libkiez_amd.so.
 #include "kz_common.h"
 
+#include <cstdlib>
+
 static thread_local char g_err[512] = "";
 
 void kz_set_error(const char* fmt, ...) {
@@ -43,6 +45,8 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->force_nres = -1;
     c->min_splits = 1;
     c->stagger = 0;
+    c->kernel_variant = 0;
+    if (const char* kv = getenv("KZ_KERNEL_VARIANT")) c->kernel_variant = (kv[0] == '1') ? 1 : 0;  // A/B runs of the test-suite
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -91,6 +95,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "force_splits") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
         c->force_splits = (int)value;
+    } else if (strcmp(name, "kernel_variant") == 0) {
+        KZ_REQUIRE(value == 0 || value == 1, "kernel_variant must be 0 or 1");
+        c->kernel_variant = (int)value;
     } else if (strcmp(name, "stagger") == 0) {
         KZ_REQUIRE(value >= -1 && value <= 1e7, "stagger must be in [-1, 1e7] cycles");
         c->stagger = (int)value;
