@@ -341,6 +341,9 @@ __global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(Knn
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef KZ_SETPRIO
+            __builtin_amdgcn_s_setprio(KZ_SETPRIO);
+#endif
             const float* buf = ybuf + (g & 1) * 2048;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -358,6 +361,9 @@ __global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(Knn
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
             }
+#ifdef KZ_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #if KZ_ABLATE == 6
             // diagnostic: query-fragment loads are issued and waited for HERE (with the index loads), MFMAs keep using
@@ -476,6 +482,132 @@ __global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(Knn
             atomicAdd(p.dbg + 8, c_bar);
         }
 #endif
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Variant 2: the LDS-staged kernel with 32-k macro slices (two 16-k slices per workgroup barrier).
+// The barrier ablation priced the per-slice barrier at ~16 % (waves of a workgroup drift by the data-dependent
+// epilogue and by SIMD arbitration); twice the MFMA work between barriers halves their number.  Needs an even
+// number of 16-k slices per tile (d_pad % 32 == 0); other shapes use the 16-k kernel.
+// LDS: 2 x 16 KiB index macro slices + bias + the candidate log.
+// ---------------------------------------------------------------------------------------------------
+constexpr int KZ_CAND2_LDS_BASE = 32768 + 1024;
+constexpr int KZ_CAND2_LDS = KZ_CAND2_LDS_BASE + KZ_LOG_CAP * 256 * 8;
+
+template <int KP>
+__global__ __launch_bounds__(256, 2) void kz_knn_cand2_kernel(KnnCandParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ybuf = reinterpret_cast<float*>(smem);  // 2 x 4096 floats, then 2 x 128 bias floats
+    float* bbuf = ybuf + 8192;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int4 wd = p.work[blockIdx.x];
+    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
+    const int NM = p.kg >> 3;  // 32-k macro slices per tile
+    const int total = (t_end - t_begin) * NM;
+
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    KzCandState st;
+    st.lk = p.out_key + listoff;
+    st.li = p.out_idx + listoff;
+    st.sk = reinterpret_cast<float*>(smem + KZ_CAND2_LDS_BASE) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_CAND2_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
+#pragma unroll 4
+    for (int e = 0; e < KP; ++e) {
+        st.lk[e] = -INFINITY;
+        st.li[e] = -1;
+    }
+    st.tau = -INFINITY;
+    st.minpos = 0;
+    st.cnt = 0;
+    st.tiles_done = 0;
+    st.next_merge = 1;
+    if (total <= 0) return;
+
+    const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * p.kg) * 512);  // 1024 float4 per macro slice
+    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg + h) * 512 + (32 * wave + j) * 4;
+    auto load_q4 = [&](float4 (&q)[4], int m) {  // fragments of macro slice m: k-groups 8m + 2u + h, u = 0..3
+        const float* src = qbase + (int64_t)m * 8 * 512;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = kz_nt_load4(reinterpret_cast<const float4*>(src + u * 1024));
+    };
+    {
+        float4* nb = reinterpret_cast<float4*>(ybuf);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nb[tid + 256 * c] = ysrc[tid + 256 * c];
+        bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
+    }
+    float4 qb[4];
+    load_q4(qb, 0);
+    __syncthreads();
+
+    int g = 0;
+    f32x16 acc[4];
+    const float* bias_n = p.ybias + (tid & 127);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
+                    acc[mt][4 * g4 + 0] = v.x;
+                    acc[mt][4 * g4 + 1] = v.y;
+                    acc[mt][4 * g4 + 2] = v.z;
+                    acc[mt][4 * g4 + 3] = v.w;
+                }
+            }
+        }
+        int m = 0;
+        do {
+            // prefetch the next macro slice (unconditional; the clamp re-reads the last one at the very end)
+            const int gn = min(g + 1, total - 1);
+            const float4* src = ysrc + (int64_t)gn * 1024;
+            float4 ya[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ya[c] = src[tid + 256 * c];
+            const int tile_n = min(tile + 1, p.n_ytiles - 1);
+            const float bn = bias_n[(int64_t)tile_n * KZ_TILE];
+            float4 qn[4];
+            load_q4(qn, (m + 1 == NM) ? 0 : m + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float* buf = ybuf + (g & 1) * 4096;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // k-groups 2u + h of the macro slice
+                float4 a[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    a[mt] = *reinterpret_cast<const float4*>(buf + ((2 * u + h) * KZ_TILE + 32 * mt + j) * 4);
+                const float4 bq = qb[u];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 1) & 1) * 4096);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) nb[tid + 256 * c] = ya[c];
+                bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qb[u] = qn[u];
+            }
+            __syncthreads();
+            ++g;
+        } while (++m < NM);
+        __builtin_amdgcn_sched_barrier(0);
+        kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
     }
 }
 
@@ -945,6 +1077,23 @@ static int kz_cand_occupancy(int* blocks_per_cu) {
 }
 
 template <int KP>
+static int kz_cand2_occupancy(int* blocks_per_cu) {
+    auto kern = kz_knn_cand2_kernel<KP>;
+    KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_CAND2_LDS));
+    int nb = 0;
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_CAND2_LDS));
+    *blocks_per_cu = nb < 1 ? 1 : nb;
+    return KZ_OK;
+}
+
+template <int KP>
+static int kz_launch_cand2(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
+    hipLaunchKernelGGL(kz_knn_cand2_kernel<KP>, dim3(n_blocks), dim3(256), KZ_CAND2_LDS, ctx->stream, p);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+template <int KP>
 static int kz_direct_occupancy(int* blocks_per_cu) {
     auto kern = kz_knn_cand_direct_kernel<KP>;
     int nb = 0;
@@ -1034,11 +1183,14 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     int nres = 0;
     if (ctx->force_nres > 0 && ctx->force_nres <= nres_max) nres = ctx->force_nres;
     const bool direct = ctx->kernel_variant == 1;  // 1: barrier-free direct-load kernel, 0: LDS-staged kernel
+    const bool macro32 = ctx->kernel_variant == 2 && (index->kg % 8) == 0 && nres == 0;  // 2: 32-k macro slices
     int blocks_per_cu = 1;
     {
         int rc0;
         if (direct)
             KZ_DISPATCH_DIRECT(rc0, kz_direct_occupancy, (&blocks_per_cu));
+        else if (macro32)
+            KZ_DISPATCH_DIRECT(rc0, kz_cand2_occupancy, (&blocks_per_cu));
         else
             KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
         if (rc0 != KZ_OK) return rc0;
@@ -1178,6 +1330,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         if (direct)
             KZ_DISPATCH_DIRECT(rc, kz_launch_direct, (ctx, cp, W));
+        else if (macro32)
+            KZ_DISPATCH_DIRECT(rc, kz_launch_cand2, (ctx, cp, W));
         else
             KZ_DISPATCH_CAND(rc, kz_launch_cand, (ctx, cp, W));
         if (rc != KZ_OK) return rc;
