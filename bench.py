@@ -193,6 +193,8 @@ def main():
                          "launches": n_launch, "avg_launch_ms": kernel_s / max(n_launch, 1) * 1e3,
                          "algorithmic_flop_per_launch": flops / max(n_launch, 1)},
             "certification_fallback_rows": int(fallback_rows),
+            "other_kernels_ms": {"finalize_avg": sum(st["finalize_ms"] for _, _, st in knn_log) / max(n_launch, 1),
+                                 "fallback_total": sum(st["fallback_ms"] for _, _, st in knn_log)},
         }
         if check is not None:
             line["check"] = check
