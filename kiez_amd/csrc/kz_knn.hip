@@ -67,8 +67,15 @@ struct KnnCandParams {
     int stagger_cycles;   // start-up delay unit: workgroup b sleeps ((b / n_cus) % 3) * stagger_cycles (phase-shifts co-resident groups)
     int n_cus;
     int* cu_tickets;      // [16*256] zeroed per launch
+    int* err;             // device error word (ring kernel: spin time-out)
+    int phase_tiles;      // ring kernel: > 0 enables the circular sweep with per-workgroup start offsets
     unsigned long long* dbg;  // diagnostic stamp build only (-DKZ_STAMP): cycle sums {slices, epilogue, init, waves}
 };
+
+constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows
+constexpr int KZ_QGROUP = 24;                   // query tiles sharing an XCD at a time (x splits ~= resident workgroups)
+constexpr int KZ_LOG_CAP = 16;                  // per-lane candidate log entries (keys + rows: 32 KiB per workgroup)
+constexpr int KZ_CAND_LDS = KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 8;
 
 // Replace the minimum of an unsorted K'-entry list by (v, idx) and find the new minimum.  All keys are fetched
 // before the compare chain starts so that the LDS latency is paid once, not per element.
@@ -96,10 +103,7 @@ __device__ __forceinline__ void kz_list_replace_min(float* lk, int* li, float v,
     minpos = mp;
 }
 
-constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows
-constexpr int KZ_QGROUP = 24;                   // query tiles sharing an XCD at a time (x splits ~= resident workgroups)
-constexpr int KZ_LOG_CAP = 16;                  // per-lane candidate log entries (keys + rows: 32 KiB per workgroup)
-constexpr int KZ_CAND_LDS = KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 8;
+
 
 __device__ __forceinline__ void kz_wave_sync() {
     // cross-lane exchange through LDS inside ONE wave: LDS ops of a wave execute in order, the fences only stop
@@ -124,7 +128,7 @@ struct KzCandState {
 // Tile epilogue shared by both fused kernels.  C layout of the 32x32 MFMA: col = lane & 31 (query),
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Lanes l and l+32 hold the two half-lists of ONE query: a key below the OTHER
 // half's K'-th best cannot be in the merged top-K' either, so both halves prune with the larger of the two thresholds.
-template <int KP>
+template <int KP, int CAP = KZ_LOG_CAP>
 __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
                                                  const int h, const float never) {
     float tau_eff = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
@@ -161,7 +165,7 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
                             const float v = acc[mt][r];
                             const unsigned long long bit = 1ull << (16 * mt + r);
                             if (v > tau_eff && !(done & bit)) {
-                                if (st.cnt < KZ_LOG_CAP) {
+                                if (st.cnt < CAP) {
                                     int rb = rowbase;
                                     asm volatile("" : "+v"(rb));  // keep the 64 row ids out of registers: computed on demand
                                     st.sk[st.cnt * 256] = v;
@@ -189,7 +193,7 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
         if (!any_ovf) break;  // (a scheduled merge after an overflow round happens on the next pass)
     }
     if (st.tiles_done == st.next_merge) {
-        const int step = st.tiles_done * KZ_LOG_CAP / KP;
+        const int step = st.tiles_done * CAP / KP;
         st.next_merge = st.tiles_done + (step > 0 ? step : 1);
     }
 }
@@ -415,7 +419,9 @@ __global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(Knn
 #elif KZ_ABLATE == 8
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // diagnostic: no workgroup barrier (races; timing only)
 #else
-            __syncthreads();
+            // Raw barrier: __syncthreads() is fence + s_barrier and the fence drains vmcnt(0), i.e. it would wait here for
+            // the query-fragment loads that are only needed at the top of the next slice.  LDS visibility needs lgkmcnt only.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 #endif
             ++g;
@@ -608,6 +614,185 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand2_kernel(KnnCandParams p) {
         } while (++m < NM);
         __builtin_amdgcn_sched_barrier(0);
         kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Variant 3: LDS ring with per-wave progress counters instead of workgroup barriers.
+// Same tiling as kz_knn_cand_kernel, but the four waves of a workgroup are decoupled: the index slices go through a
+// ring of 4 LDS buffers, slice g+2 is staged during slice g, and a wave may start slice g as soon as EVERY wave has
+// completed slice g-2 (then all quarters of slice g are in LDS and nobody still reads the buffer that slice g+2
+// overwrites).  Progress is one LDS word per wave, written after the wave's own LDS traffic of the slice has
+// retired (LDS executes a wave's operations in order).  No s_barrier in the sweep; spins are bounded and a time-out
+// raises an error on the host.  (Barrier ablation: 139 vs 122 TF on C1.)
+// LDS: 4 x 8 KiB ring + bias rows + progress words + an 8-entry candidate log per lane.
+// ---------------------------------------------------------------------------------------------------
+constexpr int KZ_RING_CAP = 8;
+constexpr int KZ_RING_BIAS = 32768;                 // byte offset of the 2 x 128 bias floats
+constexpr int KZ_RING_PROG = KZ_RING_BIAS + 1024;   // 4 progress words (+ padding)
+constexpr int KZ_RING_LOG = KZ_RING_PROG + 64;
+constexpr int KZ_RING_LDS = KZ_RING_LOG + KZ_RING_CAP * 256 * 8;
+
+template <int KP>
+__global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ybuf = reinterpret_cast<float*>(smem);
+    float* bbuf = reinterpret_cast<float*>(smem + KZ_RING_BIAS);
+    int* prog = reinterpret_cast<int*>(smem + KZ_RING_PROG);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int4 wd = p.work[blockIdx.x];
+    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
+    const int NS = p.kg >> 2;  // >= 4 (host)
+    const int total = (t_end - t_begin) * NS;
+
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    KzCandState st;
+    st.lk = p.out_key + listoff;
+    st.li = p.out_idx + listoff;
+    st.sk = reinterpret_cast<float*>(smem + KZ_RING_LOG) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_RING_LOG + KZ_RING_CAP * 256 * 4) + tid;
+#pragma unroll 4
+    for (int e = 0; e < KP; ++e) {
+        st.lk[e] = -INFINITY;
+        st.li[e] = -1;
+    }
+    st.tau = -INFINITY;
+    st.minpos = 0;
+    st.cnt = 0;
+    st.tiles_done = 0;
+    st.next_merge = 1;
+    if (total <= 0) return;
+
+    // Circular sweep: workgroup b starts a third of the range further than b-1, so workgroups that are co-resident
+    // on one CU stream DIFFERENT index tiles at any time (no same-line pending stalls in the CU's L1); tiles are
+    // visited in the order t_begin + (i + off) % nt.  The candidate logic is order-independent.
+    const int nt = t_end - t_begin;
+    const int off = p.phase_tiles > 0 ? (int)(((int64_t)(blockIdx.x % 3) * nt) / 3) : 0;
+    const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * NS) * 2048);
+    auto slice_src = [&](int gi) {  // global slice counter -> address of that slice under the circular tile order
+        const int ti = gi / NS;
+        const int sli = gi - ti * NS;
+        int tp = ti + off;
+        if (tp >= nt) tp -= nt;
+        return ysrc + ((int64_t)tp * NS + sli) * 512;
+    };
+    auto tile_of = [&](int ti) {
+        int tp = ti + off;
+        if (tp >= nt) tp -= nt;
+        return t_begin + tp;
+    };
+    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg) * 512 + (32 * (tid >> 6) + j) * 4;
+    // prologue: slices 0 and 1, bias rows of the first tile, progress words; ONE workgroup barrier
+    {
+        float4* nb = reinterpret_cast<float4*>(ybuf);
+        const float4* s0 = slice_src(0);
+        nb[tid] = s0[tid];
+        nb[tid + 256] = s0[256 + tid];
+        const float4* s1 = slice_src(min(1, total - 1));
+        nb[512 + tid] = s1[tid];
+        nb[512 + tid + 256] = s1[256 + tid];
+        bbuf[(tid & 127)] = p.ybias[(int64_t)tile_of(0) * KZ_TILE + (tid & 127)];
+        if (tid < 4) prog[tid] = 0;
+    }
+    // query fragments: current slice (qb) and the next one (qn) in registers, the one after that in flight
+    float4 qb0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (0 + h) * 512));
+    float4 qb1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (2 + h) * 512));
+    float4 qn0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 + h) * 512));   // slice 1 (NS >= 4)
+    float4 qn1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (6 + h) * 512));
+    __syncthreads();
+
+    int g = 0;
+    f32x16 acc[4];
+    const float* bias_n = p.ybias + (tid & 127);
+    for (int ti = 0; ti < nt; ++ti) {
+        const int tile = tile_of(ti);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* bp = bbuf + (ti & 1) * 128 + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
+                    acc[mt][4 * g4 + 0] = v.x;
+                    acc[mt][4 * g4 + 1] = v.y;
+                    acc[mt][4 * g4 + 2] = v.z;
+                    acc[mt][4 * g4 + 3] = v.w;
+                }
+            }
+        }
+        int sl = 0;
+        do {
+            // (a) every wave must have completed slice g-2
+            if (g >= 2) {
+                int spins = 0;
+                for (;;) {
+                    const int p0 = __hip_atomic_load(prog + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int p1 = __hip_atomic_load(prog + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int p2 = __hip_atomic_load(prog + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int p3 = __hip_atomic_load(prog + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int pm = min(min(p0, p1), min(p2, p3));
+                    if (__builtin_amdgcn_readfirstlane(pm) >= g - 1) break;
+                    if (++spins > (1 << 22)) {  // ~seconds: give up loudly instead of hanging the GPU
+                        if (lane == 0) atomicOr(p.err, 1);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                asm volatile("" ::: "memory");  // compiler-only ordering: LDS itself is in order per wave, no caches
+            }
+            // (b) prefetch: index slice g+2 (-> registers), bias rows of the next tile, query fragments of slice g+1
+            const int gn = min(g + 2, total - 1);
+            const float4* src = slice_src(gn);
+            const float4 ya0 = src[tid];
+            const float4 ya1 = src[256 + tid];
+            const int tile_n = tile_of(min(ti + 1, nt - 1));
+            const float bn = bias_n[(int64_t)tile_n * KZ_TILE];
+            const int sl2 = (sl + 2 >= NS) ? sl + 2 - NS : sl + 2;  // query fragments TWO slices ahead
+            const float4 qm0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sl2 + h) * 512));
+            const float4 qm1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sl2 + 2 + h) * 512));
+            __builtin_amdgcn_sched_barrier(0);
+            // (c) 32 MFMAs out of ring buffer g % 4
+            const float* buf = ybuf + (g & 3) * 2048;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float4 a[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    a[mt] = *reinterpret_cast<const float4*>(buf + ((2 * t + h) * KZ_TILE + 32 * mt + j) * 4);
+                const float4 bq = t ? qb1 : qb0;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (d) stage slice g+2 into ring buffer (g+2) % 4
+            {
+                float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 2) & 3) * 2048);
+                nb[tid] = ya0;
+                nb[tid + 256] = ya1;
+                bbuf[((ti + 1) & 1) * 128 + (tid & 127)] = bn;
+                qb0 = qn0;
+                qb1 = qn1;
+                qn0 = qm0;
+                qn1 = qm1;
+            }
+            // (e) publish: this wave has completed slice g (its reads of buffer g%4 and its writes are retired)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS traffic retired; do NOT drain vmcnt (query loads in flight)
+            if (lane == 0) __hip_atomic_store(prog + wave, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ++g;
+        } while (++sl < NS);
+        __builtin_amdgcn_sched_barrier(0);
+        kz_tile_epilogue<KP, KZ_RING_CAP>(acc, st, tile, ti == nt - 1, h, (float)p.kg);
     }
 }
 
@@ -1094,6 +1279,22 @@ static int kz_launch_cand2(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
 }
 
 template <int KP>
+static int kz_ring_occupancy(int* blocks_per_cu) {
+    auto kern = kz_knn_cand_ring_kernel<KP>;
+    int nb = 0;
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_RING_LDS));
+    *blocks_per_cu = nb < 1 ? 1 : nb;
+    return KZ_OK;
+}
+
+template <int KP>
+static int kz_launch_ring(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
+    hipLaunchKernelGGL(kz_knn_cand_ring_kernel<KP>, dim3(n_blocks), dim3(256), KZ_RING_LDS, ctx->stream, p);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+template <int KP>
 static int kz_direct_occupancy(int* blocks_per_cu) {
     auto kern = kz_knn_cand_direct_kernel<KP>;
     int nb = 0;
@@ -1184,6 +1385,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     if (ctx->force_nres > 0 && ctx->force_nres <= nres_max) nres = ctx->force_nres;
     const bool direct = ctx->kernel_variant == 1;  // 1: barrier-free direct-load kernel, 0: LDS-staged kernel
     const bool macro32 = ctx->kernel_variant == 2 && (index->kg % 8) == 0 && nres == 0;  // 2: 32-k macro slices
+    const bool ring = ctx->kernel_variant == 3 && n_slices >= 4 && nres == 0;            // 3: LDS ring, no workgroup barriers
     int blocks_per_cu = 1;
     {
         int rc0;
@@ -1191,6 +1393,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             KZ_DISPATCH_DIRECT(rc0, kz_direct_occupancy, (&blocks_per_cu));
         else if (macro32)
             KZ_DISPATCH_DIRECT(rc0, kz_cand2_occupancy, (&blocks_per_cu));
+        else if (ring)
+            KZ_DISPATCH_DIRECT(rc0, kz_ring_occupancy, (&blocks_per_cu));
         else
             KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
         if (rc0 != KZ_OK) return rc0;
@@ -1256,7 +1460,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         int* fail_list = (int*)((char*)scratch + 2 * key_bytes);
         int4* d_work = (int4*)((char*)scratch + 2 * key_bytes + fail_bytes);
         int* fail_count = ctx->d_counters + 8;
-        KZ_HIP(hipMemsetAsync(fail_count, 0, sizeof(int), ctx->stream));
+        KZ_HIP(hipMemsetAsync(fail_count, 0, 2 * sizeof(int), ctx->stream));  // fail counter + kernel error word
         {
             // host-side table (pinned staging grows on demand)
             const size_t need = work_bytes;
@@ -1321,6 +1525,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         cp.stagger_cycles = ctx->stagger >= 0 ? ctx->stagger : (index->kg / 4) * 2048;  // default: one tile of MFMA time
         cp.n_cus = ctx->n_cus;
         cp.cu_tickets = ctx->d_tickets;
+        cp.err = ctx->d_counters + 9;
+        cp.phase_tiles = ctx->stagger > 0 ? 1 : 0;   // (re-uses the "stagger" knob)
         if (cp.stagger_cycles > 0) KZ_HIP(hipMemsetAsync(ctx->d_tickets, 0, 4096 * sizeof(int), ctx->stream));
         cp.dbg = nullptr;
 #ifdef KZ_STAMP
@@ -1332,6 +1538,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             KZ_DISPATCH_DIRECT(rc, kz_launch_direct, (ctx, cp, W));
         else if (macro32)
             KZ_DISPATCH_DIRECT(rc, kz_launch_cand2, (ctx, cp, W));
+        else if (ring)
+            KZ_DISPATCH_DIRECT(rc, kz_launch_ring, (ctx, cp, W));
         else
             KZ_DISPATCH_CAND(rc, kz_launch_cand, (ctx, cp, W));
         if (rc != KZ_OK) return rc;
@@ -1382,9 +1590,13 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         }
         KZ_HIP(hipGetLastError());
         KZ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-        KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         KZ_HIP(hipStreamSynchronize(ctx->stream));
         const int n_fail = ctx->h_counters[8];
+        if (ctx->h_counters[9] != 0) {
+            kz_set_error("kz_knn: fused kernel reported an internal synchronisation time-out (error word %d)", ctx->h_counters[9]);
+            return KZ_ERR_HIP;
+        }
 #ifdef KZ_STAMP
         {
             unsigned long long hd[10];
