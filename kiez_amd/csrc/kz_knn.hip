@@ -674,6 +674,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
     const int off = p.phase_tiles > 0 ? (int)(((int64_t)(blockIdx.x % 3) * nt) / 3) : 0;
     const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * NS) * 2048);
     auto slice_src = [&](int gi) {  // global slice counter -> address of that slice under the circular tile order
+        if (off == 0) return ysrc + (int64_t)gi * 512;
         const int ti = gi / NS;
         const int sli = gi - ti * NS;
         int tp = ti + off;
@@ -725,6 +726,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
                 }
             }
         }
+        // bias rows of the next tile: ONE load per tile (parked in LDS during the first slice, see (d))
+        const float bn = bias_n[(int64_t)tile_of(min(ti + 1, nt - 1)) * KZ_TILE];
         int sl = 0;
         do {
             // (a) every wave must have completed slice g-2
@@ -750,8 +753,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
             const float4* src = slice_src(gn);
             const float4 ya0 = src[tid];
             const float4 ya1 = src[256 + tid];
-            const int tile_n = tile_of(min(ti + 1, nt - 1));
-            const float bn = bias_n[(int64_t)tile_n * KZ_TILE];
             const int sl2 = (sl + 2 >= NS) ? sl + 2 - NS : sl + 2;  // query fragments TWO slices ahead
             const float4 qm0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sl2 + h) * 512));
             const float4 qm1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sl2 + 2 + h) * 512));
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
                 float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 2) & 3) * 2048);
                 nb[tid] = ya0;
                 nb[tid + 256] = ya1;
-                bbuf[((ti + 1) & 1) * 128 + (tid & 127)] = bn;
+                if (sl == 0) bbuf[((ti + 1) & 1) * 128 + (tid & 127)] = bn;  // every wave passes slice 0 before any starts tile ti+1
                 qb0 = qn0;
                 qb1 = qn1;
                 qn0 = qm0;
