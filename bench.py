@@ -70,6 +70,10 @@ def cpu_baseline(source, target, metric, k, budget_rows=10_000):
 
 
 def main():
+    # Keep stdout clean for the ONE JSON line: librccl prints a start-up banner to fd 1 when the communicator is created.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -88,7 +92,8 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     import torch.distributed as dist
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # started through torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -126,7 +131,7 @@ def main():
         return sk.kneighbors(k)
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -139,7 +144,7 @@ def main():
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.cpu()[0])
@@ -214,8 +219,9 @@ def main():
                                 "note": "Kiez(...).fit(numpy, numpy).kneighbors(k) -> numpy: includes H2D of both matrices and D2H of the result"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(source_h, target_h, metric, k)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -203,7 +203,7 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 // doubled the L2 traffic and evicted the shared index stream (profiles/r01_b_c1_pmc_lpt_schedule.json: 23 GB
 // fetched per launch, 57 % L2 miss).  Slices beyond NRES are streamed from L2 as before.
 template <int KP, int NRES>
-__global__ __launch_bounds__(256, NRES == 0 ? 3 : 2) void kz_knn_cand_kernel(KnnCandParams p) {
+__global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);  // 2 x 2048 floats (+ 2 x 128 bias floats behind them)
     const int tid = threadIdx.x;

@@ -166,9 +166,11 @@ class Comm:
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # test hook: run the collectives even with one rank (exercises the RCCL calls on a single-GPU box)
+        self.always = dist.is_initialized() and os.environ.get("KIEZ_AMD_FORCE_COLLECTIVES") == "1"
 
     def broadcast(self, t, src=0):
-        if self.world > 1:
+        if self.world > 1 or self.always:
             self.dist.broadcast(t, src=src, group=self.group)
         return t
 
@@ -183,7 +185,7 @@ class Comm:
     def all_gather_rows(self, t, counts):
         """Concatenate ragged row blocks [n_r, ...] of all ranks in rank order (padded all_gather)."""
         torch = _torch()
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return t
         mx = max(counts)
         pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -200,7 +202,7 @@ class Comm:
 
     def all_gather_ints(self, value: int, device):
         torch = _torch()
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return [int(value)]
         mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
         parts = [torch.empty_like(mine) for _ in range(self.world)]
@@ -208,7 +210,7 @@ class Comm:
         return [int(x.cpu()[0]) for x in parts]
 
     def all_reduce_min(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.always:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return t
 
@@ -281,7 +283,7 @@ class ShardedKiez:
         if self.single:
             tgt = src_full
         else:
-            if target_from_rank0 and comm.world > 1:
+            if target_from_rank0 and (comm.world > 1 or comm.always):
                 torch = _torch()
                 shape = None
                 if comm.rank == 0:
