@@ -1,0 +1,118 @@
+"""BASELINE.json's full-size configuration (C1/C2: 100k x 100k, d=128, k=10) on the GPU: size-independent properties
+plus an oracle spot check on a row sample, and edge cases the domain has (exact duplicates, zero rows, tiny inputs)."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c1_data():
+    rng = np.random.RandomState(0)   # the reference's docstring data style (kiez/kiez.py:50-52), float32
+    return rng.rand(100_000, 128).astype(np.float32), rng.rand(100_000, 128).astype(np.float32)
+
+
+def _props(dist, ind, n_index, k):
+    assert dist.shape == ind.shape == (dist.shape[0], k)
+    assert ind.dtype == np.int64 and dist.dtype == np.float64
+    assert (ind >= 0).all() and (ind < n_index).all()
+    s = np.sort(ind, axis=1)
+    assert (s[:, 1:] != s[:, :-1]).all(), "duplicate neighbour ids in a row"
+    assert np.isfinite(dist).all()
+
+
+def test_c1_full_size_properties_and_sample(c1_data):
+    from kiez_amd import Kiez
+    from oracle import kiez_oracle as O
+    s, t = c1_data
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = Kiez(n_candidates=10, algorithm="SklearnNN", algorithm_kwargs={"metric": "euclidean"}).fit(s, t)
+        d10, i10 = kz.kneighbors(10)
+        d5, i5 = kz.kneighbors(5)
+    _props(d10, i10, len(t), 10)
+    assert (np.diff(d10, axis=1) >= 0).all(), "rows must be sorted ascending"
+    np.testing.assert_array_equal(i5, i10[:, :5])          # k-prefix property
+    np.testing.assert_array_equal(d5, d10[:, :5])
+    rows = np.random.RandomState(1).choice(len(s), 512, replace=False)
+    od, oi = O.knn_exact(s[rows], t, 10, "euclidean")
+    np.testing.assert_array_equal(i10[rows], oi)
+    np.testing.assert_array_equal(d10[rows], od)            # float32 inputs: bit-identical distances (sqrt rule)
+    # exact distance recomputed in float64 for a few entries
+    r = rows[:16]
+    ref = np.sqrt(((s[r, None, :].astype(np.float64) - t[i10[r]].astype(np.float64)) ** 2).sum(-1))
+    np.testing.assert_allclose(d10[r], ref, rtol=2e-7)
+    assert kz.algorithm.last_stats["n_fallback_rows"] < 100
+
+
+def test_c2_full_size_csls_sample(c1_data):
+    from kiez_amd import Kiez
+    from oracle import kiez_oracle as O
+    s, t = c1_data
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = Kiez(n_candidates=10, algorithm="SklearnNN", algorithm_kwargs={"metric": "euclidean"}, hubness="CSLS").fit(s, t)
+        d, i = kz.kneighbors(10)
+    _props(d, i, len(t), 10)
+    assert (np.diff(d, axis=1) >= 0).all()
+    # CSLS on a row sample: the fit state needs all rows of the reverse pass, so take it from the device
+    r_train = kz.hubness._r_train_dev.numpy()
+    rows = np.arange(0, 100_000, 997)
+    fd, fi = O.knn_exact(s[rows], t, 10, "euclidean")
+    tr = 2 * fd - fd.mean(axis=1).reshape(-1, 1) - r_train[fi]
+    od, oi = O.sort_topk(tr, fi, 10)
+    np.testing.assert_array_equal(i[rows], oi)
+    np.testing.assert_allclose(d[rows], od, rtol=1e-9, atol=1e-12)
+    # r_train itself against the oracle on a sample of target rows
+    trows = np.arange(0, 100_000, 1999)
+    rd, _ = O.knn_exact(t[trows], s, 10, "euclidean")
+    np.testing.assert_array_equal(r_train[trows], rd.mean(axis=1))
+
+
+def test_exact_duplicates_order_by_index():
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.RandomState(4)
+    base = rng.rand(50, 16)
+    t = np.vstack([base, base, base[:10]])          # exact copies -> exact distance ties
+    s = rng.rand(40, 16)
+    ctx = N.Context.get()
+    d, i, st = N.knn(ctx, N.DeviceMatrix(ctx, s, "euclidean"), N.DeviceMatrix(ctx, t, "euclidean"), 12)
+    od, oi = O.knn_exact(s, t, 12, "euclidean")
+    np.testing.assert_array_equal(i.numpy(), oi)
+    np.testing.assert_allclose(d.numpy(), od, rtol=1e-12, atol=1e-12)
+
+
+def test_cosine_with_zero_rows_and_tiny_inputs():
+    from kiez_amd import Kiez
+    from oracle import kiez_oracle as O
+    rng = np.random.RandomState(8)
+    s, t = rng.rand(7, 3), rng.rand(9, 3)
+    t[4] = 0.0                                        # sklearn normalize(): a zero row stays zero -> distance 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for hub in (None, "CSLS", "LocalScaling"):
+            d, i = Kiez(n_candidates=4, algorithm="SklearnNN", algorithm_kwargs={"metric": "cosine"}, hubness=hub).fit(s, t).kneighbors(3)
+            od, oi = O.kiez_pipeline(s, t, 4, 3, "cosine", 2, hub, {})
+            np.testing.assert_array_equal(i, oi)
+            np.testing.assert_allclose(d, od, rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):   # empty matrices are rejected (sklearn: "Found array with 0 sample(s)")
+        Kiez(hubness="CSLS").fit(np.zeros((0, 3)), t)
+    with pytest.raises(ValueError):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Kiez().fit(np.zeros((0, 3)), t).kneighbors(1)
+
+
+def test_float32_cosine_keeps_reference_output_dtype():
+    from kiez_amd import Kiez
+    rng = np.random.RandomState(2)
+    s, t = rng.rand(50, 8).astype(np.float32), rng.rand(60, 8).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d, i = Kiez(n_candidates=5, algorithm="SklearnNN", algorithm_kwargs={"metric": "cosine"}).fit(s, t).kneighbors(5)
+        d2, _ = Kiez(n_candidates=5, algorithm="SklearnNN", algorithm_kwargs={"metric": "cosine"}, hubness="CSLS").fit(s, t).kneighbors(5)
+        d3, _ = Kiez(n_candidates=5, algorithm="SklearnNN", algorithm_kwargs={"metric": "euclidean"}).fit(s, t).kneighbors(5)
+    assert d.dtype == np.float32 and d2.dtype == np.float32 and d3.dtype == np.float64 and i.dtype == np.int64
