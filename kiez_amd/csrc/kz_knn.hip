@@ -14,6 +14,11 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+// LDS-DMA: each lane copies 16 bytes from its own global address to (wave-uniform LDS base) + lane*16
+__device__ __forceinline__ void kz_glds16(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 __device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-temporal 16-byte load (streaming cache policy)
     const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
@@ -798,6 +803,117 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Variant 4: stationary query tile.  For d_pad == 16*NSR (NSR = 4 or 8, i.e. d <= 64 / d <= 128) the query fragments of
+// all slices stay in registers for the whole sweep (64 VGPRs at NSR = 8), so the per-slice query-fragment loads of the
+// streaming kernel disappear (diagnostic build without them: 149 vs 122 TF on C1).  To keep three waves per SIMD the
+// index slices are staged with LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write); the packed image is
+// copied linearly, which is exactly the lane-linear layout LDS-DMA writes.  One workgroup barrier per slice; its
+// fence also retires the DMA of the next slice.
+// ---------------------------------------------------------------------------------------------------
+template <int KP, int NSR>
+__global__ __launch_bounds__(256, 3) void kz_knn_cand_res_kernel(KnnCandParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ybuf = reinterpret_cast<float*>(smem);            // 2 x 2048 floats
+    float* bbuf = ybuf + 4096;                                // 2 x 128 bias floats
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int4 wd = p.work[blockIdx.x];
+    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
+    const int total = (t_end - t_begin) * NSR;
+
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    KzCandState st;
+    st.lk = p.out_key + listoff;
+    st.li = p.out_idx + listoff;
+    st.sk = reinterpret_cast<float*>(smem + KZ_CAND_LDS_BASE) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
+#pragma unroll 4
+    for (int e = 0; e < KP; ++e) {
+        st.lk[e] = -INFINITY;
+        st.li[e] = -1;
+    }
+    st.tau = -INFINITY;
+    st.minpos = 0;
+    st.cnt = 0;
+    st.tiles_done = 0;
+    st.next_merge = 1;
+    if (total <= 0) return;
+
+    // LDS-DMA: lane l of wave w copies 16 B from gsrc + (64*(w + 4c) + l)*16 to LDS slice + (64*(w + 4c))*16 + l*16, c = 0, 1
+    const float* ysrc = p.ypack + ((int64_t)t_begin * NSR) * 2048 + tid * 4;   // per-lane source of slice 0, chunk 0
+    auto dma_slice = [&](int gi, int buf) {
+        const float* src = ysrc + (int64_t)gi * 2048;
+        float* dst = ybuf + buf * 2048 + wave * 256;  // wave-uniform LDS base (floats)
+        kz_glds16(src, dst);
+        kz_glds16(src + 1024, dst + 1024);
+    };
+    // prologue: slice 0 by DMA, bias rows of the first tile, resident query fragments
+    dma_slice(0, 0);
+    bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
+    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * (4 * NSR) + h) * 512 + (32 * (tid >> 6) + j) * 4;
+    float4 qres[NSR][2];
+#pragma unroll
+    for (int u = 0; u < NSR; ++u) {
+        qres[u][0] = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * u) * 512));
+        qres[u][1] = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * u + 2) * 512));
+    }
+    __syncthreads();
+
+    int g = 0;
+    f32x16 acc[4];
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
+                    acc[mt][4 * g4 + 0] = v.x;
+                    acc[mt][4 * g4 + 1] = v.y;
+                    acc[mt][4 * g4 + 2] = v.z;
+                    acc[mt][4 * g4 + 3] = v.w;
+                }
+            }
+        }
+        // bias rows of the next tile (one 4-byte load per thread per tile; parked in LDS after slice 0)
+        const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
+#pragma unroll
+        for (int u = 0; u < NSR; ++u) {
+            dma_slice(min(g + 1, total - 1), (g + 1) & 1);   // next slice lands in the other buffer while we compute
+            __builtin_amdgcn_sched_barrier(0);
+            const float* buf = ybuf + (g & 1) * 2048;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float4 a[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    a[mt] = *reinterpret_cast<const float4*>(buf + ((2 * t + h) * KZ_TILE + 32 * mt + j) * 4);
+                const float4 bq = qres[u][t];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+            __syncthreads();   // fence drains vmcnt: the DMA of slice g+1 has landed; everyone is done with buffer g&1
+            ++g;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Barrier-free variant: every wave feeds its MFMAs straight from L1/L2.
 // The LDS-staged kernel above shares one index slice among its 4 waves and pays one workgroup barrier per slice;
 // removing only those barriers (diagnostic build) raised C1 from 119 to 139 TF, i.e. the waves of a workgroup drift
@@ -1279,6 +1395,31 @@ static int kz_launch_cand2(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
     return KZ_OK;
 }
 
+template <int KP, int NSR>
+static int kz_res_occupancy(int* blocks_per_cu) {
+    auto kern = kz_knn_cand_res_kernel<KP, NSR>;
+    int nb = 0;
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_CAND_LDS));
+    *blocks_per_cu = nb < 1 ? 1 : nb;
+    return KZ_OK;
+}
+
+template <int KP, int NSR>
+static int kz_launch_res(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
+    hipLaunchKernelGGL((kz_knn_cand_res_kernel<KP, NSR>), dim3(n_blocks), dim3(256), KZ_CAND_LDS, ctx->stream, p);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+#define KZ_DISPATCH_RES(rc, fn, args)                                                   \
+    do {                                                                                \
+        if (n_slices == 8) {                                                            \
+            if (KP == 16) rc = fn<16, 8> args; else rc = fn<32, 8> args;                \
+        } else {                                                                        \
+            if (KP == 16) rc = fn<16, 4> args; else rc = fn<32, 4> args;                \
+        }                                                                               \
+    } while (0)
+
 template <int KP>
 static int kz_ring_occupancy(int* blocks_per_cu) {
     auto kern = kz_knn_cand_ring_kernel<KP>;
@@ -1387,6 +1528,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     const bool direct = ctx->kernel_variant == 1;  // 1: barrier-free direct-load kernel, 0: LDS-staged kernel
     const bool macro32 = ctx->kernel_variant == 2 && (index->kg % 8) == 0 && nres == 0;  // 2: 32-k macro slices
     const bool ring = ctx->kernel_variant == 3 && n_slices >= 4 && nres == 0;            // 3: LDS ring, no workgroup barriers
+    const bool resident = ctx->kernel_variant == 4 && (n_slices == 8 || n_slices == 4) && KP <= 32;  // 4: stationary query tile
     int blocks_per_cu = 1;
     {
         int rc0;
@@ -1396,6 +1538,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             KZ_DISPATCH_DIRECT(rc0, kz_cand2_occupancy, (&blocks_per_cu));
         else if (ring)
             KZ_DISPATCH_DIRECT(rc0, kz_ring_occupancy, (&blocks_per_cu));
+        else if (resident)
+            KZ_DISPATCH_RES(rc0, kz_res_occupancy, (&blocks_per_cu));
         else
             KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
         if (rc0 != KZ_OK) return rc0;
@@ -1541,6 +1685,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             KZ_DISPATCH_DIRECT(rc, kz_launch_cand2, (ctx, cp, W));
         else if (ring)
             KZ_DISPATCH_DIRECT(rc, kz_launch_ring, (ctx, cp, W));
+        else if (resident)
+            KZ_DISPATCH_RES(rc, kz_launch_res, (ctx, cp, W));
         else
             KZ_DISPATCH_CAND(rc, kz_launch_cand, (ctx, cp, W));
         if (rc != KZ_OK) return rc;
