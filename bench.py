@@ -35,6 +35,8 @@ WORKLOADS = {
             "C3 (scaled to 100k x 100k): d=200, cosine, k=50, MutualProximity empiric"),
     "c4s": (250_000, 1_000_000, 300, "euclidean", 10, 10, "CSLS", {},
             "C4 per-GPU share: 250k source rows x 1M target, d=300, k=10, CSLS"),
+    "c1g": (100_000, 100_000, 128, "euclidean", 10, 10, None, {},
+            "C1 on gaussian data (rng.randn) for contrast with uniform: 100k x 100k, d=128, euclidean, k=10, hubness=None"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
 
@@ -80,7 +82,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="verify a row sample of the result against the oracle")
+    ap.add_argument("--check", action="store_true", help="verify 2000 rows of the result against the oracle (default: 256 rows, hubness=None only)")
+    ap.add_argument("--no-check", action="store_true", help="skip the default oracle spot check")
     ap.add_argument("--opt", action="append", default=[], help="context option name=value (tuning experiments)")
     args = ap.parse_args()
 
@@ -108,8 +111,9 @@ def main():
 
     # synthetic data in the reference's style (kiez/kiez.py:50-52): rng.rand, source first, then target
     rng = np.random.RandomState(0 if rank == 0 else 1000 + rank)
-    source_h = rng.rand(n_s, d).astype(np.float32)
-    target_h = rng.rand(n_t, d).astype(np.float32) if rank == 0 else None
+    gen = rng.randn if args.workload.endswith("g") else rng.rand
+    source_h = gen(n_s, d).astype(np.float32)
+    target_h = gen(n_t, d).astype(np.float32) if rank == 0 else None
     source = eng.to_engine(source_h)
     target = eng.to_engine(target_h) if rank == 0 else None
     eng.sync()
@@ -164,13 +168,15 @@ def main():
             traffic = None
 
     check = None
-    if args.check and rank == 0:
+    do_check = args.check or (not args.no_check and hub is None and world == 1 and n_t <= 200_000)
+    if do_check and rank == 0:
         from oracle import kiez_oracle as O
-        rows = 2000
+        rows = 2000 if args.check else 256
         dd, ii = res
         od, oi = O.kiez_pipeline(source_h, target_h, K, k, metric, 2, hub, hub_kw, query_rows=rows)
         got_i = ii[:len(oi)].cpu().numpy()
         check = {"rows": int(len(oi)), "index_rows_identical": int((got_i == oi).all(axis=1).sum()),
+                 "recall_at_k": float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got_i, oi)])),
                  "max_rel_dist_err": float(np.max(np.abs(dd[:len(od)].cpu().numpy() - od) / np.maximum(np.abs(od), 1e-12)))}
 
     if rank == 0:
