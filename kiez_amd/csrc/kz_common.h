@@ -23,6 +23,7 @@ struct kz_ctx {
     int force_nres;   // test knob: resident query slices (-1 = automatic)
     int kernel_variant;  // 0: LDS-staged fused kernel, 1: barrier-free direct-load fused kernel
     int stagger;      // tuning knob: start-up phase shift in cycles (-1 = one tile of MFMA time, 0 = off)
+    int chunk_rows;   // test knob: query rows per chunk (0 = default 524288)
     int min_splits;   // tuning knob: minimum index splits per query tile in the large-item region
     // scratch (grown on demand, reused across calls)
     void* scratch;

@@ -1546,7 +1546,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     }
     const int slots = blocks_per_cu * ctx->n_cus;
     // query rows are processed in chunks so that the candidate lists stay below ~1 GiB
-    const int64_t max_rows_per_chunk = 128 * 4096;
+    const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096;
     double main_ms = 0, fin_ms = 0, fb_ms = 0;
     int64_t n_fail_total = 0;
     int last_splits = 1, last_blocks = 0;

@@ -101,6 +101,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "stagger") == 0) {
         KZ_REQUIRE(value >= -1 && value <= 1e7, "stagger must be in [-1, 1e7] cycles");
         c->stagger = (int)value;
+    } else if (strcmp(name, "chunk_rows") == 0) {
+        KZ_REQUIRE(value >= 0 && value <= 1e9, "chunk_rows must be >= 0");
+        c->chunk_rows = (int)value;
     } else if (strcmp(name, "min_splits") == 0) {
         KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
         c->min_splits = (int)value;

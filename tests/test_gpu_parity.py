@@ -227,3 +227,27 @@ def test_medium_size_all_rows_bit_identical():
     assert np.array_equal(i.numpy(), oi)
     np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=0)
     assert st["n_fallback_rows"] < 20
+
+
+def test_query_chunking_and_row_ranges():
+    """kz_knn processes long query sets in chunks and accepts a row range (multi-GPU sharding): both must not change results."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    s, t = _data(1000, 700, 24, np.float32, seed=33)
+    ctx = N.Context.get()
+    ym = N.DeviceMatrix(ctx, t, "euclidean")
+    qm = N.DeviceMatrix(ctx, s, "euclidean")
+    od, oi = O.knn_exact(s, t, 10, "euclidean")
+    ctx.set_option("chunk_rows", 300)   # not a multiple of the 128-row tile
+    try:
+        d, i, _ = N.knn(ctx, qm, ym, 10)
+        np.testing.assert_array_equal(i.numpy(), oi)
+        d2, i2, _ = N.knn(ctx, qm, ym, 10, q_begin=137, q_count=555)
+        np.testing.assert_array_equal(i2.numpy(), oi[137:137 + 555])
+        np.testing.assert_array_equal(d2.numpy(), od[137:137 + 555])
+        # self-stripping with a row range (global row ids)
+        dm, im, _ = N.knn(ctx, ym, ym, 5, exclude_self=True, q_begin=129, q_count=400)
+        sd, si = O.knn_exact(t, t, 5, "euclidean", exclude_self=True)
+        np.testing.assert_array_equal(im.numpy(), si[129:529])
+    finally:
+        ctx.set_option("chunk_rows", 0)
