@@ -127,6 +127,19 @@ int kz_dsl_finalize(kz_ctx* ctx, double* d_out, int64_t count, double min_value,
 int kz_select_topk(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K, int k,
                    double* d_odist, int64_t* d_oind);
 
+/* ---- "next" row (f-1): kiez.analysis.hubness_score on the neighbour index matrix (kiez/analysis/estimation.py:197-351) */
+/* min / max of an int64 device array (validation + bincount length). */
+int kz_minmax_i64(kz_ctx* ctx, const int64_t* d_in, int64_t count, int64_t* h_min, int64_t* h_max);
+/* k-occurrence: np.bincount(nn_ind[:, :k].ravel(), minlength=n_bins) with negative ids dropped (estimation.py:283-292).
+ * d_ind: [n_rows, cols] int64; d_kocc: [n_bins] int64. */
+int kz_k_occurrence(kz_ctx* ctx, const int64_t* d_ind, int64_t n_rows, int cols, int k, int64_t n_bins, int64_t* d_kocc);
+/* Reductions of the k-occurrence vector for skewness, Robin Hood, Atkinson, hub/antihub statistics and (optionally, O(n^2))
+ * the Gini numerator.  h_out[10] (host): sum, sum|x-mean|, sum(x-mean)^2, sum(x-mean)^3, sum sqrt(x), max, #zeros,
+ * sum over hubs (x >= hub_threshold), #hubs, gini numerator. */
+int kz_kocc_stats(kz_ctx* ctx, const int64_t* d_kocc, int64_t n, double hub_threshold, int with_gini, double* h_out);
+/* np.argwhere(kocc == 0) (mode 0) / np.argwhere(kocc >= thr) (mode 1), ascending; d_out must hold n entries. */
+int kz_kocc_select(kz_ctx* ctx, const int64_t* d_kocc, int64_t n, int mode, double thr, int64_t* d_out, int64_t* h_count);
+
 /* float64 -> float32 cast of an [count] array (cosine + float32 inputs keep the reference's output dtype). */
 int kz_cast_f64_f32(kz_ctx* ctx, const double* d_in, float* d_out, int64_t count);
 

@@ -77,6 +77,10 @@ SYMBOLS = [
     ("kz_dsl_finalize", C.c_int, [_P, _P, _I64, C.c_double, C.c_int]),
     ("kz_select_topk", C.c_int, [_P, _P, _P, _I64, C.c_int, C.c_int, _P, _P]),
     ("kz_cast_f64_f32", C.c_int, [_P, _P, _P, _I64]),
+    ("kz_minmax_i64", C.c_int, [_P, _P, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
+    ("kz_k_occurrence", C.c_int, [_P, _P, _I64, C.c_int, C.c_int, _I64, _P]),
+    ("kz_kocc_stats", C.c_int, [_P, _P, _I64, C.c_double, C.c_int, C.POINTER(C.c_double)]),
+    ("kz_kocc_select", C.c_int, [_P, _P, _I64, C.c_int, C.c_double, _P, C.POINTER(_I64)]),
 ]
 
 

@@ -129,6 +129,21 @@ def main():
         out[f"tie32_k{k}_dist"], out[f"tie32_k{k}_ind"] = d, i
     np.savez_compressed(OUT / "sort.npz", **out)
     print("wrote sort")
+    # 7. kiez.analysis.hubness_score: the reference's own test fixtures (tests/analysis/test_estimation.py:14,56-69):
+    #    tests/nn_ind.npy is copied as data, the pickled expected scores are re-encoded as json / npz
+    import pickle
+    import shutil
+    ref_tests = Path("/root/reference/tests")
+    shutil.copy(ref_tests / "nn_ind.npy", OUT / "ref_nn_ind.npy")
+    exp, arrs = {}, {}
+    for k in (2, 5, 10, 50):
+        with open(ref_tests / f"expected_k{k}_hub_scores.pkl", "rb") as fh:
+            d = pickle.load(fh)
+        exp[str(k)] = {a: float(b) for a, b in d.items() if not isinstance(b, np.ndarray)}
+        arrs.update({f"k{k}__{a}": b for a, b in d.items() if isinstance(b, np.ndarray)})
+    (OUT / "ref_hub_scores.json").write_text(json.dumps(exp, indent=1) + "\n")
+    np.savez_compressed(OUT / "ref_hub_scores_arrays.npz", **arrs)
+    print("wrote hubness-score fixtures")
     import scipy
     import sklearn
     manifest = {
