@@ -140,6 +140,11 @@ int kz_kocc_stats(kz_ctx* ctx, const int64_t* d_kocc, int64_t n, double hub_thre
 /* np.argwhere(kocc == 0) (mode 0) / np.argwhere(kocc >= thr) (mode 1), ascending; d_out must hold n entries. */
 int kz_kocc_select(kz_ctx* ctx, const int64_t* d_kocc, int64_t n, int mode, double thr, int64_t* d_out, int64_t* h_count);
 
+/* "next" row (f-2): kiez.evaluate.hits (kiez/evaluate/eval_metrics.py:23-61).  d_gold[i] = gold target of source row i or
+ * INT64_MIN when the row has no gold entry; d_hist[c] (c < cols) = rows whose gold id sits at position c, d_hist[cols] =
+ * rows whose gold id is absent.  hits@k = sum(d_hist[:k]) / len(gold). */
+int kz_hit_positions(kz_ctx* ctx, const int64_t* d_ind, const int64_t* d_gold, int64_t n, int cols, int64_t* d_hist);
+
 /* float64 -> float32 cast of an [count] array (cosine + float32 inputs keep the reference's output dtype). */
 int kz_cast_f64_f32(kz_ctx* ctx, const double* d_in, float* d_out, int64_t count);
 

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("kz_k_occurrence", C.c_int, [_P, _P, _I64, C.c_int, C.c_int, _I64, _P]),
     ("kz_kocc_stats", C.c_int, [_P, _P, _I64, C.c_double, C.c_int, C.POINTER(C.c_double)]),
     ("kz_kocc_select", C.c_int, [_P, _P, _I64, C.c_int, C.c_double, _P, C.POINTER(_I64)]),
+    ("kz_hit_positions", C.c_int, [_P, _P, _P, _I64, C.c_int, _P]),
 ]
 
 

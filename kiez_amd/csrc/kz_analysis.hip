@@ -139,7 +139,33 @@ __global__ __launch_bounds__(1024) void kz_kocc_select_kernel(const long long* _
     if (tid == 0) *count = s_base;
 }
 
+// hits@k (kiez/evaluate/eval_metrics.py:7-12): position of gold[i] inside nn_ind[i, :], histogrammed over rows
+__global__ void kz_hit_positions_kernel(const int64_t* __restrict__ ind, const int64_t* __restrict__ gold, int64_t n, int cols,
+                                        unsigned long long* __restrict__ hist) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t gt = gold[r];
+    if (gt == INT64_MIN) return;  // row has no gold entry
+    int pos = cols;                // "not found"
+    for (int c = 0; c < cols; ++c)
+        if (ind[r * cols + c] == gt) {
+            pos = c;
+            break;
+        }
+    atomicAdd(hist + pos, 1ull);
+}
+
 extern "C" {
+
+int kz_hit_positions(kz_ctx* ctx, const int64_t* d_ind, const int64_t* d_gold, int64_t n, int cols, int64_t* d_hist) {
+    KZ_REQUIRE(ctx && d_ind && d_gold && d_hist && n > 0 && cols >= 1, "kz_hit_positions: bad argument");
+    KZ_HIP(hipSetDevice(ctx->device));
+    KZ_HIP(hipMemsetAsync(d_hist, 0, (size_t)(cols + 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(kz_hit_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ind, d_gold, n, cols,
+                       (unsigned long long*)d_hist);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
 
 int kz_minmax_i64(kz_ctx* ctx, const int64_t* d_in, int64_t count, int64_t* h_min, int64_t* h_max) {
     KZ_REQUIRE(ctx && d_in && h_min && h_max && count > 0, "kz_minmax_i64: bad argument");

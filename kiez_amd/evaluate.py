@@ -1,0 +1,55 @@
+"""hits@k — `kiez.evaluate.hits` (kiez/evaluate/eval_metrics.py:23-61) with the row scan on the GPU.
+
+For array input the neighbour matrix may live on the device (`Kiez.kneighbors_device`).  Dict input with arbitrary
+labels is first encoded to integer ids on the host (data preparation); the matching itself runs in `kz_hit_positions`."""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+
+from . import _native as N
+
+_NO_GOLD = np.iinfo(np.int64).min
+
+
+def hits(nn_ind: Union[np.ndarray, list, Dict[Any, List], "N.DeviceArray"], gold: Dict[Any, Any], k=None,
+         ctx: Optional[N.Context] = None) -> Dict[int, float]:
+    """Relative hits@k for every k in `k` (default [1, 5, 10]); same semantics as the reference."""
+    if k is None:
+        k = [1, 5, 10]
+    k = sorted(k)
+    if isinstance(nn_ind, dict):
+        # encode labels: neighbour labels and gold targets share one code table; rows follow the dict order
+        codes: Dict[Any, int] = {}
+
+        def code(x):
+            return codes.setdefault(x, len(codes))
+        keys = list(nn_ind.keys())
+        width = max((len(v) for v in nn_ind.values()), default=0)
+        mat = np.full((len(keys), max(width, 1)), -1, dtype=np.int64)
+        for r, key in enumerate(keys):
+            row = [code(x) for x in nn_ind[key]]
+            mat[r, : len(row)] = row
+        gold_arr = np.array([code(gold[key]) if key in gold else _NO_GOLD for key in keys], dtype=np.int64)
+        ind_host = mat
+    elif isinstance(nn_ind, N.DeviceArray):
+        ind_host = None
+        n_rows = nn_ind.shape[0]
+        gold_arr = np.array([int(gold[i]) if i in gold else _NO_GOLD for i in range(n_rows)], dtype=np.int64)
+    else:
+        ind_host = np.ascontiguousarray(np.asarray(nn_ind), dtype=np.int64)
+        if ind_host.ndim != 2:
+            raise ValueError("nn_ind must be a 2D neighbour index matrix")
+        gold_arr = np.array([int(gold[i]) if i in gold else _NO_GOLD for i in range(ind_host.shape[0])], dtype=np.int64)
+    if isinstance(nn_ind, N.DeviceArray):
+        ctx = nn_ind.ctx
+        ind_dev = nn_ind
+    else:
+        ctx = ctx or N.Context.get()
+        ind_dev = ctx.to_device(ind_host)
+    n, cols = ind_dev.shape
+    hist = ctx.empty((cols + 1,), np.int64)
+    N._check(ctx.lib.kz_hit_positions(ctx.handle, ind_dev.ptr, ctx.to_device(gold_arr).ptr, n, cols, hist.ptr), "kz_hit_positions")
+    cum = np.cumsum(hist.numpy()[:cols])
+    return {kk: (float(cum[min(kk, cols) - 1]) / len(gold) if kk >= 1 else 0.0) for kk in k}

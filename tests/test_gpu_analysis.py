@@ -92,3 +92,27 @@ def test_device_input_from_the_hot_path():
     b = hubness_score(i_host, 300, store_k_occurrence=True)
     np.testing.assert_array_equal(a["k_occurrence"], b["k_occurrence"])
     assert a["robinhood"] == b["robinhood"]
+
+
+# ---- kiez.evaluate.hits: the reference's literal cases (tests/evaluate/test_eval_metrics.py:6-45) -------------------
+@pytest.mark.parametrize(("nn_ind", "gold", "k", "expected"), [
+    ([[1, 2, 3], [2, 3, 4], [3, 4, 5], [4, 5, 6]], {0: 2, 1: 4, 2: 3, 3: 4}, [1, 2, 3], {1: 0.5, 2: 0.75, 3: 1.0}),
+    ([[1, 2, 3], [2, 3, 4], [3, 4, 5], [4, 5, 6]], {0: 5, 1: 6, 2: 7, 3: 8}, None, {1: 0.0, 5: 0.0, 10: 0.0}),
+    ({0: [1, 2, 3], 1: [2, 3, 4], 2: [3, 4, 5], 3: [4, 5, 6]}, {0: 2, 1: 4, 2: 3, 3: 4}, [1, 2, 3], {1: 0.5, 2: 0.75, 3: 1.0}),
+    ({0: [1, 2, 3], 1: [2, 3, 4], 2: [3, 4, 5], 3: [4, 5, 6]}, {0: 5, 1: 6, 2: 7, 3: 8}, None, {1: 0.0, 5: 0.0, 10: 0.0}),
+    ({"0": ["1", "2", "3"], "1": ["2", "3", "4"], "2": ["3", "4", "5"], "3": ["4", "5", "6"]},
+     {"0": "2", "1": "4", "2": "3", "3": "4"}, [1, 2, 3], {1: 0.5, 2: 0.75, 3: 1.0}),
+])
+def test_hits(nn_ind, gold, k, expected):
+    from kiez_amd.evaluate import hits
+    assert hits(nn_ind, gold, k) == expected
+
+
+def test_hits_docstring_example_and_device_input():
+    from kiez_amd import _native as N
+    from kiez_amd.evaluate import hits
+    nn = np.array([[1, 2, 3], [2, 3, 4], [3, 4, 5], [4, 5, 6]])
+    gold = {0: 2, 1: 4, 2: 3, 3: 4}
+    assert hits(nn, gold) == {1: 0.5, 5: 1.0, 10: 1.0}
+    assert hits(N.Context.get().to_device(nn.astype(np.int64)), gold) == {1: 0.5, 5: 1.0, 10: 1.0}
+    assert hits(nn, {0: 2, 7: 1}) == {1: 0.0, 5: 0.5, 10: 0.5}     # gold rows outside the matrix count in the denominator
