@@ -210,6 +210,12 @@ class DeviceArray:
                 pass
             self._owned = False
 
+    @property
+    def __cuda_array_interface__(self):
+        """Zero-copy export (torch.as_tensor(device_array, device="cuda"), cupy, numba)."""
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr.value or 0, False), "version": 3,
+                "strides": None}
+
     def numpy(self) -> np.ndarray:
         out = np.empty(self.shape, dtype=self.dtype)
         if self.nbytes:

@@ -123,6 +123,13 @@ class HubnessReduction(ABC):
         """base.py:89-105: forward candidates, rescale, final top-k."""
         if self._gpu_nn:
             od, oi = self.kneighbors_device(k)
+            src = self.nn_algo.source_
+            from .neighbors import _is_tensor, _torch_if_loaded
+            if _is_tensor(src):   # tensors in -> tensors out, on the source's device
+                torch = _torch_if_loaded()
+                self.ctx.sync()
+                return (torch.as_tensor(od, device="cuda").clone().to(src.device),
+                        torch.as_tensor(oi, device="cuda").clone().to(src.device))
             return od.numpy(), oi.numpy()
         n_neighbors = self._set_k_if_needed(k)
         query_dist, query_ind = self.nn_algo.kneighbors(query=None, k=self.nn_algo.n_candidates, return_distance=True)

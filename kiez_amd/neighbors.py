@@ -121,6 +121,18 @@ class NNAlgorithm(ABC):
                                 is_self_querying=is_self_querying)
 
 
+def _torch_if_loaded():
+    """torch, but only if the caller already imported it (this package never imports torch on its own: the HIP runtime
+    bundled with torch has to be loaded BEFORE libkiez_amd.so, kiez_amd/_native.py)."""
+    import sys
+    return sys.modules.get("torch")
+
+
+def _is_tensor(x) -> bool:
+    t = _torch_if_loaded()
+    return t is not None and isinstance(x, t.Tensor)
+
+
 def canonical_metric(metric: str, p=2) -> str:
     """Map the reference's metric spelling to one the HIP kernels implement; anything else fails loudly."""
     if metric == "minkowski":
@@ -182,7 +194,33 @@ class SklearnNN(NNAlgorithm):
             arr = arr.astype(np.float64)
         return np.ascontiguousarray(arr)
 
+    def _check_input_types(self, value):
+        # torch tensors are accepted like the reference's Faiss backend does (kiez/neighbors/approximate/faiss.py:64-65):
+        # CUDA tensors are consumed in place (zero-copy fit), CPU tensors through their numpy view
+        if not isinstance(value, tuple):
+            value = (value,)
+        super()._check_input_types(tuple(None if _is_tensor(x) else x for x in value))
+
     def _make_matrix(self, data, dtype=None) -> N.DeviceMatrix:
+        if _is_tensor(data):
+            torch = _torch_if_loaded()
+            t = data.detach()
+            if t.dim() != 2:
+                raise ValueError(f"Expected 2D array, got {t.dim()}D array instead")
+            if t.dtype not in (torch.float32, torch.float64):
+                t = t.to(torch.float64)
+            if dtype is not None and np.dtype(str(t.dtype).replace("torch.", "")) != dtype:
+                t = t.to(torch.float32 if dtype == np.float32 else torch.float64)
+            if not t.is_cuda:
+                return self._make_matrix(t.contiguous().numpy(), dtype)
+            t = t.contiguous()
+            if t.device.index != self.ctx.device:
+                raise ValueError(f"tensor lives on cuda:{t.device.index}, the NN backend on device {self.ctx.device}")
+            torch.cuda.current_stream(t.device).synchronize()   # the producer stream is not ours
+            m = N.DeviceMatrix(self.ctx, None, self._metric_c, device_ptr=t.data_ptr(), shape=tuple(t.shape),
+                               dtype=np.float32 if t.dtype == torch.float32 else np.float64)
+            self.ctx.sync()                                      # rows are copied into the matrix: the tensor may go away
+            return m
         if isinstance(data, N.DeviceArray):
             if len(data.shape) != 2 or data.dtype not in (np.float32, np.float64):
                 raise ValueError("device inputs must be 2D float32/float64 arrays")
@@ -249,6 +287,17 @@ class SklearnNN(NNAlgorithm):
         qm = self._matrix_for(query)
         dist, ind, stats = N.knn(self.ctx, qm, index, k, exclude_self=is_self_querying)
         self.last_stats = stats
+        if _is_tensor(query):   # tensors in -> tensors out (on the query's device), as the reference does with Faiss
+            torch = _torch_if_loaded()
+            self.ctx.sync()
+            dev = query.device
+            ind_t = torch.as_tensor(ind, device="cuda").clone().to(dev)
+            if not return_distance:
+                return ind_t
+            dist_t = torch.as_tensor(dist, device="cuda").clone().to(dev)
+            if self._out_dtype(index) == np.float32:
+                dist_t = dist_t.to(torch.float32)
+            return dist_t, ind_t
         ind_h = ind.numpy()
         if not return_distance:
             return ind_h
