@@ -12,201 +12,13 @@
 // Result: neighbour order == order of the float64 distances the reference computes; no approximation.
 #include "kz_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-// LDS-DMA: each lane copies 16 bytes from its own global address to (wave-uniform LDS base) + lane*16
-__device__ __forceinline__ void kz_glds16(const float* gsrc, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-temporal 16-byte load (streaming cache policy)
-    const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
+#include "kz_knn_device.h"
 
-// Diagnostic builds only (tools/ablate.sh): -DKZ_ABLATE=n removes parts of the fused kernel to price them
-// (1: no list inserts, 2: + no epilogue max, 3: + no LDS refill / barrier, 4: + no global prefetch).  Results are
-// wrong in those builds; the shipped library is built with KZ_ABLATE undefined (= 0).
-#ifndef KZ_ABLATE
-#define KZ_ABLATE 0
-#endif
-// -DKZ_STAMP: in-kernel s_memtime stamps per section, summed into p.dbg (diagnostic build, never shipped/timed).
-#ifdef KZ_STAMP
-#define KZ_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#else
-#define KZ_T(var)
-#endif
-
-// ---------------------------------------------------------------------------------------------------
-// Stage 1: fused similarity + candidate selection
-// ---------------------------------------------------------------------------------------------------
-// similarity key(q, y) = q.y + bias(y)     bias = -|y|^2/2 (euclidean: argmax key == argmin |q-y|^2), 0 (cosine)
-//
-// Workgroup = 256 threads = 4 waves, tile = 128 index rows (MFMA M) x 128 queries (MFMA N).
-// Wave w owns queries [32w, 32w+32) and all 128 index rows of the tile: 4 accumulators of 32x32.
-// With the query on the MFMA column (= lane & 31), the 64 keys a lane holds after a tile all belong to ONE
-// query, so each lane keeps a PRIVATE candidate list (query, lane-half) and needs no atomics or barriers:
-//   list(q, h) sees index rows with (row & 4) == 4h; union of the two halves' top-K' contains the top-K'.
-// Index operand: streamed HBM/L2 -> registers -> LDS (double buffered 8 KiB slices, one barrier per slice).
-// Query operand: per-lane fragments straight from L2 (no reuse across waves, so no LDS round trip).
-// Candidate-list storage: queries of region-1 tiles own c1 slots of 2*KP entries, queries of region-2 tiles c2 slots.
-__host__ __device__ __forceinline__ int64_t kz_list_base(int64_t list_row, int reg_a, int c1, int c2, int KP) {
-    const int64_t a_rows = (int64_t)reg_a * KZ_TILE;
-    if (list_row < a_rows) return list_row * (int64_t)(c1 * 2 * KP);
-    return a_rows * (int64_t)(c1 * 2 * KP) + (list_row - a_rows) * (int64_t)(c2 * 2 * KP);
-}
-
-struct KnnCandParams {
-    const float* qpack;   // packed query matrix
-    const float* ypack;   // packed index matrix
-    const float* ybias;   // accumulator init per index row
-    const int4* work;     // one descriptor per workgroup: {query tile (local), first index tile, end index tile, list slot}
-    int qt0;              // first query tile of this launch (global tile index into qpack)
-    int n_ytiles;         // index tiles
-    int reg_a;            // query tiles [0, reg_a) keep reg_c1 list slots per query, the rest reg_c2 (kz_list_base)
-    int reg_c1;
-    int reg_c2;
-    int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
-    float* out_key;       // region 1: [reg_a*128][reg_c1][2][KP], then region 2: [(n_qtiles-reg_a)*128][reg_c2][2][KP]
-    int* out_idx;
-    int stagger_cycles;   // start-up delay unit: workgroup b sleeps ((b / n_cus) % 3) * stagger_cycles (phase-shifts co-resident groups)
-    int n_cus;
-    int* cu_tickets;      // [16*256] zeroed per launch
-    int* err;             // device error word (ring kernel: spin time-out)
-    int phase_tiles;      // ring kernel: > 0 enables the circular sweep with per-workgroup start offsets
-    unsigned long long* dbg;  // diagnostic stamp build only (-DKZ_STAMP): cycle sums {slices, epilogue, init, waves}
-};
-
-constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows
-constexpr int KZ_QGROUP = 24;                   // query tiles sharing an XCD at a time (x splits ~= resident workgroups)
-constexpr int KZ_LOG_CAP = 16;                  // per-lane candidate log entries (keys + rows: 32 KiB per workgroup)
-constexpr int KZ_CAND_LDS = KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 8;
-
-// Replace the minimum of an unsorted K'-entry list by (v, idx) and find the new minimum.  All keys are fetched
-// before the compare chain starts so that the LDS latency is paid once, not per element.
-template <int KP, int LSTRIDE>
-__device__ __forceinline__ void kz_list_replace_min(float* lk, int* li, float v, int idx, float& tau, int& minpos) {
-    lk[minpos * LSTRIDE] = v;
-    li[minpos * LSTRIDE] = idx;
-    float mn = INFINITY;
-    int mp = 0;
-#pragma unroll
-    for (int c0 = 0; c0 < KP; c0 += 16) {
-        float kk[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) kk[e] = lk[(c0 + e) * LSTRIDE];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (kk[e] < mn) {
-                mn = kk[e];
-                mp = c0 + e;
-            }
-        }
-    }
-    tau = mn;
-    minpos = mp;
-}
-
-
-
-__device__ __forceinline__ void kz_wave_sync() {
-    // cross-lane exchange through LDS inside ONE wave: LDS ops of a wave execute in order, the fences only stop
-    // the compiler from reordering the accesses.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Per-lane candidate state of one (query, lane-half) pair (see kz_knn_cand_kernel).
-struct KzCandState {
-    float* lk;   // list keys  (global, K' entries, unsorted)
-    int* li;     // list rows
-    float* sk;   // log keys   (LDS, stride 256)
-    int* si;     // log rows
-    float tau;   // K'-th best key of the list as of the last merge
-    int minpos;
-    int cnt;     // log entries
-    int tiles_done, next_merge;
-};
-
-// Tile epilogue shared by both fused kernels.  C layout of the 32x32 MFMA: col = lane & 31 (query),
-// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Lanes l and l+32 hold the two half-lists of ONE query: a key below the OTHER
-// half's K'-th best cannot be in the merged top-K' either, so both halves prune with the larger of the two thresholds.
-template <int KP, int CAP = KZ_LOG_CAP>
-__device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
-                                                 const int h, const float never) {
-    float tau_eff = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
-    const int rowbase = tile * KZ_TILE + 4 * h;
-    ++st.tiles_done;
-    const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
-    unsigned long long done = 0ull;  // elements of this tile already logged (bit 16*mt + r)
-    for (;;) {
-        bool ovf = false;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#if KZ_ABLATE >= 2 && KZ_ABLATE <= 4
-#pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[mt][r]));
-            float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#else
-            float m4[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                m4[g4] = fmaxf(fmaxf(acc[mt][4 * g4], acc[mt][4 * g4 + 1]), fmaxf(acc[mt][4 * g4 + 2], acc[mt][4 * g4 + 3]));
-#endif
-            const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-#if KZ_ABLATE >= 1 && KZ_ABLATE <= 4
-            if (m > tau_eff + 1e30f * never) {  // runtime-impossible: keeps the max tree, drops the logging
-#else
-            if (m > tau_eff) {
-#endif
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    if (m4[g4] > tau_eff) {
-#pragma unroll
-                        for (int r4 = 0; r4 < 4; ++r4) {
-                            const int r = 4 * g4 + r4;
-                            const float v = acc[mt][r];
-                            const unsigned long long bit = 1ull << (16 * mt + r);
-                            if (v > tau_eff && !(done & bit)) {
-                                if (st.cnt < CAP) {
-                                    int rb = rowbase;
-                                    asm volatile("" : "+v"(rb));  // keep the 64 row ids out of registers: computed on demand
-                                    st.sk[st.cnt * 256] = v;
-                                    st.si[st.cnt * 256] = rb + 32 * mt + (r & 3) + 8 * (r >> 2);
-                                    ++st.cnt;
-                                    done |= bit;
-                                } else {
-                                    ovf = true;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        const bool any_ovf = __any(ovf);
-        if (!any_ovf && !sched) break;
-        // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
-        for (int e = 0; e < st.cnt; ++e) {
-            const float v = st.sk[e * 256];
-            if (v > st.tau) kz_list_replace_min<KP, 1>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
-        }
-        st.cnt = 0;
-        tau_eff = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
-        if (!any_ovf) break;  // (a scheduled merge after an overflow round happens on the next pass)
-    }
-    if (st.tiles_done == st.next_merge) {
-        const int step = st.tiles_done * CAP / KP;
-        st.next_merge = st.tiles_done + (step > 0 ? step : 1);
-    }
-}
-
+// The shipped fused kernel (kernel_variant 0).
 // NRES = number of leading 16-k slices whose QUERY fragments stay resident in registers for the whole sweep
-// (8 slices = d 128 = 64 VGPRs).  The query tile is the stationary operand: re-fetching it for every index tile
-// doubled the L2 traffic and evicted the shared index stream (profiles/r01_b_c1_pmc_lpt_schedule.json: 23 GB
-// fetched per launch, 57 % L2 miss).  Slices beyond NRES are streamed from L2 as before.
+// (8 slices = d 128 = 64 VGPRs); slices beyond NRES are streamed from L2 with non-temporal loads.  Residency is opt-in
+// (force_nres): at the register budget of three waves per SIMD it spills and measured slower than streaming
+// (DESIGN.md section 7); NRES = 0 is what runs by default.
 template <int KP, int NRES>
 __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -324,13 +136,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
 #else
             const int gn = min(g + 1, total - 1);
             const float4* src = ysrc + (int64_t)gn * 512;
-#ifdef KZ_Y_NT
-            const float4 ya0 = kz_nt_load4(src + tid);
-            const float4 ya1 = kz_nt_load4(src + 256 + tid);
-#else
             const float4 ya0 = src[tid];
             const float4 ya1 = src[256 + tid];
-#endif
             const int tile_n = min(tile + 1, p.n_ytiles - 1);
             const float bn = bias_n[(int64_t)tile_n * KZ_TILE];
 #endif
@@ -350,9 +157,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifdef KZ_SETPRIO
-            __builtin_amdgcn_s_setprio(KZ_SETPRIO);
-#endif
             const float* buf = ybuf + (g & 1) * 2048;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -370,22 +174,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
             }
-#ifdef KZ_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             __builtin_amdgcn_sched_barrier(0);
-#if KZ_ABLATE == 6
-            // diagnostic: query-fragment loads are issued and waited for HERE (with the index loads), MFMAs keep using
-            // the loop-invariant first fragments: prices the traffic without the top-of-slice wait
-            if (stream_q) asm volatile("" ::"v"(qn0.x), "v"(qn1.x));
-            {
-                float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 1) & 1) * 2048);
-                nb[tid] = ya0;
-                nb[tid + 256] = ya1;
-                bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
-            }
-            __syncthreads();
-#elif KZ_ABLATE >= 3
+#if KZ_ABLATE >= 3 && KZ_ABLATE <= 4
             asm volatile("" ::"v"(ya0.x), "v"(ya1.x), "v"(bn));
             if (stream_q) {
                 qb0 = qn0;
@@ -402,9 +192,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
             }
 #endif
             {
-#ifdef KZ_VARIANT_QWAIT_END
-                if (stream_q) asm volatile("" ::"v"(qn0.x), "v"(qn1.x));  // retire the query-fragment loads before the barrier
-#endif
                 float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 1) & 1) * 2048);
                 nb[tid] = ya0;
                 nb[tid + 256] = ya1;
@@ -496,547 +283,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Variant 2: the LDS-staged kernel with 32-k macro slices (two 16-k slices per workgroup barrier).
-// The barrier ablation priced the per-slice barrier at ~16 % (waves of a workgroup drift by the data-dependent
-// epilogue and by SIMD arbitration); twice the MFMA work between barriers halves their number.  Needs an even
-// number of 16-k slices per tile (d_pad % 32 == 0); other shapes use the 16-k kernel.
-// LDS: 2 x 16 KiB index macro slices + bias + the candidate log.
-// ---------------------------------------------------------------------------------------------------
-constexpr int KZ_CAND2_LDS_BASE = 32768 + 1024;
-constexpr int KZ_CAND2_LDS = KZ_CAND2_LDS_BASE + KZ_LOG_CAP * 256 * 8;
-
-template <int KP>
-__global__ __launch_bounds__(256, 2) void kz_knn_cand2_kernel(KnnCandParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ybuf = reinterpret_cast<float*>(smem);  // 2 x 4096 floats, then 2 x 128 bias floats
-    float* bbuf = ybuf + 8192;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int j = lane & 31;
-    const int h = lane >> 5;
-    const int4 wd = p.work[blockIdx.x];
-    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
-    const int NM = p.kg >> 3;  // 32-k macro slices per tile
-    const int total = (t_end - t_begin) * NM;
-
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
-    KzCandState st;
-    st.lk = p.out_key + listoff;
-    st.li = p.out_idx + listoff;
-    st.sk = reinterpret_cast<float*>(smem + KZ_CAND2_LDS_BASE) + tid;
-    st.si = reinterpret_cast<int*>(smem + KZ_CAND2_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
-#pragma unroll 4
-    for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
-    }
-    st.tau = -INFINITY;
-    st.minpos = 0;
-    st.cnt = 0;
-    st.tiles_done = 0;
-    st.next_merge = 1;
-    if (total <= 0) return;
-
-    const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * p.kg) * 512);  // 1024 float4 per macro slice
-    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg + h) * 512 + (32 * wave + j) * 4;
-    auto load_q4 = [&](float4 (&q)[4], int m) {  // fragments of macro slice m: k-groups 8m + 2u + h, u = 0..3
-        const float* src = qbase + (int64_t)m * 8 * 512;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = kz_nt_load4(reinterpret_cast<const float4*>(src + u * 1024));
-    };
-    {
-        float4* nb = reinterpret_cast<float4*>(ybuf);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) nb[tid + 256 * c] = ysrc[tid + 256 * c];
-        bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
-    }
-    float4 qb[4];
-    load_q4(qb, 0);
-    __syncthreads();
-
-    int g = 0;
-    f32x16 acc[4];
-    const float* bias_n = p.ybias + (tid & 127);
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
-                    acc[mt][4 * g4 + 0] = v.x;
-                    acc[mt][4 * g4 + 1] = v.y;
-                    acc[mt][4 * g4 + 2] = v.z;
-                    acc[mt][4 * g4 + 3] = v.w;
-                }
-            }
-        }
-        int m = 0;
-        do {
-            // prefetch the next macro slice (unconditional; the clamp re-reads the last one at the very end)
-            const int gn = min(g + 1, total - 1);
-            const float4* src = ysrc + (int64_t)gn * 1024;
-            float4 ya[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ya[c] = src[tid + 256 * c];
-            const int tile_n = min(tile + 1, p.n_ytiles - 1);
-            const float bn = bias_n[(int64_t)tile_n * KZ_TILE];
-            float4 qn[4];
-            load_q4(qn, (m + 1 == NM) ? 0 : m + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const float* buf = ybuf + (g & 1) * 4096;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {  // k-groups 2u + h of the macro slice
-                float4 a[4];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    a[mt] = *reinterpret_cast<const float4*>(buf + ((2 * u + h) * KZ_TILE + 32 * mt + j) * 4);
-                const float4 bq = qb[u];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 1) & 1) * 4096);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) nb[tid + 256 * c] = ya[c];
-                bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) qb[u] = qn[u];
-            }
-            __syncthreads();
-            ++g;
-        } while (++m < NM);
-        __builtin_amdgcn_sched_barrier(0);
-        kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Variant 3: LDS ring with per-wave progress counters instead of workgroup barriers.
-// Same tiling as kz_knn_cand_kernel, but the four waves of a workgroup are decoupled: the index slices go through a
-// ring of 4 LDS buffers, slice g+2 is staged during slice g, and a wave may start slice g as soon as EVERY wave has
-// completed slice g-2 (then all quarters of slice g are in LDS and nobody still reads the buffer that slice g+2
-// overwrites).  Progress is one LDS word per wave, written after the wave's own LDS traffic of the slice has
-// retired (LDS executes a wave's operations in order).  No s_barrier in the sweep; spins are bounded and a time-out
-// raises an error on the host.  (Barrier ablation: 139 vs 122 TF on C1.)
-// LDS: 4 x 8 KiB ring + bias rows + progress words + an 8-entry candidate log per lane.
-// ---------------------------------------------------------------------------------------------------
-constexpr int KZ_RING_CAP = 8;
-constexpr int KZ_RING_BIAS = 32768;                 // byte offset of the 2 x 128 bias floats
-constexpr int KZ_RING_PROG = KZ_RING_BIAS + 1024;   // 4 progress words (+ padding)
-constexpr int KZ_RING_LOG = KZ_RING_PROG + 64;
-constexpr int KZ_RING_LDS = KZ_RING_LOG + KZ_RING_CAP * 256 * 8;
-
-template <int KP>
-__global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ybuf = reinterpret_cast<float*>(smem);
-    float* bbuf = reinterpret_cast<float*>(smem + KZ_RING_BIAS);
-    int* prog = reinterpret_cast<int*>(smem + KZ_RING_PROG);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31;
-    const int h = lane >> 5;
-    const int4 wd = p.work[blockIdx.x];
-    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
-    const int NS = p.kg >> 2;  // >= 4 (host)
-    const int total = (t_end - t_begin) * NS;
-
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
-    KzCandState st;
-    st.lk = p.out_key + listoff;
-    st.li = p.out_idx + listoff;
-    st.sk = reinterpret_cast<float*>(smem + KZ_RING_LOG) + tid;
-    st.si = reinterpret_cast<int*>(smem + KZ_RING_LOG + KZ_RING_CAP * 256 * 4) + tid;
-#pragma unroll 4
-    for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
-    }
-    st.tau = -INFINITY;
-    st.minpos = 0;
-    st.cnt = 0;
-    st.tiles_done = 0;
-    st.next_merge = 1;
-    if (total <= 0) return;
-
-    // Circular sweep: workgroup b starts a third of the range further than b-1, so workgroups that are co-resident
-    // on one CU stream DIFFERENT index tiles at any time (no same-line pending stalls in the CU's L1); tiles are
-    // visited in the order t_begin + (i + off) % nt.  The candidate logic is order-independent.
-    const int nt = t_end - t_begin;
-    const int off = p.phase_tiles > 0 ? (int)(((int64_t)(blockIdx.x % 3) * nt) / 3) : 0;
-    const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * NS) * 2048);
-    auto slice_src = [&](int gi) {  // global slice counter -> address of that slice under the circular tile order
-        if (off == 0) return ysrc + (int64_t)gi * 512;
-        const int ti = gi / NS;
-        const int sli = gi - ti * NS;
-        int tp = ti + off;
-        if (tp >= nt) tp -= nt;
-        return ysrc + ((int64_t)tp * NS + sli) * 512;
-    };
-    auto tile_of = [&](int ti) {
-        int tp = ti + off;
-        if (tp >= nt) tp -= nt;
-        return t_begin + tp;
-    };
-    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg) * 512 + (32 * (tid >> 6) + j) * 4;
-    // prologue: slices 0 and 1, bias rows of the first tile, progress words; ONE workgroup barrier
-    {
-        float4* nb = reinterpret_cast<float4*>(ybuf);
-        const float4* s0 = slice_src(0);
-        nb[tid] = s0[tid];
-        nb[tid + 256] = s0[256 + tid];
-        const float4* s1 = slice_src(min(1, total - 1));
-        nb[512 + tid] = s1[tid];
-        nb[512 + tid + 256] = s1[256 + tid];
-        bbuf[(tid & 127)] = p.ybias[(int64_t)tile_of(0) * KZ_TILE + (tid & 127)];
-        if (tid < 4) prog[tid] = 0;
-    }
-    // query fragments: current slice (qb) and the next one (qn) in registers, the one after that in flight
-    float4 qb0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (0 + h) * 512));
-    float4 qb1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (2 + h) * 512));
-    float4 qn0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 + h) * 512));   // slice 1 (NS >= 4)
-    float4 qn1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (6 + h) * 512));
-    __syncthreads();
-
-    int g = 0;
-    f32x16 acc[4];
-    const float* bias_n = p.ybias + (tid & 127);
-    for (int ti = 0; ti < nt; ++ti) {
-        const int tile = tile_of(ti);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const float* bp = bbuf + (ti & 1) * 128 + 4 * h;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
-                    acc[mt][4 * g4 + 0] = v.x;
-                    acc[mt][4 * g4 + 1] = v.y;
-                    acc[mt][4 * g4 + 2] = v.z;
-                    acc[mt][4 * g4 + 3] = v.w;
-                }
-            }
-        }
-        // bias rows of the next tile: ONE load per tile (parked in LDS during the first slice, see (d))
-        const float bn = bias_n[(int64_t)tile_of(min(ti + 1, nt - 1)) * KZ_TILE];
-        int sl = 0;
-        do {
-            // (a) every wave must have completed slice g-2
-            if (g >= 2) {
-                int spins = 0;
-                for (;;) {
-                    const int p0 = __hip_atomic_load(prog + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int p1 = __hip_atomic_load(prog + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int p2 = __hip_atomic_load(prog + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int p3 = __hip_atomic_load(prog + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int pm = min(min(p0, p1), min(p2, p3));
-                    if (__builtin_amdgcn_readfirstlane(pm) >= g - 1) break;
-                    if (++spins > (1 << 22)) {  // ~seconds: give up loudly instead of hanging the GPU
-                        if (lane == 0) atomicOr(p.err, 1);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                asm volatile("" ::: "memory");  // compiler-only ordering: LDS itself is in order per wave, no caches
-            }
-            // (b) prefetch: index slice g+2 (-> registers), bias rows of the next tile, query fragments of slice g+1
-            const int gn = min(g + 2, total - 1);
-            const float4* src = slice_src(gn);
-            const float4 ya0 = src[tid];
-            const float4 ya1 = src[256 + tid];
-            const int sl2 = (sl + 2 >= NS) ? sl + 2 - NS : sl + 2;  // query fragments TWO slices ahead
-            const float4 qm0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sl2 + h) * 512));
-            const float4 qm1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sl2 + 2 + h) * 512));
-            __builtin_amdgcn_sched_barrier(0);
-            // (c) 32 MFMAs out of ring buffer g % 4
-            const float* buf = ybuf + (g & 3) * 2048;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float4 a[4];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    a[mt] = *reinterpret_cast<const float4*>(buf + ((2 * t + h) * KZ_TILE + 32 * mt + j) * 4);
-                const float4 bq = t ? qb1 : qb0;
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // (d) stage slice g+2 into ring buffer (g+2) % 4
-            {
-                float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 2) & 3) * 2048);
-                nb[tid] = ya0;
-                nb[tid + 256] = ya1;
-                if (sl == 0) bbuf[((ti + 1) & 1) * 128 + (tid & 127)] = bn;  // every wave passes slice 0 before any starts tile ti+1
-                qb0 = qn0;
-                qb1 = qn1;
-                qn0 = qm0;
-                qn1 = qm1;
-            }
-            // (e) publish: this wave has completed slice g (its reads of buffer g%4 and its writes are retired)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS traffic retired; do NOT drain vmcnt (query loads in flight)
-            if (lane == 0) __hip_atomic_store(prog + wave, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            ++g;
-        } while (++sl < NS);
-        __builtin_amdgcn_sched_barrier(0);
-        kz_tile_epilogue<KP, KZ_RING_CAP>(acc, st, tile, ti == nt - 1, h, (float)p.kg);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Variant 4: stationary query tile.  For d_pad == 16*NSR (NSR = 4 or 8, i.e. d <= 64 / d <= 128) the query fragments of
-// all slices stay in registers for the whole sweep (64 VGPRs at NSR = 8), so the per-slice query-fragment loads of the
-// streaming kernel disappear (diagnostic build without them: 149 vs 122 TF on C1).  To keep three waves per SIMD the
-// index slices are staged with LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write); the packed image is
-// copied linearly, which is exactly the lane-linear layout LDS-DMA writes.  One workgroup barrier per slice; its
-// fence also retires the DMA of the next slice.
-// ---------------------------------------------------------------------------------------------------
-template <int KP, int NSR>
-__global__ __launch_bounds__(256, 3) void kz_knn_cand_res_kernel(KnnCandParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ybuf = reinterpret_cast<float*>(smem);            // 2 x 2048 floats
-    float* bbuf = ybuf + 4096;                                // 2 x 128 bias floats
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31;
-    const int h = lane >> 5;
-    const int4 wd = p.work[blockIdx.x];
-    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
-    const int total = (t_end - t_begin) * NSR;
-
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
-    KzCandState st;
-    st.lk = p.out_key + listoff;
-    st.li = p.out_idx + listoff;
-    st.sk = reinterpret_cast<float*>(smem + KZ_CAND_LDS_BASE) + tid;
-    st.si = reinterpret_cast<int*>(smem + KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
-#pragma unroll 4
-    for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
-    }
-    st.tau = -INFINITY;
-    st.minpos = 0;
-    st.cnt = 0;
-    st.tiles_done = 0;
-    st.next_merge = 1;
-    if (total <= 0) return;
-
-    // LDS-DMA: lane l of wave w copies 16 B from gsrc + (64*(w + 4c) + l)*16 to LDS slice + (64*(w + 4c))*16 + l*16, c = 0, 1
-    const float* ysrc = p.ypack + ((int64_t)t_begin * NSR) * 2048 + tid * 4;   // per-lane source of slice 0, chunk 0
-    auto dma_slice = [&](int gi, int buf) {
-        const float* src = ysrc + (int64_t)gi * 2048;
-        float* dst = ybuf + buf * 2048 + wave * 256;  // wave-uniform LDS base (floats)
-        kz_glds16(src, dst);
-        kz_glds16(src + 1024, dst + 1024);
-    };
-    // prologue: slice 0 by DMA, bias rows of the first tile, resident query fragments
-    dma_slice(0, 0);
-    bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
-    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * (4 * NSR) + h) * 512 + (32 * (tid >> 6) + j) * 4;
-    float4 qres[NSR][2];
-#pragma unroll
-    for (int u = 0; u < NSR; ++u) {
-        qres[u][0] = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * u) * 512));
-        qres[u][1] = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * u + 2) * 512));
-    }
-    __syncthreads();
-
-    int g = 0;
-    f32x16 acc[4];
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
-                    acc[mt][4 * g4 + 0] = v.x;
-                    acc[mt][4 * g4 + 1] = v.y;
-                    acc[mt][4 * g4 + 2] = v.z;
-                    acc[mt][4 * g4 + 3] = v.w;
-                }
-            }
-        }
-        // bias rows of the next tile (one 4-byte load per thread per tile; parked in LDS after slice 0)
-        const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
-#pragma unroll
-        for (int u = 0; u < NSR; ++u) {
-            dma_slice(min(g + 1, total - 1), (g + 1) & 1);   // next slice lands in the other buffer while we compute
-            __builtin_amdgcn_sched_barrier(0);
-            const float* buf = ybuf + (g & 1) * 2048;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float4 a[4];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    a[mt] = *reinterpret_cast<const float4*>(buf + ((2 * t + h) * KZ_TILE + 32 * mt + j) * 4);
-                const float4 bq = qres[u][t];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
-            __syncthreads();   // fence drains vmcnt: the DMA of slice g+1 has landed; everyone is done with buffer g&1
-            ++g;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Barrier-free variant: every wave feeds its MFMAs straight from L1/L2.
-// The LDS-staged kernel above shares one index slice among its 4 waves and pays one workgroup barrier per slice;
-// removing only those barriers (diagnostic build) raised C1 from 119 to 139 TF, i.e. the waves of a workgroup drift
-// on their SIMDs and the barrier stalls cost ~16 %.  Here each lane loads its own A fragments from the packed image
-// (512-B coalesced segments, the 4 waves of a workgroup and the co-resident workgroups hit the same lines in L1/L2),
-// double-buffered one half-slice (16 MFMAs) ahead, so waves never wait for each other.  LDS only holds the
-// candidate logs and a per-wave copy of the tile's bias rows.
-// ---------------------------------------------------------------------------------------------------
-constexpr int KZ_DIRECT_LDS = KZ_LOG_CAP * 256 * 8 + 4 * 2 * 128 * 4;
-
-template <int KP>
-__global__ __launch_bounds__(256, 3) void kz_knn_cand_direct_kernel(KnnCandParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int j = lane & 31;
-    const int h = lane >> 5;
-    const int4 wd = p.work[blockIdx.x];
-    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
-    const int HS = p.kg >> 1;  // half-slices (8 k each side of the lane halves = 16 MFMAs) per tile
-    const int total = (t_end - t_begin) * HS;
-
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
-    KzCandState st;
-    st.lk = p.out_key + listoff;
-    st.li = p.out_idx + listoff;
-    st.sk = reinterpret_cast<float*>(smem) + tid;
-    st.si = reinterpret_cast<int*>(smem + KZ_LOG_CAP * 256 * 4) + tid;
-#pragma unroll 4
-    for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
-    }
-    st.tau = -INFINITY;
-    st.minpos = 0;
-    st.cnt = 0;
-    st.tiles_done = 0;
-    st.next_merge = 1;
-    if (total <= 0) return;
-
-    float* bbuf = reinterpret_cast<float*>(smem + KZ_LOG_CAP * 256 * 8) + wave * 256;  // this wave's 2 x 128 bias floats
-    // Linear stream of half-slices: G = (tile - t_begin) * HS + hs; lane (j, h) reads k-group 2*hs + h of rows 32*mt + j:
-    //   address(G, mt) = ybase + G*1024 + h*512 + (32*mt + j)*4   (floats)
-    const float* ybase = p.ypack + ((int64_t)t_begin * p.kg) * 512 + h * 512 + j * 4;
-    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg + h) * 512 + (32 * wave + j) * 4;
-    auto load_a = [&](float4 (&a)[4], int G) {
-        const float* src = ybase + (int64_t)G * 1024;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const float4*>(src + mt * 128);
-    };
-    auto load_q = [&](int hs) { return kz_nt_load4(reinterpret_cast<const float4*>(qbase + (int64_t)hs * 1024)); };
-    auto mfma16 = [&](f32x16 (&acc)[4], const float4 (&a)[4], const float4& bq) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
-    };
-
-    // prologue: fragments of half-slice 0, bias rows of the first tile (each wave keeps its own copy: no barriers)
-    float4 a0[4], a1[4];
-    load_a(a0, 0);
-    float4 q0 = load_q(0), q1;
-    {
-        const float* bsrc = p.ybias + (int64_t)t_begin * KZ_TILE;
-        bbuf[(t_begin & 1) * 128 + lane] = bsrc[lane];
-        bbuf[(t_begin & 1) * 128 + 64 + lane] = bsrc[64 + lane];
-    }
-    kz_wave_sync();
-
-    int G = 0;
-    f32x16 acc[4];
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
-                    acc[mt][4 * g4 + 0] = v.x;
-                    acc[mt][4 * g4 + 1] = v.y;
-                    acc[mt][4 * g4 + 2] = v.z;
-                    acc[mt][4 * g4 + 3] = v.w;
-                }
-            }
-        }
-        // bias rows of the next tile: loaded now, parked in LDS after the slices
-        const int tile_n = min(tile + 1, p.n_ytiles - 1);
-        const float bn0 = p.ybias[(int64_t)tile_n * KZ_TILE + lane];
-        const float bn1 = p.ybias[(int64_t)tile_n * KZ_TILE + 64 + lane];
-        int hs = 0;
-        do {  // two half-slices per trip so that the fragment buffers alternate without register moves (HS is even)
-            {
-                const int Gn = min(G + 1, total - 1);
-                load_a(a1, Gn);
-                q1 = load_q(hs + 1);  // hs + 1 < HS always (hs even)
-                __builtin_amdgcn_sched_barrier(0);
-                mfma16(acc, a0, q0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            {
-                const int Gn = min(G + 2, total - 1);
-                load_a(a0, Gn);
-                q0 = load_q(hs + 2 == HS ? 0 : hs + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma16(acc, a1, q1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            G += 2;
-            hs += 2;
-        } while (hs < HS);
-        bbuf[((tile + 1) & 1) * 128 + lane] = bn0;
-        bbuf[((tile + 1) & 1) * 128 + 64 + lane] = bn1;
-        kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
-        kz_wave_sync();  // bias rows visible to this wave's own lanes before the next tile's init
-    }
-}
+#include "kz_knn_variants.h"
 
 // ---------------------------------------------------------------------------------------------------
 // Stage 2: merge + certify + float64 re-rank

@@ -1,0 +1,196 @@
+// Device-side building blocks shared by the fused distance + candidate-selection kernels (kz_knn.hip and the
+// experimental variants in kz_knn_variants.h): parameter block, candidate list / log state, tile epilogue.
+#pragma once
+#include "kz_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// LDS-DMA: each lane copies 16 bytes from its own global address to (wave-uniform LDS base) + lane*16
+__device__ __forceinline__ void kz_glds16(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-temporal 16-byte load (streaming cache policy)
+    const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// Diagnostic builds only (tools/ablate.sh): -DKZ_ABLATE=n removes parts of the fused kernel to price them
+// (1: no list inserts, 2: + no epilogue max, 3: + no LDS refill / barrier, 4: + no global prefetch).  Results are
+// wrong in those builds; the shipped library is built with KZ_ABLATE undefined (= 0).
+#ifndef KZ_ABLATE
+#define KZ_ABLATE 0
+#endif
+// -DKZ_STAMP: in-kernel s_memtime stamps per section, summed into p.dbg (diagnostic build, never shipped/timed).
+#ifdef KZ_STAMP
+#define KZ_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define KZ_T(var)
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// Stage 1: fused similarity + candidate selection
+// ---------------------------------------------------------------------------------------------------
+// similarity key(q, y) = q.y + bias(y)     bias = -|y|^2/2 (euclidean: argmax key == argmin |q-y|^2), 0 (cosine)
+//
+// Workgroup = 256 threads = 4 waves, tile = 128 index rows (MFMA M) x 128 queries (MFMA N).
+// Wave w owns queries [32w, 32w+32) and all 128 index rows of the tile: 4 accumulators of 32x32.
+// With the query on the MFMA column (= lane & 31), the 64 keys a lane holds after a tile all belong to ONE
+// query, so each lane keeps a PRIVATE candidate list (query, lane-half) and needs no atomics or barriers:
+//   list(q, h) sees index rows with (row & 4) == 4h; union of the two halves' top-K' contains the top-K'.
+// Index operand: streamed HBM/L2 -> registers -> LDS (double buffered 8 KiB slices, one barrier per slice).
+// Query operand: per-lane fragments straight from L2 (no reuse across waves, so no LDS round trip).
+// Candidate-list storage: queries of region-1 tiles own c1 slots of 2*KP entries, queries of region-2 tiles c2 slots.
+__host__ __device__ __forceinline__ int64_t kz_list_base(int64_t list_row, int reg_a, int c1, int c2, int KP) {
+    const int64_t a_rows = (int64_t)reg_a * KZ_TILE;
+    if (list_row < a_rows) return list_row * (int64_t)(c1 * 2 * KP);
+    return a_rows * (int64_t)(c1 * 2 * KP) + (list_row - a_rows) * (int64_t)(c2 * 2 * KP);
+}
+
+struct KnnCandParams {
+    const float* qpack;   // packed query matrix
+    const float* ypack;   // packed index matrix
+    const float* ybias;   // accumulator init per index row
+    const int4* work;     // one descriptor per workgroup: {query tile (local), first index tile, end index tile, list slot}
+    int qt0;              // first query tile of this launch (global tile index into qpack)
+    int n_ytiles;         // index tiles
+    int reg_a;            // query tiles [0, reg_a) keep reg_c1 list slots per query, the rest reg_c2 (kz_list_base)
+    int reg_c1;
+    int reg_c2;
+    int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
+    float* out_key;       // region 1: [reg_a*128][reg_c1][2][KP], then region 2: [(n_qtiles-reg_a)*128][reg_c2][2][KP]
+    int* out_idx;
+    int stagger_cycles;   // start-up delay unit: workgroup b sleeps ((b / n_cus) % 3) * stagger_cycles (phase-shifts co-resident groups)
+    int n_cus;
+    int* cu_tickets;      // [16*256] zeroed per launch
+    int* err;             // device error word (ring kernel: spin time-out)
+    int phase_tiles;      // ring kernel: > 0 enables the circular sweep with per-workgroup start offsets
+    unsigned long long* dbg;  // diagnostic stamp build only (-DKZ_STAMP): cycle sums {slices, epilogue, init, waves}
+};
+
+constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows
+constexpr int KZ_QGROUP = 24;                   // query tiles sharing an XCD at a time (x splits ~= resident workgroups)
+constexpr int KZ_LOG_CAP = 16;                  // per-lane candidate log entries (keys + rows: 32 KiB per workgroup)
+constexpr int KZ_CAND_LDS = KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 8;
+
+// Replace the minimum of an unsorted K'-entry list by (v, idx) and find the new minimum.  All keys are fetched
+// before the compare chain starts so that the LDS latency is paid once, not per element.
+template <int KP, int LSTRIDE>
+__device__ __forceinline__ void kz_list_replace_min(float* lk, int* li, float v, int idx, float& tau, int& minpos) {
+    lk[minpos * LSTRIDE] = v;
+    li[minpos * LSTRIDE] = idx;
+    float mn = INFINITY;
+    int mp = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < KP; c0 += 16) {
+        float kk[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) kk[e] = lk[(c0 + e) * LSTRIDE];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (kk[e] < mn) {
+                mn = kk[e];
+                mp = c0 + e;
+            }
+        }
+    }
+    tau = mn;
+    minpos = mp;
+}
+
+
+
+__device__ __forceinline__ void kz_wave_sync() {
+    // cross-lane exchange through LDS inside ONE wave: LDS ops of a wave execute in order, the fences only stop
+    // the compiler from reordering the accesses.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Per-lane candidate state of one (query, lane-half) pair (see kz_knn_cand_kernel).
+struct KzCandState {
+    float* lk;   // list keys  (global, K' entries, unsorted)
+    int* li;     // list rows
+    float* sk;   // log keys   (LDS, stride 256)
+    int* si;     // log rows
+    float tau;   // K'-th best key of the list as of the last merge
+    int minpos;
+    int cnt;     // log entries
+    int tiles_done, next_merge;
+};
+
+// Tile epilogue shared by both fused kernels.  C layout of the 32x32 MFMA: col = lane & 31 (query),
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Lanes l and l+32 hold the two half-lists of ONE query: a key below the OTHER
+// half's K'-th best cannot be in the merged top-K' either, so both halves prune with the larger of the two thresholds.
+template <int KP, int CAP = KZ_LOG_CAP>
+__device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
+                                                 const int h, const float never) {
+    float tau_eff = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
+    const int rowbase = tile * KZ_TILE + 4 * h;
+    ++st.tiles_done;
+    const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
+    unsigned long long done = 0ull;  // elements of this tile already logged (bit 16*mt + r)
+    for (;;) {
+        bool ovf = false;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#if KZ_ABLATE >= 2 && KZ_ABLATE <= 4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[mt][r]));
+            float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#else
+            float m4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                m4[g4] = fmaxf(fmaxf(acc[mt][4 * g4], acc[mt][4 * g4 + 1]), fmaxf(acc[mt][4 * g4 + 2], acc[mt][4 * g4 + 3]));
+#endif
+            const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+#if KZ_ABLATE >= 1 && KZ_ABLATE <= 4
+            if (m > tau_eff + 1e30f * never) {  // runtime-impossible: keeps the max tree, drops the logging
+#else
+            if (m > tau_eff) {
+#endif
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if (m4[g4] > tau_eff) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int r = 4 * g4 + r4;
+                            const float v = acc[mt][r];
+                            const unsigned long long bit = 1ull << (16 * mt + r);
+                            if (v > tau_eff && !(done & bit)) {
+                                if (st.cnt < CAP) {
+                                    int rb = rowbase;
+                                    asm volatile("" : "+v"(rb));  // keep the 64 row ids out of registers: computed on demand
+                                    st.sk[st.cnt * 256] = v;
+                                    st.si[st.cnt * 256] = rb + 32 * mt + (r & 3) + 8 * (r >> 2);
+                                    ++st.cnt;
+                                    done |= bit;
+                                } else {
+                                    ovf = true;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const bool any_ovf = __any(ovf);
+        if (!any_ovf && !sched) break;
+        // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
+        for (int e = 0; e < st.cnt; ++e) {
+            const float v = st.sk[e * 256];
+            if (v > st.tau) kz_list_replace_min<KP, 1>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+        }
+        st.cnt = 0;
+        tau_eff = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
+        if (!any_ovf) break;  // (a scheduled merge after an overflow round happens on the next pass)
+    }
+    if (st.tiles_done == st.next_merge) {
+        const int step = st.tiles_done * CAP / KP;
+        st.next_merge = st.tiles_done + (step > 0 ? step : 1);
+    }
+}
+
