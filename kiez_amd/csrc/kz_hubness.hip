@@ -157,36 +157,90 @@ __global__ void kz_mp_normal_kernel(const double* __restrict__ dist, const int64
 //   out[i,j] = 1 - #{m : d[i,m] > d[i,j] and T_j[m] > d[i,j]} / K
 //   T_j[m]   = dist_t2s[c_j, p] if ind_t2s[c_j, p] == c_m (c_m is a TARGET id matched against SOURCE ids: the
 //              reference's behaviour) else dist_t2s[c_j, Kt-1] + 1e-6
+// The K candidate ids of the query are rank-sorted once into LDS; for every j the Kt reverse-list ids of c_j are
+// looked up by binary search (K log K instead of K^2 id compares per j) and scattered into T.
+constexpr int KZ_MP_MAXK = 128;
+
 __global__ __launch_bounds__(256) void kz_mp_empiric_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind,
                                                             int64_t n, int K, const double* __restrict__ dist_t2s,
                                                             const int64_t* __restrict__ ind_t2s, int64_t n_t, int Kt,
                                                             double* __restrict__ out) {
+    __shared__ long long s_sorted[4][KZ_MP_MAXK];  // candidate ids in ascending order
+    __shared__ double s_T[4][KZ_MP_MAXK];          // T_j indexed by SORTED candidate position
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
-    if (i >= n) return;
+    if (i >= n) return;  // whole wave; only wave-level synchronisation below
     const double* d_i = dist + i * (int64_t)K;
     const int64_t* c_i = ind + i * (int64_t)K;
+    long long* sorted = s_sorted[wave];
+    double* T = s_T[wave];
+    // this lane's candidates m = lane, lane + 64: distance, id, rank of the id among the K ids
+    double dm[2] = {0.0, 0.0};
+    long long cm[2] = {0, 0};
+    int rk[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int m = lane + 64 * u;
+        if (m < K) {
+            dm[u] = d_i[m];
+            cm[u] = c_i[m];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int m = lane + 64 * u;
+        if (m < K) {
+            int r = 0;
+            for (int o = 0; o < K; ++o) {
+                const long long co = c_i[o];
+                r += (co < cm[u] || (co == cm[u] && o < m)) ? 1 : 0;
+            }
+            rk[u] = r;
+            sorted[r] = cm[u];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int j = 0; j < K; ++j) {
         const double dj = d_i[j];
         const int64_t cj = c_i[j];
         const double* rd = dist_t2s + cj * (int64_t)Kt;
         const int64_t* ri = ind_t2s + cj * (int64_t)Kt;
         const double fill = rd[Kt - 1] + 1e-6;
-        int cnt = 0;
-        for (int m = lane; m < K; m += 64) {
-            const double dm = d_i[m];
-            if (dm > dj) {
-                const int64_t cm = c_i[m];
-                double T = fill;
-                for (int pp = 0; pp < Kt; ++pp)
-                    if (ri[pp] == cm) T = rd[pp];
-                cnt += (T > dj) ? 1 : 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (lane + 64 * u < K) T[lane + 64 * u] = fill;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // every reverse-list entry p looks its id up among the sorted candidate ids
+        for (int pp = lane; pp < Kt; pp += 64) {
+            const long long id = ri[pp];
+            int lo = 0, hi = K - 1, pos = -1;
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1;
+                const long long v = sorted[mid];
+                if (v == id) {
+                    pos = mid;
+                    break;
+                }
+                if (v < id) lo = mid + 1; else hi = mid - 1;
             }
+            if (pos >= 0) T[pos] = rd[pp];  // ids inside one kNN row are distinct: at most one writer per position
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (lane + 64 * u < K && dm[u] > dj && T[rk[u]] > dj) ++cnt;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
         if (lane == 0) out[i * (int64_t)K + j] = 1.0 - (double)cnt / (double)K;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
