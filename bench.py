@@ -33,6 +33,8 @@ WORKLOADS = {
            "C2: 100k x 100k, d=128, euclidean, k=10, hubness=CSLS"),
     "c3s": (100_000, 100_000, 200, "cosine", 50, 50, "MutualProximity", {"method": "empiric"},
             "C3 (scaled to 100k x 100k): d=200, cosine, k=50, MutualProximity empiric"),
+    "c3": (500_000, 500_000, 200, "cosine", 50, 50, "MutualProximity", {"method": "empiric"},
+           "C3: 500k x 500k, d=200, cosine, k=50, MutualProximity empiric"),
     "c4s": (250_000, 1_000_000, 300, "euclidean", 10, 10, "CSLS", {},
             "C4 per-GPU share: 250k source rows x 1M target, d=300, k=10, CSLS"),
     "c1g": (100_000, 100_000, 128, "euclidean", 10, 10, None, {},

@@ -54,6 +54,7 @@ struct kz_matrix {
     int kg;           // d_pad / 4 (number of 4-wide k-groups), d_pad = round_up(d, 16)
     void* raw;        // [n, d] dtype, row-major (exact data, used by the float64 re-rank)
     float* packed;    // [n_tiles][kg][128][4] float32 MFMA operand image
+    unsigned short* packed_bf;  // [n_tiles][kg/4][4 planes][128][8] bf16 split image: planes hi(k 0-7), hi(k 8-15), lo, lo
     float* bias;      // [n_tiles*128] accumulator init: -|y|^2/2 (euclidean family), 0 (cosine), -inf (pad rows)
     double* sqn;      // [n] float64: squared norms (euclidean family) or norms with 0 -> 1 (cosine)
     double max_norm;  // max_j |y_j|  (host copy)

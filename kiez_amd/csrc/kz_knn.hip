@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
-#if KZ_ABLATE >= 4
+#if (KZ_ABLATE >= 4 && KZ_ABLATE <= 5) || KZ_ABLATE == 22
             const float4 ya0 = make_float4(0.f, 0.f, 0.f, 0.f), ya1 = ya0;
             const float bn = 0.f;
 #else
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
 #endif
             float4 qn0, qn1;
             if (stream_q) {
-#if KZ_ABLATE == 5
+#if KZ_ABLATE == 5 || KZ_ABLATE == 21
                 qn0 = bq1;  // diagnostic: no query-fragment loads
                 qn1 = bq0;
 #else
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
 }
 
 #include "kz_knn_variants.h"
+#include "kz_knn_bf16.h"
 
 // ---------------------------------------------------------------------------------------------------
 // Stage 2: merge + certify + float64 re-rank
@@ -658,6 +659,71 @@ static int kz_launch_res(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
     return KZ_OK;
 }
 
+template <int KP, int NSR>
+static int kz_bf_occupancy(int* blocks_per_cu) {
+    auto kern = kz_knn_cand_bf_kernel<KP, NSR>;
+    KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_BF_LDS));
+    int nb = 0;
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_BF_LDS));
+    *blocks_per_cu = nb < 1 ? 1 : nb;
+    return KZ_OK;
+}
+
+template <int KP, int NSR>
+static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
+    hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, NSR>), dim3(n_blocks), dim3(256), KZ_BF_LDS, ctx->stream, p);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+#define KZ_DISPATCH_BF_NSR(rc, fn, args, KPV)             \
+    do {                                                  \
+        switch (n_slices) {                               \
+            case 2: rc = fn<KPV, 2> args; break;          \
+            case 3: rc = fn<KPV, 3> args; break;          \
+            case 4: rc = fn<KPV, 4> args; break;          \
+            case 5: rc = fn<KPV, 5> args; break;          \
+            case 6: rc = fn<KPV, 6> args; break;          \
+            case 7: rc = fn<KPV, 7> args; break;          \
+            default: rc = fn<KPV, 8> args; break;         \
+        }                                                 \
+    } while (0)
+#define KZ_DISPATCH_BF(rc, fn, args)                                  \
+    do {                                                              \
+        switch (KP) {                                                 \
+            case 16: KZ_DISPATCH_BF_NSR(rc, fn, args, 16); break;     \
+            case 32: KZ_DISPATCH_BF_NSR(rc, fn, args, 32); break;     \
+            case 64: KZ_DISPATCH_BF_NSR(rc, fn, args, 64); break;     \
+            default: KZ_DISPATCH_BF_NSR(rc, fn, args, 128); break;    \
+        }                                                             \
+    } while (0)
+
+template <int KP, int NB>
+static int kz_il_occupancy(int* blocks_per_cu) {
+    auto kern = kz_knn_cand_il_kernel<KP, NB>;
+    int nb = 0;
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KzIl<NB>::LDS));
+    *blocks_per_cu = nb < 1 ? 1 : nb;
+    return KZ_OK;
+}
+
+template <int KP, int NB>
+static int kz_launch_il(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
+    hipLaunchKernelGGL((kz_knn_cand_il_kernel<KP, NB>), dim3(n_blocks), dim3(256), KzIl<NB>::LDS, ctx->stream, p);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+#define KZ_DISPATCH_IL(rc, fn, args)                                                    \
+    do {                                                                                \
+        switch (KP) {                                                                   \
+            case 16: if (il_nb == 3) rc = fn<16, 3> args; else rc = fn<16, 2> args; break;   \
+            case 32: if (il_nb == 3) rc = fn<32, 3> args; else rc = fn<32, 2> args; break;   \
+            case 64: if (il_nb == 3) rc = fn<64, 3> args; else rc = fn<64, 2> args; break;   \
+            default: if (il_nb == 3) rc = fn<128, 3> args; else rc = fn<128, 2> args; break; \
+        }                                                                               \
+    } while (0)
+
 #define KZ_DISPATCH_RES(rc, fn, args)                                                   \
     do {                                                                                \
         if (n_slices == 8) {                                                            \
@@ -764,7 +830,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     const int max_splits_m = KZ_FIN_MAXM / (2 * KP);
     // rounding bound factor: (d_pad + 16) * 2^-24 covers the d+1 step fma chain, the float32 rounding of the bias
     // and (float64 inputs) of the operands; 1e-12 covers the float64 re-rank's own rounding.
-    const double gamma = ((double)(index->kg * 4 + 16) * 5.9604644775390625e-08 + 1e-12) * ctx->eps_scale;
+    const double gamma_f32 = ((double)(index->kg * 4 + 16) * 5.9604644775390625e-08 + 1e-12) * ctx->eps_scale;
+    const double gamma_bf = kz_bf16_gamma(index->kg * 4) * ctx->eps_scale;
 
     const int n_slices = index->kg / 4;
     // Resident query slices (registers).  Measured on C1 (d=128): 0 resident slices at 3 workgroups/CU beat 8 resident
@@ -776,28 +843,50 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     const bool macro32 = ctx->kernel_variant == 2 && (index->kg % 8) == 0 && nres == 0;  // 2: 32-k macro slices
     const bool ring = ctx->kernel_variant == 3 && n_slices >= 4 && nres == 0;            // 3: LDS ring, no workgroup barriers
     const bool resident = ctx->kernel_variant == 4 && (n_slices == 8 || n_slices == 4) && KP <= 32;  // 4: stationary query tile
-    int blocks_per_cu = 1;
-    {
-        int rc0;
-        if (direct)
-            KZ_DISPATCH_DIRECT(rc0, kz_direct_occupancy, (&blocks_per_cu));
-        else if (macro32)
-            KZ_DISPATCH_DIRECT(rc0, kz_cand2_occupancy, (&blocks_per_cu));
-        else if (ring)
-            KZ_DISPATCH_DIRECT(rc0, kz_ring_occupancy, (&blocks_per_cu));
-        else if (resident)
-            KZ_DISPATCH_RES(rc0, kz_res_occupancy, (&blocks_per_cu));
-        else
-            KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
-        if (rc0 != KZ_OK) return rc0;
-    }
-    const int slots = blocks_per_cu * ctx->n_cus;
+    const bool interleaved = (ctx->kernel_variant == 5 || ctx->kernel_variant == 6) && nres == 0;  // 5/6: interleaved stream
+    const int il_nb = ctx->kernel_variant == 6 ? 3 : 2;
+    // Precision tiers: the split-bf16 first pass (kz_knn_bf16.h) when the query tile fits in registers (d_pad <= 128);
+    // a chunk in which too many rows fail the (wider) bf16 certification is re-done by the float32-MFMA kernel, and
+    // so are all later chunks of this call.
+    bool tier_bf = ctx->kernel_variant == 7 && n_slices >= 2 && n_slices <= 8;
+    int slots_f32 = 0, slots_bf = 0;
+    auto slots_for = [&](bool bf, int* out) -> int {
+        int& cache = bf ? slots_bf : slots_f32;
+        if (cache == 0) {
+            int blocks_per_cu = 1;
+            int rc0;
+            if (bf)
+                KZ_DISPATCH_BF(rc0, kz_bf_occupancy, (&blocks_per_cu));
+            else if (interleaved)
+                KZ_DISPATCH_IL(rc0, kz_il_occupancy, (&blocks_per_cu));
+            else if (direct)
+                KZ_DISPATCH_DIRECT(rc0, kz_direct_occupancy, (&blocks_per_cu));
+            else if (macro32)
+                KZ_DISPATCH_DIRECT(rc0, kz_cand2_occupancy, (&blocks_per_cu));
+            else if (ring)
+                KZ_DISPATCH_DIRECT(rc0, kz_ring_occupancy, (&blocks_per_cu));
+            else if (resident)
+                KZ_DISPATCH_RES(rc0, kz_res_occupancy, (&blocks_per_cu));
+            else
+                KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
+            if (rc0 != KZ_OK) return rc0;
+            cache = blocks_per_cu * ctx->n_cus;
+        }
+        *out = cache;
+        return KZ_OK;
+    };
     // query rows are processed in chunks so that the candidate lists stay below ~1 GiB
     const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096;
     double main_ms = 0, fin_ms = 0, fb_ms = 0;
-    int64_t n_fail_total = 0;
+    int64_t n_fail_total = 0, n_escalated = 0;
     int last_splits = 1, last_blocks = 0;
-    for (int64_t c0 = 0; c0 < q_count; c0 += max_rows_per_chunk) {
+    for (int64_t c0 = 0; c0 < q_count;) {
+        int slots = 0;
+        {
+            const int rcs = slots_for(tier_bf, &slots);
+            if (rcs != KZ_OK) return rcs;
+        }
+        const double gamma = tier_bf ? gamma_bf : gamma_f32;
         const int64_t cq_begin = q_begin + c0;
         const int64_t cq_count = (q_count - c0 < max_rows_per_chunk) ? (q_count - c0) : max_rows_per_chunk;
         const int qt0 = (int)(cq_begin / KZ_TILE);
@@ -902,8 +991,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         }
 
         KnnCandParams cp;
-        cp.qpack = query->packed;
-        cp.ypack = index->packed;
+        cp.qpack = tier_bf ? (const float*)query->packed_bf : query->packed;
+        cp.ypack = tier_bf ? (const float*)index->packed_bf : index->packed;
         cp.ybias = index->bias;
         cp.work = d_work;
         cp.qt0 = qt0;
@@ -926,7 +1015,11 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         KZ_HIP(hipMemsetAsync(cp.dbg, 0, 10 * sizeof(unsigned long long), ctx->stream));
 #endif
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-        if (direct)
+        if (tier_bf)
+            KZ_DISPATCH_BF(rc, kz_launch_bf, (ctx, cp, W));
+        else if (interleaved)
+            KZ_DISPATCH_IL(rc, kz_launch_il, (ctx, cp, W));
+        else if (direct)
             KZ_DISPATCH_DIRECT(rc, kz_launch_direct, (ctx, cp, W));
         else if (macro32)
             KZ_DISPATCH_DIRECT(rc, kz_launch_cand2, (ctx, cp, W));
@@ -1009,6 +1102,13 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         fin_ms += ms;
         last_splits = c1;
         last_blocks = W;
+        if (tier_bf && (int64_t)n_fail * 50 > cq_count + 3200) {
+            // more than ~2 % (+64) of the chunk's rows could not be certified under the split-bf16 margin: this data
+            // needs the float32 operands; redo the chunk (and run the rest of the call) with the float32-MFMA kernel
+            tier_bf = false;
+            n_escalated += cq_count;
+            continue;
+        }
         n_fail_total += n_fail;
 
         if (n_fail > 0) {
@@ -1056,7 +1156,9 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
             fb_ms += ms;
         }
+        c0 += max_rows_per_chunk;
     }
+    (void)n_escalated;
     if (stats) {
         stats->main_kernel_ms = main_ms;
         stats->finalize_ms = fin_ms;

@@ -1,0 +1,138 @@
+// Split-bf16 first pass of the fused kNN kernel (included by kz_knn.hip).
+//
+// Same contract as kz_knn_cand_kernel -- per-(query, lane-half) unsorted candidate lists of approximate keys
+// key~ = q.y + bias(y), later certified and re-ranked in float64 by kz_knn_finalize_kernel -- but the products run on
+// the bf16 matrix pipe, 16x the float32 MFMA rate.  Every operand is split as x = hi + lo + r (kz_pack.hip) and
+//     q.y  ~=  hi_q.hi_y + hi_q.lo_y + lo_q.hi_y                  (3 x v_mfma_f32_32x32x16_bf16 per 16 k)
+// accumulated in float32.  bf16 x bf16 products are exact in float32; the dropped terms are bounded by
+// 3.1 * 2^-16 |q||y| (kz_bf16_gamma below), which only widens the certification margin: rows whose candidate set
+// cannot be certified under the wider margin are re-done by the float32-MFMA kernel / the exact float64 kernels,
+// so the result is still the float64 neighbour order.
+//
+// Structure (d_pad = 16 * NSR <= 128):
+//   * the query tile is STATIONARY: the hi/lo fragments of all NSR slices stay in registers (8 VGPRs per slice),
+//     so the only global stream is the index image -- which is what made the float32 kernel lose ~20 % (section 7);
+//   * index slices go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write) into a ring
+//     of four 8 KiB slots; ONE workgroup barrier per two slices, placed on the global slice counter so that tile
+//     boundaries (epilogues) and barriers are independent;
+//   * 2 workgroups per CU (the register budget of the stationary tile), 4 waves x 32 queries each.
+#pragma once
+
+typedef __bf16 kz_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int KZ_BF_LDS_BASE = 4 * 8192 + 1024;   // ring of 4 slices + 2 x 128 bias floats
+constexpr int KZ_BF_CAP = 16;
+constexpr int KZ_BF_LDS = KZ_BF_LDS_BASE + KZ_BF_CAP * 256 * 8;
+
+// Relative rounding bound of the split-bf16 key (multiplies |y|max^2/2 + |q||y|max like the float32 bound does):
+//   split:        |x - hi - lo| <= 2^-16 (1 + 2^-7) |x|  per operand  ->  dropped terms <= 3.1 * 2^-16 |q||y|
+//   accumulation: 3 d_pad products + bias summed in float32 by the matrix pipe in an unspecified order; (n + 16) u
+//                 is the any-order bound for round-to-nearest, doubled to allow for truncating internal adds.
+static inline double kz_bf16_gamma(int d_pad) {
+    return 3.1 * 1.52587890625e-05 + 2.0 * (double)(3 * d_pad + 16) * 5.9604644775390625e-08 + 1e-12;
+}
+
+template <int KP, int NSR>
+__global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ybuf = reinterpret_cast<float*>(smem);   // 4 slots x 2048 floats (8 KiB: planes hi0, hi1, lo0, lo1)
+    float* bbuf = ybuf + 4 * 2048;                   // 2 x 128 bias floats
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int4 wd = p.work[blockIdx.x];
+    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
+    const int total = (t_end - t_begin) * NSR;
+
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    KzCandState st;
+    st.lk = p.out_key + listoff;
+    st.li = p.out_idx + listoff;
+    st.sk = reinterpret_cast<float*>(smem + KZ_BF_LDS_BASE) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_BF_LDS_BASE + KZ_BF_CAP * 256 * 4) + tid;
+#pragma unroll 4
+    for (int e = 0; e < KP; ++e) {
+        st.lk[e] = -INFINITY;
+        st.li[e] = -1;
+    }
+    st.tau = -INFINITY;
+    st.minpos = 0;
+    st.cnt = 0;
+    st.tiles_done = 0;
+    st.next_merge = 1;
+    if (total <= 0) return;
+
+    // LDS-DMA of one 8 KiB slice: lane l of wave w copies 16 B from src + (64 (w + 4c) + l) * 16 to the same offset
+    // of the slot, c = 0, 1 (the image is copied linearly: it already is the LDS layout)
+    const float* ysrc = p.ypack + ((int64_t)t_begin * NSR) * 2048 + tid * 4;
+    auto dma_slice = [&](int gi) {
+        const float* src = ysrc + (int64_t)min(gi, total - 1) * 2048;
+        float* dst = ybuf + (gi & 3) * 2048 + wave * 256;  // wave-uniform LDS base (floats)
+        kz_glds16(src, dst);
+        kz_glds16(src + 1024, dst + 1024);
+    };
+    dma_slice(0);
+    dma_slice(1);
+    dma_slice(2);
+    dma_slice(3);
+    bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
+    // stationary query fragments: lane (j, h) holds k = 16 u + 8 h + 0..7 of query row 32 wave + j, hi and lo
+    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * NSR) * 2048 + (h * KZ_TILE + 32 * (tid >> 6) + j) * 4;
+    kz_bf16x8 qh[NSR], ql[NSR];
+#pragma unroll
+    for (int u = 0; u < NSR; ++u) {
+        qh[u] = *reinterpret_cast<const kz_bf16x8*>(qbase + u * 2048);
+        ql[u] = *reinterpret_cast<const kz_bf16x8*>(qbase + u * 2048 + 1024);
+    }
+    __syncthreads();
+
+    const float* fbase = ybuf + (h * KZ_TILE + j) * 4;  // this lane's fragment inside a slot: plane h, row j (+ 32 mt)
+    int g = 0;
+    f32x16 acc[4];
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        {
+            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
+                    acc[mt][4 * g4 + 0] = v.x;
+                    acc[mt][4 * g4 + 1] = v.y;
+                    acc[mt][4 * g4 + 2] = v.z;
+                    acc[mt][4 * g4 + 3] = v.w;
+                }
+            }
+        }
+        // bias rows of the next tile (one 4-byte load per thread per tile; parked in LDS after the first slice)
+        const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
+#pragma unroll
+        for (int u = 0; u < NSR; ++u) {
+            const float* fb = fbase + (g & 3) * 2048;
+            kz_bf16x8 ah[4], al[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                ah[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt);
+                al[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt + 1024);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], qh[u], acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], ql[u], acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], qh[u], acc[mt], 0, 0, 0);
+            if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+            if (g & 1) {
+                // slices g-1 and g are consumed: after the barrier their slots take slices g+3 and g+4, while g+1 and
+                // g+2 (issued one barrier ago, drained by the fence of __syncthreads) are ready to be read
+                __syncthreads();
+                dma_slice(g + 3);
+                dma_slice(g + 4);
+            }
+            ++g;
+        }
+        kz_tile_epilogue<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
+    }
+}

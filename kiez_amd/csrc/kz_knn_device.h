@@ -73,6 +73,10 @@ constexpr int KZ_QGROUP = 24;                   // query tiles sharing an XCD at
 constexpr int KZ_LOG_CAP = 16;                  // per-lane candidate log entries (keys + rows: 32 KiB per workgroup)
 constexpr int KZ_CAND_LDS = KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 8;
 
+#ifndef KZ_SCAN_CHUNK
+#define KZ_SCAN_CHUNK 16  // list keys fetched per batch in kz_list_replace_min (register temporaries of the merge path)
+#endif
+
 // Replace the minimum of an unsorted K'-entry list by (v, idx) and find the new minimum.  All keys are fetched
 // before the compare chain starts so that the LDS latency is paid once, not per element.
 template <int KP, int LSTRIDE>
@@ -82,13 +86,13 @@ __device__ __forceinline__ void kz_list_replace_min(float* lk, int* li, float v,
     float mn = INFINITY;
     int mp = 0;
 #pragma unroll
-    for (int c0 = 0; c0 < KP; c0 += 16) {
-        float kk[16];
+    for (int c0 = 0; c0 < KP; c0 += KZ_SCAN_CHUNK) {
+        float kk[KZ_SCAN_CHUNK];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) kk[e] = lk[(c0 + e) * LSTRIDE];
+        for (int e = 0; e < KZ_SCAN_CHUNK; ++e) kk[e] = lk[(c0 + e) * LSTRIDE];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < KZ_SCAN_CHUNK; ++e) {
             if (kk[e] < mn) {
                 mn = kk[e];
                 mp = c0 + e;

@@ -217,6 +217,14 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
         bbuf[(tid & 127)] = p.ybias[(int64_t)tile_of(0) * KZ_TILE + (tid & 127)];
         if (tid < 4) prog[tid] = 0;
     }
+    // index slices are loaded THREE slices ahead and parked in registers for one more slice before they go to LDS:
+    // the load -> LDS-write distance is two slices of MFMA time instead of one
+    float4 yp0, yp1;   // slice g+2 (loaded during slice g-1), written to LDS at the end of slice g
+    {
+        const float4* s2 = slice_src(min(2, total - 1));
+        yp0 = s2[tid];
+        yp1 = s2[256 + tid];
+    }
     // query fragments: current slice (qb) and the next one (qn) in registers, the one after that in flight
     float4 qb0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (0 + h) * 512));
     float4 qb1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (2 + h) * 512));
@@ -267,9 +275,9 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
                 asm volatile("" ::: "memory");  // compiler-only ordering: LDS itself is in order per wave, no caches
             }
             // (b) prefetch: index slice g+2 (-> registers), bias rows of the next tile, query fragments of slice g+1
-            const int gn = min(g + 2, total - 1);
+            const int gn = min(g + 3, total - 1);
             const float4* src = slice_src(gn);
-            const float4 ya0 = src[tid];
+            const float4 ya0 = src[tid];     // slice g+3: written to LDS at the end of slice g+1
             const float4 ya1 = src[256 + tid];
             const int sl2 = (sl + 2 >= NS) ? sl + 2 - NS : sl + 2;  // query fragments TWO slices ahead
             const float4 qm0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sl2 + h) * 512));
@@ -297,8 +305,10 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
             // (d) stage slice g+2 into ring buffer (g+2) % 4
             {
                 float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 2) & 3) * 2048);
-                nb[tid] = ya0;
-                nb[tid + 256] = ya1;
+                nb[tid] = yp0;               // slice g+2, loaded one slice ago
+                nb[tid + 256] = yp1;
+                yp0 = ya0;
+                yp1 = ya1;
                 if (sl == 0) bbuf[((ti + 1) & 1) * 128 + (tid & 127)] = bn;  // every wave passes slice 0 before any starts tile ti+1
                 qb0 = qn0;
                 qb1 = qn1;
@@ -415,8 +425,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_res_kernel(KnnCandParams p
                 for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);  // keep only one t-group of A fragments live (register budget)
             }
-            __builtin_amdgcn_sched_barrier(0);
             if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
             __syncthreads();   // fence drains vmcnt: the DMA of slice g+1 has landed; everyone is done with buffer g&1
             ++g;
@@ -551,3 +561,168 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_direct_kernel(KnnCandParam
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Variant 5: interleaved instruction stream.  Same data flow as the shipped kernel (index slices staged through LDS,
+// query fragments streamed one slice ahead, one workgroup barrier per slice), but the per-slice global loads, the
+// LDS reads of the second k-half and the LDS refill are placed BETWEEN groups of four MFMAs instead of in front of /
+// behind the 32-MFMA block.  A wave issues in order: a vector-memory instruction that has to wait for a slot in the
+// CU's address path holds back everything behind it, so in the shipped stream [5 loads][4 ds_read][wait][32 MFMA] a
+// busy memory path delays the wave's MFMAs; here each memory instruction issues in the shadow of the MFMAs that were
+// issued just before it.  PMC: the shipped kernel keeps the MFMA pipe 78.5 % busy, the same build without its global
+// loads 89.7 % at the same clock (tools/pmc_clock.sh).
+// NB = 2: two slice buffers; the first k-half's fragments are read right after the barrier.
+// NB = 3: three slice buffers (log capacity 12 instead of 16 to stay at three workgroups per CU); slices are staged
+//         two ahead, so the next slice's first fragments are read before the barrier, under this slice's MFMAs.
+// ---------------------------------------------------------------------------------------------------
+template <int NB>
+struct KzIl {
+    static constexpr int CAP = NB == 3 ? 12 : 16;
+    static constexpr int LOG_BASE = NB * 8192 + 1024;
+    static constexpr int LDS = LOG_BASE + CAP * 256 * 8;
+};
+
+#define KZ_MFMA4(A, C, B)                                                                                     \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc[mt] =                                                \
+        __builtin_amdgcn_mfma_f32_32x32x2f32(A[mt].C, B.C, acc[mt], 0, 0, 0)
+#define KZ_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int KP, int NB>
+__global__ __launch_bounds__(256, 3) void kz_knn_cand_il_kernel(KnnCandParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CAP = KzIl<NB>::CAP;
+    float* ybuf = reinterpret_cast<float*>(smem);   // NB x 2048 floats
+    float* bbuf = ybuf + NB * 2048;                  // 2 x 128 bias floats
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int4 wd = p.work[blockIdx.x];
+    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
+    const int NS = p.kg >> 2;
+    const int total = (t_end - t_begin) * NS;
+
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    KzCandState st;
+    st.lk = p.out_key + listoff;
+    st.li = p.out_idx + listoff;
+    st.sk = reinterpret_cast<float*>(smem + KzIl<NB>::LOG_BASE) + tid;
+    st.si = reinterpret_cast<int*>(smem + KzIl<NB>::LOG_BASE + CAP * 256 * 4) + tid;
+#pragma unroll 4
+    for (int e = 0; e < KP; ++e) {
+        st.lk[e] = -INFINITY;
+        st.li[e] = -1;
+    }
+    st.tau = -INFINITY;
+    st.minpos = 0;
+    st.cnt = 0;
+    st.tiles_done = 0;
+    st.next_merge = 1;
+    if (total <= 0) return;
+
+    const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * NS) * 2048);
+    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg) * 512 + (32 * wave + j) * 4;
+    // prologue: the first NB-1 slices and the bias rows of the first tile
+    {
+        float4* nb = reinterpret_cast<float4*>(ybuf);
+#pragma unroll
+        for (int u = 0; u < NB - 1; ++u) {
+            const float4* s0 = ysrc + (int64_t)min(u, total - 1) * 512;
+            nb[u * 512 + tid] = s0[tid];
+            nb[u * 512 + 256 + tid] = s0[256 + tid];
+        }
+        bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
+    }
+    // query fragments: qb = current slice, qn = next slice (loaded early in the slice, copied at its end)
+    float4 qb0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (0 + h) * 512));
+    float4 qb1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (2 + h) * 512));
+    __syncthreads();
+
+    // fragment address of this lane inside a slice buffer: k-half t -> k-group 2t + h, rows 32 mt + j
+    const float* fbase = ybuf + (h * KZ_TILE + j) * 4;
+    auto frag = [&](float4 (&a)[4], const int b, const int t) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            a[mt] = *reinterpret_cast<const float4*>(fbase + b * 2048 + (2 * t * KZ_TILE + 32 * mt) * 4);
+    };
+    float4 a0[4], a1[4];
+    int g = 0;
+    int bcur = 0;  // buffer holding slice g
+    if (NB == 3) frag(a0, 0, 0);
+    f32x16 acc[4];
+    const float* bias_n = p.ybias + (tid & 127);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        KZ_SB();
+        {
+            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
+                    acc[mt][4 * g4 + 0] = v.x;
+                    acc[mt][4 * g4 + 1] = v.y;
+                    acc[mt][4 * g4 + 2] = v.z;
+                    acc[mt][4 * g4 + 3] = v.w;
+                }
+            }
+        }
+        // bias rows of the next tile: one load per tile, parked in LDS by every slice's refill (same value)
+        const float bn = bias_n[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE];
+        KZ_SB();
+        int sl = 0;
+        do {
+            const int sln = (sl + 1 == NS) ? 0 : sl + 1;
+            const int gn = min(g + NB - 1, total - 1);
+            const float4* src = ysrc + (int64_t)gn * 512;
+            const int bnext = bcur + 1 == NB ? 0 : bcur + 1;                        // buffer of slice g+1
+            const int bfill = NB == 2 ? bnext : (bnext + 1 == NB ? 0 : bnext + 1);  // buffer of slice g+NB-1
+            if (NB == 2) frag(a0, bcur, 0);
+            KZ_SB();
+            KZ_MFMA4(a0, x, qb0);
+            KZ_SB();
+            const float4 ya0 = src[tid];
+            const float4 ya1 = src[256 + tid];
+            KZ_SB();
+            KZ_MFMA4(a0, y, qb0);
+            KZ_SB();
+            const float4 qn0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sln + h) * 512));
+            const float4 qn1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sln + 2 + h) * 512));
+            KZ_SB();
+            KZ_MFMA4(a0, z, qb0);
+            KZ_SB();
+            frag(a1, bcur, 1);
+            KZ_SB();
+            KZ_MFMA4(a0, w, qb0);
+            KZ_SB();
+            KZ_MFMA4(a1, x, qb1);
+            KZ_SB();
+            if (NB == 3) frag(a0, bnext, 0);   // slice g+1 became visible at the previous barrier
+            KZ_SB();
+            KZ_MFMA4(a1, y, qb1);
+            KZ_SB();
+            KZ_MFMA4(a1, z, qb1);
+            KZ_SB();
+            {
+                float4* nb = reinterpret_cast<float4*>(ybuf + bfill * 2048);
+                nb[tid] = ya0;
+                nb[tid + 256] = ya1;
+                bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+            }
+            KZ_SB();
+            KZ_MFMA4(a1, w, qb1);
+            KZ_SB();
+            // keep the current fragments live up to here: the next ones then get registers of their own and the
+            // copies (and the wait for the loads behind them) stay at the end of the slice
+            asm volatile("" ::"v"(qb0.x), "v"(qb0.y), "v"(qb0.z), "v"(qb0.w), "v"(qb1.x), "v"(qb1.y), "v"(qb1.z), "v"(qb1.w));
+            qb0 = qn0;
+            qb1 = qn1;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            bcur = bnext;
+            ++g;
+        } while (++sl < NS);
+        KZ_SB();
+        kz_tile_epilogue<KP, CAP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
+    }
+}

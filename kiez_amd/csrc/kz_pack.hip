@@ -5,11 +5,24 @@
 // One 16-k slice of one tile is 4 consecutive kgroups = a contiguous 8 KiB block, and consecutive slices
 // (also across tile boundaries) are consecutive in memory, so the kernel's HBM stream is purely linear.
 // Inside a kgroup the 128 rows x 16 B are exactly the conflict-free ds_read_b128 image of the MFMA A/B operand.
+//
+// Split-bf16 image (first-pass operand of the bf16x2 kernel, same geometry and size): x = hi + lo + r with
+// hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-16 |x| (1 + 2^-7).  One 16-k slice = four 2 KiB planes
+//     packed_bf[tile][slice][plane][row_in_tile][8]     plane 0/1 = hi of k 0-7 / 8-15, plane 2/3 = lo of the same
+// i.e. plane p of lane-half h is the 16-byte fragment v_mfma_f32_32x32x16_bf16 expects (lane l: row l&31, k 8(l>>5)+j).
 #include "kz_common.h"
+
+// round-to-nearest-even float32 -> bf16 bits (finite inputs)
+__device__ __forceinline__ unsigned short kz_bf16_rn(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float kz_bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void kz_pack_kernel(const T* __restrict__ raw, int64_t n, int d, int metric, int kg,
                                                       int64_t n_pad, float* __restrict__ packed,
+                                                      unsigned short* __restrict__ packed_bf,
                                                       float* __restrict__ bias, double* __restrict__ sqn,
                                                       unsigned long long* __restrict__ maxnorm_bits,
                                                       int* __restrict__ bad_flag) {
@@ -22,8 +35,15 @@ __global__ __launch_bounds__(256) void kz_pack_kernel(const T* __restrict__ raw,
         const int64_t tile = row >> 7;
         const int r = (int)(row & 127);
         float* dst = packed + (tile * kg) * (int64_t)(KZ_TILE * 4) + r * 4;
+        // bf16 image: element k of this row -> slice k/16, plane (k/8)&1 (+2 for lo), 8 values per row and plane
+        unsigned short* dbf = packed_bf + (tile * kg) * (int64_t)(KZ_TILE * 8) + r * 8;
+        auto bf_off = [](int k) { return (int64_t)(k >> 4) * (4 * KZ_TILE * 8) + ((k >> 3) & 1) * (KZ_TILE * 8) + (k & 7); };
         if (row >= n) {
-            for (int k = lane; k < d_pad; k += 64) dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = 0.0f;
+            for (int k = lane; k < d_pad; k += 64) {
+                dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = 0.0f;
+                dbf[bf_off(k)] = 0;
+                dbf[bf_off(k) + 2 * KZ_TILE * 8] = 0;
+            }
             if (lane == 0) bias[row] = -INFINITY;
             continue;
         }
@@ -50,9 +70,13 @@ __global__ __launch_bounds__(256) void kz_pack_kernel(const T* __restrict__ raw,
             wmax = fmax(wmax, sqrt(sq));
         }
         for (int k = lane; k < d_pad; k += 64) {
-            float v = 0.0f;
-            if (k < d) v = (metric == KZ_COSINE) ? (float)((double)x[k] / scale_div) : (float)x[k];
-            dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = v;
+            double vd = 0.0;
+            if (k < d) vd = (metric == KZ_COSINE) ? (double)x[k] / scale_div : (double)x[k];
+            dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = (float)vd;
+            const unsigned short hi = kz_bf16_rn((float)vd);
+            const unsigned short lo = kz_bf16_rn((float)(vd - (double)kz_bf16_to_f32(hi)));
+            dbf[bf_off(k)] = hi;
+            dbf[bf_off(k) + 2 * KZ_TILE * 8] = lo;
         }
     }
     if (lane == 0) s_max[wave] = wmax;
@@ -94,9 +118,10 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
         return code;
     };
     if (kz_pool_alloc(ctx, raw_bytes, &m->raw) != KZ_OK || kz_pool_alloc(ctx, packed_bytes, (void**)&m->packed) != KZ_OK ||
+        kz_pool_alloc(ctx, packed_bytes, (void**)&m->packed_bf) != KZ_OK ||
         kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&m->bias) != KZ_OK ||
         kz_pool_alloc(ctx, (size_t)n * 8, (void**)&m->sqn) != KZ_OK) {
-        kz_set_error("kz_matrix_create: out of device memory (raw %zu B + packed %zu B)", raw_bytes, packed_bytes);
+        kz_set_error("kz_matrix_create: out of device memory (raw %zu B + 2 x packed %zu B)", raw_bytes, packed_bytes);
         return fail(KZ_ERR_NOMEM);
     }
     hipError_t e = hipMemcpyAsync(m->raw, rows, raw_bytes, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -117,10 +142,10 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     int* bad = ctx->d_counters + 2;
     if (dtype == KZ_F32)
         hipLaunchKernelGGL(kz_pack_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)m->raw, n, (int)d,
-                           metric, m->kg, n_pad, m->packed, m->bias, m->sqn, mx, bad);
+                           metric, m->kg, n_pad, m->packed, m->packed_bf, m->bias, m->sqn, mx, bad);
     else
         hipLaunchKernelGGL(kz_pack_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)m->raw, n,
-                           (int)d, metric, m->kg, n_pad, m->packed, m->bias, m->sqn, mx, bad);
+                           (int)d, metric, m->kg, n_pad, m->packed, m->packed_bf, m->bias, m->sqn, mx, bad);
     e = hipGetLastError();
     if (e == hipSuccess)
         e = hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
@@ -146,6 +171,7 @@ int kz_matrix_destroy(kz_matrix* m) {
         (void)hipSetDevice(m->ctx->device);
         kz_pool_free(m->ctx, m->raw, 0);
         kz_pool_free(m->ctx, m->packed, 0);
+        kz_pool_free(m->ctx, m->packed_bf, 0);
         kz_pool_free(m->ctx, m->bias, 0);
         kz_pool_free(m->ctx, m->sqn, 0);
     }

@@ -46,7 +46,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->min_splits = 1;
     c->stagger = 0;
     c->kernel_variant = 0;
-    if (const char* kv = getenv("KZ_KERNEL_VARIANT")) c->kernel_variant = (kv[0] >= '0' && kv[0] <= '4') ? kv[0] - '0' : 0;  // A/B runs of the test-suite
+    if (const char* kv = getenv("KZ_KERNEL_VARIANT")) c->kernel_variant = (kv[0] >= '0' && kv[0] <= '7') ? kv[0] - '0' : 0;  // A/B runs of the test-suite
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -96,7 +96,7 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
         KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
         c->force_splits = (int)value;
     } else if (strcmp(name, "kernel_variant") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 4 && value == (int)value, "kernel_variant must be 0..4");
+        KZ_REQUIRE(value >= 0 && value <= 7 && value == (int)value, "kernel_variant must be 0..7");
         c->kernel_variant = (int)value;
     } else if (strcmp(name, "stagger") == 0) {
         KZ_REQUIRE(value >= -1 && value <= 1e7, "stagger must be in [-1, 1e7] cycles");
