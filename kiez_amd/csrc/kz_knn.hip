@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
     //   log   up to KZ_LOG_CAP keys that beat the pruning threshold since the last merge (LDS, append-only).
     // The threshold is only refreshed at merges, which follow a geometric schedule in the number of tiles seen
     // (identical for every lane, so merges run with all 64 lanes busy); a full log forces an early merge.
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
 struct KnnFinParams {
     const float* in_key;  // [rows][M]
     const int* in_idx;
-    int reg_a, reg_c1, reg_c2;  // list layout (kz_list_base)
+    KzListLayout lay;     // list layout (kz_list_base)
     int max_m;            // largest entry count of a query in this launch (sizes the dynamic LDS)
     int64_t q_first, q_last;  // local query range [q_first, q_last) handled by this launch
     int KP;
@@ -395,10 +395,10 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
     const int k_eff = p.k + (p.exclude_self ? 1 : 0);
 
     const int64_t lrow = p.list_row0 + q;
-    const int64_t lbase = kz_list_base(lrow, p.reg_a, p.reg_c1, p.reg_c2, KP);
+    const int64_t lbase = kz_list_base(lrow, p.lay, KP);
     const float* gk = p.in_key + lbase;
     const int* gi = p.in_idx + lbase;
-    const int M = (lrow < (int64_t)p.reg_a * KZ_TILE ? p.reg_c1 : p.reg_c2) * 2 * KP;
+    const int M = p.lay.pieces[kz_list_region(lrow, p.lay)] * 2 * KP;
     for (int e = lane; e < M; e += 64) {
         ekey[e] = gk[e];
         eidx[e] = gi[e];
@@ -660,18 +660,18 @@ static int kz_launch_res(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
 }
 
 template <int KP, int NSR>
-static int kz_bf_occupancy(int* blocks_per_cu) {
+static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad) {
     auto kern = kz_knn_cand_bf_kernel<KP, NSR>;
-    KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_BF_LDS));
+    KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_BF_LDS + lds_pad));
     int nb = 0;
-    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_BF_LDS));
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_BF_LDS + lds_pad));
     *blocks_per_cu = nb < 1 ? 1 : nb;
     return KZ_OK;
 }
 
 template <int KP, int NSR>
 static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, NSR>), dim3(n_blocks), dim3(256), KZ_BF_LDS, ctx->stream, p);
+    hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, NSR>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad, ctx->stream, p);
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }
@@ -856,7 +856,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             int blocks_per_cu = 1;
             int rc0;
             if (bf)
-                KZ_DISPATCH_BF(rc0, kz_bf_occupancy, (&blocks_per_cu));
+                KZ_DISPATCH_BF(rc0, kz_bf_occupancy, (&blocks_per_cu, ctx->lds_pad));
             else if (interleaved)
                 KZ_DISPATCH_IL(rc0, kz_il_occupancy, (&blocks_per_cu));
             else if (direct)
@@ -893,10 +893,12 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         const int qt1 = (int)((cq_begin + cq_count - 1) / KZ_TILE);
         const int n_qtiles = qt1 - qt0 + 1;
         // ---- schedule: which workgroup sweeps which (query tile, index-tile range) ------------------------------
-        // Region 1: as many FULL rounds of equal, large items as fit (slots = resident workgroups on the chip);
-        // region 2: the remaining query tiles cut into small items that fill the tail round (dispatch is in block-id
-        // order, so large items go first).  force_splits (test knob) = one region with exactly that many splits.
-        int s1, A, s2;
+        // Greedy rounds.  slots = workgroups resident on the chip; dispatch is in block-id order, so the items of one
+        // region start together and sweep the index in lockstep (each index tile is fetched into L2 once per round).
+        // With R query tiles left, a round cuts the index into s = ceil(slots / R) ranges and takes A = slots / s
+        // query tiles: every round fills the chip with equal-length items, the items shrink from round to round and
+        // only the last few query tiles get the shortest allowed ranges.  force_splits (test knob) = one region
+        // with exactly that many ranges.
         const int by_len = n_ytiles / 8 > 1 ? n_ytiles / 8 : 1;  // keep >= 8 tiles (1024 rows) per item
         auto clamp_s = [&](int v) {
             if (v > max_splits_m) v = max_splits_m;
@@ -904,32 +906,42 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             if (v < 1) v = 1;
             return v;
         };
-        if (ctx->force_splits > 0) {
-            s1 = ctx->force_splits < n_ytiles ? ctx->force_splits : n_ytiles;
-            if (s1 > max_splits_m) s1 = max_splits_m;
-            A = n_qtiles;
-            s2 = s1;
-        } else {
-            s1 = clamp_s((slots + n_qtiles - 1) / n_qtiles);
-            if (s1 < ctx->min_splits) s1 = clamp_s(ctx->min_splits);  // splits per query tile: L2 grouping (KZ_QGROUP)
-            const int rounds = (int)(((int64_t)n_qtiles * s1) / slots);
-            if (rounds == 0) {
-                s1 = clamp_s((slots + n_qtiles - 1) / n_qtiles);  // fewer items than slots: maximise parallelism
-                A = n_qtiles;
-                s2 = s1;
-            } else {
-                A = (int)(((int64_t)rounds * slots) / s1);
-                if (A > n_qtiles) A = n_qtiles;
-                s2 = clamp_s(max_splits_m);
-                if (s2 < s1) s2 = s1;
-            }
-        }
         auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
         auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
-        const int c1 = split_cnt(s1), c2 = split_cnt(s2);
-        const int W1 = A * c1, W2 = (n_qtiles - A) * c2;
-        const int W = W1 + W2;
-        const size_t list_elems = (size_t)kz_list_base((int64_t)n_qtiles * KZ_TILE, A, c1, c2, KP);
+        KzListLayout lay;
+        memset(&lay, 0, sizeof(lay));
+        int reg_q0[KZ_MAX_REGIONS], reg_nq[KZ_MAX_REGIONS], reg_s[KZ_MAX_REGIONS], reg_w0[KZ_MAX_REGIONS];
+        int W = 0;
+        size_t list_elems = 0;
+        {
+            int R = n_qtiles, q0 = 0;
+            while (R > 0) {
+                int sp, A;
+                if (ctx->force_splits > 0) {
+                    sp = ctx->force_splits < n_ytiles ? ctx->force_splits : n_ytiles;
+                    if (sp > max_splits_m) sp = max_splits_m;
+                    A = R;
+                } else {
+                    sp = clamp_s((slots + R - 1) / R);
+                    if (lay.n_regions == 0 && sp < ctx->min_splits) sp = clamp_s(ctx->min_splits);  // L2 grouping knob
+                    A = slots / split_cnt(sp);
+                    if (A < 1) A = 1;
+                    if (A > R || lay.n_regions == KZ_MAX_REGIONS - 1) A = R;
+                }
+                const int r = lay.n_regions++;
+                reg_q0[r] = q0;
+                reg_nq[r] = A;
+                reg_s[r] = sp;
+                reg_w0[r] = W;
+                lay.qt_end[r] = q0 + A;
+                lay.pieces[r] = split_cnt(sp);
+                lay.base[r] = (long long)list_elems;
+                list_elems += (size_t)A * KZ_TILE * (size_t)(lay.pieces[r] * 2 * KP);
+                W += A * lay.pieces[r];
+                q0 += A;
+                R -= A;
+            }
+        }
         const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
         const size_t fail_bytes = ((size_t)cq_count * 4 + 255) & ~(size_t)255;
         const size_t work_bytes = ((size_t)W * sizeof(int4) + 255) & ~(size_t)255;
@@ -985,8 +997,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
                     }
                 }
             };
-            fill_region(0, W1, 0, A, s1);
-            fill_region(W1, W2, A, n_qtiles - A, s2);
+            for (int r = 0; r < lay.n_regions; ++r) fill_region(reg_w0[r], reg_nq[r] * lay.pieces[r], reg_q0[r], reg_nq[r], reg_s[r]);
             KZ_HIP(hipMemcpyAsync(d_work, hw, (size_t)W * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
         }
 
@@ -997,9 +1008,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         cp.work = d_work;
         cp.qt0 = qt0;
         cp.n_ytiles = n_ytiles;
-        cp.reg_a = A;
-        cp.reg_c1 = c1;
-        cp.reg_c2 = c2;
+        cp.lay = lay;
         cp.kg = index->kg;
         cp.out_key = out_key;
         cp.out_idx = out_idx;
@@ -1035,9 +1044,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         KnnFinParams fp;
         fp.in_key = out_key;
         fp.in_idx = out_idx;
-        fp.reg_a = A;
-        fp.reg_c1 = c1;
-        fp.reg_c2 = c2;
+        fp.lay = lay;
         fp.KP = KP;
         fp.list_row0 = cq_begin - (int64_t)qt0 * KZ_TILE;
         fp.q_begin = cq_begin;
@@ -1059,14 +1066,13 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         fp.fail_list = fail_list;
         {
             // one launch per list region: the dynamic LDS follows the region's entry count (occupancy of the gather)
-            const int64_t split_q = (int64_t)A * KZ_TILE - fp.list_row0;  // first local query of region 2
-            const int64_t bounds[3] = {0, split_q < 0 ? 0 : (split_q > cq_count ? cq_count : split_q), cq_count};
-            const int ms[2] = {c1 * 2 * KP, c2 * 2 * KP};
-            for (int rg = 0; rg < 2; ++rg) {
-                if (bounds[rg + 1] <= bounds[rg]) continue;
-                fp.q_first = bounds[rg];
-                fp.q_last = bounds[rg + 1];
-                fp.max_m = ms[rg];
+            for (int rg = 0; rg < lay.n_regions; ++rg) {
+                const int64_t lo = (int64_t)(rg > 0 ? lay.qt_end[rg - 1] : 0) * KZ_TILE - fp.list_row0;
+                const int64_t hi = (int64_t)lay.qt_end[rg] * KZ_TILE - fp.list_row0;
+                fp.q_first = lo < 0 ? 0 : lo;
+                fp.q_last = hi > cq_count ? cq_count : hi;
+                if (fp.q_last <= fp.q_first) continue;
+                fp.max_m = lay.pieces[rg] * 2 * KP;
                 const int fin_blocks = (int)((fp.q_last - fp.q_first + 3) / 4);
                 const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, KP);
                 if (index->dtype == KZ_F32)
@@ -1093,6 +1099,9 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
                     hd[0] / wt, hd[1] / wt, hd[4] / wt, hd[5] / wt, hd[2] / wt, hd[3]);
             fprintf(stderr, "[kz stamp]   inside slices, per wave-tile: query-frag wait %.0f  index-slice wait %.0f  barrier %.0f\n",
                     hd[6] / wt, hd[7] / wt, hd[8] / wt);
+            if (tier_bf)
+                fprintf(stderr, "[kz stamp]   bf16 kernel, per wave-tile: merge cycles %.0f, merge passes %.4f, max-lane inserts %.3f\n",
+                        hd[4] / wt, hd[5] / wt, hd[6] / wt);
         }
 #endif
         float ms = 0;
@@ -1100,7 +1109,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         main_ms += ms;
         KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
         fin_ms += ms;
-        last_splits = c1;
+        last_splits = lay.pieces[0];
         last_blocks = W;
         if (tier_bf && (int64_t)n_fail * 50 > cq_count + 3200) {
             // more than ~2 % (+64) of the chunk's rows could not be certified under the split-bf16 margin: this data

@@ -22,7 +22,7 @@ typedef __bf16 kz_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KZ_BF_LDS_BASE = 4 * 8192 + 1024;   // ring of 4 slices + 2 x 128 bias floats
 constexpr int KZ_BF_CAP = 16;
-constexpr int KZ_BF_LDS = KZ_BF_LDS_BASE + KZ_BF_CAP * 256 * 8;
+constexpr int KZ_BF_LDS = KZ_BF_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 8;   // log rows 0..CAP-1 + one scratch row
 
 // Relative rounding bound of the split-bf16 key (multiplies |y|max^2/2 + |q||y|max like the float32 bound does):
 //   split:        |x - hi - lo| <= 2^-16 (1 + 2^-7) |x|  per operand  ->  dropped terms <= 3.1 * 2^-16 |q||y|
@@ -46,12 +46,12 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
     const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
     st.sk = reinterpret_cast<float*>(smem + KZ_BF_LDS_BASE) + tid;
-    st.si = reinterpret_cast<int*>(smem + KZ_BF_LDS_BASE + KZ_BF_CAP * 256 * 4) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_BF_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
         st.lk[e] = -INFINITY;
@@ -91,7 +91,11 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
     const float* fbase = ybuf + (h * KZ_TILE + j) * 4;  // this lane's fragment inside a slot: plane h, row j (+ 32 mt)
     int g = 0;
     f32x16 acc[4];
+#ifdef KZ_STAMP
+    unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0;
+#endif
     for (int tile = t_begin; tile < t_end; ++tile) {
+        KZ_T(t0);
         {
             const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
 #pragma unroll
@@ -133,6 +137,25 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
             }
             ++g;
         }
-        kz_tile_epilogue<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
+#ifdef KZ_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h, c_merge, n_pass, n_ins);
+        __builtin_amdgcn_sched_barrier(0);
+        c_slices += t1 - t0;
+        c_epi += __builtin_amdgcn_s_memtime() - t1;
+#else
+        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h);
+#endif
     }
+#ifdef KZ_STAMP
+    if (lane == 0 && p.dbg) {
+        atomicAdd(p.dbg + 0, c_slices);
+        atomicAdd(p.dbg + 1, c_epi);
+        atomicAdd(p.dbg + 3, (unsigned long long)(t_end - t_begin));
+        atomicAdd(p.dbg + 4, c_merge);
+        atomicAdd(p.dbg + 5, n_pass);
+        atomicAdd(p.dbg + 6, n_ins);
+    }
+#endif
 }

@@ -40,11 +40,25 @@ __device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-tempora
 //   list(q, h) sees index rows with (row & 4) == 4h; union of the two halves' top-K' contains the top-K'.
 // Index operand: streamed HBM/L2 -> registers -> LDS (double buffered 8 KiB slices, one barrier per slice).
 // Query operand: per-lane fragments straight from L2 (no reuse across waves, so no LDS round trip).
-// Candidate-list storage: queries of region-1 tiles own c1 slots of 2*KP entries, queries of region-2 tiles c2 slots.
-__host__ __device__ __forceinline__ int64_t kz_list_base(int64_t list_row, int reg_a, int c1, int c2, int KP) {
-    const int64_t a_rows = (int64_t)reg_a * KZ_TILE;
-    if (list_row < a_rows) return list_row * (int64_t)(c1 * 2 * KP);
-    return a_rows * (int64_t)(c1 * 2 * KP) + (list_row - a_rows) * (int64_t)(c2 * 2 * KP);
+// Candidate-list storage.  The host schedule (kz_knn) cuts the query tiles of a launch into a few REGIONS; every
+// query of region r owns pieces[r] lists of 2*KP entries (one per index-range piece and lane half).
+constexpr int KZ_MAX_REGIONS = 8;
+struct KzListLayout {
+    int n_regions;
+    int qt_end[KZ_MAX_REGIONS];      // region r = query tiles [qt_end[r-1], qt_end[r])  (local tile numbers)
+    int pieces[KZ_MAX_REGIONS];      // index-range pieces per query tile
+    long long base[KZ_MAX_REGIONS];  // element offset of the region's first list
+};
+__host__ __device__ __forceinline__ int kz_list_region(int64_t list_row, const KzListLayout& L) {
+    const int qt = (int)(list_row / KZ_TILE);
+    int r = 0;
+    while (r + 1 < L.n_regions && qt >= L.qt_end[r]) ++r;
+    return r;
+}
+__host__ __device__ __forceinline__ int64_t kz_list_base(int64_t list_row, const KzListLayout& L, int KP) {
+    const int r = kz_list_region(list_row, L);
+    const int64_t row0 = r > 0 ? (int64_t)L.qt_end[r - 1] * KZ_TILE : 0;
+    return L.base[r] + (list_row - row0) * (int64_t)(L.pieces[r] * 2 * KP);
 }
 
 struct KnnCandParams {
@@ -54,11 +68,9 @@ struct KnnCandParams {
     const int4* work;     // one descriptor per workgroup: {query tile (local), first index tile, end index tile, list slot}
     int qt0;              // first query tile of this launch (global tile index into qpack)
     int n_ytiles;         // index tiles
-    int reg_a;            // query tiles [0, reg_a) keep reg_c1 list slots per query, the rest reg_c2 (kz_list_base)
-    int reg_c1;
-    int reg_c2;
+    KzListLayout lay;     // candidate-list layout of this launch (kz_list_base)
     int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
-    float* out_key;       // region 1: [reg_a*128][reg_c1][2][KP], then region 2: [(n_qtiles-reg_a)*128][reg_c2][2][KP]
+    float* out_key;       // per region: [query rows][pieces][2 lane halves][KP]
     int* out_idx;
     int stagger_cycles;   // start-up delay unit: workgroup b sleeps ((b / n_cus) % 3) * stagger_cycles (phase-shifts co-resident groups)
     int n_cus;
@@ -198,3 +210,86 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
     }
 }
 
+
+// Tile epilogue, second form (used by the split-bf16 kernel, where the epilogue is no longer hidden under MFMA time).
+// Work is proportional to the number of candidate EVENTS instead of the number of value groups entered:
+//   * groups of four values are tested with a 3-instruction max and ONE wave-level branch (ballot), no exec juggling;
+//   * inside a group that holds an event of some lane, each value costs a compare + branch, and only lanes with an
+//     event run the append;
+//   * the append itself is straight-line code; the log has CAP + 1 rows, row CAP is a scratch row;
+//   * no per-element "already logged" bitmask: a lane whose log overflows remembers the ordinal of its first dropped
+//     event; after the merge the tile is scanned again against the SAME event threshold (tau_a), events before that
+//     ordinal are skipped, later ones are appended if they still beat the refreshed threshold (tau_b).
+#ifdef KZ_STAMP
+#define KZ_EPI2_STAMP_ARGS , unsigned long long& c_merge, unsigned long long& n_pass, unsigned long long& n_ins
+#else
+#define KZ_EPI2_STAMP_ARGS
+#endif
+template <int KP, int CAP>
+__device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
+                                                  const int h KZ_EPI2_STAMP_ARGS) {
+    const float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
+    float tau_b = tau_a;
+    int skip = 0;
+    const int rowbase = tile * KZ_TILE + 4 * h;
+    ++st.tiles_done;
+    const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
+    for (;;) {
+        int ev = 0;           // events (values above tau_a) met so far in this pass
+        int first_drop = -1;  // ordinal of the first event that did not fit into the log
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // max of the group in two instructions (inline asm: fmaxf() would first canonicalise every MFMA result)
+                float m;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[mt][4 * g4]), "v"(acc[mt][4 * g4 + 1]), "v"(acc[mt][4 * g4 + 2]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][4 * g4 + 3]));
+                if (__builtin_amdgcn_ballot_w64(m > tau_a) != 0ull) {
+                    float ta = tau_a;
+                    asm volatile("" : "+v"(ta));  // keeps the per-value compares inside the (rarely taken) branch
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float v = acc[mt][4 * g4 + r4];
+                        if (v > ta) {
+                            // straight-line append (no inner branches): events that must not be logged, or do not fit,
+                            // go to the scratch row CAP of the log, which is never read
+                            const int k = ev++;
+                            const bool take = (k >= skip) & (v > tau_b);
+                            const bool fits = st.cnt < CAP;
+                            const int slot = (take & fits) ? st.cnt : CAP;
+                            int rb = rowbase;
+                            asm volatile("" : "+v"(rb));  // row ids are computed on demand, not kept in registers
+                            st.sk[slot * 256] = v;
+                            st.si[slot * 256] = rb + 32 * mt + 8 * g4 + r4;
+                            first_drop = (take & !fits & (first_drop < 0)) ? k : first_drop;
+                            st.cnt += (take & fits) ? 1 : 0;
+                        }
+                    }
+                }
+            }
+        }
+        const bool any_ovf = __any(first_drop >= 0);
+        if (!any_ovf && !sched) break;
+        // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
+        KZ_T(tm0);
+        for (int e = 0; e < st.cnt; ++e) {
+            const float v = st.sk[e * 256];
+            if (v > st.tau) kz_list_replace_min<KP, 1>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+        }
+#ifdef KZ_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        c_merge += __builtin_amdgcn_s_memtime() - tm0;
+        n_pass += 1;
+        n_ins += __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, st.cnt));
+#endif
+        st.cnt = 0;
+        if (!any_ovf) break;
+        tau_b = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
+        skip = first_drop >= 0 ? first_drop : 0x7fffffff;  // lanes without overflow have everything logged
+    }
+    if (st.tiles_done == st.next_merge) {
+        const int step = st.tiles_done * CAP / KP;
+        st.next_merge = st.tiles_done + (step > 0 ? step : 1);
+    }
+}

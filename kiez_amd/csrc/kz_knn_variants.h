@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand2_kernel(KnnCandParams p) {
     const int NM = p.kg >> 3;  // 32-k macro slices per tile
     const int total = (t_end - t_begin) * NM;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
     const int NS = p.kg >> 2;  // >= 4 (host)
     const int total = (t_end - t_begin) * NS;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_res_kernel(KnnCandParams p
     const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_direct_kernel(KnnCandParam
     const int HS = p.kg >> 1;  // half-slices (8 k each side of the lane halves = 16 MFMAs) per tile
     const int total = (t_end - t_begin) * HS;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_il_kernel(KnnCandParams p)
     const int NS = p.kg >> 2;
     const int total = (t_end - t_begin) * NS;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.reg_a, p.reg_c1, p.reg_c2, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;

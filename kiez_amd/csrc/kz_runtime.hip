@@ -44,6 +44,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->force_splits = 0;
     c->force_nres = -1;
     c->min_splits = 1;
+    c->lds_pad = 0;
     c->stagger = 0;
     c->kernel_variant = 0;
     if (const char* kv = getenv("KZ_KERNEL_VARIANT")) c->kernel_variant = (kv[0] >= '0' && kv[0] <= '7') ? kv[0] - '0' : 0;  // A/B runs of the test-suite
@@ -104,6 +105,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "chunk_rows") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 1e9, "chunk_rows must be >= 0");
         c->chunk_rows = (int)value;
+    } else if (strcmp(name, "lds_pad") == 0) {
+        KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
+        c->lds_pad = (int)value;
     } else if (strcmp(name, "min_splits") == 0) {
         KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
         c->min_splits = (int)value;
