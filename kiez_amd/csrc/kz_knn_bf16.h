@@ -21,8 +21,8 @@
 typedef __bf16 kz_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KZ_BF_LDS_BASE = 4 * 8192 + 1024;   // ring of 4 slices + 2 x 128 bias floats
-constexpr int KZ_BF_CAP = 16;
-constexpr int KZ_BF_LDS = KZ_BF_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 8;   // log rows 0..CAP-1 + one scratch row
+constexpr int KZ_BF_CAP = 20;    // log rows per lane; a group of four values is only scanned while every lane has 4 free
+constexpr int KZ_BF_LDS = KZ_BF_LDS_BASE + KZ_BF_CAP * 256 * 8;
 
 // Relative rounding bound of the split-bf16 key (multiplies |y|max^2/2 + |q||y|max like the float32 bound does):
 //   split:        |x - hi - lo| <= 2^-16 (1 + 2^-7) |x|  per operand  ->  dropped terms <= 3.1 * 2^-16 |q||y|
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
     st.sk = reinterpret_cast<float*>(smem + KZ_BF_LDS_BASE) + tid;
-    st.si = reinterpret_cast<int*>(smem + KZ_BF_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 4) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_BF_LDS_BASE + KZ_BF_CAP * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
         st.lk[e] = -INFINITY;

@@ -211,66 +211,64 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 }
 
 
-// Tile epilogue, second form (used by the split-bf16 kernel, where the epilogue is no longer hidden under MFMA time).
-// Work is proportional to the number of candidate EVENTS instead of the number of value groups entered:
-//   * groups of four values are tested with a 3-instruction max and ONE wave-level branch (ballot), no exec juggling;
-//   * inside a group that holds an event of some lane, each value costs a compare + branch, and only lanes with an
-//     event run the append;
-//   * the append itself is straight-line code; the log has CAP + 1 rows, row CAP is a scratch row;
-//   * no per-element "already logged" bitmask: a lane whose log overflows remembers the ordinal of its first dropped
-//     event; after the merge the tile is scanned again against the SAME event threshold (tau_a), events before that
-//     ordinal are skipped, later ones are appended if they still beat the refreshed threshold (tau_b).
 #ifdef KZ_STAMP
 #define KZ_EPI2_STAMP_ARGS , unsigned long long& c_merge, unsigned long long& n_pass, unsigned long long& n_ins
 #else
 #define KZ_EPI2_STAMP_ARGS
 #endif
+// Tile epilogue, second form (used by the split-bf16 kernel, where the epilogue is no longer hidden under MFMA time).
+// Work is proportional to the number of candidate EVENTS instead of the number of values:
+//   * the 16 groups of four values are tested first, back to back (four compares + three scalar ORs each, 16 wave-level
+//     masks in SGPRs), so the tests do not form a dependent compare -> branch chain per group;
+//   * only groups in which some lane has an event are entered; per value: compare + branch, per event: address, one
+//     ds_write2, count -- the log can never overflow inside a group because a group is only entered when every lane
+//     has room for four entries;
+//   * if some lane lacks that room the wave leaves the scan at that group, merges its logs (which also refreshes the
+//     threshold) and resumes the scan at the same group: no per-lane bookkeeping of what was already logged.
 template <int KP, int CAP>
 __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
                                                   const int h KZ_EPI2_STAMP_ARGS) {
-    const float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
-    float tau_b = tau_a;
-    int skip = 0;
+    float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
     const int rowbase = tile * KZ_TILE + 4 * h;
     ++st.tiles_done;
     const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
+    unsigned long long gm[16];
+    // (compares, not an inline-asm max tree: hipcc's hazard recognizer must see every instruction that reads an MFMA
+    //  result, and fmaxf() would first canonicalise each of them)
+#pragma unroll
+    for (int gi = 0; gi < 16; ++gi) {
+        const int mt = gi >> 2, g4 = gi & 3;
+        gm[gi] = __builtin_amdgcn_ballot_w64(acc[mt][4 * g4] > tau_a) | __builtin_amdgcn_ballot_w64(acc[mt][4 * g4 + 1] > tau_a) |
+                 __builtin_amdgcn_ballot_w64(acc[mt][4 * g4 + 2] > tau_a) | __builtin_amdgcn_ballot_w64(acc[mt][4 * g4 + 3] > tau_a);
+    }
+    int resume = 0;  // first group not yet scanned (wave-uniform)
     for (;;) {
-        int ev = 0;           // events (values above tau_a) met so far in this pass
-        int first_drop = -1;  // ordinal of the first event that did not fit into the log
+        bool need_room = false;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                // max of the group in two instructions (inline asm: fmaxf() would first canonicalise every MFMA result)
-                float m;
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[mt][4 * g4]), "v"(acc[mt][4 * g4 + 1]), "v"(acc[mt][4 * g4 + 2]));
-                asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][4 * g4 + 3]));
-                if (__builtin_amdgcn_ballot_w64(m > tau_a) != 0ull) {
+        for (int gi = 0; gi < 16; ++gi) {
+            const int mt = gi >> 2, g4 = gi & 3;
+            if (gi >= resume && !need_room && gm[gi] != 0ull) {
+                if (__any(st.cnt > CAP - 4)) {
+                    need_room = true;
+                    resume = gi;
+                } else {
                     float ta = tau_a;
                     asm volatile("" : "+v"(ta));  // keeps the per-value compares inside the (rarely taken) branch
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const float v = acc[mt][4 * g4 + r4];
                         if (v > ta) {
-                            // straight-line append (no inner branches): events that must not be logged, or do not fit,
-                            // go to the scratch row CAP of the log, which is never read
-                            const int k = ev++;
-                            const bool take = (k >= skip) & (v > tau_b);
-                            const bool fits = st.cnt < CAP;
-                            const int slot = (take & fits) ? st.cnt : CAP;
                             int rb = rowbase;
                             asm volatile("" : "+v"(rb));  // row ids are computed on demand, not kept in registers
-                            st.sk[slot * 256] = v;
-                            st.si[slot * 256] = rb + 32 * mt + 8 * g4 + r4;
-                            first_drop = (take & !fits & (first_drop < 0)) ? k : first_drop;
-                            st.cnt += (take & fits) ? 1 : 0;
+                            st.sk[st.cnt * 256] = v;
+                            st.si[st.cnt * 256] = rb + 32 * mt + 8 * g4 + r4;
+                            ++st.cnt;
                         }
                     }
                 }
             }
         }
-        const bool any_ovf = __any(first_drop >= 0);
-        if (!any_ovf && !sched) break;
+        if (!need_room && !sched) break;
         // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
         KZ_T(tm0);
         for (int e = 0; e < st.cnt; ++e) {
@@ -284,9 +282,8 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         n_ins += __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, st.cnt));
 #endif
         st.cnt = 0;
-        if (!any_ovf) break;
-        tau_b = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
-        skip = first_drop >= 0 ? first_drop : 0x7fffffff;  // lanes without overflow have everything logged
+        if (!need_room) break;
+        tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));  // fresher threshold for the rest of the tile
     }
     if (st.tiles_done == st.next_merge) {
         const int step = st.tiles_done * CAP / KP;
