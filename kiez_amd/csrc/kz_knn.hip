@@ -445,28 +445,6 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
     const T* qptr = reinterpret_cast<const T*>(p.qraw) + qrow * (int64_t)p.d;
     const double qs = p.qsqn[qrow];
 
-    // Certification.  |key~ - key| <= eps for every index row (float32 fma-chain bound, DESIGN.md "Certified
-    // candidate sets").  If the K'-th candidate key is more than 2*eps below the k-th, no row outside the list
-    // can belong to the exact top-k.  V < KP means no list ever evicted anything: the set is complete.
-    bool certified;
-    if (V < KP) {
-        certified = (V >= min((int64_t)k_eff, p.n_i));
-    } else {
-        double eps;
-        if (p.metric == KZ_COSINE)
-            eps = p.gamma * 1.001;
-        else
-            eps = p.gamma * (0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax);
-        certified = (double)ck[KP - 1] < (double)ck[k_eff - 1] - 2.0 * eps;
-    }
-    if (!certified) {
-        if (lane == 0) {
-            const int pos = atomicAdd(p.fail_count, 1);
-            p.fail_list[pos] = (int)q;
-        }
-        return;
-    }
-
     // exact float64 re-rank of the V candidates, four rows in flight per pass (the per-candidate arithmetic is exactly
     // kz_wave_dot: per-lane fma chain over k = lane, lane+64, ... then the butterfly sum)
     const T* yraw = reinterpret_cast<const T*>(p.yraw);
@@ -520,6 +498,33 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
         si[rank] = id;
     }
     kz_wave_sync();
+
+    // Certification (DESIGN.md "Certified candidate sets").  |key~ - key| <= eps for every index row.  A row outside
+    // the candidate set has key~ <= ck[KP-1] (the K'-th best approximate key), hence an exact key <= ck[KP-1] + eps.
+    // The exact key of the k-th re-ranked candidate is known: (|q|^2 - d2_k)/2 (euclidean family), 1 - dist_k (cosine).
+    // If it is strictly larger, no outside row can enter -- or tie with -- the exact top-k.  V < KP means no list
+    // ever evicted anything: the set is complete.
+    bool certified;
+    if (V < KP) {
+        certified = (V >= min((int64_t)k_eff, p.n_i));
+    } else {
+        double eps, key_k;
+        if (p.metric == KZ_COSINE) {
+            eps = p.gamma * 1.001;
+            key_k = 1.0 - sv[k_eff - 1];
+        } else {
+            eps = p.gamma * (0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax);
+            key_k = 0.5 * (qs - sv[k_eff - 1]);
+        }
+        certified = (double)ck[KP - 1] + eps < key_k;
+    }
+    if (!certified) {
+        if (lane == 0) {
+            const int pos = atomicAdd(p.fail_count, 1);
+            p.fail_list[pos] = (int)q;
+        }
+        return;
+    }
     kz_emit_sorted<T>(sv, si, V, p.k, p.exclude_self, qrow, p.metric, p.out_dist + q * (int64_t)p.k,
                       p.out_ind + q * (int64_t)p.k, lane);
 }
@@ -1125,7 +1130,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             // goes to a separate allocation so that the list is not overwritten by a scratch regrow.
             KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
             int* fl = nullptr;
-            KZ_HIP(hipMalloc((void**)&fl, (size_t)n_fail * sizeof(int)));
+            rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&fl);  // stream-ordered pool: no device sync
+            if (rc != KZ_OK) return rc;
             KZ_HIP(hipMemcpyAsync(fl, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
             int64_t batch = ((int64_t)256 << 20) / (index->n * 8);
             if (batch < 1) batch = 1;
@@ -1134,7 +1140,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             void* vals = nullptr;
             rc = kz_scratch(ctx, (size_t)batch * (size_t)index->n * 8, &vals);
             if (rc != KZ_OK) {
-                (void)hipFree(fl);
+                kz_pool_free(ctx, fl, 0);
                 return rc;
             }
             const int dist_blocks = (int)((index->n + 3) / 4);
@@ -1157,7 +1163,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(ctx->ev[4], ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            (void)hipFree(fl);
+            kz_pool_free(ctx, fl, 0);
             if (e != hipSuccess) {
                 kz_set_error("kz_knn: exact fallback failed: %s", hipGetErrorString(e));
                 return KZ_ERR_HIP;
