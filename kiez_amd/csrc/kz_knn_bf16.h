@@ -89,11 +89,25 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
     __syncthreads();
 
     const float* fbase = ybuf + (h * KZ_TILE + j) * 4;  // this lane's fragment inside a slot: plane h, row j (+ 32 mt)
+    auto load_frags = [&](kz_bf16x8 (&fh)[4], kz_bf16x8 (&fl)[4], const int gi) {
+        const float* fb = fbase + (gi & 3) * 2048;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            fh[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt);
+            fl[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt + 1024);
+        }
+    };
     int g = 0;
     f32x16 acc[4];
 #ifdef KZ_STAMP
     unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0;
 #endif
+    // Even NSR: software pipeline over pairs of slices.  Fragment set A holds slice g (even), set B slice g+1; B is
+    // fetched under A's MFMAs, the workgroup barrier sits in the middle of B's MFMAs (which only need registers), and
+    // the first fragments of the NEXT pair are fetched right behind the barrier, under B's remaining MFMAs -- also
+    // across a tile boundary, where they stay in registers during the epilogue.
+    kz_bf16x8 ah[4], al[4], bh[4], bl[4];
+    if (NSR % 2 == 0) load_frags(ah, al, 0);
     for (int tile = t_begin; tile < t_end; ++tile) {
         KZ_T(t0);
         {
@@ -112,30 +126,60 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
         }
         // bias rows of the next tile (one 4-byte load per thread per tile; parked in LDS after the first slice)
         const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
+        if (NSR % 2 == 0) {
 #pragma unroll
-        for (int u = 0; u < NSR; ++u) {
-            const float* fb = fbase + (g & 3) * 2048;
-            kz_bf16x8 ah[4], al[4];
+            for (int u = 0; u < NSR; u += 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(bh, bl, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                ah[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt);
-                al[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt + 1024);
-            }
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], qh[u], acc[mt], 0, 0, 0);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], qh[u], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], ql[u], acc[mt], 0, 0, 0);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], ql[u], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], qh[u], acc[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], qh[u], acc[mt], 0, 0, 0);
-            if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
-            if (g & 1) {
-                // slices g-1 and g are consumed: after the barrier their slots take slices g+3 and g+4, while g+1 and
-                // g+2 (issued one barrier ago, drained by the fence of __syncthreads) are ready to be read
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[mt], qh[u + 1], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[mt], ql[u + 1], acc[mt], 0, 0, 0);
+                if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+                __builtin_amdgcn_sched_barrier(0);
+                // slices g and g+1 are consumed (their fragments are in registers): after the barrier their slots take
+                // slices g+4 and g+5, while g+2 and g+3 (issued one barrier ago, drained by the fence) become readable
                 __syncthreads();
-                dma_slice(g + 3);
                 dma_slice(g + 4);
+                dma_slice(g + 5);
+                load_frags(ah, al, g + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 2; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[mt], ql[u + 1], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[mt], qh[u + 1], acc[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                g += 2;
             }
-            ++g;
+        } else {
+#pragma unroll
+            for (int u = 0; u < NSR; ++u) {
+                kz_bf16x8 ch[4], cl[4];
+                load_frags(ch, cl, g);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[mt], qh[u], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[mt], ql[u], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[mt], qh[u], acc[mt], 0, 0, 0);
+                if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+                if (g & 1) {
+                    // slices g-1 and g are consumed: after the barrier their slots take slices g+3 and g+4, while g+1
+                    // and g+2 (issued one barrier ago, drained by the fence of __syncthreads) are ready to be read
+                    __syncthreads();
+                    dma_slice(g + 3);
+                    dma_slice(g + 4);
+                }
+                ++g;
+            }
         }
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);
