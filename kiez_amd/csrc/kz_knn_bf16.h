@@ -20,7 +20,7 @@
 
 typedef __bf16 kz_bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int KZ_BF_LDS_BASE = 4 * 8192 + 1024;   // ring of 4 slices + 2 x 128 bias floats
+constexpr int KZ_BF_LDS_BASE = 4 * 8192 + 1024 + 256;   // ring of 4 slices + 2 x 128 bias floats + merge flags
 constexpr int KZ_BF_CAP = 20;    // log rows per lane; a group of four values is only scanned while every lane has 4 free
 constexpr int KZ_BF_LDS = KZ_BF_LDS_BASE + KZ_BF_CAP * 256 * 8;
 
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);   // 4 slots x 2048 floats (8 KiB: planes hi0, hi1, lo0, lo1)
     float* bbuf = ybuf + 4 * 2048;                   // 2 x 128 bias floats
+    int* msync = reinterpret_cast<int*>(bbuf + 256);  // 4 merge flags (kz_tile_epilogue2)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
     dma_slice(2);
     dma_slice(3);
     bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
+    if (tid < 4) msync[tid] = 0;
     // stationary query fragments: lane (j, h) holds k = 16 u + 8 h + 0..7 of query row 32 wave + j, hi and lo
     const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * NSR) * 2048 + (h * KZ_TILE + 32 * (tid >> 6) + j) * 4;
     kz_bf16x8 qh[NSR], ql[NSR];
@@ -184,12 +186,12 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h, c_merge, n_pass, n_ins);
+        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h, msync, c_merge, n_pass, n_ins);
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
 #else
-        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h);
+        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h, msync);
 #endif
     }
 #ifdef KZ_STAMP

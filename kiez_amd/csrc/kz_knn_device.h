@@ -225,13 +225,37 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 //     has room for four entries;
 //   * if some lane lacks that room the wave leaves the scan at that group, merges its logs (which also refreshes the
 //     threshold) and resumes the scan at the same group: no per-lane bookkeeping of what was already logged.
+//   * merges are made workgroup-synchronous: the waves of a workgroup meet at a barrier every two slices, so a wave
+//     that merges alone (~16k cycles) stalls its three siblings.  A wave whose fullest log passes CAP - 8 raises a flag
+//     in LDS (sync[tile & 3]); every wave reads it at the start of the NEXT tile's epilogue and merges then, together.
+//     (The flag of tile t is written during epilogue t, read during epilogue t+1, cleared during epilogue t+2; waves of
+//     a workgroup are never more than one tile apart, and a workgroup barrier lies between any two epilogues.)
 template <int KP, int CAP>
 __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
-                                                  const int h KZ_EPI2_STAMP_ARGS) {
-    float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
-    const int rowbase = tile * KZ_TILE + 4 * h;
+                                                  const int h, int* sync KZ_EPI2_STAMP_ARGS) {
     ++st.tiles_done;
     const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
+    {
+        const int t = st.tiles_done;
+        const bool together = __builtin_amdgcn_readfirstlane(sync[(t - 1) & 3]) != 0;
+        if ((threadIdx.x & 63) == 0) sync[(t + 1) & 3] = 0;
+        if (together) {
+            KZ_T(tm0);
+            for (int e = 0; e < st.cnt; ++e) {
+                const float v = st.sk[e * 256];
+                if (v > st.tau) kz_list_replace_min<KP, 1>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+            }
+#ifdef KZ_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            c_merge += __builtin_amdgcn_s_memtime() - tm0;
+            n_pass += 1;
+            n_ins += __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, st.cnt));
+#endif
+            st.cnt = 0;
+        }
+    }
+    float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
+    const int rowbase = tile * KZ_TILE + 4 * h;
     unsigned long long gm[16];
     // (compares, not an inline-asm max tree: hipcc's hazard recognizer must see every instruction that reads an MFMA
     //  result, and fmaxf() would first canonicalise each of them)
@@ -285,6 +309,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         if (!need_room) break;
         tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));  // fresher threshold for the rest of the tile
     }
+    if (__any(st.cnt > CAP - 8) && (threadIdx.x & 63) == 0) sync[st.tiles_done & 3] = 1;
     if (st.tiles_done == st.next_merge) {
         const int step = st.tiles_done * CAP / KP;
         st.next_merge = st.tiles_done + (step > 0 ? step : 1);
