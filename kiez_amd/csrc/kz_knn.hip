@@ -1105,8 +1105,9 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
             fprintf(stderr, "[kz stamp]   inside slices, per wave-tile: query-frag wait %.0f  index-slice wait %.0f  barrier %.0f\n",
                     hd[6] / wt, hd[7] / wt, hd[8] / wt);
             if (tier_bf)
-                fprintf(stderr, "[kz stamp]   bf16 kernel, per wave-tile: merge cycles %.0f, merge passes %.4f, max-lane inserts %.3f\n",
-                        hd[4] / wt, hd[5] / wt, hd[6] / wt);
+                fprintf(stderr, "[kz stamp]   bf16 kernel, per wave-tile: merge cycles %.0f, merge passes %.4f, max-lane inserts %.3f, dma wait %.0f, barrier wait %.0f\n",
+                        hd[4] / wt, hd[5] / wt, hd[6] / wt, hd[7] / wt, hd[8] / wt);
+            if (tier_bf) fprintf(stderr, "[kz stamp]   bf16 epilogue: masks phase %.0f, first scan pass %.0f\n", hd[2] / wt, hd[9] / wt);
         }
 #endif
         float ms = 0;

@@ -22,7 +22,7 @@ typedef __bf16 kz_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KZ_BF_LDS_BASE = 4 * 8192 + 1024 + 256;   // ring of 4 slices + 2 x 128 bias floats + merge flags
 constexpr int KZ_BF_CAP = 20;    // log rows per lane; a group of four values is only scanned while every lane has 4 free
-constexpr int KZ_BF_LDS = KZ_BF_LDS_BASE + KZ_BF_CAP * 256 * 8;
+constexpr int KZ_BF_LDS = KZ_BF_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 8;   // log rows 0..CAP-1 + one scratch row
 
 // Relative rounding bound of the split-bf16 key (multiplies |y|max^2/2 + |q||y|max like the float32 bound does):
 //   split:        |x - hi - lo| <= 2^-16 (1 + 2^-7) |x|  per operand  ->  dropped terms <= 3.1 * 2^-16 |q||y|
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
     st.sk = reinterpret_cast<float*>(smem + KZ_BF_LDS_BASE) + tid;
-    st.si = reinterpret_cast<int*>(smem + KZ_BF_LDS_BASE + KZ_BF_CAP * 256 * 4) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_BF_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
         st.lk[e] = -INFINITY;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
     int g = 0;
     f32x16 acc[4];
 #ifdef KZ_STAMP
-    unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0;
+    unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0;
 #endif
     // Even NSR: software pipeline over pairs of slices.  Fragment set A holds slice g (even), set B slice g+1; B is
     // fetched under A's MFMAs, the workgroup barrier sits in the middle of B's MFMAs (which only need registers), and
@@ -149,7 +149,20 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
                 __builtin_amdgcn_sched_barrier(0);
                 // slices g and g+1 are consumed (their fragments are in registers): after the barrier their slots take
                 // slices g+4 and g+5, while g+2 and g+3 (issued one barrier ago, drained by the fence) become readable
+#ifdef KZ_STAMP
+                {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+                    __syncthreads();
+                    c_dma += w1 - w0;
+                    c_bar += __builtin_amdgcn_s_memtime() - w1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
                 __syncthreads();
+#endif
                 dma_slice(g + 4);
                 dma_slice(g + 5);
                 load_frags(ah, al, g + 2);
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h, msync, c_merge, n_pass, n_ins);
+        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, tile, tile == t_end - 1, h, msync, c_merge, n_pass, n_ins, c_e1, c_e2);
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
@@ -202,6 +215,10 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p)
         atomicAdd(p.dbg + 4, c_merge);
         atomicAdd(p.dbg + 5, n_pass);
         atomicAdd(p.dbg + 6, n_ins);
+        atomicAdd(p.dbg + 7, c_dma);
+        atomicAdd(p.dbg + 8, c_bar);
+        atomicAdd(p.dbg + 2, c_e1);
+        atomicAdd(p.dbg + 9, c_e2);
     }
 #endif
 }

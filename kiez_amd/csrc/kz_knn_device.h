@@ -212,7 +212,7 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 
 
 #ifdef KZ_STAMP
-#define KZ_EPI2_STAMP_ARGS , unsigned long long& c_merge, unsigned long long& n_pass, unsigned long long& n_ins
+#define KZ_EPI2_STAMP_ARGS , unsigned long long& c_merge, unsigned long long& n_pass, unsigned long long& n_ins, unsigned long long& c_e1, unsigned long long& c_e2
 #else
 #define KZ_EPI2_STAMP_ARGS
 #endif
@@ -220,9 +220,9 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 // Work is proportional to the number of candidate EVENTS instead of the number of values:
 //   * the 16 groups of four values are tested first, back to back (four compares + three scalar ORs each, 16 wave-level
 //     masks in SGPRs), so the tests do not form a dependent compare -> branch chain per group;
-//   * only groups in which some lane has an event are entered; per value: compare + branch, per event: address, one
-//     ds_write2, count -- the log can never overflow inside a group because a group is only entered when every lane
-//     has room for four entries;
+//   * only groups in which some lane has an event are entered; inside, the four values are appended by straight-line
+//     code executed by all lanes (lanes without an event write to a scratch row of the log) -- the log can never
+//     overflow inside a group because a group is only entered when every lane has room for four entries;
 //   * if some lane lacks that room the wave leaves the scan at that group, merges its logs (which also refreshes the
 //     threshold) and resumes the scan at the same group: no per-lane bookkeeping of what was already logged.
 //   * merges are made workgroup-synchronous: the waves of a workgroup meet at a barrier every two slices, so a wave
@@ -233,6 +233,7 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 template <int KP, int CAP>
 __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
                                                   const int h, int* sync KZ_EPI2_STAMP_ARGS) {
+    KZ_T(te0);
     ++st.tiles_done;
     const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
     {
@@ -265,6 +266,13 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         gm[gi] = __builtin_amdgcn_ballot_w64(acc[mt][4 * g4] > tau_a) | __builtin_amdgcn_ballot_w64(acc[mt][4 * g4 + 1] > tau_a) |
                  __builtin_amdgcn_ballot_w64(acc[mt][4 * g4 + 2] > tau_a) | __builtin_amdgcn_ballot_w64(acc[mt][4 * g4 + 3] > tau_a);
     }
+#ifdef KZ_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" :: "s"(gm[0]), "s"(gm[15]));
+    const unsigned long long te1 = __builtin_amdgcn_s_memtime();
+    c_e1 += te1 - te0;
+    bool first_pass = true;
+#endif
     int resume = 0;  // first group not yet scanned (wave-uniform)
     for (;;) {
         bool need_room = false;
@@ -278,20 +286,30 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
                 } else {
                     float ta = tau_a;
                     asm volatile("" : "+v"(ta));  // keeps the per-value compares inside the (rarely taken) branch
+                    int rb = rowbase;
+                    asm volatile("" : "+v"(rb));      // row ids are computed on demand, not kept in registers
+                    // straight-line, all lanes: a lane without an event writes to the scratch row CAP (never read),
+                    // so there is no exec juggling and no dependent compare -> saveexec -> branch chain per value
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const float v = acc[mt][4 * g4 + r4];
-                        if (v > ta) {
-                            int rb = rowbase;
-                            asm volatile("" : "+v"(rb));  // row ids are computed on demand, not kept in registers
-                            st.sk[st.cnt * 256] = v;
-                            st.si[st.cnt * 256] = rb + 32 * mt + 8 * g4 + r4;
-                            ++st.cnt;
-                        }
+                        const bool ev = v > ta;
+                        const int slot = ev ? st.cnt : CAP;
+                        st.sk[slot * 256] = v;
+                        st.si[slot * 256] = rb + 32 * mt + 8 * g4 + r4;
+                        st.cnt += ev ? 1 : 0;
                     }
                 }
             }
         }
+#ifdef KZ_STAMP
+        if (first_pass) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" :: "v"(st.cnt));
+            c_e2 += __builtin_amdgcn_s_memtime() - te1;
+            first_pass = false;
+        }
+#endif
         if (!need_room && !sched) break;
         // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
         KZ_T(tm0);
