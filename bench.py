@@ -40,7 +40,8 @@ WORKLOADS = {
     "c1g": (100_000, 100_000, 128, "euclidean", 10, 10, None, {},
             "C1 on gaussian data (rng.randn) for contrast with uniform: 100k x 100k, d=128, euclidean, k=10, hubness=None"),
 }
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, 'Peak BF16/FP16 MFMA ~2.5 PF dense'
 
 
 def cpu_baseline(source, target, metric, k, budget_rows=10_000):
@@ -160,14 +161,19 @@ def main():
     kernel_s = sum(st["main_kernel_ms"] for _, _, st in knn_log) * 1e-3
     n_launch = len(knn_log)
     achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
-    fallback_rows = sum(st["n_fallback_rows"] for _, _, st in knn_log)
-    traffic = None
-    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    # which fused kernel did (most of) the work: split-bf16 first pass (3 bf16 MFMA products per multiply-add) or float32 MFMA
+    bf_ms = sum(st["main_kernel_ms"] for _, _, st in knn_log if st.get("first_pass") == 1)
+    tier_bf = bf_ms * 2 > kernel_s * 1e3
+    peak = PEAK_BF16_MFMA_TFLOPS if tier_bf else PEAK_F32_MFMA_TFLOPS
+    pmc = ROOT / "profiles" / "pmc_traffic.json"   # HBM bytes per launch from separate rocprofv3 --pmc passes
     if pmc.exists():
         try:
-            traffic = json.loads(pmc.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+            key = args.workload + ("_bf16" if tier_bf else "_f32")
+            traffic = json.loads(pmc.read_text()).get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    fallback_rows = sum(st["n_fallback_rows"] for _, _, st in knn_log)
+    traffic = None
 
     check = None
     do_check = args.check or (not args.no_check and hub is None and world == 1 and n_t <= 200_000)
@@ -194,18 +200,24 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16x2" if tier_bf else "f32",
             "data": "synthetic",
             "config": {"workload": desc, "n_source_per_gpu": n_s, "n_target": n_t, "d": d, "metric": metric,
                        "n_candidates": K, "k": k, "hubness": hub, "hubness_kwargs": hub_kw,
                        "inputs": "float32 rng.rand, resident in HBM; results left in HBM",
                        "parallelism": f"source row-sharded x{world}, target replicated (RCCL broadcast)"},
-            "roofline": {"bound": "mfma", "kernel": "kz_knn_cand_kernel (fp32 MFMA 32x32x2 fused distance+top-k)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("kz_knn_cand_bf_kernel (split-bf16 MFMA 32x32x16, 3 products per multiply-add, fused distance+top-k)"
+                                    if tier_bf else "kz_knn_cand_kernel (fp32 MFMA 32x32x2 fused distance+top-k)"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "launches": n_launch, "avg_launch_ms": kernel_s / max(n_launch, 1) * 1e3,
-                         "algorithmic_flop_per_launch": flops / max(n_launch, 1)},
+                         "algorithmic_flop_per_launch": flops / max(n_launch, 1),
+                         "mfma_products_per_mac": 3 if tier_bf else 1,
+                         "executed_mfma_frac": achieved * (3 if tier_bf else 1) / peak,
+                         "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS},
             "certification_fallback_rows": int(fallback_rows),
+            "escalated_rows": int(sum(st.get("n_escalated_rows", 0) for _, _, st in knn_log)),
             "other_kernels_ms": {"finalize_avg": sum(st["finalize_ms"] for _, _, st in knn_log) / max(n_launch, 1),
                                  "fallback_total": sum(st["fallback_ms"] for _, _, st in knn_log)},
         }

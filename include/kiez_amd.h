@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 1
+#define KZ_ABI_VERSION 2
 
 /* status codes */
 enum { KZ_OK = 0, KZ_ERR_INVALID = 1, KZ_ERR_HIP = 2, KZ_ERR_UNSUPPORTED = 3, KZ_ERR_NOMEM = 4, KZ_ERR_NONFINITE = 5 };
@@ -49,7 +49,10 @@ typedef struct kz_knn_stats {
     int32_t list_len;        /* K' = per-list candidate count kept by the fused kernel                     */
     int32_t n_splits;        /* index range splits (grid.y)                                                */
     int32_t n_blocks;        /* workgroups launched                                                        */
-    int32_t reserved;
+    int32_t first_pass;      /* operand precision of the fused kernel that produced the result of the last
+                                chunk: 0 = float32 MFMA, 1 = split-bf16 (bf16x2) MFMA                        */
+    int64_t n_escalated_rows; /* query rows first tried with the split-bf16 pass and re-done with float32
+                                operands because too many of their chunk failed the wider certification    */
 } kz_knn_stats;
 
 /* ---- library / context -------------------------------------------------------------------------------- */
@@ -60,8 +63,11 @@ int kz_device_count(int* n);
 int kz_ctx_create(int device, void* stream, kz_ctx** out);
 int kz_ctx_destroy(kz_ctx* ctx);
 int kz_ctx_sync(kz_ctx* ctx);
-/* test/diagnostic knob: "eps_scale" multiplies the certification bound (huge value => every row takes the
- * exact fallback); "force_splits" fixes the index split count (0 = automatic). */
+/* Options.  "precision": 0 (default) = split-bf16 first pass where the query tile fits in registers (d <= 128),
+ * escalating to float32 operands / exact float64 per chunk as certification demands; 1 = float32 operands only.
+ * The neighbour order is the float64 one either way.  Test/diagnostic knobs: "eps_scale" multiplies the
+ * certification bound (huge value => every row takes the exact fallback); "force_splits" fixes the index split
+ * count (0 = automatic); "kernel_variant" selects experimental float32 kernels. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 
 int kz_malloc(kz_ctx* ctx, size_t bytes, void** d_ptr);

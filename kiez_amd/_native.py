@@ -40,11 +40,12 @@ class KnnStats(C.Structure):
         ("list_len", C.c_int32),
         ("n_splits", C.c_int32),
         ("n_blocks", C.c_int32),
-        ("reserved", C.c_int32),
+        ("first_pass", C.c_int32),
+        ("n_escalated_rows", C.c_int64),
     ]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 # every symbol include/kiez_amd.h declares: (name, restype, argtypes)
@@ -110,8 +111,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.kz_abi_version() != 1:
-            raise RuntimeError(f"{path}: ABI version {lib.kz_abi_version()} != 1")
+        if lib.kz_abi_version() != 2:
+            raise RuntimeError(f"{path}: ABI version {lib.kz_abi_version()} != 2")
         _lib = lib
     return _lib
 

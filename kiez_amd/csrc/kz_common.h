@@ -25,6 +25,7 @@ struct kz_ctx {
     int stagger;      // tuning knob: start-up phase shift in cycles (-1 = one tile of MFMA time, 0 = off)
     int chunk_rows;   // test knob: query rows per chunk (0 = default 524288)
     int min_splits;   // tuning knob: minimum index splits per query tile in the large-item region
+    int precision;    // 0: split-bf16 first pass where eligible (default), 1: float32 operands only
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)
     void* scratch;

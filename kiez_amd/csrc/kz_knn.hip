@@ -853,7 +853,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     // Precision tiers: the split-bf16 first pass (kz_knn_bf16.h) when the query tile fits in registers (d_pad <= 128);
     // a chunk in which too many rows fail the (wider) bf16 certification is re-done by the float32-MFMA kernel, and
     // so are all later chunks of this call.
-    bool tier_bf = ctx->kernel_variant == 7 && n_slices >= 2 && n_slices <= 8;
+    bool tier_bf = ctx->precision == 0 && (ctx->kernel_variant == 0 || ctx->kernel_variant == 7) && nres == 0 &&
+                   n_slices >= 2 && n_slices <= 8;
     int slots_f32 = 0, slots_bf = 0;
     auto slots_for = [&](bool bf, int* out) -> int {
         int& cache = bf ? slots_bf : slots_f32;
@@ -1174,7 +1175,6 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         }
         c0 += max_rows_per_chunk;
     }
-    (void)n_escalated;
     if (stats) {
         stats->main_kernel_ms = main_ms;
         stats->finalize_ms = fin_ms;
@@ -1183,6 +1183,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         stats->list_len = KP;
         stats->n_splits = last_splits;
         stats->n_blocks = last_blocks;
+        stats->first_pass = tier_bf ? 1 : 0;
+        stats->n_escalated_rows = n_escalated;
     }
     return KZ_OK;
 }

@@ -45,6 +45,8 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->force_nres = -1;
     c->min_splits = 1;
     c->lds_pad = 0;
+    c->precision = 0;
+    if (const char* pv = getenv("KZ_PRECISION")) c->precision = (strcmp(pv, "fp32") == 0 || strcmp(pv, "1") == 0) ? 1 : 0;  // A/B runs of the test-suite
     c->stagger = 0;
     c->kernel_variant = 0;
     if (const char* kv = getenv("KZ_KERNEL_VARIANT")) c->kernel_variant = (kv[0] >= '0' && kv[0] <= '7') ? kv[0] - '0' : 0;  // A/B runs of the test-suite
@@ -105,6 +107,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "chunk_rows") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 1e9, "chunk_rows must be >= 0");
         c->chunk_rows = (int)value;
+    } else if (strcmp(name, "precision") == 0) {
+        KZ_REQUIRE(value == 0 || value == 1, "precision must be 0 (split-bf16 first pass) or 1 (float32 operands only)");
+        c->precision = (int)value;
     } else if (strcmp(name, "lds_pad") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
         c->lds_pad = (int)value;

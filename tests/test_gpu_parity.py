@@ -251,3 +251,66 @@ def test_query_chunking_and_row_ranges():
         np.testing.assert_array_equal(im.numpy(), si[129:529])
     finally:
         ctx.set_option("chunk_rows", 0)
+
+
+@pytest.mark.parametrize("n_s,n_t,d,dtype,metric,k,single", [
+    (900, 2100, 128, np.float32, "euclidean", 10, False),   # 8 slices: pipelined pairs
+    (700, 1500, 40, np.float64, "sqeuclidean", 7, False),   # 3 slices: odd count, barrier parity changes per tile
+    (1300, 1300, 96, np.float32, "cosine", 25, True),       # list length 32, self stripped
+    (400, 5000, 17, np.float32, "euclidean", 50, False),    # 2 slices, list length 64
+    (300, 800, 16, np.float32, "euclidean", 5, False),      # 1 slice: split-bf16 not eligible, float32 kernel
+    (300, 800, 200, np.float32, "euclidean", 5, False),     # 13 slices: not eligible either
+])
+def test_precision_tiers_agree_bit_for_bit(n_s, n_t, d, dtype, metric, k, single):
+    """The split-bf16 first pass (default) and the float32-operand kernel must return the same float64 answer."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    s, t = _data(n_s, n_t, d, dtype, seed=d + k)
+    if single:
+        t = s
+    ctx = N.Context.get()
+    res = {}
+    for prec in (0, 1):
+        ctx.set_option("precision", prec)
+        try:
+            qm = N.DeviceMatrix(ctx, s, metric)
+            ym = qm if single else N.DeviceMatrix(ctx, t, metric)
+            dd, ii, st = N.knn(ctx, qm, ym, k, exclude_self=single)
+            res[prec] = (dd.numpy(), ii.numpy(), st)
+        finally:
+            ctx.set_option("precision", 0)
+    n_slices = (d + 15) // 16
+    assert res[0][2]["first_pass"] == (1 if 2 <= n_slices <= 8 else 0)
+    assert res[1][2]["first_pass"] == 0
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    od, oi = O.knn_exact(s, t, k, O.canonical_metric(metric), exclude_self=single)
+    np.testing.assert_array_equal(res[0][1], oi)
+
+
+def test_bf16_pass_escalates_to_float32_operands_on_tight_clusters():
+    """A tight cluster far from the origin: neighbour gaps sit between the float32 and the split-bf16 rounding bounds,
+    so most rows fail the bf16 certification; the chunk must be re-done with float32 operands and stay exact."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.RandomState(17)
+    centre = rng.rand(32)
+    centre *= 10.0 / np.linalg.norm(centre)
+    t = (centre + 0.05 * rng.randn(3000, 32)).astype(np.float32)
+    s = (centre + 0.05 * rng.randn(500, 32)).astype(np.float32)
+    ctx = N.Context.get()
+    qm, ym = N.DeviceMatrix(ctx, s, "euclidean"), N.DeviceMatrix(ctx, t, "euclidean")
+    d, i, st = N.knn(ctx, qm, ym, 10)
+    assert st["n_escalated_rows"] == 500 and st["first_pass"] == 0
+    od, oi = O.knn_exact(s, t, 10, "euclidean")
+    np.testing.assert_array_equal(i.numpy(), oi)
+    np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=0)
+    # the float32-only setting gives the same answer without the detour
+    ctx.set_option("precision", 1)
+    try:
+        d1, i1, st1 = N.knn(ctx, qm, ym, 10)
+    finally:
+        ctx.set_option("precision", 0)
+    assert st1["n_escalated_rows"] == 0
+    np.testing.assert_array_equal(i1.numpy(), i.numpy())
+    np.testing.assert_array_equal(d1.numpy(), d.numpy())
