@@ -666,7 +666,7 @@ static int kz_launch_res(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
 
 template <int KP, int NSR>
 static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad) {
-    auto kern = kz_knn_cand_bf_kernel<KP, NSR>;
+    auto kern = kz_knn_cand_bf_kernel<KP, NSR, (NSR <= 8 ? 2 : 1)>;
     KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_BF_LDS + lds_pad));
     int nb = 0;
     KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_BF_LDS + lds_pad));
@@ -676,21 +676,30 @@ static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad) {
 
 template <int KP, int NSR>
 static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, NSR>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad, ctx->stream, p);
+    hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, NSR, (NSR <= 8 ? 2 : 1)>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad,
+                       ctx->stream, p);
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }
 
 #define KZ_DISPATCH_BF_NSR(rc, fn, args, KPV)             \
     do {                                                  \
-        switch (n_slices) {                               \
+        switch (n_slices_bf) {                            \
             case 2: rc = fn<KPV, 2> args; break;          \
             case 3: rc = fn<KPV, 3> args; break;          \
             case 4: rc = fn<KPV, 4> args; break;          \
             case 5: rc = fn<KPV, 5> args; break;          \
             case 6: rc = fn<KPV, 6> args; break;          \
             case 7: rc = fn<KPV, 7> args; break;          \
-            default: rc = fn<KPV, 8> args; break;         \
+            case 8: rc = fn<KPV, 8> args; break;          \
+            case 10: rc = fn<KPV, 10> args; break;        \
+            case 12: rc = fn<KPV, 12> args; break;        \
+            case 14: rc = fn<KPV, 14> args; break;        \
+            case 16: rc = fn<KPV, 16> args; break;        \
+            case 18: rc = fn<KPV, 18> args; break;        \
+            case 20: rc = fn<KPV, 20> args; break;        \
+            case 22: rc = fn<KPV, 22> args; break;        \
+            default: rc = fn<KPV, 24> args; break;        \
         }                                                 \
     } while (0)
 #define KZ_DISPATCH_BF(rc, fn, args)                                  \
@@ -836,7 +845,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     // rounding bound factor: (d_pad + 16) * 2^-24 covers the d+1 step fma chain, the float32 rounding of the bias
     // and (float64 inputs) of the operands; 1e-12 covers the float64 re-rank's own rounding.
     const double gamma_f32 = ((double)(index->kg * 4 + 16) * 5.9604644775390625e-08 + 1e-12) * ctx->eps_scale;
-    const double gamma_bf = kz_bf16_gamma(index->kg * 4) * ctx->eps_scale;
+    const double gamma_bf = kz_bf16_gamma(index->kg_bf * 4) * ctx->eps_scale;
+    const int n_slices_bf = index->kg_bf / 4;
 
     const int n_slices = index->kg / 4;
     // Resident query slices (registers).  Measured on C1 (d=128): 0 resident slices at 3 workgroups/CU beat 8 resident
@@ -854,7 +864,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     // a chunk in which too many rows fail the (wider) bf16 certification is re-done by the float32-MFMA kernel, and
     // so are all later chunks of this call.
     bool tier_bf = ctx->precision == 0 && (ctx->kernel_variant == 0 || ctx->kernel_variant == 7) && nres == 0 &&
-                   n_slices >= 2 && n_slices <= 8;
+                   n_slices_bf >= 2 && n_slices_bf <= 24 && query->kg_bf == index->kg_bf;
     int slots_f32 = 0, slots_bf = 0;
     auto slots_for = [&](bool bf, int* out) -> int {
         int& cache = bf ? slots_bf : slots_f32;
@@ -1015,7 +1025,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         cp.qt0 = qt0;
         cp.n_ytiles = n_ytiles;
         cp.lay = lay;
-        cp.kg = index->kg;
+        cp.kg = tier_bf ? index->kg_bf : index->kg;
         cp.out_key = out_key;
         cp.out_idx = out_idx;
         cp.stagger_cycles = ctx->stagger >= 0 ? ctx->stagger : (index->kg / 4) * 2048;  // default: one tile of MFMA time

@@ -9,7 +9,7 @@
 // cannot be certified under the wider margin are re-done by the float32-MFMA kernel / the exact float64 kernels,
 // so the result is still the float64 neighbour order.
 //
-// Structure (d_pad = 16 * NSR <= 128):
+// Structure (d_pad = 16 * NSR; NSR <= 8 at two workgroups per CU, NSR <= 24 (d <= 384) at one):
 //   * the query tile is STATIONARY: the hi/lo fragments of all NSR slices stay in registers (8 VGPRs per slice),
 //     so the only global stream is the index image -- which is what made the float32 kernel lose ~20 % (section 7);
 //   * index slices go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write) into a ring
@@ -32,8 +32,10 @@ static inline double kz_bf16_gamma(int d_pad) {
     return 3.1 * 1.52587890625e-05 + 2.0 * (double)(3 * d_pad + 16) * 5.9604644775390625e-08 + 1e-12;
 }
 
-template <int KP, int NSR>
-__global__ __launch_bounds__(256, 2) void kz_knn_cand_bf_kernel(KnnCandParams p) {
+// WPS = waves per SIMD the register budget allows: 2 up to 8 slices (d_pad <= 128), 1 beyond (up to 24 slices, the
+// stationary query fragments alone take 8 VGPRs per slice).
+template <int KP, int NSR, int WPS>
+__global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);   // 4 slots x 2048 floats (8 KiB: planes hi0, hi1, lo0, lo1)
     float* bbuf = ybuf + 4 * 2048;                   // 2 x 128 bias floats

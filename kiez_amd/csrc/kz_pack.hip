@@ -21,7 +21,7 @@ __device__ __forceinline__ float kz_bf16_to_f32(unsigned short b) { return __uin
 
 template <typename T>
 __global__ __launch_bounds__(256) void kz_pack_kernel(const T* __restrict__ raw, int64_t n, int d, int metric, int kg,
-                                                      int64_t n_pad, float* __restrict__ packed,
+                                                      int kg_bf, int64_t n_pad, float* __restrict__ packed,
                                                       unsigned short* __restrict__ packed_bf,
                                                       float* __restrict__ bias, double* __restrict__ sqn,
                                                       unsigned long long* __restrict__ maxnorm_bits,
@@ -30,17 +30,18 @@ __global__ __launch_bounds__(256) void kz_pack_kernel(const T* __restrict__ raw,
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int d_pad = kg * 4;
+    const int d_pad_bf = kg_bf * 4;
     double wmax = 0.0;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_pad; row += (int64_t)gridDim.x * 4) {
         const int64_t tile = row >> 7;
         const int r = (int)(row & 127);
         float* dst = packed + (tile * kg) * (int64_t)(KZ_TILE * 4) + r * 4;
         // bf16 image: element k of this row -> slice k/16, plane (k/8)&1 (+2 for lo), 8 values per row and plane
-        unsigned short* dbf = packed_bf + (tile * kg) * (int64_t)(KZ_TILE * 8) + r * 8;
+        unsigned short* dbf = packed_bf + (tile * kg_bf) * (int64_t)(KZ_TILE * 8) + r * 8;
         auto bf_off = [](int k) { return (int64_t)(k >> 4) * (4 * KZ_TILE * 8) + ((k >> 3) & 1) * (KZ_TILE * 8) + (k & 7); };
         if (row >= n) {
-            for (int k = lane; k < d_pad; k += 64) {
-                dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = 0.0f;
+            for (int k = lane; k < d_pad_bf; k += 64) {
+                if (k < d_pad) dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = 0.0f;
                 dbf[bf_off(k)] = 0;
                 dbf[bf_off(k) + 2 * KZ_TILE * 8] = 0;
             }
@@ -69,10 +70,10 @@ __global__ __launch_bounds__(256) void kz_pack_kernel(const T* __restrict__ raw,
             }
             wmax = fmax(wmax, sqrt(sq));
         }
-        for (int k = lane; k < d_pad; k += 64) {
+        for (int k = lane; k < d_pad_bf; k += 64) {
             double vd = 0.0;
             if (k < d) vd = (metric == KZ_COSINE) ? (double)x[k] / scale_div : (double)x[k];
-            dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = (float)vd;
+            if (k < d_pad) dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = (float)vd;
             const unsigned short hi = kz_bf16_rn((float)vd);
             const unsigned short lo = kz_bf16_rn((float)(vd - (double)kz_bf16_to_f32(hi)));
             dbf[bf_off(k)] = hi;
@@ -109,6 +110,9 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     m->n_tiles = (n + KZ_TILE - 1) / KZ_TILE;
     const int64_t d_pad = ((d + KZ_KSLICE - 1) / KZ_KSLICE) * KZ_KSLICE;
     m->kg = (int)(d_pad / 4);
+    const int64_t d_pad_bf = d_pad > 128 ? ((d + 31) / 32) * 32 : d_pad;
+    m->kg_bf = (int)(d_pad_bf / 4);
+    const size_t packed_bf_bytes = (size_t)(m->n_tiles * KZ_TILE) * (size_t)d_pad_bf * 4;
     const int64_t n_pad = m->n_tiles * KZ_TILE;
     const size_t esz = dtype == KZ_F32 ? 4 : 8;
     const size_t raw_bytes = (size_t)n * (size_t)d * esz;
@@ -118,7 +122,7 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
         return code;
     };
     if (kz_pool_alloc(ctx, raw_bytes, &m->raw) != KZ_OK || kz_pool_alloc(ctx, packed_bytes, (void**)&m->packed) != KZ_OK ||
-        kz_pool_alloc(ctx, packed_bytes, (void**)&m->packed_bf) != KZ_OK ||
+        kz_pool_alloc(ctx, packed_bf_bytes, (void**)&m->packed_bf) != KZ_OK ||
         kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&m->bias) != KZ_OK ||
         kz_pool_alloc(ctx, (size_t)n * 8, (void**)&m->sqn) != KZ_OK) {
         kz_set_error("kz_matrix_create: out of device memory (raw %zu B + 2 x packed %zu B)", raw_bytes, packed_bytes);
@@ -142,10 +146,10 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     int* bad = ctx->d_counters + 2;
     if (dtype == KZ_F32)
         hipLaunchKernelGGL(kz_pack_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)m->raw, n, (int)d,
-                           metric, m->kg, n_pad, m->packed, m->packed_bf, m->bias, m->sqn, mx, bad);
+                           metric, m->kg, m->kg_bf, n_pad, m->packed, m->packed_bf, m->bias, m->sqn, mx, bad);
     else
         hipLaunchKernelGGL(kz_pack_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)m->raw, n,
-                           (int)d, metric, m->kg, n_pad, m->packed, m->packed_bf, m->bias, m->sqn, mx, bad);
+                           (int)d, metric, m->kg, m->kg_bf, n_pad, m->packed, m->packed_bf, m->bias, m->sqn, mx, bad);
     e = hipGetLastError();
     if (e == hipSuccess)
         e = hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
