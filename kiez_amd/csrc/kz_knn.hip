@@ -309,6 +309,7 @@ struct KnnFinParams {
     int metric;
     int k;                // neighbours to return
     int exclude_self;
+    const int64_t* self_ids;  // optional: index row to strip per local query (escalated subsets); NULL = q_begin + q
     double gamma;         // rounding-bound factor (already multiplied by eps_scale)
     double ymax;          // max index-row norm
     double* out_dist;     // [q_count][k]
@@ -525,8 +526,8 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
         }
         return;
     }
-    kz_emit_sorted<T>(sv, si, V, p.k, p.exclude_self, qrow, p.metric, p.out_dist + q * (int64_t)p.k,
-                      p.out_ind + q * (int64_t)p.k, lane);
+    kz_emit_sorted<T>(sv, si, V, p.k, p.exclude_self, p.self_ids ? p.self_ids[q] : qrow, p.metric,
+                      p.out_dist + q * (int64_t)p.k, p.out_ind + q * (int64_t)p.k, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -550,7 +551,8 @@ __global__ __launch_bounds__(256) void kz_exact_dist_kernel(const int* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restrict__ fail_list, int batch0, int64_t q_begin,
                                                               const double* __restrict__ vals, int64_t n_i, int k,
-                                                              int exclude_self, int metric, double* __restrict__ out_dist,
+                                                              int exclude_self, const int64_t* __restrict__ self_ids,
+                                                              int metric, double* __restrict__ out_dist,
                                                               int64_t* __restrict__ out_ind) {
     __shared__ double s_v[4];
     __shared__ int s_i[4];
@@ -605,8 +607,8 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
         __syncthreads();
     }
     if (wave == 0)
-        kz_emit_sorted<T>(s_sv, s_si, k_eff, k, exclude_self, q_begin + q, metric, out_dist + (int64_t)q * k,
-                          out_ind + (int64_t)q * k, lane);
+        kz_emit_sorted<T>(s_sv, s_si, k_eff, k, exclude_self, self_ids ? self_ids[q] : q_begin + q, metric,
+                          out_dist + (int64_t)q * k, out_ind + (int64_t)q * k, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -816,8 +818,34 @@ static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
         }                                                     \
     } while (0)
 
-extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index, int k,
-                      int exclude_self, double* d_dist, int64_t* d_ind, kz_knn_stats* stats) {
+// Rows of a query matrix gathered into a dense block (escalation of uncertified rows to the float32-operand kernel)
+__global__ __launch_bounds__(256) void kz_gather_rows_kernel(const char* __restrict__ raw, const int* __restrict__ rows,
+                                                             int64_t row0, int n_rows, int64_t row_bytes,
+                                                             char* __restrict__ out, int64_t* __restrict__ self_ids) {
+    const int r = blockIdx.x;
+    if (r >= n_rows) return;
+    const int64_t src = row0 + rows[r];
+    const char* sp = raw + src * row_bytes;
+    char* dp = out + (int64_t)r * row_bytes;
+    for (int64_t b = threadIdx.x * 4; b < row_bytes; b += 256 * 4) *reinterpret_cast<int*>(dp + b) = *reinterpret_cast<const int*>(sp + b);
+    if (self_ids && threadIdx.x == 0) self_ids[r] = src;
+}
+
+__global__ __launch_bounds__(256) void kz_scatter_rows_kernel(const double* __restrict__ sd, const int64_t* __restrict__ si,
+                                                              const int* __restrict__ rows, int n_rows, int k,
+                                                              double* __restrict__ od, int64_t* __restrict__ oi) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)n_rows * k) return;
+    const int r = (int)(t / k), c = (int)(t - (int64_t)r * k);
+    od[(int64_t)rows[r] * k + c] = sd[t];
+    oi[(int64_t)rows[r] * k + c] = si[t];
+}
+
+// d_self_ids (device, optional): index row to strip per query when exclude_self is set and the query matrix is not the
+// index matrix itself (escalated subsets).  precision_override: -1 = the context's setting, 1 = float32 operands only.
+static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index, int k,
+                       int exclude_self, const int64_t* d_self_ids, int precision_override, double* d_dist, int64_t* d_ind,
+                       kz_knn_stats* stats) {
     KZ_REQUIRE(ctx && query && index && d_dist && d_ind, "kz_knn: null argument");
     KZ_REQUIRE(query->ctx == ctx && index->ctx == ctx, "kz_knn: matrices belong to a different context");
     KZ_REQUIRE(query->d == index->d, "kz_knn: feature dimensions differ (%lld vs %lld)", (long long)query->d,
@@ -829,7 +857,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     const int k_eff = k + (exclude_self ? 1 : 0);
     KZ_REQUIRE((int64_t)k_eff <= index->n, "kz_knn: Expected n_neighbors %s n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld",
                exclude_self ? "<" : "<=", k, (long long)index->n);
-    if (exclude_self) KZ_REQUIRE(query->n == index->n, "kz_knn: exclude_self needs query and index of equal length");
+    if (exclude_self && !d_self_ids)
+        KZ_REQUIRE(query->n == index->n, "kz_knn: exclude_self needs query and index of equal length");
     const int KP = kz_pick_list_len(k_eff);
     if (KP == 0) {
         kz_set_error("kz_knn: k=%d exceeds the supported maximum of 110 neighbours per query", k_eff);
@@ -863,7 +892,8 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
     // Precision tiers: the split-bf16 first pass (kz_knn_bf16.h) when the query tile fits in registers (d_pad <= 128);
     // a chunk in which too many rows fail the (wider) bf16 certification is re-done by the float32-MFMA kernel, and
     // so are all later chunks of this call.
-    bool tier_bf = ctx->precision == 0 && (ctx->kernel_variant == 0 || ctx->kernel_variant == 7) && nres == 0 &&
+    const int precision = precision_override >= 0 ? precision_override : ctx->precision;
+    bool tier_bf = precision == 0 && (ctx->kernel_variant == 0 || ctx->kernel_variant == 7) && nres == 0 &&
                    n_slices_bf >= 2 && n_slices_bf <= 24 && query->kg_bf == index->kg_bf;
     int slots_f32 = 0, slots_bf = 0;
     auto slots_for = [&](bool bf, int* out) -> int {
@@ -1074,6 +1104,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         fp.metric = metric;
         fp.k = k;
         fp.exclude_self = exclude_self ? 1 : 0;
+        fp.self_ids = d_self_ids;
         fp.gamma = gamma;
         fp.ymax = index->max_norm;
         fp.out_dist = d_dist + c0 * (int64_t)k;
@@ -1128,11 +1159,78 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         fin_ms += ms;
         last_splits = lay.pieces[0];
         last_blocks = W;
-        if (tier_bf && (int64_t)n_fail * 50 > cq_count + 3200) {
-            // more than ~2 % (+64) of the chunk's rows could not be certified under the split-bf16 margin: this data
+        if (tier_bf && (int64_t)n_fail * 4 > cq_count) {
+            // more than a quarter of the chunk's rows could not be certified under the split-bf16 margin: this data
             // needs the float32 operands; redo the chunk (and run the rest of the call) with the float32-MFMA kernel
             tier_bf = false;
             n_escalated += cq_count;
+            continue;
+        }
+        if (tier_bf && n_fail > 0) {
+            // Escalate only the uncertified rows: gather them into a dense query block, run the float32-operand kernel
+            // on it (its own uncertified rows go on to the exact float64 kernels), scatter the results back.
+            KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+            const size_t row_bytes = (size_t)query->d * (query->dtype == KZ_F32 ? 4 : 8);
+            int* fl = nullptr;
+            void* sub_raw = nullptr;
+            int64_t* sub_self = nullptr;
+            double* sub_dist = nullptr;
+            int64_t* sub_ind = nullptr;
+            kz_matrix* qsub = nullptr;
+            auto release = [&]() {
+                if (qsub) kz_matrix_destroy(qsub);
+                kz_pool_free(ctx, fl, 0);
+                kz_pool_free(ctx, sub_raw, 0);
+                kz_pool_free(ctx, sub_self, 0);
+                kz_pool_free(ctx, sub_dist, 0);
+                kz_pool_free(ctx, sub_ind, 0);
+            };
+            rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&fl);
+            if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * row_bytes, &sub_raw);
+            if (rc == KZ_OK && exclude_self) rc = kz_pool_alloc(ctx, (size_t)n_fail * 8, (void**)&sub_self);
+            if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * k * 8, (void**)&sub_dist);
+            if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * k * 8, (void**)&sub_ind);
+            if (rc != KZ_OK) {
+                release();
+                return rc;
+            }
+            hipError_t e = hipMemcpyAsync(fl, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(kz_gather_rows_kernel, dim3(n_fail), dim3(256), 0, ctx->stream, (const char*)query->raw, fl,
+                                   cq_begin, n_fail, (int64_t)row_bytes, (char*)sub_raw, sub_self);
+                e = hipGetLastError();
+            }
+            if (e != hipSuccess) {
+                release();
+                kz_set_error("kz_knn: gathering the escalated rows failed: %s", hipGetErrorString(e));
+                return KZ_ERR_HIP;
+            }
+            if (exclude_self && d_self_ids) {
+                // (an escalated subset of an escalated subset cannot happen: the inner call runs with float32 operands)
+            }
+            rc = kz_matrix_create(ctx, sub_raw, 1, n_fail, query->d, query->dtype, query->metric, &qsub);
+            kz_knn_stats st2;
+            memset(&st2, 0, sizeof(st2));
+            if (rc == KZ_OK)
+                rc = kz_knn_impl(ctx, qsub, 0, n_fail, index, k, exclude_self, sub_self, 1, sub_dist, sub_ind, &st2);
+            if (rc == KZ_OK) {
+                hipLaunchKernelGGL(kz_scatter_rows_kernel, dim3((unsigned)(((int64_t)n_fail * k + 255) / 256)), dim3(256), 0,
+                                   ctx->stream, sub_dist, sub_ind, fl, n_fail, k, fp.out_dist, fp.out_ind);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipEventRecord(ctx->ev[4], ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) {
+                    kz_set_error("kz_knn: scattering the escalated rows failed: %s", hipGetErrorString(e));
+                    rc = KZ_ERR_HIP;
+                }
+            }
+            release();
+            if (rc != KZ_OK) return rc;
+            KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+            fb_ms += ms;
+            n_escalated += n_fail;
+            n_fail_total += st2.n_fallback_rows;
+            c0 += max_rows_per_chunk;
             continue;
         }
         n_fail_total += n_fail;
@@ -1163,13 +1261,13 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
                                        cq_begin, (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn,
                                        index->n, (int)index->d, metric, (double*)vals);
                     hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(nb), dim3(256), 0, ctx->stream, fl, b0, cq_begin,
-                                       (const double*)vals, index->n, k, exclude_self ? 1 : 0, metric, fp.out_dist, fp.out_ind);
+                                       (const double*)vals, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, fp.out_dist, fp.out_ind);
                 } else {
                     hipLaunchKernelGGL(kz_exact_dist_kernel<double>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
                                        cq_begin, (const double*)query->raw, (const double*)index->raw, query->sqn, index->sqn,
                                        index->n, (int)index->d, metric, (double*)vals);
                     hipLaunchKernelGGL(kz_exact_select_kernel<double>, dim3(nb), dim3(256), 0, ctx->stream, fl, b0, cq_begin,
-                                       (const double*)vals, index->n, k, exclude_self ? 1 : 0, metric, fp.out_dist, fp.out_ind);
+                                       (const double*)vals, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, fp.out_dist, fp.out_ind);
                 }
             }
             hipError_t e = hipGetLastError();
@@ -1197,4 +1295,9 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
         stats->n_escalated_rows = n_escalated;
     }
     return KZ_OK;
+}
+
+extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index, int k,
+                      int exclude_self, double* d_dist, int64_t* d_ind, kz_knn_stats* stats) {
+    return kz_knn_impl(ctx, query, q_begin, q_count, index, k, exclude_self, nullptr, -1, d_dist, d_ind, stats);
 }

@@ -316,3 +316,30 @@ def test_bf16_pass_escalates_to_float32_operands_on_tight_clusters():
     assert st1["n_escalated_rows"] == 0
     np.testing.assert_array_equal(i1.numpy(), i.numpy())
     np.testing.assert_array_equal(d1.numpy(), d.numpy())
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_bf16_pass_escalates_only_the_uncertified_rows(single):
+    """Uniform data plus one tight far-away cluster: only the cluster's queries fail the split-bf16 certification; they
+    alone are gathered and re-done with float32 operands (self-stripping by explicit row id in single-source mode)."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.RandomState(23)
+    centre = rng.rand(48)
+    centre *= 12.0 / np.linalg.norm(centre)
+    t = np.vstack([rng.rand(3000, 48), centre + 0.05 * rng.randn(300, 48)]).astype(np.float32)
+    perm = rng.permutation(len(t))
+    t = t[perm]
+    if single:
+        s = t
+    else:
+        s = np.vstack([rng.rand(900, 48), centre + 0.05 * rng.randn(100, 48)]).astype(np.float32)
+    ctx = N.Context.get()
+    ym = N.DeviceMatrix(ctx, t, "euclidean")
+    qm = ym if single else N.DeviceMatrix(ctx, s, "euclidean")
+    d, i, st = N.knn(ctx, qm, ym, 10, exclude_self=single)
+    assert st["first_pass"] == 1
+    assert 0 < st["n_escalated_rows"] <= (300 if single else 100)
+    od, oi = O.knn_exact(s, t, 10, "euclidean", exclude_self=single)
+    np.testing.assert_array_equal(i.numpy(), oi)
+    np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=0)
