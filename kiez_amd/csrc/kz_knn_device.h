@@ -218,8 +218,8 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 #endif
 // Tile epilogue, second form (used by the split-bf16 kernel, where the epilogue is no longer hidden under MFMA time).
 // Work is proportional to the number of candidate EVENTS instead of the number of values:
-//   * the 16 groups of four values are tested first, back to back (four compares + three scalar ORs each, 16 wave-level
-//     masks in SGPRs), so the tests do not form a dependent compare -> branch chain per group;
+//   * the 16 groups of four values are tested first, back to back (max3 + max + compare each, 16 wave-level masks in
+//     SGPRs), so the tests do not form a dependent compare -> branch chain per group;
 //   * only groups in which some lane has an event are entered; inside, the four values are appended by straight-line
 //     code executed by all lanes (lanes without an event write to a scratch row of the log) -- the log can never
 //     overflow inside a group because a group is only entered when every lane has room for four entries;
@@ -258,13 +258,19 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
     float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
     const int rowbase = tile * KZ_TILE + 4 * h;
     unsigned long long gm[16];
-    // (compares, not an inline-asm max tree: hipcc's hazard recognizer must see every instruction that reads an MFMA
-    //  result, and fmaxf() would first canonicalise each of them)
+    // Group maxima by v_max3 / v_max in inline asm (fmaxf() would first canonicalise every MFMA result: 4 extra VALU
+    // per group).  hipcc's hazard recognizer does not see through inline asm, and an MFMA result must not be read by
+    // a VALU instruction for up to 19 wait states after the MFMA issued: the volatile statement below takes all four
+    // accumulators as in/out operands -- every MFMA precedes it, every later read of acc follows it -- and spends
+    // those wait states explicitly.
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
     for (int gi = 0; gi < 16; ++gi) {
         const int mt = gi >> 2, g4 = gi & 3;
-        gm[gi] = __builtin_amdgcn_ballot_w64(acc[mt][4 * g4] > tau_a) | __builtin_amdgcn_ballot_w64(acc[mt][4 * g4 + 1] > tau_a) |
-                 __builtin_amdgcn_ballot_w64(acc[mt][4 * g4 + 2] > tau_a) | __builtin_amdgcn_ballot_w64(acc[mt][4 * g4 + 3] > tau_a);
+        float m;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[mt][4 * g4]), "v"(acc[mt][4 * g4 + 1]), "v"(acc[mt][4 * g4 + 2]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][4 * g4 + 3]));
+        gm[gi] = __builtin_amdgcn_ballot_w64(m > tau_a);
     }
 #ifdef KZ_STAMP
     __builtin_amdgcn_sched_barrier(0);
