@@ -94,6 +94,13 @@ int kz_matrix_shape(const kz_matrix* m, int64_t* n, int64_t* d, int* dtype, int*
 int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index,
            int k, int exclude_self, double* d_dist, int64_t* d_ind, kz_knn_stats* stats);
 
+/* Host-only (no GPU needed): the work schedule kz_knn builds for a launch with `slots` resident workgroups
+ * (DESIGN.md section 3.1 "greedy rounds").  Round r covers round_qtiles[r] query tiles of 128 rows, each swept as
+ * round_pieces[r] index ranges of round_piece_tiles[r] tiles of 128 rows (the last range may be shorter).  Arrays
+ * hold up to 8 rounds.  k_eff = neighbours kept per query (k + 1 in single-source mode). */
+int kz_knn_plan(int64_t n_query_rows, int64_t n_index_rows, int k_eff, int slots, int force_splits, int min_splits,
+                int* n_rounds, int* round_qtiles, int* round_pieces, int* round_piece_tiles);
+
 /* ---- per-row statistics of a [n, K] distance array (numpy summation order) ----------------------------- */
 /* mean: ndarray.mean(axis=1); std: np.nanstd(axis=1) (ddof=0); last: column K-1.  Any output may be NULL.
  * Used for the fit state of CSLS (csls.py:90), NICDM (local_scaling.py:143), LS (:136), MP normal

@@ -68,6 +68,8 @@ SYMBOLS = [
     ("kz_matrix_destroy", C.c_int, [_P]),
     ("kz_matrix_shape", C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("kz_knn", C.c_int, [_P, _P, _I64, _I64, _P, C.c_int, C.c_int, _P, _P, C.POINTER(KnnStats)]),
+    ("kz_knn_plan", C.c_int, [_I64, _I64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                              C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("kz_row_stats", C.c_int, [_P, _P, _I64, C.c_int, _P, _P, _P]),
     ("kz_csls", C.c_int, [_P, _P, _P, _I64, C.c_int, _P, _P]),
     ("kz_local_scaling", C.c_int, [_P, _P, _P, _I64, C.c_int, _P, C.c_int, _P]),

@@ -818,6 +818,65 @@ static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
         }                                                     \
     } while (0)
 
+// Host schedule of one launch: greedy rounds.  slots = workgroups resident on the chip; dispatch is in block-id order, so
+// the items of one round start together and sweep the index in lockstep (each index tile is fetched into L2 once per
+// round).  With R query tiles left, a round cuts the index into s = ceil(slots / R) ranges and takes slots / s query
+// tiles: every round fills the chip with equal-length items, the items shrink from round to round and only the last few
+// query tiles get the shortest allowed ranges (>= 8 index tiles, <= max_pieces ranges).  force_splits (test knob) = one
+// round with exactly that many ranges; min_splits raises the first round's range count (L2 grouping knob).
+// Outputs: per round the number of query tiles and the requested range count (the actual number of ranges is
+// ceil(n_ytiles / ceil(n_ytiles / s))).
+static void kz_plan_rounds(int n_qtiles, int n_ytiles, int slots, int max_pieces, int force_splits, int min_splits,
+                           int* n_rounds, int* round_qtiles, int* round_splits) {
+    const int by_len = n_ytiles / 8 > 1 ? n_ytiles / 8 : 1;
+    auto clamp_s = [&](int v) {
+        if (v > max_pieces) v = max_pieces;
+        if (v > by_len) v = by_len;
+        if (v < 1) v = 1;
+        return v;
+    };
+    auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
+    auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
+    int R = n_qtiles, n = 0;
+    while (R > 0) {
+        int sp, A;
+        if (force_splits > 0) {
+            sp = force_splits < n_ytiles ? force_splits : n_ytiles;
+            if (sp > max_pieces) sp = max_pieces;
+            A = R;
+        } else {
+            sp = clamp_s((slots + R - 1) / R);
+            if (n == 0 && sp < min_splits) sp = clamp_s(min_splits);
+            A = slots / split_cnt(sp);
+            if (A < 1) A = 1;
+            if (A > R || n == KZ_MAX_REGIONS - 1) A = R;
+        }
+        round_qtiles[n] = A;
+        round_splits[n] = sp;
+        ++n;
+        R -= A;
+    }
+    *n_rounds = n;
+}
+
+extern "C" int kz_knn_plan(int64_t n_query_rows, int64_t n_index_rows, int k_eff, int slots, int force_splits, int min_splits,
+                           int* n_rounds, int* round_qtiles, int* round_pieces, int* round_piece_tiles) {
+    KZ_REQUIRE(n_rounds && round_qtiles && round_pieces && round_piece_tiles, "kz_knn_plan: null argument");
+    KZ_REQUIRE(n_query_rows > 0 && n_index_rows > 0 && slots > 0, "kz_knn_plan: sizes must be positive");
+    const int KP = kz_pick_list_len(k_eff);
+    KZ_REQUIRE(KP > 0, "kz_knn_plan: k=%d exceeds the supported maximum of 110 neighbours per query", k_eff);
+    const int n_qtiles = (int)((n_query_rows + KZ_TILE - 1) / KZ_TILE);
+    const int n_ytiles = (int)((n_index_rows + KZ_TILE - 1) / KZ_TILE);
+    int sp[KZ_MAX_REGIONS];
+    kz_plan_rounds(n_qtiles, n_ytiles, slots, KZ_FIN_MAXM / (2 * KP), force_splits, min_splits, n_rounds, round_qtiles, sp);
+    for (int r = 0; r < *n_rounds; ++r) {
+        const int len = (n_ytiles + sp[r] - 1) / sp[r];
+        round_piece_tiles[r] = len;
+        round_pieces[r] = (n_ytiles + len - 1) / len;
+    }
+    return KZ_OK;
+}
+
 // Rows of a query matrix gathered into a dense block (escalation of uncertified rows to the float32-operand kernel)
 __global__ __launch_bounds__(256) void kz_gather_rows_kernel(const char* __restrict__ raw, const int* __restrict__ rows,
                                                              int64_t row0, int n_rows, int64_t row_bytes,
@@ -938,20 +997,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         const int qt0 = (int)(cq_begin / KZ_TILE);
         const int qt1 = (int)((cq_begin + cq_count - 1) / KZ_TILE);
         const int n_qtiles = qt1 - qt0 + 1;
-        // ---- schedule: which workgroup sweeps which (query tile, index-tile range) ------------------------------
-        // Greedy rounds.  slots = workgroups resident on the chip; dispatch is in block-id order, so the items of one
-        // region start together and sweep the index in lockstep (each index tile is fetched into L2 once per round).
-        // With R query tiles left, a round cuts the index into s = ceil(slots / R) ranges and takes A = slots / s
-        // query tiles: every round fills the chip with equal-length items, the items shrink from round to round and
-        // only the last few query tiles get the shortest allowed ranges.  force_splits (test knob) = one region
-        // with exactly that many ranges.
-        const int by_len = n_ytiles / 8 > 1 ? n_ytiles / 8 : 1;  // keep >= 8 tiles (1024 rows) per item
-        auto clamp_s = [&](int v) {
-            if (v > max_splits_m) v = max_splits_m;
-            if (v > by_len) v = by_len;
-            if (v < 1) v = 1;
-            return v;
-        };
+        // ---- schedule: which workgroup sweeps which (query tile, index-tile range): kz_plan_rounds above ---------
         auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
         auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
         KzListLayout lay;
@@ -960,33 +1006,20 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         int W = 0;
         size_t list_elems = 0;
         {
-            int R = n_qtiles, q0 = 0;
-            while (R > 0) {
-                int sp, A;
-                if (ctx->force_splits > 0) {
-                    sp = ctx->force_splits < n_ytiles ? ctx->force_splits : n_ytiles;
-                    if (sp > max_splits_m) sp = max_splits_m;
-                    A = R;
-                } else {
-                    sp = clamp_s((slots + R - 1) / R);
-                    if (lay.n_regions == 0 && sp < ctx->min_splits) sp = clamp_s(ctx->min_splits);  // L2 grouping knob
-                    A = slots / split_cnt(sp);
-                    if (A < 1) A = 1;
-                    if (A > R || lay.n_regions == KZ_MAX_REGIONS - 1) A = R;
-                }
-                const int r = lay.n_regions++;
+            int n_reg = 0;
+            kz_plan_rounds(n_qtiles, n_ytiles, slots, max_splits_m, ctx->force_splits, ctx->min_splits, &n_reg, reg_nq, reg_s);
+            int q0 = 0;
+            for (int r = 0; r < n_reg; ++r) {
                 reg_q0[r] = q0;
-                reg_nq[r] = A;
-                reg_s[r] = sp;
                 reg_w0[r] = W;
-                lay.qt_end[r] = q0 + A;
-                lay.pieces[r] = split_cnt(sp);
+                lay.qt_end[r] = q0 + reg_nq[r];
+                lay.pieces[r] = split_cnt(reg_s[r]);
                 lay.base[r] = (long long)list_elems;
-                list_elems += (size_t)A * KZ_TILE * (size_t)(lay.pieces[r] * 2 * KP);
-                W += A * lay.pieces[r];
-                q0 += A;
-                R -= A;
+                list_elems += (size_t)reg_nq[r] * KZ_TILE * (size_t)(lay.pieces[r] * 2 * KP);
+                W += reg_nq[r] * lay.pieces[r];
+                q0 += reg_nq[r];
             }
+            lay.n_regions = n_reg;
         }
         const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
         const size_t fail_bytes = ((size_t)cq_count * 4 + 255) & ~(size_t)255;
