@@ -408,37 +408,59 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
 
     // top-KP of the M entries by (key desc, idx asc)
     int V = 0;
-    for (int r = 0; r < KP; ++r) {
-        float bk = -INFINITY;
-        int bi = 0x7fffffff, be = -1;
-        for (int e = lane; e < M; e += 64) {
-            const float x = ekey[e];
-            const int xi = eidx[e];
-            if (xi >= 0 && (x > bk || (x == bk && xi < bi))) {
-                bk = x;
-                bi = xi;
-                be = e;
-            }
+    if (M <= 64) {
+        // one entry per lane: its rank among the valid entries is a count over 64 uniform-lane broadcasts (v_readlane),
+        // no cross-lane reduction chains; entries with rank < KP land in ck/ci already ordered
+        const bool have = lane < M;
+        const float x = have ? ekey[lane] : -INFINITY;
+        const int xi = have ? eidx[lane] : -1;
+        const bool valid = xi >= 0;
+        int rank = 0;
+#pragma unroll 8
+        for (int jj = 0; jj < M; ++jj) {
+            const float ox = __shfl(x, jj, 64);
+            const int oi = __shfl(xi, jj, 64);
+            rank += (oi >= 0 && (ox > x || (ox == x && oi < xi))) ? 1 : 0;
         }
+        if (valid && rank < KP) {
+            ck[rank] = x;
+            ci[rank] = xi;
+        }
+        const int n_valid = __popcll(__ballot(valid));
+        V = n_valid < KP ? n_valid : KP;
+    } else {
+        for (int r = 0; r < KP; ++r) {
+            float bk = -INFINITY;
+            int bi = 0x7fffffff, be = -1;
+            for (int e = lane; e < M; e += 64) {
+                const float x = ekey[e];
+                const int xi = eidx[e];
+                if (xi >= 0 && (x > bk || (x == bk && xi < bi))) {
+                    bk = x;
+                    bi = xi;
+                    be = e;
+                }
+            }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ok = __shfl_xor(bk, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            const int oe = __shfl_xor(be, off, 64);
-            if (oe >= 0 && (be < 0 || ok > bk || (ok == bk && oi < bi))) {
-                bk = ok;
-                bi = oi;
-                be = oe;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ok = __shfl_xor(bk, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                const int oe = __shfl_xor(be, off, 64);
+                if (oe >= 0 && (be < 0 || ok > bk || (ok == bk && oi < bi))) {
+                    bk = ok;
+                    bi = oi;
+                    be = oe;
+                }
             }
+            if (be < 0) break;  // uniform: every lane holds the same winner
+            if (lane == 0) {
+                ck[r] = bk;
+                ci[r] = bi;
+                eidx[be] = -1;  // consumed
+            }
+            V = r + 1;
+            kz_wave_sync();
         }
-        if (be < 0) break;  // uniform: every lane holds the same winner
-        if (lane == 0) {
-            ck[r] = bk;
-            ci[r] = bi;
-            eidx[be] = -1;  // consumed
-        }
-        V = r + 1;
-        kz_wave_sync();
     }
     kz_wave_sync();
 
