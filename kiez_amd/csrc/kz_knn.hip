@@ -377,6 +377,41 @@ __host__ __device__ __forceinline__ int kz_fin_wave_bytes(int max_m, int KP) {
     return ((max_m * 8 + KP * 28) + 15) & ~15;
 }
 
+// Rank-based selection of the KP best of M <= 64*E list entries (key descending, row ascending; entries with row < 0 are
+// empty).  Lane l holds entries l, l+64, ...; returns the number of entries written to ck/ci (ordered by rank).
+template <int E>
+__device__ __forceinline__ int kz_rank_select(const float* ekey, const int* eidx, int M, int KP, float* ck, int* ci, int lane) {
+    float x[E];
+    int xi[E], rank[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const int e = lane + 64 * u;
+        x[u] = e < M ? ekey[e] : -INFINITY;
+        xi[u] = e < M ? eidx[e] : -1;
+        rank[u] = 0;
+    }
+    int n_valid = 0;
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        n_valid += __popcll(__ballot(xi[v] >= 0));
+        const int lim = min(64, M - 64 * v);
+        for (int jj = 0; jj < lim; ++jj) {  // jj is wave-uniform: the broadcasts are v_readlane, not ds_bpermute
+            const float ox = __shfl(x[v], jj, 64);
+            const int oi = __shfl(xi[v], jj, 64);
+#pragma unroll
+            for (int u = 0; u < E; ++u) rank[u] += (oi >= 0 && (ox > x[u] || (ox == x[u] && oi < xi[u]))) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        if (xi[u] >= 0 && rank[u] < KP) {
+            ck[rank[u]] = x[u];
+            ci[rank[u]] = xi[u];
+        }
+    }
+    return n_valid < KP ? n_valid : KP;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
@@ -408,26 +443,15 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
 
     // top-KP of the M entries by (key desc, idx asc)
     int V = 0;
-    if (M <= 64) {
-        // one entry per lane: its rank among the valid entries is a count over 64 uniform-lane broadcasts (v_readlane),
-        // no cross-lane reduction chains; entries with rank < KP land in ck/ci already ordered
-        const bool have = lane < M;
-        const float x = have ? ekey[lane] : -INFINITY;
-        const int xi = have ? eidx[lane] : -1;
-        const bool valid = xi >= 0;
-        int rank = 0;
-#pragma unroll 8
-        for (int jj = 0; jj < M; ++jj) {
-            const float ox = __shfl(x, jj, 64);
-            const int oi = __shfl(xi, jj, 64);
-            rank += (oi >= 0 && (ox > x || (ox == x && oi < xi))) ? 1 : 0;
-        }
-        if (valid && rank < KP) {
-            ck[rank] = x;
-            ci[rank] = xi;
-        }
-        const int n_valid = __popcll(__ballot(valid));
-        V = n_valid < KP ? n_valid : KP;
+    if (M <= 256) {
+        // E entries per lane: the rank of an entry among the valid entries is a count over uniform-lane broadcasts
+        // (v_readlane), no cross-lane reduction chains; entries with rank < KP land in ck/ci already ordered
+        if (M <= 64)
+            V = kz_rank_select<1>(ekey, eidx, M, KP, ck, ci, lane);
+        else if (M <= 128)
+            V = kz_rank_select<2>(ekey, eidx, M, KP, ck, ci, lane);
+        else
+            V = kz_rank_select<4>(ekey, eidx, M, KP, ck, ci, lane);
     } else {
         for (int r = 0; r < KP; ++r) {
             float bk = -INFINITY;
