@@ -560,8 +560,12 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
             eps = p.gamma * 1.001;
             key_k = 1.0 - sv[k_eff - 1];
         } else {
-            eps = p.gamma * (0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax);
+            const double scale = 0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax;
+            eps = p.gamma * scale;
             key_k = 0.5 * (qs - sv[k_eff - 1]);
+            // the relative bound assumes the products stay in the normal float32 range (data at the 1e-19 scale and below
+            // underflows in the matrix pipe): such rows are left to the exact float64 kernels
+            if (scale < 1e-30) eps = INFINITY;
         }
         certified = (double)ck[KP - 1] + eps < key_k;
     }

@@ -343,3 +343,19 @@ def test_bf16_pass_escalates_only_the_uncertified_rows(single):
     od, oi = O.knn_exact(s, t, 10, "euclidean", exclude_self=single)
     np.testing.assert_array_equal(i.numpy(), oi)
     np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=0)
+
+
+def test_data_below_the_float32_product_range_stays_exact():
+    """Rows at the 1e-20 scale: q.y underflows in float32, so no approximate key can be trusted; every row must take the
+    exact float64 path and still match."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.RandomState(5)
+    s, t = 1e-20 * rng.rand(200, 24), 1e-20 * rng.rand(900, 24)
+    ctx = N.Context.get()
+    qm, ym = N.DeviceMatrix(ctx, s, "sqeuclidean"), N.DeviceMatrix(ctx, t, "sqeuclidean")
+    d, i, st = N.knn(ctx, qm, ym, 5)
+    assert st["n_fallback_rows"] == 200
+    od, oi = O.knn_exact(s, t, 5, "sqeuclidean")
+    np.testing.assert_array_equal(i.numpy(), oi)
+    np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=0)
