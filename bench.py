@@ -218,6 +218,8 @@ def main():
                          "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS},
             "certification_fallback_rows": int(fallback_rows),
             "escalated_rows": int(sum(st.get("n_escalated_rows", 0) for _, _, st in knn_log)),
+            "rounding_bound_self_check": {"max_err_over_eps": max((st.get("max_err_ratio", 0.0) for _, _, st in knn_log), default=0.0),
+                                          "note": "max |approximate key - exact key| / eps over all re-ranked candidates; the certification needs < 1"},
             "other_kernels_ms": {"finalize_avg": sum(st["finalize_ms"] for _, _, st in knn_log) / max(n_launch, 1),
                                  "fallback_total": sum(st["fallback_ms"] for _, _, st in knn_log)},
         }

@@ -52,7 +52,9 @@ typedef struct kz_knn_stats {
     int32_t first_pass;      /* operand precision of the fused kernel that produced the result of the last
                                 chunk: 0 = float32 MFMA, 1 = split-bf16 (bf16x2) MFMA                        */
     int64_t n_escalated_rows; /* query rows first tried with the split-bf16 pass and re-done with float32
-                                operands because too many of their chunk failed the wider certification    */
+                                operands because they (or too many rows of their chunk) failed its certification */
+    double max_err_ratio;    /* self-check: max over all re-ranked candidates of |approximate key - exact key| / eps,
+                                eps = the rounding bound the certification uses; must stay below 1          */
 } kz_knn_stats;
 
 /* ---- library / context -------------------------------------------------------------------------------- */

@@ -42,6 +42,7 @@ class KnnStats(C.Structure):
         ("n_blocks", C.c_int32),
         ("first_pass", C.c_int32),
         ("n_escalated_rows", C.c_int64),
+        ("max_err_ratio", C.c_double),
     ]
 
     def as_dict(self):

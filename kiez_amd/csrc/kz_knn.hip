@@ -316,6 +316,7 @@ struct KnnFinParams {
     int64_t* out_ind;
     int* fail_count;
     int* fail_list;
+    unsigned long long* err_ratio_bits;  // max over certified candidates of |key~ - key| / eps (bits of a non-negative double)
 };
 
 template <typename T>
@@ -545,6 +546,27 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
         si[rank] = id;
     }
     kz_wave_sync();
+
+    // Self-check of the rounding bound the certification rests on: for every candidate both the approximate key
+    // (ck, from the fused kernel) and the exact key (from the float64 re-rank) are known here.
+    double eps_q;
+    if (p.metric == KZ_COSINE)
+        eps_q = p.gamma * 1.001;
+    else
+        eps_q = p.gamma * (0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax);
+    if (eps_q > 0.0 && p.err_ratio_bits) {
+        double worst = 0.0;
+        for (int c = lane; c < V; c += 64) {
+            const double v = cv[c];
+            if (v > 0.0) {  // (a distance clamped at 0 no longer carries the exact key)
+                const double key = (p.metric == KZ_COSINE) ? 1.0 - v : 0.5 * (qs - v);
+                worst = fmax(worst, fabs((double)ck[c] - key) / eps_q);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off, 64));
+        if (lane == 0 && worst > 0.0) atomicMax(p.err_ratio_bits, (unsigned long long)__double_as_longlong(worst));
+    }
 
     // Certification (DESIGN.md "Certified candidate sets").  |key~ - key| <= eps for every index row.  A row outside
     // the candidate set has key~ <= ck[KP-1] (the K'-th best approximate key), hence an exact key <= ck[KP-1] + eps.
@@ -1034,6 +1056,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
     const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096;
     double main_ms = 0, fin_ms = 0, fb_ms = 0;
     int64_t n_fail_total = 0, n_escalated = 0;
+    double max_err_ratio = 0.0;
     int last_splits = 1, last_blocks = 0;
     for (int64_t c0 = 0; c0 < q_count;) {
         int slots = 0;
@@ -1082,7 +1105,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         int* fail_list = (int*)((char*)scratch + 2 * key_bytes);
         int4* d_work = (int4*)((char*)scratch + 2 * key_bytes + fail_bytes);
         int* fail_count = ctx->d_counters + 8;
-        KZ_HIP(hipMemsetAsync(fail_count, 0, 2 * sizeof(int), ctx->stream));  // fail counter + kernel error word
+        KZ_HIP(hipMemsetAsync(fail_count, 0, 4 * sizeof(int), ctx->stream));  // fail counter, kernel error word, error-ratio bits
         {
             // host-side table (pinned staging grows on demand)
             const size_t need = work_bytes;
@@ -1194,6 +1217,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         fp.out_ind = d_ind + c0 * (int64_t)k;
         fp.fail_count = fail_count;
         fp.fail_list = fail_list;
+        fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
         {
             // one launch per list region: the dynamic LDS follows the region's entry count (occupancy of the gather)
             for (int rg = 0; rg < lay.n_regions; ++rg) {
@@ -1213,9 +1237,14 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         }
         KZ_HIP(hipGetLastError());
         KZ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-        KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         KZ_HIP(hipStreamSynchronize(ctx->stream));
         const int n_fail = ctx->h_counters[8];
+        {
+            double ratio;
+            memcpy(&ratio, ctx->h_counters + 10, 8);
+            if (ratio > max_err_ratio) max_err_ratio = ratio;
+        }
         if (ctx->h_counters[9] != 0) {
             kz_set_error("kz_knn: fused kernel reported an internal synchronisation time-out (error word %d)", ctx->h_counters[9]);
             return KZ_ERR_HIP;
@@ -1313,6 +1342,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
             fb_ms += ms;
             n_escalated += n_fail;
             n_fail_total += st2.n_fallback_rows;
+            if (st2.max_err_ratio > max_err_ratio) max_err_ratio = st2.max_err_ratio;
             c0 += max_rows_per_chunk;
             continue;
         }
@@ -1376,6 +1406,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         stats->n_blocks = last_blocks;
         stats->first_pass = tier_bf ? 1 : 0;
         stats->n_escalated_rows = n_escalated;
+        stats->max_err_ratio = max_err_ratio;
     }
     return KZ_OK;
 }

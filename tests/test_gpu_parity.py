@@ -359,3 +359,25 @@ def test_data_below_the_float32_product_range_stays_exact():
     od, oi = O.knn_exact(s, t, 5, "sqeuclidean")
     np.testing.assert_array_equal(i.numpy(), oi)
     np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("n_s,n_t,d,dtype,metric,gauss", [
+    (2000, 6000, 128, np.float32, "euclidean", False),
+    (2000, 6000, 128, np.float32, "euclidean", True),
+    (1500, 4000, 300, np.float64, "cosine", True),
+    (1500, 4000, 64, np.float64, "sqeuclidean", False),
+])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_rounding_bound_holds_with_margin(n_s, n_t, d, dtype, metric, gauss, precision):
+    """The certification rests on |approximate key - exact key| <= eps.  kz_knn measures the worst ratio over every
+    re-ranked candidate (tens of thousands of keys per call): it must stay well below 1 for both operand precisions."""
+    from kiez_amd import _native as N
+    s, t = _data(n_s, n_t, d, dtype, seed=3 * d, gauss=gauss)
+    ctx = N.Context.get()
+    ctx.set_option("precision", precision)
+    try:
+        qm, ym = N.DeviceMatrix(ctx, s, metric), N.DeviceMatrix(ctx, t, metric)
+        _, _, st = N.knn(ctx, qm, ym, 10)
+    finally:
+        ctx.set_option("precision", 0)
+    assert 0.0 < st["max_err_ratio"] < 0.5, st
