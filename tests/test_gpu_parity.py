@@ -258,6 +258,9 @@ def test_query_chunking_and_row_ranges():
     (700, 1500, 40, np.float64, "sqeuclidean", 7, False),   # 3 slices: odd count, barrier parity changes per tile
     (1300, 1300, 96, np.float32, "cosine", 25, True),       # list length 32, self stripped
     (400, 5000, 17, np.float32, "euclidean", 50, False),    # 2 slices, list length 64
+    (500, 1900, 70, np.float32, "euclidean", 10, False),    # 5 slices
+    (500, 1900, 100, np.float64, "euclidean", 100, False),  # 7 slices, list length 128
+    (640, 2500, 384, np.float32, "sqeuclidean", 10, False), # 24 slices: the largest stationary query tile
     (300, 800, 16, np.float32, "euclidean", 5, False),      # 1 slice: split-bf16 not eligible, float32 kernel
     (300, 800, 200, np.float32, "euclidean", 5, False),     # 14 slices (d padded to 224): one workgroup per CU
     (260, 900, 300, np.float64, "cosine", 10, False),       # 20 slices
