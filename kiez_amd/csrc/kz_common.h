@@ -54,7 +54,7 @@ struct kz_matrix {
     int dtype, metric;
     int64_t n_tiles;  // ceil(n / 128)
     int kg;           // d_pad / 4 (number of 4-wide k-groups), d_pad = round_up(d, 16)
-    int kg_bf;        // same for the split-bf16 image: d > 128 is padded to a multiple of 32 there (even slice count)
+    int kg_bf;        // same for the split-bf16 image (currently equal to kg)
     void* raw;        // [n, d] dtype, row-major (exact data, used by the float64 re-rank)
     float* packed;    // [n_tiles][kg][128][4] float32 MFMA operand image
     unsigned short* packed_bf;  // [n_tiles][kg/4][4 planes][128][8] bf16 split image: planes hi(k 0-7), hi(k 8-15), lo, lo

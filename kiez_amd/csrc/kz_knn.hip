@@ -766,13 +766,21 @@ static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
             case 6: rc = fn<KPV, 6> args; break;          \
             case 7: rc = fn<KPV, 7> args; break;          \
             case 8: rc = fn<KPV, 8> args; break;          \
+            case 9: rc = fn<KPV, 9> args; break;          \
             case 10: rc = fn<KPV, 10> args; break;        \
+            case 11: rc = fn<KPV, 11> args; break;        \
             case 12: rc = fn<KPV, 12> args; break;        \
+            case 13: rc = fn<KPV, 13> args; break;        \
             case 14: rc = fn<KPV, 14> args; break;        \
+            case 15: rc = fn<KPV, 15> args; break;        \
             case 16: rc = fn<KPV, 16> args; break;        \
+            case 17: rc = fn<KPV, 17> args; break;        \
             case 18: rc = fn<KPV, 18> args; break;        \
+            case 19: rc = fn<KPV, 19> args; break;        \
             case 20: rc = fn<KPV, 20> args; break;        \
+            case 21: rc = fn<KPV, 21> args; break;        \
             case 22: rc = fn<KPV, 22> args; break;        \
+            case 23: rc = fn<KPV, 23> args; break;        \
             default: rc = fn<KPV, 24> args; break;        \
         }                                                 \
     } while (0)

@@ -110,7 +110,7 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     m->n_tiles = (n + KZ_TILE - 1) / KZ_TILE;
     const int64_t d_pad = ((d + KZ_KSLICE - 1) / KZ_KSLICE) * KZ_KSLICE;
     m->kg = (int)(d_pad / 4);
-    const int64_t d_pad_bf = d_pad > 128 ? ((d + 31) / 32) * 32 : d_pad;
+    const int64_t d_pad_bf = d_pad;  // (kept separate from d_pad: the bf16 kernel is free to use its own slice count)
     m->kg_bf = (int)(d_pad_bf / 4);
     const size_t packed_bf_bytes = (size_t)(m->n_tiles * KZ_TILE) * (size_t)d_pad_bf * 4;
     const int64_t n_pad = m->n_tiles * KZ_TILE;

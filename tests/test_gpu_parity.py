@@ -262,8 +262,8 @@ def test_query_chunking_and_row_ranges():
     (500, 1900, 100, np.float64, "euclidean", 100, False),  # 7 slices, list length 128
     (640, 2500, 384, np.float32, "sqeuclidean", 10, False), # 24 slices: the largest stationary query tile
     (300, 800, 16, np.float32, "euclidean", 5, False),      # 1 slice: split-bf16 not eligible, float32 kernel
-    (300, 800, 200, np.float32, "euclidean", 5, False),     # 14 slices (d padded to 224): one workgroup per CU
-    (260, 900, 300, np.float64, "cosine", 10, False),       # 20 slices
+    (300, 800, 200, np.float32, "euclidean", 5, False),     # 13 slices: one workgroup per CU, odd slice count
+    (260, 900, 300, np.float64, "cosine", 10, False),       # 19 slices
     (200, 600, 400, np.float32, "euclidean", 5, False),     # 26 slices: not eligible, float32 kernel
 ])
 def test_precision_tiers_agree_bit_for_bit(n_s, n_t, d, dtype, metric, k, single):
@@ -284,7 +284,7 @@ def test_precision_tiers_agree_bit_for_bit(n_s, n_t, d, dtype, metric, k, single
             res[prec] = (dd.numpy(), ii.numpy(), st)
         finally:
             ctx.set_option("precision", 0)
-    n_slices = (d + 15) // 16 if d <= 128 else 2 * ((d + 31) // 32)
+    n_slices = (d + 15) // 16
     assert res[0][2]["first_pass"] == (1 if 2 <= n_slices <= 24 else 0)
     assert res[1][2]["first_pass"] == 0
     np.testing.assert_array_equal(res[0][1], res[1][1])
