@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
     //   log   up to KZ_LOG_CAP keys that beat the pruning threshold since the last merge (LDS, append-only).
     // The threshold is only refreshed at merges, which follow a geometric schedule in the number of tiles seen
     // (identical for every lane, so merges run with all 64 lanes busy); a full log forces an early merge.
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP, s) + h * 32 + j;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
     st.si = reinterpret_cast<int*>(smem + KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
+        st.lk[e * KZ_LSTRIDE] = -INFINITY;
+        st.li[e * KZ_LSTRIDE] = -1;
     }
     st.tau = -INFINITY;
     st.minpos = 0;
@@ -432,13 +432,18 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
     const int k_eff = p.k + (p.exclude_self ? 1 : 0);
 
     const int64_t lrow = p.list_row0 + q;
-    const int64_t lbase = kz_list_base(lrow, p.lay, KP);
-    const float* gk = p.in_key + lbase;
-    const int* gi = p.in_idx + lbase;
-    const int M = p.lay.pieces[kz_list_region(lrow, p.lay)] * 2 * KP;
+    const int n_pieces = p.lay.pieces[kz_list_region(lrow, p.lay)];
+    const int M = n_pieces * 2 * KP;
+    // entry e of this query: piece e / (2 KP), lane-half (e / KP) & 1, list entry e % KP  (layout: kz_list_wave_base)
+    const int64_t lwave = kz_list_wave_base(lrow, p.lay, KP, 0) + (lrow & 31);
     for (int e = lane; e < M; e += 64) {
-        ekey[e] = gk[e];
-        eidx[e] = gi[e];
+        const int piece = e / (2 * KP);
+        const int rem = e - piece * 2 * KP;
+        const int hh = rem / KP;
+        const int ee = rem - hh * KP;
+        const int64_t off = lwave + ((int64_t)piece * KP + ee) * KZ_LSTRIDE + hh * 32;
+        ekey[e] = p.in_key[off];
+        eidx[e] = p.in_idx[off];
     }
     kz_wave_sync();
 

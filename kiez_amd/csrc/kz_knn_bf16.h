@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
     const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + h * 32 + j;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
     st.si = reinterpret_cast<int*>(smem + KZ_BF_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
+        st.lk[e * KZ_LSTRIDE] = -INFINITY;
+        st.li[e * KZ_LSTRIDE] = -1;
     }
     st.tau = -INFINITY;
     st.minpos = 0;

@@ -55,10 +55,16 @@ __host__ __device__ __forceinline__ int kz_list_region(int64_t list_row, const K
     while (r + 1 < L.n_regions && qt >= L.qt_end[r]) ++r;
     return r;
 }
-__host__ __device__ __forceinline__ int64_t kz_list_base(int64_t list_row, const KzListLayout& L, int KP) {
+// Lists are stored interleaved per WAVE: the 64 (query, lane-half) lists a wave owns for one piece form a block
+// [KP entries][64 lanes], so entry e of all 64 lists is one 256-byte line -- the fused kernels' merges scan their lists
+// with coalesced wave-loads (per-lane contiguous lists cost 64 cache lines per load instruction).
+//   offset(list_row, piece, half h, entry e) = kz_list_wave_base(...) + e * 64 + h * 32 + list_row % 32
+constexpr int KZ_LSTRIDE = 64;
+__host__ __device__ __forceinline__ int64_t kz_list_wave_base(int64_t list_row, const KzListLayout& L, int KP, int piece) {
     const int r = kz_list_region(list_row, L);
     const int64_t row0 = r > 0 ? (int64_t)L.qt_end[r - 1] * KZ_TILE : 0;
-    return L.base[r] + (list_row - row0) * (int64_t)(L.pieces[r] * 2 * KP);
+    const int64_t wb = (list_row - row0) >> 5;  // 32 queries per wave
+    return L.base[r] + ((wb * L.pieces[r] + piece) * (int64_t)KP) * KZ_LSTRIDE;
 }
 
 struct KnnCandParams {
@@ -198,7 +204,7 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
         // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
         for (int e = 0; e < st.cnt; ++e) {
             const float v = st.sk[e * 256];
-            if (v > st.tau) kz_list_replace_min<KP, 1>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+            if (v > st.tau) kz_list_replace_min<KP, KZ_LSTRIDE>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
         }
         st.cnt = 0;
         tau_eff = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
@@ -244,7 +250,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
             KZ_T(tm0);
             for (int e = 0; e < st.cnt; ++e) {
                 const float v = st.sk[e * 256];
-                if (v > st.tau) kz_list_replace_min<KP, 1>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+                if (v > st.tau) kz_list_replace_min<KP, KZ_LSTRIDE>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
             }
 #ifdef KZ_STAMP
             __builtin_amdgcn_sched_barrier(0);
@@ -321,7 +327,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         KZ_T(tm0);
         for (int e = 0; e < st.cnt; ++e) {
             const float v = st.sk[e * 256];
-            if (v > st.tau) kz_list_replace_min<KP, 1>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+            if (v > st.tau) kz_list_replace_min<KP, KZ_LSTRIDE>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
         }
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand2_kernel(KnnCandParams p) {
     const int NM = p.kg >> 3;  // 32-k macro slices per tile
     const int total = (t_end - t_begin) * NM;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP, s) + h * 32 + j;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand2_kernel(KnnCandParams p) {
     st.si = reinterpret_cast<int*>(smem + KZ_CAND2_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
+        st.lk[e * KZ_LSTRIDE] = -INFINITY;
+        st.li[e * KZ_LSTRIDE] = -1;
     }
     st.tau = -INFINITY;
     st.minpos = 0;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
     const int NS = p.kg >> 2;  // >= 4 (host)
     const int total = (t_end - t_begin) * NS;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + h * 32 + j;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_ring_kernel(KnnCandParams 
     st.si = reinterpret_cast<int*>(smem + KZ_RING_LOG + KZ_RING_CAP * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
+        st.lk[e * KZ_LSTRIDE] = -INFINITY;
+        st.li[e * KZ_LSTRIDE] = -1;
     }
     st.tau = -INFINITY;
     st.minpos = 0;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_res_kernel(KnnCandParams p
     const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + h * 32 + j;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_res_kernel(KnnCandParams p
     st.si = reinterpret_cast<int*>(smem + KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
+        st.lk[e * KZ_LSTRIDE] = -INFINITY;
+        st.li[e * KZ_LSTRIDE] = -1;
     }
     st.tau = -INFINITY;
     st.minpos = 0;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_direct_kernel(KnnCandParam
     const int HS = p.kg >> 1;  // half-slices (8 k each side of the lane halves = 16 MFMAs) per tile
     const int total = (t_end - t_begin) * HS;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP, s) + h * 32 + j;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_direct_kernel(KnnCandParam
     st.si = reinterpret_cast<int*>(smem + KZ_LOG_CAP * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
+        st.lk[e * KZ_LSTRIDE] = -INFINITY;
+        st.li[e * KZ_LSTRIDE] = -1;
     }
     st.tau = -INFINITY;
     st.minpos = 0;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_il_kernel(KnnCandParams p)
     const int NS = p.kg >> 2;
     const int total = (t_end - t_begin) * NS;
 
-    const int64_t listoff = kz_list_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP) + (int64_t)(s * 2 + h) * KP;
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * wave + j, p.lay, KP, s) + h * 32 + j;
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
@@ -611,8 +611,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_il_kernel(KnnCandParams p)
     st.si = reinterpret_cast<int*>(smem + KzIl<NB>::LOG_BASE + CAP * 256 * 4) + tid;
 #pragma unroll 4
     for (int e = 0; e < KP; ++e) {
-        st.lk[e] = -INFINITY;
-        st.li[e] = -1;
+        st.lk[e * KZ_LSTRIDE] = -INFINITY;
+        st.li[e * KZ_LSTRIDE] = -1;
     }
     st.tau = -INFINITY;
     st.minpos = 0;
