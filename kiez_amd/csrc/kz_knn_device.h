@@ -97,20 +97,20 @@ constexpr int KZ_CAND_LDS = KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 8;
 
 // Replace the minimum of an unsorted K'-entry list by (v, idx) and find the new minimum.  All keys are fetched
 // before the compare chain starts so that the LDS latency is paid once, not per element.
-template <int KP, int LSTRIDE>
+template <int KP, int LSTRIDE, int CHUNK = KZ_SCAN_CHUNK>
 __device__ __forceinline__ void kz_list_replace_min(float* lk, int* li, float v, int idx, float& tau, int& minpos) {
     lk[minpos * LSTRIDE] = v;
     li[minpos * LSTRIDE] = idx;
     float mn = INFINITY;
     int mp = 0;
 #pragma unroll
-    for (int c0 = 0; c0 < KP; c0 += KZ_SCAN_CHUNK) {
-        float kk[KZ_SCAN_CHUNK];
+    for (int c0 = 0; c0 < KP; c0 += CHUNK) {
+        float kk[CHUNK];
 #pragma unroll
-        for (int e = 0; e < KZ_SCAN_CHUNK; ++e) kk[e] = lk[(c0 + e) * LSTRIDE];
+        for (int e = 0; e < CHUNK; ++e) kk[e] = lk[(c0 + e) * LSTRIDE];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < KZ_SCAN_CHUNK; ++e) {
+        for (int e = 0; e < CHUNK; ++e) {
             if (kk[e] < mn) {
                 mn = kk[e];
                 mp = c0 + e;
@@ -236,7 +236,8 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 //     in LDS (sync[tile & 3]); every wave reads it at the start of the NEXT tile's epilogue and merges then, together.
 //     (The flag of tile t is written during epilogue t, read during epilogue t+1, cleared during epilogue t+2; waves of
 //     a workgroup are never more than one tile apart, and a workgroup barrier lies between any two epilogues.)
-template <int KP, int CAP>
+// SCAN = list keys fetched per batch by a merge insert (all in flight together: one L2 round trip per batch).
+template <int KP, int CAP, int SCAN>
 __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
                                                   const int h, int* sync KZ_EPI2_STAMP_ARGS) {
     KZ_T(te0);
@@ -250,7 +251,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
             KZ_T(tm0);
             for (int e = 0; e < st.cnt; ++e) {
                 const float v = st.sk[e * 256];
-                if (v > st.tau) kz_list_replace_min<KP, KZ_LSTRIDE>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+                if (v > st.tau) kz_list_replace_min<KP, KZ_LSTRIDE, SCAN>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
             }
 #ifdef KZ_STAMP
             __builtin_amdgcn_sched_barrier(0);
@@ -327,7 +328,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         KZ_T(tm0);
         for (int e = 0; e < st.cnt; ++e) {
             const float v = st.sk[e * 256];
-            if (v > st.tau) kz_list_replace_min<KP, KZ_LSTRIDE>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+            if (v > st.tau) kz_list_replace_min<KP, KZ_LSTRIDE, SCAN>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
         }
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);
