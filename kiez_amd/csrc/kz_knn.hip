@@ -570,7 +570,11 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off, 64));
-        if (lane == 0 && worst > 0.0) atomicMax(p.err_ratio_bits, (unsigned long long)__double_as_longlong(worst));
+        if (lane == 0 && worst > 0.0) {
+            // 100k waves hit ONE address: read first, only the (rare) new maxima pay for the atomic
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(worst);
+            if (bits > __hip_atomic_load(p.err_ratio_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.err_ratio_bits, bits);
+        }
     }
 
     // Certification (DESIGN.md "Certified candidate sets").  |key~ - key| <= eps for every index row.  A row outside
