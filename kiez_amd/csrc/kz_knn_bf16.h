@@ -62,6 +62,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
     }
     st.tau = -INFINITY;
     st.minpos = 0;
+    KzBlockMin<KP> bmin;
+    bmin.init();
     st.cnt = 0;
     st.tiles_done = 0;
     st.next_merge = 1;
@@ -201,12 +203,12 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        kz_tile_epilogue2<KP, KZ_BF_CAP, (KP <= 16 ? 16 : (WPS == 1 ? (KP < 64 ? KP : 64) : 32))>(acc, st, tile, tile == t_end - 1, h, msync, c_merge, n_pass, n_ins, c_e1, c_e2);
+        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync, c_merge, n_pass, n_ins, c_e1, c_e2);
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
 #else
-        kz_tile_epilogue2<KP, KZ_BF_CAP, (KP <= 16 ? 16 : (WPS == 1 ? (KP < 64 ? KP : 64) : 32))>(acc, st, tile, tile == t_end - 1, h, msync);
+        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync);
 #endif
     }
 #ifdef KZ_STAMP

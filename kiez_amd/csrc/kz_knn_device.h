@@ -222,6 +222,67 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 #else
 #define KZ_EPI2_STAMP_ARGS
 #endif
+// Two-level minimum of an unsorted K'-entry list: the list is cut into NB blocks, the minimum of every block (value and
+// position inside the block) is kept in registers.  Replacing the global minimum then touches ONE block: write the new
+// entry, re-read that block (K'/NB keys, one L2 round trip), refresh its minimum -- instead of re-scanning all K' keys.
+template <int KP>
+struct KzBlockMin {
+    static constexpr int NB = KP >= 64 ? 8 : 4;
+    static constexpr int BS = KP / NB;
+    float bm[NB];
+    int bp[NB];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            bm[i] = -INFINITY;
+            bp[i] = 0;
+        }
+    }
+};
+
+// Insert (v, idx) over the current minimum (caller guarantees v > tau); returns the new minimum in tau.
+template <int KP, int LSTRIDE>
+__device__ __forceinline__ void kz_list_insert_blocked(float* lk, int* li, KzBlockMin<KP>& bs, float v, int idx, float& tau) {
+    constexpr int NB = KzBlockMin<KP>::NB, BS = KzBlockMin<KP>::BS;
+    float m = bs.bm[0];
+    int b = 0;
+#pragma unroll
+    for (int i = 1; i < NB; ++i) {
+        if (bs.bm[i] < m) {
+            m = bs.bm[i];
+            b = i;
+        }
+    }
+    int pos = bs.bp[0];
+#pragma unroll
+    for (int i = 1; i < NB; ++i) pos = (b == i) ? bs.bp[i] : pos;
+    float* blk = lk + (b * BS) * LSTRIDE;
+    float kk[BS];
+#pragma unroll
+    for (int jj = 0; jj < BS; ++jj) kk[jj] = blk[jj * LSTRIDE];   // issued before the store: its slot is patched below
+    __builtin_amdgcn_sched_barrier(0);
+    blk[pos * LSTRIDE] = v;
+    li[(b * BS + pos) * LSTRIDE] = idx;
+    float nm = INFINITY;
+    int np = 0;
+#pragma unroll
+    for (int jj = 0; jj < BS; ++jj) {
+        const float x = (jj == pos) ? v : kk[jj];
+        if (x < nm) {
+            nm = x;
+            np = jj;
+        }
+    }
+    float t = INFINITY;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        bs.bm[i] = (b == i) ? nm : bs.bm[i];
+        bs.bp[i] = (b == i) ? np : bs.bp[i];
+        t = fminf(t, bs.bm[i]);
+    }
+    tau = t;
+}
+
 // Tile epilogue, second form (used by the split-bf16 kernel, where the epilogue is no longer hidden under MFMA time).
 // Work is proportional to the number of candidate EVENTS instead of the number of values:
 //   * the 16 groups of four values are tested first, back to back (max3 + max + compare each, 16 wave-level masks in
@@ -236,10 +297,9 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 //     in LDS (sync[tile & 3]); every wave reads it at the start of the NEXT tile's epilogue and merges then, together.
 //     (The flag of tile t is written during epilogue t, read during epilogue t+1, cleared during epilogue t+2; waves of
 //     a workgroup are never more than one tile apart, and a workgroup barrier lies between any two epilogues.)
-// SCAN = list keys fetched per batch by a merge insert (all in flight together: one L2 round trip per batch).
-template <int KP, int CAP, int SCAN>
-__device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
-                                                  const int h, int* sync KZ_EPI2_STAMP_ARGS) {
+template <int KP, int CAP>
+__device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, KzBlockMin<KP>& bs, const int tile,
+                                                  const bool last_tile, const int h, int* sync KZ_EPI2_STAMP_ARGS) {
     KZ_T(te0);
     ++st.tiles_done;
     const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
@@ -251,7 +311,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
             KZ_T(tm0);
             for (int e = 0; e < st.cnt; ++e) {
                 const float v = st.sk[e * 256];
-                if (v > st.tau) kz_list_replace_min<KP, KZ_LSTRIDE, SCAN>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+                if (v > st.tau) kz_list_insert_blocked<KP, KZ_LSTRIDE>(st.lk, st.li, bs, v, st.si[e * 256], st.tau);
             }
 #ifdef KZ_STAMP
             __builtin_amdgcn_sched_barrier(0);
@@ -328,7 +388,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         KZ_T(tm0);
         for (int e = 0; e < st.cnt; ++e) {
             const float v = st.sk[e * 256];
-            if (v > st.tau) kz_list_replace_min<KP, KZ_LSTRIDE, SCAN>(st.lk, st.li, v, st.si[e * 256], st.tau, st.minpos);
+            if (v > st.tau) kz_list_insert_blocked<KP, KZ_LSTRIDE>(st.lk, st.li, bs, v, st.si[e * 256], st.tau);
         }
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);
