@@ -9,6 +9,12 @@ from tests.golden_util import GOLDEN, HUB, case_params, ktag, load_case
 
 pytestmark = pytest.mark.gpu
 
+# A/B runs of the suite pin a kernel through the environment (KZ_KERNEL_VARIANT, KZ_PRECISION); the tests that assert WHICH
+# tier ran only make sense for the default selection.
+import os
+_PINNED = bool(os.environ.get("KZ_KERNEL_VARIANT", "0") not in ("", "0") or os.environ.get("KZ_PRECISION"))
+default_tiers_only = pytest.mark.skipif(_PINNED, reason="a kernel is pinned through the environment")
+
 RTOL = 1e-5   # north-star tolerance for rescaled distances
 ATOL = 1e-6   # self distances of a single-source reverse pass: exact 0 here vs sqrt(1e-14) in sklearn
 
@@ -253,6 +259,7 @@ def test_query_chunking_and_row_ranges():
         ctx.set_option("chunk_rows", 0)
 
 
+@default_tiers_only
 @pytest.mark.parametrize("n_s,n_t,d,dtype,metric,k,single", [
     (900, 2100, 128, np.float32, "euclidean", 10, False),   # 8 slices: pipelined pairs
     (700, 1500, 40, np.float64, "sqeuclidean", 7, False),   # 3 slices: odd count, barrier parity changes per tile
@@ -293,6 +300,7 @@ def test_precision_tiers_agree_bit_for_bit(n_s, n_t, d, dtype, metric, k, single
     np.testing.assert_array_equal(res[0][1], oi)
 
 
+@default_tiers_only
 def test_bf16_pass_escalates_to_float32_operands_on_tight_clusters():
     """A tight cluster far from the origin: neighbour gaps sit between the float32 and the split-bf16 rounding bounds,
     so most rows fail the bf16 certification; the chunk must be re-done with float32 operands and stay exact."""
@@ -321,6 +329,7 @@ def test_bf16_pass_escalates_to_float32_operands_on_tight_clusters():
     np.testing.assert_array_equal(d1.numpy(), d.numpy())
 
 
+@default_tiers_only
 @pytest.mark.parametrize("single", [False, True])
 def test_bf16_pass_escalates_only_the_uncertified_rows(single):
     """Uniform data plus one tight far-away cluster: only the cluster's queries fail the split-bf16 certification; they
@@ -364,6 +373,7 @@ def test_data_below_the_float32_product_range_stays_exact():
     np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=0)
 
 
+@default_tiers_only
 @pytest.mark.parametrize("n_s,n_t,d,dtype,metric,gauss", [
     (2000, 6000, 128, np.float32, "euclidean", False),
     (2000, 6000, 128, np.float32, "euclidean", True),
