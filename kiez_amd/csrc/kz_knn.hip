@@ -370,6 +370,7 @@ __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* si
     }
 }
 
+constexpr int KZ_FIN_ROWS = 4;     // candidate rows re-ranked together by one wave
 constexpr int KZ_FIN_MAXM = 1024;  // list entries per query: 4 waves x (1024*8 + 128*28) B = 47 KiB of LDS at most
 constexpr int KZ_FIN_MAXKP = 128;
 
@@ -498,14 +499,14 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
     const T* qptr = reinterpret_cast<const T*>(p.qraw) + qrow * (int64_t)p.d;
     const double qs = p.qsqn[qrow];
 
-    // exact float64 re-rank of the V candidates, four rows in flight per pass (the per-candidate arithmetic is exactly
+    // exact float64 re-rank of the V candidates, KZ_FIN_ROWS rows in flight per pass (independent gathers and butterfly sums overlap) (the per-candidate arithmetic is exactly
     // kz_wave_dot: per-lane fma chain over k = lane, lane+64, ... then the butterfly sum)
     const T* yraw = reinterpret_cast<const T*>(p.yraw);
-    for (int c0 = 0; c0 < V; c0 += 4) {
-        const T* yp[4];
-        double ys[4], acc[4];
+    for (int c0 = 0; c0 < V; c0 += KZ_FIN_ROWS) {
+        const T* yp[KZ_FIN_ROWS];
+        double ys[KZ_FIN_ROWS], acc[KZ_FIN_ROWS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < KZ_FIN_ROWS; ++u) {
             const int yi = ci[min(c0 + u, V - 1)];
             yp[u] = yraw + (int64_t)yi * p.d;
             ys[u] = p.ysqn[yi];
@@ -515,17 +516,17 @@ __global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
             for (int k = lane; k < p.d; k += 64) {
                 const double qk = (double)qptr[k] / qs;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = fma(qk, (double)yp[u][k] / ys[u], acc[u]);
+                for (int u = 0; u < KZ_FIN_ROWS; ++u) acc[u] = fma(qk, (double)yp[u][k] / ys[u], acc[u]);
             }
         } else {
             for (int k = lane; k < p.d; k += 64) {
                 const double qk = (double)qptr[k];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = fma(qk, (double)yp[u][k], acc[u]);
+                for (int u = 0; u < KZ_FIN_ROWS; ++u) acc[u] = fma(qk, (double)yp[u][k], acc[u]);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < KZ_FIN_ROWS; ++u) {
             const double dot = kz_wave_sum(acc[u]);
             double v;
             if (p.metric == KZ_COSINE) {
