@@ -750,18 +750,24 @@ static int kz_launch_res(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
 
 template <int KP, int NSR>
 static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad) {
-    auto kern = kz_knn_cand_bf_kernel<KP, NSR, (NSR <= 8 ? 2 : 1)>;
-    KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_BF_LDS + lds_pad));
+    const void* kern = NSR <= 8 ? (const void*)kz_knn_cand_bf_kernel<KP, (NSR <= 8 ? NSR : 8), 2>
+                                : (const void*)kz_knn_cand_bf_ov_kernel<KP, (NSR > 8 ? NSR : 9)>;
+    const int lds = (NSR <= 8 ? KZ_BF_LDS : KZ_OV_LDS) + lds_pad;
+    KZ_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     int nb = 0;
-    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_BF_LDS + lds_pad));
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds));
     *blocks_per_cu = nb < 1 ? 1 : nb;
     return KZ_OK;
 }
 
 template <int KP, int NSR>
 static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, NSR, (NSR <= 8 ? 2 : 1)>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad,
-                       ctx->stream, p);
+    if (NSR <= 8)
+        hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, (NSR <= 8 ? NSR : 8), 2>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad,
+                           ctx->stream, p);
+    else
+        hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<KP, (NSR > 8 ? NSR : 9)>), dim3(n_blocks), dim3(256), KZ_OV_LDS + ctx->lds_pad,
+                           ctx->stream, p);
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }

@@ -203,13 +203,234 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync, c_merge, n_pass, n_ins, c_e1, c_e2);
+        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync, 0, c_merge, n_pass, n_ins, c_e1, c_e2);
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
 #else
-        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync);
+        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync, 0);
 #endif
+    }
+#ifdef KZ_STAMP
+    if (lane == 0 && p.dbg) {
+        atomicAdd(p.dbg + 0, c_slices);
+        atomicAdd(p.dbg + 1, c_epi);
+        atomicAdd(p.dbg + 3, (unsigned long long)(t_end - t_begin));
+        atomicAdd(p.dbg + 4, c_merge);
+        atomicAdd(p.dbg + 5, n_pass);
+        atomicAdd(p.dbg + 6, n_ins);
+        atomicAdd(p.dbg + 7, c_dma);
+        atomicAdd(p.dbg + 8, c_bar);
+        atomicAdd(p.dbg + 2, c_e1);
+        atomicAdd(p.dbg + 9, c_e2);
+    }
+#endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Overlapped form for one workgroup per CU (one wave per SIMD, nothing else to hide the epilogue behind): two accumulator
+// sets; while the MFMAs of tile t run into one set, the candidate scan of tile t-1 is issued between the MFMA groups on
+// the other set -- a wave issues in order, but an issued MFMA executes for 32 cycles in the matrix pipe, and the scan's
+// VALU / LDS instructions fit into that shadow.  After the slice loop only the rare parts remain serial: merges and the
+// groups that found a full log (kz_tile_epilogue2 with resume0).  512 VGPRs per lane at one wave per SIMD: 128
+// accumulators + 8 NSR query registers + 32 fragment registers.
+// ---------------------------------------------------------------------------------------------------
+constexpr int KZ_OV_RING = 8;                                   // index-slice slots of the overlapped kernel
+constexpr int KZ_OV_LDS_BASE = KZ_OV_RING * 8192 + 1024 + 256;  // ring + 2 x 128 bias floats + merge flags
+constexpr int KZ_OV_LDS = KZ_OV_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 8;
+
+template <int KP, int NSR>
+__global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ybuf = reinterpret_cast<float*>(smem);          // KZ_OV_RING slots x 2048 floats
+    float* bbuf = ybuf + KZ_OV_RING * 2048;
+    int* msync = reinterpret_cast<int*>(bbuf + 256);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int4 wd = p.work[blockIdx.x];
+    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
+    const int total = (t_end - t_begin) * NSR;
+
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + h * 32 + j;
+    KzCandState st;
+    st.lk = p.out_key + listoff;
+    st.li = p.out_idx + listoff;
+    st.sk = reinterpret_cast<float*>(smem + KZ_OV_LDS_BASE) + tid;
+    st.si = reinterpret_cast<int*>(smem + KZ_OV_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 4) + tid;
+#pragma unroll 4
+    for (int e = 0; e < KP; ++e) {
+        st.lk[e * KZ_LSTRIDE] = -INFINITY;
+        st.li[e * KZ_LSTRIDE] = -1;
+    }
+    st.tau = -INFINITY;
+    st.minpos = 0;
+    KzBlockMin<KP> bmin;
+    bmin.init();
+    st.cnt = 0;
+    st.tiles_done = 0;
+    st.next_merge = 1;
+    if (total <= 0) return;
+
+    const float* ysrc = p.ypack + ((int64_t)t_begin * NSR) * 2048 + tid * 4;
+    auto dma_slice = [&](int gi) {
+        const float* src = ysrc + (int64_t)min(gi, total - 1) * 2048;
+        float* dst = ybuf + (gi & (KZ_OV_RING - 1)) * 2048 + wave * 256;
+        kz_glds16(src, dst);
+        kz_glds16(src + 1024, dst + 1024);
+    };
+#pragma unroll
+    for (int i = 0; i < KZ_OV_RING; ++i) dma_slice(i);
+    bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
+    if (tid < 4) msync[tid] = 0;
+    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * NSR) * 2048 + (h * KZ_TILE + 32 * (tid >> 6) + j) * 4;
+    kz_bf16x8 qh[NSR], ql[NSR];
+#pragma unroll
+    for (int u = 0; u < NSR; ++u) {
+        qh[u] = *reinterpret_cast<const kz_bf16x8*>(qbase + u * 2048);
+        ql[u] = *reinterpret_cast<const kz_bf16x8*>(qbase + u * 2048 + 1024);
+    }
+    __syncthreads();
+
+    const float* fbase = ybuf + (h * KZ_TILE + j) * 4;
+    int g = 0;
+    constexpr int NG = 3 * NSR;  // MFMA groups (of four) per tile
+    // fragments of the NEXT slice are fetched under the current slice's MFMAs (one wave per SIMD: nobody else hides the
+    // LDS latency); with 8 ring slots slice g+1 is always visible while slice g is computed
+    kz_bf16x8 nh[4], nl[4];
+    auto fetch_frags = [&](const int gi) {
+        const float* fb = fbase + (gi & (KZ_OV_RING - 1)) * 2048;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            nh[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt);
+            nl[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt + 1024);
+        }
+    };
+    fetch_frags(0);
+#ifdef KZ_STAMP
+    unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0;
+#endif
+
+    // one tile: MFMAs into `cur`; scan of the previous tile's keys in `prev` between the MFMA groups; then its tail
+    auto run_tile = [&](f32x16 (&cur)[4], f32x16 (&prev)[4], const bool have_prev, const int tile) {
+        KZ_T(t0);
+        {
+            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + 32 * mt + 8 * g4);
+                    cur[mt][4 * g4 + 0] = v.x;
+                    cur[mt][4 * g4 + 1] = v.y;
+                    cur[mt][4 * g4 + 2] = v.z;
+                    cur[mt][4 * g4 + 3] = v.w;
+                }
+            }
+        }
+        const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
+        int stop = have_prev ? 16 : 0;
+        const float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
+        const int rowbase = (tile - 1) * KZ_TILE + 4 * h;
+        // the previous tile's MFMAs issued long ago, but inline asm is invisible to the hazard recognizer: fence once
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(prev[0]), "+v"(prev[1]), "+v"(prev[2]), "+v"(prev[3]));
+        unsigned long long mask = have_prev ? kz_epi_group_mask<KZ_BF_CAP>(prev, 0, tau_a) : 0ull;
+#pragma unroll
+        for (int u = 0; u < NSR; ++u) {
+            kz_bf16x8 ch[4], cl[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                ch[mt] = nh[mt];
+                cl[mt] = nl[mt];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_frags(g + 1);
+#pragma unroll
+            for (int pg = 0; pg < 3; ++pg) {
+                const int gidx = 3 * u + pg;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sidx = (gidx * 16) / NG; sidx < ((gidx + 1) * 16) / NG; ++sidx) {
+                    const unsigned long long mnext = sidx + 1 < 16 ? kz_epi_group_mask<KZ_BF_CAP>(prev, (sidx + 1) & 15, tau_a) : 0ull;
+                    kz_epi_step<KZ_BF_CAP>(prev, st, tau_a, rowbase, sidx, mask, stop);
+                    mask = mnext;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (pg == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[mt], qh[u], cur[mt], 0, 0, 0);
+                } else if (pg == 1) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[mt], ql[u], cur[mt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[mt], qh[u], cur[mt], 0, 0, 0);
+                }
+            }
+            if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
+            if (g & 1) {
+                // slices g-1 and g are consumed: their slots take slices g-1+RING and g+RING, three barrier periods ahead
+                // of their use (with one wave per SIMD nothing else covers the L2 latency of a late DMA)
+#ifdef KZ_STAMP
+                {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_barrier" ::: "memory");
+                    c_dma += w1 - w0;
+                    c_bar += __builtin_amdgcn_s_memtime() - w1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
+                // The slices needed next (g+1, g+2) were issued three barriers ago; the 8 wave-loads of the last two
+                // barriers may stay in flight (vmcnt counts in issue order: anything older than the 8 newest is done).
+                // __syncthreads() would drain vmcnt(0), i.e. wait for DMAs that are not needed for two more periods.
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+                dma_slice(g - 1 + KZ_OV_RING);
+                dma_slice(g + KZ_OV_RING);
+            }
+            ++g;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef KZ_STAMP
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (have_prev) kz_tile_epilogue2<KP, KZ_BF_CAP>(prev, st, bmin, tile - 1, false, h, msync, stop, c_merge, n_pass, n_ins, c_e1, c_e2);
+        __builtin_amdgcn_sched_barrier(0);
+        c_slices += t1 - t0;
+        c_epi += __builtin_amdgcn_s_memtime() - t1;
+#else
+        if (have_prev) kz_tile_epilogue2<KP, KZ_BF_CAP>(prev, st, bmin, tile - 1, false, h, msync, stop);
+#endif
+    };
+
+    f32x16 acc0[4], acc1[4];
+    int tile = t_begin;
+    bool have_prev = false;
+    for (;;) {
+        run_tile(acc0, acc1, have_prev, tile);
+        have_prev = true;
+        if (++tile >= t_end) {
+#ifdef KZ_STAMP
+            kz_tile_epilogue2<KP, KZ_BF_CAP>(acc0, st, bmin, tile - 1, true, h, msync, 0, c_merge, n_pass, n_ins, c_e1, c_e2);
+#else
+            kz_tile_epilogue2<KP, KZ_BF_CAP>(acc0, st, bmin, tile - 1, true, h, msync, 0);
+#endif
+            break;
+        }
+        run_tile(acc1, acc0, true, tile);
+        if (++tile >= t_end) {
+#ifdef KZ_STAMP
+            kz_tile_epilogue2<KP, KZ_BF_CAP>(acc1, st, bmin, tile - 1, true, h, msync, 0, c_merge, n_pass, n_ins, c_e1, c_e2);
+#else
+            kz_tile_epilogue2<KP, KZ_BF_CAP>(acc1, st, bmin, tile - 1, true, h, msync, 0);
+#endif
+            break;
+        }
     }
 #ifdef KZ_STAMP
     if (lane == 0 && p.dbg) {

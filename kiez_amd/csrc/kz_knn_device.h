@@ -299,7 +299,7 @@ __device__ __forceinline__ void kz_list_insert_blocked(float* lk, int* li, KzBlo
 //     a workgroup are never more than one tile apart, and a workgroup barrier lies between any two epilogues.)
 template <int KP, int CAP>
 __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, KzBlockMin<KP>& bs, const int tile,
-                                                  const bool last_tile, const int h, int* sync KZ_EPI2_STAMP_ARGS) {
+                                                  const bool last_tile, const int h, int* sync, const int resume0 KZ_EPI2_STAMP_ARGS) {
     KZ_T(te0);
     ++st.tiles_done;
     const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
@@ -321,6 +321,11 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
 #endif
             st.cnt = 0;
         }
+    }
+    if (resume0 >= 16 && !sched) {
+        // nothing left to scan (an overlapped scan covered all 16 groups) and no merge due: only the bookkeeping
+        if (__any(st.cnt > CAP - 8) && (threadIdx.x & 63) == 0) sync[st.tiles_done & 3] = 1;
+        return;
     }
     float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
     const int rowbase = tile * KZ_TILE + 4 * h;
@@ -346,7 +351,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
     c_e1 += te1 - te0;
     bool first_pass = true;
 #endif
-    int resume = 0;  // first group not yet scanned (wave-uniform)
+    int resume = resume0;  // first group not yet scanned (wave-uniform; > 0 when an overlapped scan already did the rest)
     for (;;) {
         bool need_room = false;
 #pragma unroll
@@ -404,5 +409,43 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
     if (st.tiles_done == st.next_merge) {
         const int step = st.tiles_done * CAP / KP;
         st.next_merge = st.tiles_done + (step > 0 ? step : 1);
+    }
+}
+
+// One group of the candidate scan as a free-standing step (overlapped kernel: the scan of tile t-1 is issued between
+// the MFMA groups of tile t, in the shadow of the matrix pipe).  `mask` is this group's event mask, computed one step
+// earlier so that the compare -> branch latency is covered too; `stop` is the first group NOT scanned here because
+// some lane had no room left in its log (the tail epilogue merges and resumes there).
+template <int CAP>
+__device__ __forceinline__ unsigned long long kz_epi_group_mask(const f32x16 (&acc)[4], const int gi, const float tau_a) {
+    const int mt = gi >> 2, g4 = gi & 3;
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[mt][4 * g4]), "v"(acc[mt][4 * g4 + 1]), "v"(acc[mt][4 * g4 + 2]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][4 * g4 + 3]));
+    return __builtin_amdgcn_ballot_w64(m > tau_a);
+}
+
+template <int CAP>
+__device__ __forceinline__ void kz_epi_step(const f32x16 (&acc)[4], KzCandState& st, const float tau_a, const int rowbase,
+                                            const int gi, const unsigned long long mask, int& stop) {
+    if (gi < stop && mask != 0ull) {
+        if (__any(st.cnt > CAP - 4)) {
+            stop = gi;
+        } else {
+            const int mt = gi >> 2, g4 = gi & 3;
+            float ta = tau_a;
+            asm volatile("" : "+v"(ta));
+            int rb = rowbase;
+            asm volatile("" : "+v"(rb));
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float v = acc[mt][4 * g4 + r4];
+                const bool ev = v > ta;
+                const int slot = ev ? st.cnt : CAP;
+                st.sk[slot * 256] = v;
+                st.si[slot * 256] = rb + 32 * mt + 8 * g4 + r4;
+                st.cnt += ev ? 1 : 0;
+            }
+        }
     }
 }

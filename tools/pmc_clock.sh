@@ -12,7 +12,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_C
 f=$(find "$OUT/run" -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "cand" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "cand_bf" in r["Kernel_Name"] or "cand_kernel" in r["Kernel_Name"]]
 by = collections.defaultdict(dict)
 for r in rows:
     by[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
