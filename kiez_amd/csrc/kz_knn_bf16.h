@@ -17,6 +17,7 @@
 //     boundaries (epilogues) and barriers are independent;
 //   * 2 workgroups per CU (the register budget of the stationary tile), 4 waves x 32 queries each.
 #pragma once
+#include <type_traits>
 
 typedef __bf16 kz_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -300,22 +301,26 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
     constexpr int NG = 3 * NSR;  // MFMA groups (of four) per tile
     // fragments of the NEXT slice are fetched under the current slice's MFMAs (one wave per SIMD: nobody else hides the
     // LDS latency); with 8 ring slots slice g+1 is always visible while slice g is computed
-    kz_bf16x8 nh[4], nl[4];
-    auto fetch_frags = [&](const int gi) {
+    // Two static fragment sets, selected by the parity of the global slice counter (no register copies): a tile starts
+    // at parity (tile index * NSR) & 1, which alternates exactly like the accumulator roles when NSR is odd and is
+    // always 0 when NSR is even -- so each of the two run_tile instantiations knows its parity at compile time.
+    kz_bf16x8 f0h[4], f0l[4], f1h[4], f1l[4];
+    auto fetch_frags = [&](kz_bf16x8 (&fh)[4], kz_bf16x8 (&fl)[4], const int gi) {
         const float* fb = fbase + (gi & (KZ_OV_RING - 1)) * 2048;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            nh[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt);
-            nl[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt + 1024);
+            fh[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt);
+            fl[mt] = *reinterpret_cast<const kz_bf16x8*>(fb + 128 * mt + 1024);
         }
     };
-    fetch_frags(0);
+    fetch_frags(f0h, f0l, 0);
 #ifdef KZ_STAMP
     unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0;
 #endif
 
     // one tile: MFMAs into `cur`; scan of the previous tile's keys in `prev` between the MFMA groups; then its tail
-    auto run_tile = [&](f32x16 (&cur)[4], f32x16 (&prev)[4], const bool have_prev, const int tile) {
+    auto run_tile = [&](f32x16 (&cur)[4], f32x16 (&prev)[4], const bool have_prev, const int tile, auto start_parity) {
+        constexpr int P0 = decltype(start_parity)::value;
         KZ_T(t0);
         {
             const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
@@ -340,14 +345,8 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
         unsigned long long mask = have_prev ? kz_epi_group_mask<KZ_BF_CAP>(prev, 0, tau_a) : 0ull;
 #pragma unroll
         for (int u = 0; u < NSR; ++u) {
-            kz_bf16x8 ch[4], cl[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                ch[mt] = nh[mt];
-                cl[mt] = nl[mt];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_frags(g + 1);
+            kz_bf16x8 (&ch)[4] = ((P0 + u) & 1) ? f1h : f0h;
+            kz_bf16x8 (&cl)[4] = ((P0 + u) & 1) ? f1l : f0l;
 #pragma unroll
             for (int pg = 0; pg < 3; ++pg) {
                 const int gidx = 3 * u + pg;
@@ -362,6 +361,14 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
                 if (pg == 0) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[mt], qh[u], cur[mt], 0, 0, 0);
+                    // The next slice's fragments are requested AFTER the first MFMA group has consumed this slice's: the
+                    // s_waitcnt hipcc places in front of that group then only covers reads issued a whole slice ago
+                    // (behind the scan's branches it falls back to lgkmcnt(0), which would also wait for a fresh prefetch).
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((P0 + u) & 1)
+                        fetch_frags(f0h, f0l, g + 1);
+                    else
+                        fetch_frags(f1h, f1l, g + 1);
                 } else if (pg == 1) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[mt], ql[u], cur[mt], 0, 0, 0);
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
     int tile = t_begin;
     bool have_prev = false;
     for (;;) {
-        run_tile(acc0, acc1, have_prev, tile);
+        run_tile(acc0, acc1, have_prev, tile, std::integral_constant<int, 0>{});
         have_prev = true;
         if (++tile >= t_end) {
 #ifdef KZ_STAMP
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
 #endif
             break;
         }
-        run_tile(acc1, acc0, true, tile);
+        run_tile(acc1, acc0, true, tile, std::integral_constant<int, (NSR & 1)>{});
         if (++tile >= t_end) {
 #ifdef KZ_STAMP
             kz_tile_epilogue2<KP, KZ_BF_CAP>(acc1, st, bmin, tile - 1, true, h, msync, 0, c_merge, n_pass, n_ins, c_e1, c_e2);
