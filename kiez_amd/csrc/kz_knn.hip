@@ -749,7 +749,12 @@ static int kz_launch_res(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
 }
 
 template <int KP, int NSR>
-static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad) {
+static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad, int variant) {
+    if (NSR == 8 && KP == 16 && variant == 7) {
+        KZ_HIP(hipFuncSetAttribute((const void*)kz_knn_cand_bf_ov_kernel<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_OV_LDS + lds_pad));
+        *blocks_per_cu = 1;
+        return KZ_OK;
+    }
     const void* kern = NSR <= 8 ? (const void*)kz_knn_cand_bf_kernel<KP, (NSR <= 8 ? NSR : 8), 2>
                                 : (const void*)kz_knn_cand_bf_ov_kernel<KP, (NSR > 8 ? NSR : 9)>;
     const int lds = (NSR <= 8 ? KZ_BF_LDS : KZ_OV_LDS) + lds_pad;
@@ -762,7 +767,9 @@ static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad) {
 
 template <int KP, int NSR>
 static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    if (NSR <= 8)
+    if (NSR == 8 && KP == 16 && ctx->kernel_variant == 7)   // experiment: one wave per SIMD with the overlapped scan on C1
+        hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<16, 8>), dim3(n_blocks), dim3(256), KZ_OV_LDS + ctx->lds_pad, ctx->stream, p);
+    else if (NSR <= 8)
         hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, (NSR <= 8 ? NSR : 8), 2>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad,
                            ctx->stream, p);
     else
@@ -1057,7 +1064,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
             int blocks_per_cu = 1;
             int rc0;
             if (bf)
-                KZ_DISPATCH_BF(rc0, kz_bf_occupancy, (&blocks_per_cu, ctx->lds_pad));
+                KZ_DISPATCH_BF(rc0, kz_bf_occupancy, (&blocks_per_cu, ctx->lds_pad, ctx->kernel_variant));
             else if (interleaved)
                 KZ_DISPATCH_IL(rc0, kz_il_occupancy, (&blocks_per_cu));
             else if (direct)
