@@ -748,73 +748,23 @@ static int kz_launch_res(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
     return KZ_OK;
 }
 
-template <int KP, int NSR>
-static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad, int variant) {
-    if (NSR == 8 && KP == 16 && variant == 7) {
-        KZ_HIP(hipFuncSetAttribute((const void*)kz_knn_cand_bf_ov_kernel<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_OV_LDS + lds_pad));
-        *blocks_per_cu = 1;
-        return KZ_OK;
-    }
-    const void* kern = NSR <= 8 ? (const void*)kz_knn_cand_bf_kernel<KP, (NSR <= 8 ? NSR : 8), 2>
-                                : (const void*)kz_knn_cand_bf_ov_kernel<KP, (NSR > 8 ? NSR : 9)>;
-    const int lds = (NSR <= 8 ? KZ_BF_LDS : KZ_OV_LDS) + lds_pad;
-    KZ_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    int nb = 0;
-    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds));
-    *blocks_per_cu = nb < 1 ? 1 : nb;
-    return KZ_OK;
-}
-
-template <int KP, int NSR>
-static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    if (NSR == 8 && KP == 16 && ctx->kernel_variant == 7)   // experiment: one wave per SIMD with the overlapped scan on C1
-        hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<16, 8>), dim3(n_blocks), dim3(256), KZ_OV_LDS + ctx->lds_pad, ctx->stream, p);
-    else if (NSR <= 8)
-        hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, (NSR <= 8 ? NSR : 8), 2>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad,
-                           ctx->stream, p);
-    else
-        hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<KP, (NSR > 8 ? NSR : 9)>), dim3(n_blocks), dim3(256), KZ_OV_LDS + ctx->lds_pad,
-                           ctx->stream, p);
-    KZ_HIP(hipGetLastError());
-    return KZ_OK;
-}
-
-#define KZ_DISPATCH_BF_NSR(rc, fn, args, KPV)             \
-    do {                                                  \
-        switch (n_slices_bf) {                            \
-            case 2: rc = fn<KPV, 2> args; break;          \
-            case 3: rc = fn<KPV, 3> args; break;          \
-            case 4: rc = fn<KPV, 4> args; break;          \
-            case 5: rc = fn<KPV, 5> args; break;          \
-            case 6: rc = fn<KPV, 6> args; break;          \
-            case 7: rc = fn<KPV, 7> args; break;          \
-            case 8: rc = fn<KPV, 8> args; break;          \
-            case 9: rc = fn<KPV, 9> args; break;          \
-            case 10: rc = fn<KPV, 10> args; break;        \
-            case 11: rc = fn<KPV, 11> args; break;        \
-            case 12: rc = fn<KPV, 12> args; break;        \
-            case 13: rc = fn<KPV, 13> args; break;        \
-            case 14: rc = fn<KPV, 14> args; break;        \
-            case 15: rc = fn<KPV, 15> args; break;        \
-            case 16: rc = fn<KPV, 16> args; break;        \
-            case 17: rc = fn<KPV, 17> args; break;        \
-            case 18: rc = fn<KPV, 18> args; break;        \
-            case 19: rc = fn<KPV, 19> args; break;        \
-            case 20: rc = fn<KPV, 20> args; break;        \
-            case 21: rc = fn<KPV, 21> args; break;        \
-            case 22: rc = fn<KPV, 22> args; break;        \
-            case 23: rc = fn<KPV, 23> args; break;        \
-            default: rc = fn<KPV, 24> args; break;        \
-        }                                                 \
-    } while (0)
-#define KZ_DISPATCH_BF(rc, fn, args)                                  \
-    do {                                                              \
-        switch (KP) {                                                 \
-            case 16: KZ_DISPATCH_BF_NSR(rc, fn, args, 16); break;     \
-            case 32: KZ_DISPATCH_BF_NSR(rc, fn, args, 32); break;     \
-            case 64: KZ_DISPATCH_BF_NSR(rc, fn, args, 64); break;     \
-            default: KZ_DISPATCH_BF_NSR(rc, fn, args, 128); break;    \
-        }                                                             \
+// split-bf16 kernels: instantiated per list length in kz_knn_bf_kp*.hip (parallel compilation)
+int kz_bf_occupancy_kp16(int n_slices_bf, int* blocks_per_cu, int lds_pad, int variant);
+int kz_bf_occupancy_kp32(int n_slices_bf, int* blocks_per_cu, int lds_pad, int variant);
+int kz_bf_occupancy_kp64(int n_slices_bf, int* blocks_per_cu, int lds_pad, int variant);
+int kz_bf_occupancy_kp128(int n_slices_bf, int* blocks_per_cu, int lds_pad, int variant);
+int kz_bf_launch_kp16(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
+int kz_bf_launch_kp32(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
+int kz_bf_launch_kp64(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
+int kz_bf_launch_kp128(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
+#define KZ_DISPATCH_BF(rc, fn, args)                 \
+    do {                                             \
+        switch (KP) {                                \
+            case 16: rc = fn##_kp16 args; break;     \
+            case 32: rc = fn##_kp32 args; break;     \
+            case 64: rc = fn##_kp64 args; break;     \
+            default: rc = fn##_kp128 args; break;    \
+        }                                            \
     } while (0)
 
 template <int KP, int NB>
@@ -1064,7 +1014,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
             int blocks_per_cu = 1;
             int rc0;
             if (bf)
-                KZ_DISPATCH_BF(rc0, kz_bf_occupancy, (&blocks_per_cu, ctx->lds_pad, ctx->kernel_variant));
+                KZ_DISPATCH_BF(rc0, kz_bf_occupancy, (n_slices_bf, &blocks_per_cu, ctx->lds_pad, ctx->kernel_variant));
             else if (interleaved)
                 KZ_DISPATCH_IL(rc0, kz_il_occupancy, (&blocks_per_cu));
             else if (direct)
@@ -1208,7 +1158,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
 #endif
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         if (tier_bf)
-            KZ_DISPATCH_BF(rc, kz_launch_bf, (ctx, cp, W));
+            KZ_DISPATCH_BF(rc, kz_bf_launch, (n_slices_bf, ctx, cp, W));
         else if (interleaved)
             KZ_DISPATCH_IL(rc, kz_launch_il, (ctx, cp, W));
         else if (direct)

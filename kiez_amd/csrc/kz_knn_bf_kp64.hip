@@ -1,0 +1,3 @@
+// split-bf16 fused kernels, list length K' = 64 (see kz_knn_bf_inst.h)
+#define KZ_BF_KP 64
+#include "kz_knn_bf_inst.h"
