@@ -165,6 +165,7 @@ def main():
     bf_ms = sum(st["main_kernel_ms"] for _, _, st in knn_log if st.get("first_pass") == 1)
     tier_bf = bf_ms * 2 > kernel_s * 1e3
     peak = PEAK_BF16_MFMA_TFLOPS if tier_bf else PEAK_F32_MFMA_TFLOPS
+    traffic = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"   # HBM bytes per launch from separate rocprofv3 --pmc passes
     if pmc.exists():
         try:
@@ -173,7 +174,6 @@ def main():
         except Exception:
             traffic = None
     fallback_rows = sum(st["n_fallback_rows"] for _, _, st in knn_log)
-    traffic = None
 
     check = None
     do_check = args.check or (not args.no_check and hub is None and world == 1 and n_t <= 200_000)
