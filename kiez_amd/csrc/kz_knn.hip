@@ -610,8 +610,11 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 // A workgroup finalizes KZ_FIN_QPB consecutive queries (wave w takes queries w, w+4, ...).  32 per workgroup (sharing the list
 // cache lines of one wave-interleaved block) measured 2x SLOWER than 4: finalize is latency-bound and wants many workgroups.
 constexpr int KZ_FIN_QPB = 4;
+#ifndef KZ_FIN_WAVES
+#define KZ_FIN_WAVES 8  // waves per SIMD the finalize kernel is compiled for (latency-bound gathers: occupancy matters)
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void kz_knn_finalize_kernel(KnnFinParams p) {
+__global__ __launch_bounds__(256, KZ_FIN_WAVES) void kz_knn_finalize_kernel(KnnFinParams p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
