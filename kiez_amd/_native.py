@@ -243,7 +243,7 @@ class DeviceArray:
 
 
 class DeviceMatrix:
-    """kz_matrix: an embedding matrix in HBM (exact rows + float64 norms + MFMA-packed float32 tiles)."""
+    """kz_matrix: an embedding matrix in HBM (exact rows + float64 norms + MFMA operand images: float32 and split-bf16)."""
 
     def __init__(self, ctx: Context, data, metric: str, device_ptr: Optional[int] = None, shape=None, dtype=None):
         self.ctx = ctx
