@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the precision tiers on the GPU box: for random shapes / dtypes / metrics / k the split-bf16
+default, the float32-operand kernel and (for small cases) the oracle must agree bit for bit.
+
+    python3 tools/fuzz_tiers.py [n_cases] [seed]
+"""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from kiez_amd import _native as N  # noqa: E402
+from oracle import kiez_oracle as O  # noqa: E402  (checker only)
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    ctx = N.Context.get()
+    bad = 0
+    for c in range(n_cases):
+        d = int(rng.choice([3, 16, 17, 31, 33, 48, 64, 65, 96, 100, 128, 129, 150, 200, 257, 300, 384, 385, 500]))
+        n_t = int(rng.choice([60, 127, 128, 129, 500, 1000, 2049, 4000]))
+        n_s = int(rng.choice([1, 31, 128, 130, 700, 1500]))
+        metric = str(rng.choice(["euclidean", "sqeuclidean", "cosine"]))
+        dtype = np.float32 if rng.rand() < 0.6 else np.float64
+        k = int(rng.choice([1, 2, 5, 10, 11, 12, 13, 26, 27, 50, 54, 55, 100, 110]))
+        single = rng.rand() < 0.25
+        k = min(k, n_t - 2, 109 if single else 110)
+        gen = rng.randn if rng.rand() < 0.5 else rng.rand
+        t = gen(n_t, d).astype(dtype)
+        s = t if single else gen(n_s, d).astype(dtype)
+        if metric == "cosine":
+            s, t = s.astype(np.float64), (s if single else t).astype(np.float64)
+        res = {}
+        for prec in (0, 1):
+            ctx.set_option("precision", prec)
+            try:
+                ym = N.DeviceMatrix(ctx, t, metric)
+                qm = ym if single else N.DeviceMatrix(ctx, s, metric)
+                dd, ii, st = N.knn(ctx, qm, ym, k, exclude_self=single)
+                res[prec] = (dd.numpy(), ii.numpy(), st)
+            finally:
+                ctx.set_option("precision", 0)
+        ok = np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
+        if len(s) * n_t <= 2_000_000:
+            od, oi = O.knn_exact(s, t, k, O.canonical_metric(metric), exclude_self=single)
+            ok = ok and np.array_equal(res[0][1], oi)
+        tag = "ok " if ok else "BAD"
+        bad += 0 if ok else 1
+        print(tag, f"n_s={len(s)} n_t={n_t} d={d} {metric} {np.dtype(dtype).name} k={k} single={single}",
+              "tier", res[0][2]["first_pass"], "esc", res[0][2]["n_escalated_rows"], "fb", res[0][2]["n_fallback_rows"],
+              "ratio %.3f" % res[0][2]["max_err_ratio"])
+    print("cases", n_cases, "bad", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
