@@ -201,13 +201,24 @@ class Comm:
         return torch.cat([parts[r][: counts[r]] for r in range(self.world)], dim=0)
 
     def all_gather_ints(self, value: int, device):
+        return [v[0] for v in self.all_gather_vec([int(value)], device)]
+
+    def all_gather_vec(self, values, device):
+        """All-gather a short int vector per rank: ONE collective and ONE device->host sync for all the sizes a fit needs
+        (shard row counts and, from rank 0, the target's shape) instead of one per quantity."""
         torch = _torch()
+        values = [int(v) for v in values]
         if self.world == 1 and not self.always:
-            return [int(value)]
-        mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
-        parts = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(parts, mine, group=self.group)
-        return [int(x.cpu()[0]) for x in parts]
+            return [values]
+        mine = torch.tensor(values, dtype=torch.int64, device=device)
+        out = torch.empty((self.world, len(values)), dtype=torch.int64, device=device)
+        if mine.is_cuda:
+            self.dist.all_gather_into_tensor(out, mine, group=self.group)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine, group=self.group)
+            out = torch.stack(parts)
+        return out.cpu().tolist()
 
     def all_reduce_min(self, t):
         if self.world > 1 or self.always:
@@ -272,7 +283,16 @@ class ShardedKiez:
         src = eng.to_engine(source_shard)
         if src.dim() != 2:
             raise ValueError("Expected 2D array")
-        counts = comm.all_gather_ints(src.shape[0], src.device)
+        # one collective for every size this fit needs: shard rows of all ranks + (from rank 0) the target's shape
+        torch = _torch()
+        tgt0 = None
+        meta = [src.shape[0], 0, 0, 0]
+        bcast_target = (not single_source) and target_from_rank0 and (comm.world > 1 or comm.always)
+        if bcast_target and comm.rank == 0:
+            tgt0 = eng.to_engine(target)
+            meta[1:] = [tgt0.shape[0], tgt0.shape[1], 0 if tgt0.dtype == torch.float32 else 1]
+        gathered = comm.all_gather_vec(meta, src.device)
+        counts = [g[0] for g in gathered]
         self.counts = counts
         self.s_begin = sum(counts[: comm.rank])
         self.n_local = counts[comm.rank]
@@ -283,15 +303,9 @@ class ShardedKiez:
         if self.single:
             tgt = src_full
         else:
-            if target_from_rank0 and (comm.world > 1 or comm.always):
-                torch = _torch()
-                shape = None
-                if comm.rank == 0:
-                    tgt = eng.to_engine(target)
-                    shape = (tgt.shape[0], tgt.shape[1], 0 if tgt.dtype == torch.float32 else 1)
-                n_t, d, code = comm.broadcast_shape(shape, src.device)
-                if comm.rank != 0:
-                    tgt = eng.empty((n_t, d), torch.float32 if code == 0 else torch.float64)
+            if bcast_target:
+                n_t, d, code = gathered[0][1], gathered[0][2], gathered[0][3]
+                tgt = tgt0 if comm.rank == 0 else eng.empty((n_t, d), torch.float32 if code == 0 else torch.float64)
                 comm.broadcast(tgt, 0)  # RCCL broadcast of the replicated target over xGMI
             else:
                 tgt = eng.to_engine(target)
