@@ -174,14 +174,6 @@ class Comm:
             self.dist.broadcast(t, src=src, group=self.group)
         return t
 
-    def broadcast_shape(self, shape_or_none, device, src=0):
-        torch = _torch()
-        buf = torch.zeros(4, dtype=torch.int64, device=device)
-        if self.rank == src:
-            buf[0], buf[1], buf[2] = shape_or_none[0], shape_or_none[1], shape_or_none[2]
-        self.broadcast(buf, src)
-        return int(buf[0]), int(buf[1]), int(buf[2])
-
     def all_gather_rows(self, t, counts):
         """Concatenate ragged row blocks [n_r, ...] of all ranks in rank order (padded all_gather)."""
         torch = _torch()
