@@ -429,12 +429,13 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 
     const int64_t lrow = p.list_row0 + q;
     const int n_pieces = p.lay.pieces[kz_list_region(lrow, p.lay)];
-    const int M = n_pieces * 2 * KP;
-    // entry e of this query: piece e / (2 KP), lane-half (e / KP) & 1, list entry e % KP  (layout: kz_list_wave_base)
+    const int halves = p.lay.halves;
+    const int M = n_pieces * halves * KP;
+    // entry e of this query: piece e / (halves KP), lane-half (e / KP) % halves, list entry e % KP  (kz_list_wave_base)
     const int64_t lwave = kz_list_wave_base(lrow, p.lay, KP, 0) + (lrow & 31);
     for (int e = lane; e < M; e += 64) {
-        const int piece = e / (2 * KP);
-        const int rem = e - piece * 2 * KP;
+        const int piece = e / (halves * KP);
+        const int rem = e - piece * halves * KP;
         const int hh = rem / KP;
         const int ee = rem - hh * KP;
         const int64_t off = lwave + ((int64_t)piece * KP + ee) * KZ_LSTRIDE + hh * 32;
@@ -1089,6 +1090,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
                 q0 += reg_nq[r];
             }
             lay.n_regions = n_reg;
+            lay.halves = tier_bf ? 1 : 2;
         }
         const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
         const size_t fail_bytes = ((size_t)cq_count * 4 + 255) & ~(size_t)255;
@@ -1222,7 +1224,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
                 fp.q_first = lo < 0 ? 0 : lo;
                 fp.q_last = hi > cq_count ? cq_count : hi;
                 if (fp.q_last <= fp.q_first) continue;
-                fp.max_m = lay.pieces[rg] * 2 * KP;
+                fp.max_m = lay.pieces[rg] * lay.halves * KP;
                 const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
                 const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, KP);
                 if (index->dtype == KZ_F32)

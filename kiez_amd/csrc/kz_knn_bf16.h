@@ -50,16 +50,18 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
     const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
 
-    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + h * 32 + j;
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + j;  // ONE list per query (halves = 1)
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
     st.sk = reinterpret_cast<float*>(smem + KZ_BF_LDS_BASE) + tid;
     st.si = reinterpret_cast<int*>(smem + KZ_BF_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 4) + tid;
+    if (h == 0) {  // the list belongs to the query: lane-half 0 owns it (kz_merge_logs_shared)
 #pragma unroll 4
-    for (int e = 0; e < KP; ++e) {
-        st.lk[e * KZ_LSTRIDE] = -INFINITY;
-        st.li[e * KZ_LSTRIDE] = -1;
+        for (int e = 0; e < KP; ++e) {
+            st.lk[e * KZ_LSTRIDE] = -INFINITY;
+            st.li[e * KZ_LSTRIDE] = -1;
+        }
     }
     st.tau = -INFINITY;
     st.minpos = 0;
@@ -256,16 +258,18 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
     const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
 
-    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + h * 32 + j;
+    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + j;  // ONE list per query (halves = 1)
     KzCandState st;
     st.lk = p.out_key + listoff;
     st.li = p.out_idx + listoff;
     st.sk = reinterpret_cast<float*>(smem + KZ_OV_LDS_BASE) + tid;
     st.si = reinterpret_cast<int*>(smem + KZ_OV_LDS_BASE + (KZ_BF_CAP + 1) * 256 * 4) + tid;
+    if (h == 0) {  // the list belongs to the query: lane-half 0 owns it (kz_merge_logs_shared)
 #pragma unroll 4
-    for (int e = 0; e < KP; ++e) {
-        st.lk[e * KZ_LSTRIDE] = -INFINITY;
-        st.li[e * KZ_LSTRIDE] = -1;
+        for (int e = 0; e < KP; ++e) {
+            st.lk[e * KZ_LSTRIDE] = -INFINITY;
+            st.li[e * KZ_LSTRIDE] = -1;
+        }
     }
     st.tau = -INFINITY;
     st.minpos = 0;

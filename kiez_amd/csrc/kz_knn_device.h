@@ -47,6 +47,8 @@ struct KzListLayout {
     int n_regions;
     int qt_end[KZ_MAX_REGIONS];      // region r = query tiles [qt_end[r-1], qt_end[r])  (local tile numbers)
     int pieces[KZ_MAX_REGIONS];      // index-range pieces per query tile
+    int halves;                      // lists per (query, piece): 2 = one per lane half (float32 kernels), 1 = one shared
+                                     // by both lane halves (split-bf16 kernels; column h = 1 of a list block is unused)
     long long base[KZ_MAX_REGIONS];  // element offset of the region's first list
 };
 __host__ __device__ __forceinline__ int kz_list_region(int64_t list_row, const KzListLayout& L) {
@@ -283,6 +285,30 @@ __device__ __forceinline__ void kz_list_insert_blocked(float* lk, int* li, KzBlo
     tau = t;
 }
 
+// Merge of the two lane-half logs of a query into ONE list (split-bf16 kernels).  Lanes l and l+32 see disjoint index
+// rows of the same query; with a list each, the pruning threshold of a half is the K'-th best of HALF the rows, and a
+// query logs about 2 K' ln(N/2K') events.  With one shared list the threshold is the K'-th best of ALL rows seen: about
+// K' ln(N/K') events per query -- half the appends, half the merge inserts, half the list bytes finalize reads.
+// Lane l (< 32) inserts its own log and then its partner's (the logs are lane-strided in LDS: the partner's entries
+// sit 32 words further); lanes >= 32 idle here.  Both halves leave with the same threshold.
+template <int KP>
+__device__ __forceinline__ void kz_merge_logs_shared(KzCandState& st, KzBlockMin<KP>& bs) {
+    const int lane = threadIdx.x & 63;
+    const int other = __shfl_xor(st.cnt, 32, 64);
+    if (lane < 32) {
+        for (int e = 0; e < st.cnt; ++e) {
+            const float v = st.sk[e * 256];
+            if (v > st.tau) kz_list_insert_blocked<KP, KZ_LSTRIDE>(st.lk, st.li, bs, v, st.si[e * 256], st.tau);
+        }
+        for (int e = 0; e < other; ++e) {
+            const float v = st.sk[e * 256 + 32];
+            if (v > st.tau) kz_list_insert_blocked<KP, KZ_LSTRIDE>(st.lk, st.li, bs, v, st.si[e * 256 + 32], st.tau);
+        }
+    }
+    st.cnt = 0;
+    st.tau = __shfl(st.tau, lane & 31, 64);
+}
+
 // Tile epilogue, second form (used by the split-bf16 kernel, where the epilogue is no longer hidden under MFMA time).
 // Work is proportional to the number of candidate EVENTS instead of the number of values:
 //   * the 16 groups of four values are tested first, back to back (max3 + max + compare each, 16 wave-level masks in
@@ -309,17 +335,15 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         if ((threadIdx.x & 63) == 0) sync[(t + 1) & 3] = 0;
         if (together) {
             KZ_T(tm0);
-            for (int e = 0; e < st.cnt; ++e) {
-                const float v = st.sk[e * 256];
-                if (v > st.tau) kz_list_insert_blocked<KP, KZ_LSTRIDE>(st.lk, st.li, bs, v, st.si[e * 256], st.tau);
-            }
+#ifdef KZ_STAMP
+            n_ins += __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, st.cnt + __shfl_xor(st.cnt, 32, 64)));
+#endif
+            kz_merge_logs_shared<KP>(st, bs);
 #ifdef KZ_STAMP
             __builtin_amdgcn_sched_barrier(0);
             c_merge += __builtin_amdgcn_s_memtime() - tm0;
             n_pass += 1;
-            n_ins += __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, st.cnt));
 #endif
-            st.cnt = 0;
         }
     }
     if (resume0 >= 16 && !sched) {
@@ -391,17 +415,15 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         if (!need_room && !sched) break;
         // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
         KZ_T(tm0);
-        for (int e = 0; e < st.cnt; ++e) {
-            const float v = st.sk[e * 256];
-            if (v > st.tau) kz_list_insert_blocked<KP, KZ_LSTRIDE>(st.lk, st.li, bs, v, st.si[e * 256], st.tau);
-        }
+#ifdef KZ_STAMP
+        n_ins += __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, st.cnt + __shfl_xor(st.cnt, 32, 64)));
+#endif
+        kz_merge_logs_shared<KP>(st, bs);
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);
         c_merge += __builtin_amdgcn_s_memtime() - tm0;
         n_pass += 1;
-        n_ins += __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, st.cnt));
 #endif
-        st.cnt = 0;
         if (!need_room) break;
         tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));  // fresher threshold for the rest of the tile
     }
