@@ -7,10 +7,10 @@ cd "$(dirname "$0")/.."
 mkdir -p build/abl
 if [ "$1" = "build" ]; then
   for n in ${ABL_BUILD:-1 2 3 4 5}; do
-    for f in kz_runtime kz_pack kz_knn kz_hubness kz_analysis; do
+    for f in kz_runtime kz_pack kz_knn kz_knn_bf_kp16 kz_knn_bf_kp32 kz_knn_bf_kp64 kz_knn_bf_kp128 kz_hubness kz_analysis; do
       /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DKZ_ABLATE=$n -c kiez_amd/csrc/$f.hip -o /tmp/abl_$f.o 2>/dev/null
     done
-    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/abl_kz_runtime.o /tmp/abl_kz_pack.o /tmp/abl_kz_knn.o /tmp/abl_kz_hubness.o /tmp/abl_kz_analysis.o -o build/abl/libkiez_amd_abl$n.so
+    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/abl_kz_runtime.o /tmp/abl_kz_pack.o /tmp/abl_kz_knn.o /tmp/abl_kz_knn_bf_kp16.o /tmp/abl_kz_knn_bf_kp32.o /tmp/abl_kz_knn_bf_kp64.o /tmp/abl_kz_knn_bf_kp128.o /tmp/abl_kz_hubness.o /tmp/abl_kz_analysis.o -o build/abl/libkiez_amd_abl$n.so
   done
   ls -la build/abl
 else
