@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
                 }
             }
         }
-        // bias rows of the next tile (one 4-byte load per thread per tile; parked in LDS after the first slice)
+        // bias rows of the next tile (one 4-byte load per thread per tile; parked in LDS after the first slice).
+        // Pinned BEHIND the accumulator init: hipcc orders every ds_read after an LDS-DMA with s_waitcnt vmcnt(0); hoisted
+        // above the init (as its scheduler does) this fresh load would be waited for at every tile start.
+        __builtin_amdgcn_sched_barrier(0);
         const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
         if (NSR % 2 == 0) {
 #pragma unroll
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);  // (see kz_knn_cand_bf_kernel: keep this load behind the LDS reads above)
         const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
         int stop = have_prev ? 16 : 0;
         const float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
