@@ -552,6 +552,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     // Self-check of the rounding bound the certification rests on: for every candidate both the approximate key
     // (ck, from the fused kernel) and the exact key (from the float64 re-rank) are known here.
     double eps_q;
+    bool bound_violated = false;
     if (p.metric == KZ_COSINE)
         eps_q = p.gamma * 1.001;
     else
@@ -567,6 +568,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off, 64));
+        bound_violated = worst > 1.0;   // (wave-uniform after the butterfly) never expected: see the certification below
         if (lane == 0 && worst > 0.0) {
             // 100k waves hit ONE address: read first, only the (rare) new maxima pay for the atomic
             const unsigned long long bits = (unsigned long long)__double_as_longlong(worst);
@@ -597,6 +599,9 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         }
         certified = (double)ck[KP - 1] + eps < key_k;
     }
+    // An approximate key further than eps from its exact value contradicts the bound everything above rests on (a kernel
+    // or hardware fault, not a property of the data): do not trust this row's candidate set, send it down a tier.
+    if (bound_violated) certified = false;
     if (!certified) {
         if (lane == 0) {
             const int pos = atomicAdd(p.fail_count, 1);

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
                 {
                     __builtin_amdgcn_sched_barrier(0);
                     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                     const unsigned long long w1 = __builtin_amdgcn_s_memtime();
                     asm volatile("s_barrier" ::: "memory");
                     c_dma += w1 - w0;
@@ -401,10 +401,13 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #else
-                // The slices needed next (g+1, g+2) were issued three barriers ago; the 8 wave-loads of the last two
-                // barriers may stay in flight (vmcnt counts in issue order: anything older than the 8 newest is done).
-                // __syncthreads() would drain vmcnt(0), i.e. wait for DMAs that are not needed for two more periods.
-                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // Until the next barrier this wave READS slices up to g+3 (g+1, g+2 are computed, the fragments of g+3 are
+                // prefetched during g+2).  g+3 and g+4 were issued two barriers ago, so only the 4 wave-loads of the LAST
+                // barrier (slices g+5, g+6) may stay in flight: vmcnt counts in issue order, anything older than the 4
+                // newest operations is complete.  (__syncthreads() would drain vmcnt(0): wait for DMAs not needed for two
+                // more periods.  vmcnt(8) -- forgetting the one-slice prefetch -- raced: 3 wrong rows in 3000 on a
+                // 1M-row index, caught by the rounding-bound self-check, tests/test_gpu_fullsize.py.)
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
                 dma_slice(g - 1 + KZ_OV_RING);
                 dma_slice(g + KZ_OV_RING);

@@ -116,3 +116,25 @@ def test_float32_cosine_keeps_reference_output_dtype():
         d2, _ = Kiez(n_candidates=5, algorithm="SklearnNN", algorithm_kwargs={"metric": "cosine"}, hubness="CSLS").fit(s, t).kneighbors(5)
         d3, _ = Kiez(n_candidates=5, algorithm="SklearnNN", algorithm_kwargs={"metric": "euclidean"}).fit(s, t).kneighbors(5)
     assert d.dtype == np.float32 and d2.dtype == np.float32 and d3.dtype == np.float64 and i.dtype == np.int64
+
+
+def test_long_index_keeps_the_dma_ring_honest():
+    """1M index rows x 300 features (C4's index): 7813 index tiles per sweep through the one-workgroup-per-CU kernel, whose
+    LDS-DMA ring waits with a COUNTED s_waitcnt.  A count that forgot the one-slice fragment prefetch let a wave read a slot
+    before its DMA had landed: 3 wrong rows in 3000 -- only at this length, and visible in kz_knn_stats.max_err_ratio."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.default_rng(0)
+    t = rng.random((1_000_000, 300), dtype=np.float32)
+    s = rng.random((2048, 300), dtype=np.float32)
+    ctx = N.Context.get()
+    ym = N.DeviceMatrix(ctx, t, "euclidean")
+    qm = N.DeviceMatrix(ctx, s, "euclidean")
+    worst = 0.0
+    for _ in range(3):   # the race was timing dependent
+        d, i, st = N.knn(ctx, qm, ym, 10)
+        worst = max(worst, st["max_err_ratio"])
+    assert worst < 0.5, st
+    od, oi = O.knn_exact(s[:256], t, 10, "euclidean")
+    np.testing.assert_array_equal(i.numpy()[:256], oi)
+    np.testing.assert_array_equal(d.numpy()[:256], od)
