@@ -1119,9 +1119,10 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
                 ctx->h_stage_bytes = 0;
                 KZ_HIP(hipHostMalloc(&ctx->h_stage, need * 2, hipHostMallocDefault));
                 ctx->h_stage_bytes = need * 2;
-            } else {
-                KZ_HIP(hipStreamSynchronize(ctx->stream));  // previous call's async copy must have drained
             }
+            // (No wait otherwise: every pass over this point is followed by a stream synchronisation before the table
+            //  is written again -- the fail-counter read below -- so the previous async copy out of h_stage has drained;
+            //  waiting here would only stall the host behind the pack kernels.)
             int4* hw = (int4*)ctx->h_stage;
             // logical order inside a region: split-major (consecutive items share the index range), then
             // spread over block ids so that blocks with equal (id % 8) -- one XCD -- take consecutive items
