@@ -349,6 +349,10 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
     if (resume0 >= 16 && !sched) {
         // nothing left to scan (an overlapped scan covered all 16 groups) and no merge due: only the bookkeeping
         if (__any(st.cnt > CAP - 8) && (threadIdx.x & 63) == 0) sync[st.tiles_done & 3] = 1;
+#ifdef KZ_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        c_e1 += __builtin_amdgcn_s_memtime() - te0;
+#endif
         return;
     }
     float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
