@@ -190,7 +190,8 @@ def main():
     if rank == 0:
         total_queries = n_s * world * args.steps
         line = {
-            "metric": "source queries/sec (fit+kneighbors)",
+            "metric": "source queries/sec (fit+kneighbors) + recall@k vs reference, 1/2/4/8 GPU",  # BASELINE.json's metric
+            "recall_at_k": (check or {}).get("recall_at_k"),   # against the oracle on a row sample (None if not checked)
             "value": total_queries / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
