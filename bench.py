@@ -37,6 +37,8 @@ WORKLOADS = {
            "C3: 500k x 500k, d=200, cosine, k=50, MutualProximity empiric"),
     "c4s": (250_000, 1_000_000, 300, "euclidean", 10, 10, "CSLS", {},
             "C4 per-GPU share: 250k source rows x 1M target, d=300, k=10, CSLS"),
+    "ns": (250_000, 1_000_000, 200, "euclidean", 10, 10, "CSLS", {},
+           "north-star target shape, per-GPU share: 250k source rows x 1M target, d=200, k=10, CSLS"),
     "c1g": (100_000, 100_000, 128, "euclidean", 10, 10, None, {},
             "C1 on gaussian data (rng.randn) for contrast with uniform: 100k x 100k, d=128, euclidean, k=10, hubness=None"),
 }
