@@ -9,7 +9,7 @@
 // cannot be certified under the wider margin are re-done by the float32-MFMA kernel / the exact float64 kernels,
 // so the result is still the float64 neighbour order.
 //
-// Structure (d_pad = 16 * NSR; NSR <= 8 at two workgroups per CU, NSR <= 24 (d <= 384) at one):
+// Structure (d_pad = 16 * NSR; NSR <= 16 at two workgroups per CU, NSR <= 24 (d <= 384) at one):
 //   * the query tile is STATIONARY: the hi/lo fragments of all NSR slices stay in registers (8 VGPRs per slice),
 //     so the only global stream is the index image -- which is what made the float32 kernel lose ~20 % (section 7);
 //   * index slices go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write) into a ring
@@ -33,8 +33,8 @@ static inline double kz_bf16_gamma(int d_pad) {
     return 3.1 * 1.52587890625e-05 + 2.0 * (double)(3 * d_pad + 16) * 5.9604644775390625e-08 + 1e-12;
 }
 
-// WPS = waves per SIMD the register budget allows: 2 up to 8 slices (d_pad <= 128), 1 beyond (up to 24 slices, the
-// stationary query fragments alone take 8 VGPRs per slice).
+// WPS = waves per SIMD the kernel is compiled for (always 2 here: up to 16 slices the stationary query fragments, 8 VGPRs
+// per slice, fit beside the accumulators; beyond that kz_knn_cand_bf_ov_kernel runs one workgroup per CU).
 template <int KP, int NSR, int WPS>
 __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
     // the first fragments of the NEXT pair are fetched right behind the barrier, under B's remaining MFMAs -- also
     // across a tile boundary, where they stay in registers during the epilogue.
     kz_bf16x8 ah[4], al[4], bh[4], bl[4];
-    if (NSR % 2 == 0) load_frags(ah, al, 0);
+    constexpr bool PIPE = (NSR % 2 == 0) && NSR <= 10;  // the second fragment set costs 32 VGPRs: beyond 10 slices it spills
+    if (PIPE) load_frags(ah, al, 0);
     for (int tile = t_begin; tile < t_end; ++tile) {
         KZ_T(t0);
         {
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
         // above the init (as its scheduler does) this fresh load would be waited for at every tile start.
         __builtin_amdgcn_sched_barrier(0);
         const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
-        if (NSR % 2 == 0) {
+        if (PIPE) {
 #pragma unroll
             for (int u = 0; u < NSR; u += 2) {
                 __builtin_amdgcn_sched_barrier(0);

@@ -4,6 +4,12 @@
 #include "kz_knn_device.h"
 #include "kz_knn_bf16.h"
 
+// Largest slice count that still runs the two-workgroups-per-CU kernel (beyond it: one workgroup per CU, overlapped scan)
+#ifndef KZ_BF_TWO_WAVE_MAX
+#define KZ_BF_TWO_WAVE_MAX 16
+#endif
+constexpr int KZ_TWM = KZ_BF_TWO_WAVE_MAX;
+
 #define KZ_BF_CAT2(a, b) a##b
 #define KZ_BF_CAT(a, b) KZ_BF_CAT2(a, b)
 
@@ -14,9 +20,9 @@ static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad, int variant) {
         *blocks_per_cu = 1;
         return KZ_OK;
     }
-    const void* kern = NSR <= 8 ? (const void*)kz_knn_cand_bf_kernel<KP, (NSR <= 8 ? NSR : 8), 2>
-                                : (const void*)kz_knn_cand_bf_ov_kernel<KP, (NSR > 8 ? NSR : 9)>;
-    const int lds = (NSR <= 8 ? KZ_BF_LDS : KZ_OV_LDS) + lds_pad;
+    const void* kern = NSR <= KZ_TWM ? (const void*)kz_knn_cand_bf_kernel<KP, (NSR <= KZ_TWM ? NSR : KZ_TWM), 2>
+                                     : (const void*)kz_knn_cand_bf_ov_kernel<KP, (NSR > KZ_TWM ? NSR : KZ_TWM + 1)>;
+    const int lds = (NSR <= KZ_TWM ? KZ_BF_LDS : KZ_OV_LDS) + lds_pad;
     KZ_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     int nb = 0;
     KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds));
@@ -28,11 +34,11 @@ template <int KP, int NSR>
 static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
     if (NSR == 8 && KP == 16 && ctx->kernel_variant == 7)   // experiment: one wave per SIMD with the overlapped scan on C1
         hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<16, 8>), dim3(n_blocks), dim3(256), KZ_OV_LDS + ctx->lds_pad, ctx->stream, p);
-    else if (NSR <= 8)
-        hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, (NSR <= 8 ? NSR : 8), 2>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad,
+    else if (NSR <= KZ_TWM)
+        hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, (NSR <= KZ_TWM ? NSR : KZ_TWM), 2>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad,
                            ctx->stream, p);
     else
-        hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<KP, (NSR > 8 ? NSR : 9)>), dim3(n_blocks), dim3(256), KZ_OV_LDS + ctx->lds_pad,
+        hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<KP, (NSR > KZ_TWM ? NSR : KZ_TWM + 1)>), dim3(n_blocks), dim3(256), KZ_OV_LDS + ctx->lds_pad,
                            ctx->stream, p);
     KZ_HIP(hipGetLastError());
     return KZ_OK;
