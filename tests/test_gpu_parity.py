@@ -270,6 +270,8 @@ def test_query_chunking_and_row_ranges():
     (640, 2500, 384, np.float32, "sqeuclidean", 10, False), # 24 slices: the largest stationary query tile
     (300, 800, 16, np.float32, "euclidean", 5, False),      # 1 slice: split-bf16 not eligible, float32 kernel
     (300, 800, 200, np.float32, "euclidean", 5, False),     # 13 slices: one workgroup per CU, odd slice count
+    (400, 1700, 224, np.float32, "euclidean", 10, False),   # 14 slices: two workgroups per CU, single fragment set
+    (400, 1700, 256, np.float64, "sqeuclidean", 27, True),  # 16 slices: the last shape on the two-workgroup kernel
     (260, 900, 300, np.float64, "cosine", 10, False),       # 19 slices
     (200, 600, 400, np.float32, "euclidean", 5, False),     # 26 slices: not eligible, float32 kernel
 ])

@@ -19,7 +19,7 @@ def main():
     ctx = N.Context.get()
     bad = 0
     for c in range(n_cases):
-        d = int(rng.choice([3, 16, 17, 31, 33, 48, 64, 65, 96, 100, 128, 129, 150, 200, 257, 300, 384, 385, 500]))
+        d = int(rng.choice([3, 16, 17, 31, 33, 48, 64, 65, 96, 100, 128, 129, 150, 176, 192, 200, 224, 240, 256, 257, 300, 384, 385, 500]))
         n_t = int(rng.choice([60, 127, 128, 129, 500, 1000, 2049, 4000]))
         n_s = int(rng.choice([1, 31, 128, 130, 700, 1500]))
         metric = str(rng.choice(["euclidean", "sqeuclidean", "cosine"]))
