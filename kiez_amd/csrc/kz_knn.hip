@@ -1022,7 +1022,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
     const bool resident = ctx->kernel_variant == 4 && (n_slices == 8 || n_slices == 4) && KP <= 32;  // 4: stationary query tile
     const bool interleaved = (ctx->kernel_variant == 5 || ctx->kernel_variant == 6) && nres == 0;  // 5/6: interleaved stream
     const int il_nb = ctx->kernel_variant == 6 ? 3 : 2;
-    // Precision tiers: the split-bf16 first pass (kz_knn_bf16.h) when the query tile fits in registers (d_pad <= 128);
+    // Precision tiers: the split-bf16 first pass (kz_knn_bf16.h) when the query tile fits in registers (d_pad <= 384);
     // a chunk in which too many rows fail the (wider) bf16 certification is re-done by the float32-MFMA kernel, and
     // so are all later chunks of this call.
     const int precision = precision_override >= 0 ? precision_override : ctx->precision;
