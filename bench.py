@@ -164,14 +164,17 @@ def main():
     n_launch = len(knn_log)
     achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
     # which fused kernel did (most of) the work: split-bf16 first pass (3 bf16 MFMA products per multiply-add) or float32 MFMA
-    bf_ms = sum(st["main_kernel_ms"] for _, _, st in knn_log if st.get("first_pass") == 1)
-    tier_bf = bf_ms * 2 > kernel_s * 1e3
+    tier_ms = {t: sum(st["main_kernel_ms"] for _, _, st in knn_log if st.get("first_pass") == t) for t in (0, 1, 2)}
+    tier = max(tier_ms, key=tier_ms.get)       # 0 float32 operands, 1 split-bf16 (3 products), 2 fp16 (1 product)
+    tier_bf = tier != 0                        # a 16-bit MFMA tier did the work: price against the bf16/fp16 dense peak
+    products = {0: 1, 1: 3, 2: 1}[tier]
+    tier_name = {0: "f32", 1: "bf16x2", 2: "f16"}[tier]
     peak = PEAK_BF16_MFMA_TFLOPS if tier_bf else PEAK_F32_MFMA_TFLOPS
     traffic = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"   # HBM bytes per launch from separate rocprofv3 --pmc passes
     if pmc.exists():
         try:
-            key = args.workload + ("_bf16" if tier_bf else "_f32")
+            key = args.workload + "_" + tier_name
             traffic = json.loads(pmc.read_text()).get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -203,21 +206,22 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16x2" if tier_bf else "f32",
+            "dtype": tier_name,
             "data": "synthetic",
             "config": {"workload": desc, "n_source_per_gpu": n_s, "n_target": n_t, "d": d, "metric": metric,
                        "n_candidates": K, "k": k, "hubness": hub, "hubness_kwargs": hub_kw,
                        "inputs": "float32 rng.rand, resident in HBM; results left in HBM",
                        "parallelism": f"source row-sharded x{world}, target replicated (RCCL broadcast)"},
             "roofline": {"bound": "mfma",
-                         "kernel": ("kz_knn_cand_bf_kernel (split-bf16 MFMA 32x32x16, 3 products per multiply-add, fused distance+top-k)"
-                                    if tier_bf else "kz_knn_cand_kernel (fp32 MFMA 32x32x2 fused distance+top-k)"),
+                         "kernel": {2: "kz_knn_cand_h_kernel (fp16 MFMA 32x32x16 on centred operands, 1 product per multiply-add, fused distance+top-k)",
+                                    1: "kz_knn_cand_bf_kernel (split-bf16 MFMA 32x32x16, 3 products per multiply-add, fused distance+top-k)",
+                                    0: "kz_knn_cand_kernel (fp32 MFMA 32x32x2 fused distance+top-k)"}[tier],
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "launches": n_launch, "avg_launch_ms": kernel_s / max(n_launch, 1) * 1e3,
                          "algorithmic_flop_per_launch": flops / max(n_launch, 1),
-                         "mfma_products_per_mac": 3 if tier_bf else 1,
-                         "executed_mfma_frac": achieved * (3 if tier_bf else 1) / peak,
+                         "mfma_products_per_mac": products,
+                         "executed_mfma_frac": achieved * products / peak,
                          "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS},
             "certification_fallback_rows": int(fallback_rows),
             "escalated_rows": int(sum(st.get("n_escalated_rows", 0) for _, _, st in knn_log)),

@@ -20,12 +20,10 @@ struct kz_ctx {
     hipEvent_t ev[6];
     double eps_scale;
     int force_splits;
-    int force_nres;   // test knob: resident query slices (-1 = automatic)
-    int kernel_variant;  // 0: LDS-staged fused kernel, 1: barrier-free direct-load fused kernel
-    int stagger;      // tuning knob: start-up phase shift in cycles (-1 = one tile of MFMA time, 0 = off)
+    int h_wps;        // tuning knob: 2 = run the fp16 kernel's two-workgroups-per-CU build also where three would fit
     int chunk_rows;   // test knob: query rows per chunk (0 = default 524288)
     int min_splits;   // tuning knob: minimum index splits per query tile in the large-item region
-    int precision;    // 0: split-bf16 first pass where eligible (default), 1: float32 operands only
+    int precision;    // 0: fp16 first pass where eligible (default), 2: split-bf16 first pass, 1: float32 operands only
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)
     void* scratch;
@@ -33,7 +31,6 @@ struct kz_ctx {
     int* d_counters;  // small device int array (fail counter, flags)
     int* h_counters;  // pinned host mirror
     int n_cus;        // compute units of the device
-    int* d_tickets;   // [4096] per-CU workgroup tickets (start-up phase shift)
     void* h_stage;    // pinned host staging for the per-call work table
     size_t h_stage_bytes;
     // stream-ordered free list: buffers released by kz_free / kz_matrix_destroy are reused by later allocations of a
@@ -48,6 +45,24 @@ struct kz_ctx {
 int kz_pool_alloc(kz_ctx* ctx, size_t bytes, void** out);   // returns KZ_OK / KZ_ERR_NOMEM
 void kz_pool_free(kz_ctx* ctx, void* ptr, size_t bytes);
 
+// Shift and scale shared by the fp16 images of the matrices that are searched against each other (kz_pack.hip):
+// distances are translation invariant, so both sides are centred with ONE vector mu (the column mean of the first index
+// of the pair) and scaled by ONE power of two S into the fp16 range.  Reference counted: images keep it alive.
+struct kz_center {
+    float* d_mu;      // [d_pad16] float32 shift (zero padded)
+    double* d_scale;  // device {S, 1 / S^2}
+    int refs;
+};
+
+// fp16 operand image of a matrix (first pass of the fused kernel, kz_knn_h16.h), built lazily by kz_knn
+struct kz_himage {
+    kz_center* center;
+    unsigned short* packed;  // [n_tiles][nsr][2 planes][128 rows][8] fp16: plane p = k 8p..8p+7 of the 16-k slice
+    float* bias;             // [n_tiles*128] accumulator init -S^2 |x_c|^2 / 2 (pad rows: -inf)
+    double* rowq;            // [n][3] unscaled: |x_c|^2, |x_h|, |x_c - x_h|  (x_c = float32(x - mu), x_h = fp16 operand / S)
+    double* d_max;           // device [3]: max |x_h|, max |x_c - x_h|, max |x_c|^2 over the rows
+};
+
 struct kz_matrix {
     kz_ctx* ctx;
     int64_t n, d;
@@ -56,13 +71,23 @@ struct kz_matrix {
     int kg;           // d_pad / 4 (number of 4-wide k-groups), d_pad = round_up(d, 16)
     int kg_bf;        // same for the split-bf16 image (currently equal to kg)
     void* raw;        // [n, d] dtype, row-major (exact data, used by the float64 re-rank)
-    float* packed;    // [n_tiles][kg][128][4] float32 MFMA operand image
+    bool raw_borrowed;  // raw is the caller's buffer (kz_matrix_create rows_on_device = 2), not ours to free
+    float* packed;    // [n_tiles][kg][128][4] float32 MFMA operand image (NULL until kz_matrix_image_f32)
     unsigned short* packed_bf;  // [n_tiles][kg/4][4 planes][128][8] bf16 split image: planes hi(k 0-7), hi(k 8-15), lo, lo
+                                // (NULL until kz_matrix_image_bf)
     float* bias;      // [n_tiles*128] accumulator init: -|y|^2/2 (euclidean family), 0 (cosine), -inf (pad rows)
     double* sqn;      // [n] float64: squared norms (euclidean family) or norms with 0 -> 1 (cosine)
     double max_norm;  // max_j |y_j|  (host copy)
+    double* d_stats;  // device [4]: max |y_j| (as max_norm), max |operand element| (normalised rows for cosine)
+    kz_himage* himg;  // fp16 image (NULL until a kz_knn call builds it)
     size_t raw_bytes, packed_bytes, bias_bytes, sqn_bytes;
 };
+
+// operand images are built on first use (kz_pack.hip); all enqueue on the context's stream
+int kz_matrix_image_f32(kz_matrix* m);
+int kz_matrix_image_bf(kz_matrix* m);
+int kz_himage_ensure(kz_matrix* query, kz_matrix* index);
+void kz_himage_free(kz_matrix* m);
 
 void kz_set_error(const char* fmt, ...);
 

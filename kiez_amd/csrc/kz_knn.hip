@@ -62,24 +62,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
     st.tiles_done = 0;
     st.next_merge = 1;
 
-    // The ~3 workgroups resident on one CU start together and run identical work, so without help their epilogues
-    // (no MFMA issued) coincide on every SIMD.  A start-up phase shift lets one group's epilogue hide under the others'
-    // MFMAs.  Dispatch fills the CUs breadth-first, so groups b, b + n_cus, b + 2 n_cus share a CU (speed only).
-    if (p.stagger_cycles > 0) {
-        // identify the CU from hardware registers (HW_REG_HW_ID[15:8] = se/sh/cu, HW_REG_XCC_ID[3:0]) and take a ticket
-        int phase = 0;
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
-            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
-            phase = atomicAdd(p.cu_tickets + ((xcc & 15) * 256 + (hw & 255)), 1) % 3;
-        }
-        phase = __builtin_amdgcn_readfirstlane(phase);
-        if (wave == 0) {
-            const int loops = phase * p.stagger_cycles / (127 * 64);
-            for (int i = 0; i < loops; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-        __syncthreads();
-    }
     if (total > 0) {
         const float4* ysrc = reinterpret_cast<const float4*>(p.ypack + ((int64_t)t_begin * NS) * 2048);
         const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * p.kg) * 512 + (32 * wave + j) * 4;
@@ -130,31 +112,17 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
-#if (KZ_ABLATE >= 4 && KZ_ABLATE <= 5) || KZ_ABLATE == 22
-            const float4 ya0 = make_float4(0.f, 0.f, 0.f, 0.f), ya1 = ya0;
-            const float bn = 0.f;
-#else
             const int gn = min(g + 1, total - 1);
             const float4* src = ysrc + (int64_t)gn * 512;
             const float4 ya0 = src[tid];
             const float4 ya1 = src[256 + tid];
             const int tile_n = min(tile + 1, p.n_ytiles - 1);
             const float bn = bias_n[(int64_t)tile_n * KZ_TILE];
-#endif
             float4 qn0, qn1;
             if (stream_q) {
-#if KZ_ABLATE == 5 || KZ_ABLATE == 21
-                qn0 = bq1;  // diagnostic: no query-fragment loads
-                qn1 = bq0;
-#else
-#ifndef KZ_Q_TEMPORAL  // streaming policy for the query fragments: +2.6 % on C1 (they are never re-used from L1/L2 soon)
+                // streaming policy for the query fragments: +2.6 % on C1 (they are never re-used from L1/L2 soon)
                 qn0 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sl_next + h) * 512));
                 qn1 = kz_nt_load4(reinterpret_cast<const float4*>(qbase + (4 * sl_next + 2 + h) * 512));
-#else
-                qn0 = *reinterpret_cast<const float4*>(qbase + (4 * sl_next + h) * 512);
-                qn1 = *reinterpret_cast<const float4*>(qbase + (4 * sl_next + 2 + h) * 512);
-#endif
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             const float* buf = ybuf + (g & 1) * 2048;
@@ -175,13 +143,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
                 for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-#if KZ_ABLATE >= 3 && KZ_ABLATE <= 4
-            asm volatile("" ::"v"(ya0.x), "v"(ya1.x), "v"(bn));
-            if (stream_q) {
-                qb0 = qn0;
-                qb1 = qn1;
-            }
-#else
 #ifdef KZ_STAMP
             {   // ... and for the index slice issued at the top of this slice (2 younger query loads may stay in flight)
                 __builtin_amdgcn_sched_barrier(0);
@@ -208,13 +169,10 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
                 __syncthreads();
                 c_bar += __builtin_amdgcn_s_memtime() - w0;
             }
-#elif KZ_ABLATE == 8
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // diagnostic: no workgroup barrier (races; timing only)
 #else
             // Raw barrier: __syncthreads() is fence + s_barrier and the fence drains vmcnt(0), i.e. it would wait here for
             // the query-fragment loads that are only needed at the top of the next slice.  LDS visibility needs lgkmcnt only.
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 #endif
             ++g;
         };
@@ -258,7 +216,7 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             KZ_T(t2);
-            kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h, (float)p.kg);
+            kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h);
 #ifdef KZ_STAMP
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -283,7 +241,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
     }
 }
 
-#include "kz_knn_variants.h"
 #include "kz_knn_bf16.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -312,6 +269,13 @@ struct KnnFinParams {
     const int64_t* self_ids;  // optional: index row to strip per local query (escalated subsets); NULL = q_begin + q
     double gamma;         // rounding-bound factor (already multiplied by eps_scale)
     double ymax;          // max index-row norm
+    // fp16 first pass (kz_knn_h16.h): keys are in centred, scaled units; the bound uses the measured operand residuals
+    int tier_h;
+    double eps_mult;      // eps_scale (test knob)
+    double gamma_acc;     // float32 accumulation part of the bound
+    const double* q_rowq; // query image: [n][3] = |x_c|^2, |x_h|, |x_c - x_h|
+    const double* y_hmax; // index image: max |y_h|, max |y_c - y_h|, max |y_c|^2
+    const double* hscale; // {S, 1 / S^2}
     double* out_dist;     // [q_count][k]
     int64_t* out_ind;
     int* fail_count;
@@ -549,22 +513,51 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     }
     kz_wave_sync();
 
-    // Self-check of the rounding bound the certification rests on: for every candidate both the approximate key
-    // (ck, from the fused kernel) and the exact key (from the float64 re-rank) are known here.
-    double eps_q;
-    bool bound_violated = false;
-    if (p.metric == KZ_COSINE)
+    // Rounding bound of this query's approximate keys and the exact key of a candidate from its exact value.
+    //   float32 / split-bf16 operands: |key~ - key| <= gamma (|y|max^2 / 2 + |q| |y|max), key = (|q|^2 - d^2) / 2 (euclidean
+    //   family) or 1 - dist (cosine);
+    //   fp16 operands (centred vectors x_c = float32(x - mu), operands x_h, residuals r = x_c - x_h measured at pack time):
+    //   q_h.y_h - q_c.y_c = -(r_q.y_h + q_h.r_y + r_q.r_y), so by Cauchy-Schwarz on the ACTUAL residual norms
+    //     |key~ - key_c| <= |r_q| Yh + |q_h| Ry + |r_q| Ry              (operand rounding; Yh = max |y_h|, Ry = max |r_y|)
+    //                      + gamma_acc (Yc2 / 2 + |q_h| Yh)               (float32 accumulation of exact products + bias)
+    //                      + 2^-23 (|q_c| + sqrt(Yc2))^2 + 1e-12 (...) + 1e-14 (|q|^2 + |y|max^2)
+    //                                                                     (float32 centring round-off, float64 re-rank)
+    //   with key_c = (|q_c|^2 - d^2) / 2 and d^2 = the exact squared distance (cosine: 2 dist, rows are unit vectors).
+    double eps_q, key_scale = 1.0, qref = qs;
+    const bool cosine_plain = p.metric == KZ_COSINE && !p.tier_h;
+    if (p.tier_h) {
+        const double qc2 = p.q_rowq[qrow * 3 + 0], qh = p.q_rowq[qrow * 3 + 1], qr = p.q_rowq[qrow * 3 + 2];
+        const double Yh = p.y_hmax[0], Ry = p.y_hmax[1], Yc2 = p.y_hmax[2];
+        const double qc = sqrt(qc2), yc = sqrt(Yc2);
+        // (the float64 re-rank evaluates |q|^2 + |y|^2 - 2 q.y on the UNCENTRED rows: its own round-off scales with those)
+        const double raw2 = p.metric == KZ_COSINE ? 2.0 : qs + p.ymax * p.ymax;
+        eps_q = p.eps_mult * (qr * Yh + qh * Ry + qr * Ry + p.gamma_acc * (0.5 * Yc2 + qh * Yh) +
+                              1.1920928955078125e-07 * (qc + yc) * (qc + yc) + 1e-12 * (0.5 * Yc2 + qc2) + 1e-14 * raw2);
+        key_scale = p.hscale[1];
+        qref = qc2;
+    } else if (p.metric == KZ_COSINE) {
         eps_q = p.gamma * 1.001;
-    else
-        eps_q = p.gamma * (0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax);
-    if (eps_q > 0.0 && p.err_ratio_bits) {
+    } else {
+        const double scale = 0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax;
+        eps_q = p.gamma * scale;
+        // the relative bound assumes the products stay in the normal float32 range (data at the 1e-19 scale and below
+        // underflows in the matrix pipe): such rows are left to the exact float64 kernels
+        if (scale < 1e-30) eps_q = INFINITY;
+    }
+    auto exact_key = [&](double v) {
+        if (cosine_plain) return 1.0 - v;
+        return 0.5 * (qref - (p.metric == KZ_COSINE ? 2.0 * v : v));
+    };
+
+    // Self-check of the bound the certification rests on: for every candidate both the approximate key (ck, from the
+    // fused kernel) and the exact key (from the float64 re-rank) are known here.
+    bool bound_violated = false;
+    if (eps_q > 0.0 && eps_q < INFINITY && p.err_ratio_bits) {
         double worst = 0.0;
         for (int c = lane; c < V; c += 64) {
             const double v = cv[c];
-            if (v > 0.0) {  // (a distance clamped at 0 no longer carries the exact key)
-                const double key = (p.metric == KZ_COSINE) ? 1.0 - v : 0.5 * (qs - v);
-                worst = fmax(worst, fabs((double)ck[c] - key) / eps_q);
-            }
+            if (v > 0.0)  // (a distance clamped at 0 no longer carries the exact key)
+                worst = fmax(worst, fabs((double)ck[c] * key_scale - exact_key(v)) / eps_q);
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off, 64));
@@ -578,27 +571,13 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 
     // Certification (DESIGN.md "Certified candidate sets").  |key~ - key| <= eps for every index row.  A row outside
     // the candidate set has key~ <= ck[KP-1] (the K'-th best approximate key), hence an exact key <= ck[KP-1] + eps.
-    // The exact key of the k-th re-ranked candidate is known: (|q|^2 - d2_k)/2 (euclidean family), 1 - dist_k (cosine).
-    // If it is strictly larger, no outside row can enter -- or tie with -- the exact top-k.  V < KP means no list
-    // ever evicted anything: the set is complete.
+    // The exact key of the k-th re-ranked candidate is known.  If it is strictly larger, no outside row can enter -- or
+    // tie with -- the exact top-k.  V < KP means no list ever evicted anything: the set is complete.
     bool certified;
-    if (V < KP) {
+    if (V < KP)
         certified = (V >= min((int64_t)k_eff, p.n_i));
-    } else {
-        double eps, key_k;
-        if (p.metric == KZ_COSINE) {
-            eps = p.gamma * 1.001;
-            key_k = 1.0 - sv[k_eff - 1];
-        } else {
-            const double scale = 0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax;
-            eps = p.gamma * scale;
-            key_k = 0.5 * (qs - sv[k_eff - 1]);
-            // the relative bound assumes the products stay in the normal float32 range (data at the 1e-19 scale and below
-            // underflows in the matrix pipe): such rows are left to the exact float64 kernels
-            if (scale < 1e-30) eps = INFINITY;
-        }
-        certified = (double)ck[KP - 1] + eps < key_k;
-    }
+    else
+        certified = (double)ck[KP - 1] * key_scale + eps_q < exact_key(sv[k_eff - 1]);
     // An approximate key further than eps from its exact value contradicts the bound everything above rests on (a kernel
     // or hardware fault, not a property of the data): do not trust this row's candidate set, send it down a tier.
     if (bound_violated) certified = false;
@@ -725,137 +704,23 @@ static int kz_pick_list_len(int k_eff) {
     return 0;
 }
 
-template <int KP, int NRES>
+template <int KP>
 static int kz_cand_occupancy(int* blocks_per_cu) {
-    const size_t lds = KZ_CAND_LDS;
-    auto kern = kz_knn_cand_kernel<KP, NRES>;
-    if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int nb = 0;
-    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds));
-    *blocks_per_cu = nb < 1 ? 1 : nb;
-    return KZ_OK;
-}
-
-template <int KP>
-static int kz_cand2_occupancy(int* blocks_per_cu) {
-    auto kern = kz_knn_cand2_kernel<KP>;
-    KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_CAND2_LDS));
-    int nb = 0;
-    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_CAND2_LDS));
-    *blocks_per_cu = nb < 1 ? 1 : nb;
-    return KZ_OK;
-}
-
-template <int KP>
-static int kz_launch_cand2(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    hipLaunchKernelGGL(kz_knn_cand2_kernel<KP>, dim3(n_blocks), dim3(256), KZ_CAND2_LDS, ctx->stream, p);
-    KZ_HIP(hipGetLastError());
-    return KZ_OK;
-}
-
-template <int KP, int NSR>
-static int kz_res_occupancy(int* blocks_per_cu) {
-    auto kern = kz_knn_cand_res_kernel<KP, NSR>;
+    auto kern = kz_knn_cand_kernel<KP, 0>;
     int nb = 0;
     KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_CAND_LDS));
     *blocks_per_cu = nb < 1 ? 1 : nb;
     return KZ_OK;
 }
 
-template <int KP, int NSR>
-static int kz_launch_res(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    hipLaunchKernelGGL((kz_knn_cand_res_kernel<KP, NSR>), dim3(n_blocks), dim3(256), KZ_CAND_LDS, ctx->stream, p);
+template <int KP>
+static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
+    hipLaunchKernelGGL((kz_knn_cand_kernel<KP, 0>), dim3(n_blocks), dim3(256), KZ_CAND_LDS, ctx->stream, p);
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }
 
-// split-bf16 kernels: instantiated per list length in kz_knn_bf_kp*.hip (parallel compilation)
-int kz_bf_occupancy_kp16(int n_slices_bf, int* blocks_per_cu, int lds_pad, int variant);
-int kz_bf_occupancy_kp32(int n_slices_bf, int* blocks_per_cu, int lds_pad, int variant);
-int kz_bf_occupancy_kp64(int n_slices_bf, int* blocks_per_cu, int lds_pad, int variant);
-int kz_bf_occupancy_kp128(int n_slices_bf, int* blocks_per_cu, int lds_pad, int variant);
-int kz_bf_launch_kp16(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
-int kz_bf_launch_kp32(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
-int kz_bf_launch_kp64(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
-int kz_bf_launch_kp128(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
-#define KZ_DISPATCH_BF(rc, fn, args)                 \
-    do {                                             \
-        switch (KP) {                                \
-            case 16: rc = fn##_kp16 args; break;     \
-            case 32: rc = fn##_kp32 args; break;     \
-            case 64: rc = fn##_kp64 args; break;     \
-            default: rc = fn##_kp128 args; break;    \
-        }                                            \
-    } while (0)
-
-template <int KP, int NB>
-static int kz_il_occupancy(int* blocks_per_cu) {
-    auto kern = kz_knn_cand_il_kernel<KP, NB>;
-    int nb = 0;
-    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KzIl<NB>::LDS));
-    *blocks_per_cu = nb < 1 ? 1 : nb;
-    return KZ_OK;
-}
-
-template <int KP, int NB>
-static int kz_launch_il(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    hipLaunchKernelGGL((kz_knn_cand_il_kernel<KP, NB>), dim3(n_blocks), dim3(256), KzIl<NB>::LDS, ctx->stream, p);
-    KZ_HIP(hipGetLastError());
-    return KZ_OK;
-}
-
-#define KZ_DISPATCH_IL(rc, fn, args)                                                    \
-    do {                                                                                \
-        switch (KP) {                                                                   \
-            case 16: if (il_nb == 3) rc = fn<16, 3> args; else rc = fn<16, 2> args; break;   \
-            case 32: if (il_nb == 3) rc = fn<32, 3> args; else rc = fn<32, 2> args; break;   \
-            case 64: if (il_nb == 3) rc = fn<64, 3> args; else rc = fn<64, 2> args; break;   \
-            default: if (il_nb == 3) rc = fn<128, 3> args; else rc = fn<128, 2> args; break; \
-        }                                                                               \
-    } while (0)
-
-#define KZ_DISPATCH_RES(rc, fn, args)                                                   \
-    do {                                                                                \
-        if (n_slices == 8) {                                                            \
-            if (KP == 16) rc = fn<16, 8> args; else rc = fn<32, 8> args;                \
-        } else {                                                                        \
-            if (KP == 16) rc = fn<16, 4> args; else rc = fn<32, 4> args;                \
-        }                                                                               \
-    } while (0)
-
-template <int KP>
-static int kz_ring_occupancy(int* blocks_per_cu) {
-    auto kern = kz_knn_cand_ring_kernel<KP>;
-    int nb = 0;
-    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_RING_LDS));
-    *blocks_per_cu = nb < 1 ? 1 : nb;
-    return KZ_OK;
-}
-
-template <int KP>
-static int kz_launch_ring(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    hipLaunchKernelGGL(kz_knn_cand_ring_kernel<KP>, dim3(n_blocks), dim3(256), KZ_RING_LDS, ctx->stream, p);
-    KZ_HIP(hipGetLastError());
-    return KZ_OK;
-}
-
-template <int KP>
-static int kz_direct_occupancy(int* blocks_per_cu) {
-    auto kern = kz_knn_cand_direct_kernel<KP>;
-    int nb = 0;
-    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, KZ_DIRECT_LDS));
-    *blocks_per_cu = nb < 1 ? 1 : nb;
-    return KZ_OK;
-}
-
-template <int KP>
-static int kz_launch_direct(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    hipLaunchKernelGGL(kz_knn_cand_direct_kernel<KP>, dim3(n_blocks), dim3(256), KZ_DIRECT_LDS, ctx->stream, p);
-    KZ_HIP(hipGetLastError());
-    return KZ_OK;
-}
-
-#define KZ_DISPATCH_DIRECT(rc, fn, args)        \
+#define KZ_DISPATCH_CAND(rc, fn, args)          \
     do {                                        \
         switch (KP) {                           \
             case 16: rc = fn<16> args; break;   \
@@ -865,31 +730,31 @@ static int kz_launch_direct(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
         }                                       \
     } while (0)
 
-template <int KP, int NRES>
-static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    const size_t lds = KZ_CAND_LDS;
-    auto kern = kz_knn_cand_kernel<KP, NRES>;
-    if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, ctx->stream, p);
-    KZ_HIP(hipGetLastError());
-    return KZ_OK;
-}
-
-// (list length, resident query slices) -> kernel instantiation
-#define KZ_DISPATCH_NRES(rc, fn, args, KPV)           \
-    do {                                              \
-        if (nres == 8) rc = fn<KPV, 8> args;          \
-        else if (nres == 4) rc = fn<KPV, 4> args;     \
-        else rc = fn<KPV, 0> args;                    \
-    } while (0)
-#define KZ_DISPATCH_CAND(rc, fn, args)                        \
-    do {                                                      \
-        switch (KP) {                                         \
-            case 16: KZ_DISPATCH_NRES(rc, fn, args, 16); break;   \
-            case 32: KZ_DISPATCH_NRES(rc, fn, args, 32); break;   \
-            case 64: KZ_DISPATCH_NRES(rc, fn, args, 64); break;   \
-            default: KZ_DISPATCH_NRES(rc, fn, args, 128); break;  \
-        }                                                     \
+// fp16 and split-bf16 kernels: instantiated per list length in kz_knn_h_kp*.hip / kz_knn_bf_kp*.hip (parallel compilation)
+int kz_h_occupancy_kp16(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
+int kz_h_occupancy_kp32(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
+int kz_h_occupancy_kp64(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
+int kz_h_occupancy_kp128(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
+int kz_h_launch_kp16(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
+int kz_h_launch_kp32(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
+int kz_h_launch_kp64(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
+int kz_h_launch_kp128(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
+int kz_bf_occupancy_kp16(int n_slices_bf, int* blocks_per_cu, int lds_pad);
+int kz_bf_occupancy_kp32(int n_slices_bf, int* blocks_per_cu, int lds_pad);
+int kz_bf_occupancy_kp64(int n_slices_bf, int* blocks_per_cu, int lds_pad);
+int kz_bf_occupancy_kp128(int n_slices_bf, int* blocks_per_cu, int lds_pad);
+int kz_bf_launch_kp16(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
+int kz_bf_launch_kp32(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
+int kz_bf_launch_kp64(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
+int kz_bf_launch_kp128(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
+#define KZ_DISPATCH_KP(rc, fn, args)                 \
+    do {                                             \
+        switch (KP) {                                \
+            case 16: rc = fn##_kp16 args; break;     \
+            case 32: rc = fn##_kp32 args; break;     \
+            case 64: rc = fn##_kp64 args; break;     \
+            default: rc = fn##_kp128 args; break;    \
+        }                                            \
     } while (0)
 
 // Host schedule of one launch: greedy rounds.  slots = workgroups resident on the chip; dispatch is in block-id order, so
@@ -974,9 +839,14 @@ __global__ __launch_bounds__(256) void kz_scatter_rows_kernel(const double* __re
     oi[(int64_t)rows[r] * k + c] = si[t];
 }
 
+// Operand precision of the fused kernel ("tier").  kz_knn starts at the highest tier the shapes allow; rows whose
+// candidate set cannot be certified under that tier's bound go down: fp16 / split-bf16 -> float32 operands (gathered into
+// a dense query block) -> exact float64 brute force.  The result is the float64 neighbour order at every tier.
+enum { KZ_TIER_F32 = 0, KZ_TIER_BF = 1, KZ_TIER_H = 2 };
+
 // d_self_ids (device, optional): index row to strip per query when exclude_self is set and the query matrix is not the
 // index matrix itself (escalated subsets).  precision_override: -1 = the context's setting, 1 = float32 operands only.
-static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index, int k,
+static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q_count, kz_matrix* index, int k,
                        int exclude_self, const int64_t* d_self_ids, int precision_override, double* d_dist, int64_t* d_ind,
                        kz_knn_stats* stats) {
     KZ_REQUIRE(ctx && query && index && d_dist && d_ind, "kz_knn: null argument");
@@ -1004,54 +874,39 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
     const int metric = index->metric;
     const int n_ytiles = (int)index->n_tiles;
     const int max_splits_m = KZ_FIN_MAXM / (2 * KP);
-    // rounding bound factor: (d_pad + 16) * 2^-24 covers the d+1 step fma chain, the float32 rounding of the bias
-    // and (float64 inputs) of the operands; 1e-12 covers the float64 re-rank's own rounding.
+    const int n_slices = index->kg / 4;
+    // rounding bound factors.  float32 operands: (d_pad + 16) 2^-24 covers the d+1 step fma chain, the float32 rounding of
+    // the bias and (float64 inputs) of the operands; 1e-12 covers the float64 re-rank's own rounding.  fp16 operands: the
+    // float32 accumulation of d_pad exact products + bias in an unspecified order, (n + 16) u doubled to allow for
+    // truncating internal adds (the operand rounding is measured per row, kz_pack.hip).
     const double gamma_f32 = ((double)(index->kg * 4 + 16) * 5.9604644775390625e-08 + 1e-12) * ctx->eps_scale;
     const double gamma_bf = kz_bf16_gamma(index->kg_bf * 4) * ctx->eps_scale;
-    const int n_slices_bf = index->kg_bf / 4;
+    const double gamma_acc_h = 2.0 * (double)(index->kg * 4 + 16) * 5.9604644775390625e-08;
 
-    const int n_slices = index->kg / 4;
-    // Resident query slices (registers).  Measured on C1 (d=128): 0 resident slices at 3 workgroups/CU beat 8 resident
-    // slices at 2 workgroups/CU (118 vs 101 TF), so residency is opt-in (force_nres) until the register budget allows both.
-    const int nres_max = n_slices >= 8 ? 8 : (n_slices >= 4 ? 4 : 0);
-    int nres = 0;
-    if (ctx->force_nres > 0 && ctx->force_nres <= nres_max) nres = ctx->force_nres;
-    const bool direct = ctx->kernel_variant == 1;  // 1: barrier-free direct-load kernel, 0: LDS-staged kernel
-    const bool macro32 = ctx->kernel_variant == 2 && (index->kg % 8) == 0 && nres == 0;  // 2: 32-k macro slices
-    const bool ring = ctx->kernel_variant == 3 && n_slices >= 4 && nres == 0;            // 3: LDS ring, no workgroup barriers
-    const bool resident = ctx->kernel_variant == 4 && (n_slices == 8 || n_slices == 4) && KP <= 32;  // 4: stationary query tile
-    const bool interleaved = (ctx->kernel_variant == 5 || ctx->kernel_variant == 6) && nres == 0;  // 5/6: interleaved stream
-    const int il_nb = ctx->kernel_variant == 6 ? 3 : 2;
-    // Precision tiers: the split-bf16 first pass (kz_knn_bf16.h) when the query tile fits in registers (d_pad <= 384);
-    // a chunk in which too many rows fail the (wider) bf16 certification is re-done by the float32-MFMA kernel, and
-    // so are all later chunks of this call.
+    // ---- tier of this call ------------------------------------------------------------------------------------------
     const int precision = precision_override >= 0 ? precision_override : ctx->precision;
-    bool tier_bf = precision == 0 && (ctx->kernel_variant == 0 || ctx->kernel_variant == 7) && nres == 0 &&
-                   n_slices_bf >= 2 && n_slices_bf <= 24 && query->kg_bf == index->kg_bf;
-    int slots_f32 = 0, slots_bf = 0;
-    auto slots_for = [&](bool bf, int* out) -> int {
-        int& cache = bf ? slots_bf : slots_f32;
-        if (cache == 0) {
+    int tier = KZ_TIER_F32;
+    if (precision != 1 && n_slices >= 1 && n_slices <= 24 && query->kg == index->kg) tier = precision == 2 ? KZ_TIER_BF : KZ_TIER_H;
+    if (tier == KZ_TIER_BF && n_slices < 2) tier = KZ_TIER_F32;
+    if (tier == KZ_TIER_H) {
+        const int rc = kz_himage_ensure(query, index);
+        if (rc != KZ_OK) return rc;
+    }
+    int slots_cache[3] = {0, 0, 0};
+    auto slots_for = [&](int t, int* out) -> int {
+        if (slots_cache[t] == 0) {
             int blocks_per_cu = 1;
             int rc0;
-            if (bf)
-                KZ_DISPATCH_BF(rc0, kz_bf_occupancy, (n_slices_bf, &blocks_per_cu, ctx->lds_pad, ctx->kernel_variant));
-            else if (interleaved)
-                KZ_DISPATCH_IL(rc0, kz_il_occupancy, (&blocks_per_cu));
-            else if (direct)
-                KZ_DISPATCH_DIRECT(rc0, kz_direct_occupancy, (&blocks_per_cu));
-            else if (macro32)
-                KZ_DISPATCH_DIRECT(rc0, kz_cand2_occupancy, (&blocks_per_cu));
-            else if (ring)
-                KZ_DISPATCH_DIRECT(rc0, kz_ring_occupancy, (&blocks_per_cu));
-            else if (resident)
-                KZ_DISPATCH_RES(rc0, kz_res_occupancy, (&blocks_per_cu));
+            if (t == KZ_TIER_H)
+                KZ_DISPATCH_KP(rc0, kz_h_occupancy, (n_slices, &blocks_per_cu, ctx->h_wps, ctx->lds_pad));
+            else if (t == KZ_TIER_BF)
+                KZ_DISPATCH_KP(rc0, kz_bf_occupancy, (n_slices, &blocks_per_cu, ctx->lds_pad));
             else
                 KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
             if (rc0 != KZ_OK) return rc0;
-            cache = blocks_per_cu * ctx->n_cus;
+            slots_cache[t] = blocks_per_cu * ctx->n_cus;
         }
-        *out = cache;
+        *out = slots_cache[t];
         return KZ_OK;
     };
     // query rows are processed in chunks so that the candidate lists stay below ~1 GiB
@@ -1059,14 +914,22 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
     double main_ms = 0, fin_ms = 0, fb_ms = 0;
     int64_t n_fail_total = 0, n_escalated = 0;
     double max_err_ratio = 0.0;
-    int last_splits = 1, last_blocks = 0;
+    int last_splits = 1, last_blocks = 0, first_tier = tier;
     for (int64_t c0 = 0; c0 < q_count;) {
+        if (tier == KZ_TIER_BF) {
+            int rc = kz_matrix_image_bf(query);
+            if (rc == KZ_OK) rc = kz_matrix_image_bf(index);
+            if (rc != KZ_OK) return rc;
+        } else if (tier == KZ_TIER_F32) {
+            int rc = kz_matrix_image_f32(query);
+            if (rc == KZ_OK) rc = kz_matrix_image_f32(index);
+            if (rc != KZ_OK) return rc;
+        }
         int slots = 0;
         {
-            const int rcs = slots_for(tier_bf, &slots);
+            const int rcs = slots_for(tier, &slots);
             if (rcs != KZ_OK) return rcs;
         }
-        const double gamma = tier_bf ? gamma_bf : gamma_f32;
         const int64_t cq_begin = q_begin + c0;
         const int64_t cq_count = (q_count - c0 < max_rows_per_chunk) ? (q_count - c0) : max_rows_per_chunk;
         const int qt0 = (int)(cq_begin / KZ_TILE);
@@ -1095,7 +958,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
                 q0 += reg_nq[r];
             }
             lay.n_regions = n_reg;
-            lay.halves = tier_bf ? 1 : 2;
+            lay.halves = tier == KZ_TIER_F32 ? 2 : 1;
         }
         const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
         const size_t fail_bytes = ((size_t)cq_count * 4 + 255) & ~(size_t)255;
@@ -1108,7 +971,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         int* fail_list = (int*)((char*)scratch + 2 * key_bytes);
         int4* d_work = (int4*)((char*)scratch + 2 * key_bytes + fail_bytes);
         int* fail_count = ctx->d_counters + 8;
-        KZ_HIP(hipMemsetAsync(fail_count, 0, 4 * sizeof(int), ctx->stream));  // fail counter, kernel error word, error-ratio bits
+        KZ_HIP(hipMemsetAsync(fail_count, 0, 4 * sizeof(int), ctx->stream));  // fail counter, (unused), error-ratio bits
         {
             // host-side table (pinned staging grows on demand)
             const size_t need = work_bytes;
@@ -1124,11 +987,10 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
             //  is written again -- the fail-counter read below -- so the previous async copy out of h_stage has drained;
             //  waiting here would only stall the host behind the pack kernels.)
             int4* hw = (int4*)ctx->h_stage;
-            // logical order inside a region: split-major (consecutive items share the index range), then
-            // spread over block ids so that blocks with equal (id % 8) -- one XCD -- take consecutive items
-            // Logical order inside a region: groups of KZ_QGROUP query tiles, inside a group split-major.  The ~96
-            // workgroups resident on one XCD then cover few query tiles (their fragments stay in the 4 MiB L2) times a
-            // few index ranges (each index tile is fetched once and hit by the whole group).
+            // Logical order inside a region: groups of KZ_QGROUP query tiles, inside a group split-major.  The workgroups
+            // resident on one XCD then cover few query tiles (their fragments stay in the 4 MiB L2) times a few index
+            // ranges (each index tile is fetched once and hit by the whole group); items are spread over block ids so that
+            // blocks with equal (id % 8) -- one XCD -- take consecutive items.
             auto fill_region = [&](int off, int cnt, int q0, int nq, int sp) {
                 if (cnt == 0) return;
                 const int len = split_len(sp);
@@ -1158,46 +1020,40 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         }
 
         KnnCandParams cp;
-        cp.qpack = tier_bf ? (const float*)query->packed_bf : query->packed;
-        cp.ypack = tier_bf ? (const float*)index->packed_bf : index->packed;
-        cp.ybias = index->bias;
+        memset(&cp, 0, sizeof(cp));
+        if (tier == KZ_TIER_H) {
+            cp.qpack = (const float*)query->himg->packed;
+            cp.ypack = (const float*)index->himg->packed;
+            cp.ybias = index->himg->bias;
+        } else {
+            cp.qpack = tier == KZ_TIER_BF ? (const float*)query->packed_bf : query->packed;
+            cp.ypack = tier == KZ_TIER_BF ? (const float*)index->packed_bf : index->packed;
+            cp.ybias = index->bias;
+        }
         cp.work = d_work;
         cp.qt0 = qt0;
         cp.n_ytiles = n_ytiles;
         cp.lay = lay;
-        cp.kg = tier_bf ? index->kg_bf : index->kg;
+        cp.kg = index->kg;
         cp.out_key = out_key;
         cp.out_idx = out_idx;
-        cp.stagger_cycles = ctx->stagger >= 0 ? ctx->stagger : (index->kg / 4) * 2048;  // default: one tile of MFMA time
-        cp.n_cus = ctx->n_cus;
-        cp.cu_tickets = ctx->d_tickets;
-        cp.err = ctx->d_counters + 9;
-        cp.phase_tiles = ctx->stagger > 0 ? 1 : 0;   // (re-uses the "stagger" knob)
-        if (cp.stagger_cycles > 0) KZ_HIP(hipMemsetAsync(ctx->d_tickets, 0, 4096 * sizeof(int), ctx->stream));
         cp.dbg = nullptr;
 #ifdef KZ_STAMP
         cp.dbg = (unsigned long long*)(ctx->d_counters + 16);
         KZ_HIP(hipMemsetAsync(cp.dbg, 0, 10 * sizeof(unsigned long long), ctx->stream));
 #endif
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-        if (tier_bf)
-            KZ_DISPATCH_BF(rc, kz_bf_launch, (n_slices_bf, ctx, cp, W));
-        else if (interleaved)
-            KZ_DISPATCH_IL(rc, kz_launch_il, (ctx, cp, W));
-        else if (direct)
-            KZ_DISPATCH_DIRECT(rc, kz_launch_direct, (ctx, cp, W));
-        else if (macro32)
-            KZ_DISPATCH_DIRECT(rc, kz_launch_cand2, (ctx, cp, W));
-        else if (ring)
-            KZ_DISPATCH_DIRECT(rc, kz_launch_ring, (ctx, cp, W));
-        else if (resident)
-            KZ_DISPATCH_RES(rc, kz_launch_res, (ctx, cp, W));
+        if (tier == KZ_TIER_H)
+            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps));
+        else if (tier == KZ_TIER_BF)
+            KZ_DISPATCH_KP(rc, kz_bf_launch, (n_slices, ctx, cp, W));
         else
             KZ_DISPATCH_CAND(rc, kz_launch_cand, (ctx, cp, W));
         if (rc != KZ_OK) return rc;
         KZ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
 
         KnnFinParams fp;
+        memset(&fp, 0, sizeof(fp));
         fp.in_key = out_key;
         fp.in_idx = out_idx;
         fp.lay = lay;
@@ -1215,8 +1071,16 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         fp.k = k;
         fp.exclude_self = exclude_self ? 1 : 0;
         fp.self_ids = d_self_ids;
-        fp.gamma = gamma;
+        fp.gamma = tier == KZ_TIER_BF ? gamma_bf : gamma_f32;
         fp.ymax = index->max_norm;
+        fp.tier_h = tier == KZ_TIER_H ? 1 : 0;
+        if (fp.tier_h) {
+            fp.eps_mult = ctx->eps_scale;
+            fp.gamma_acc = gamma_acc_h;
+            fp.q_rowq = query->himg->rowq;
+            fp.y_hmax = index->himg->d_max;
+            fp.hscale = index->himg->center->d_scale;
+        }
         fp.out_dist = d_dist + c0 * (int64_t)k;
         fp.out_ind = d_ind + c0 * (int64_t)k;
         fp.fail_count = fail_count;
@@ -1249,23 +1113,22 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
             memcpy(&ratio, ctx->h_counters + 10, 8);
             if (ratio > max_err_ratio) max_err_ratio = ratio;
         }
-        if (ctx->h_counters[9] != 0) {
-            kz_set_error("kz_knn: fused kernel reported an internal synchronisation time-out (error word %d)", ctx->h_counters[9]);
-            return KZ_ERR_HIP;
-        }
 #ifdef KZ_STAMP
         {
             unsigned long long hd[10];
             KZ_HIP(hipMemcpy(hd, ctx->d_counters + 16, sizeof(hd), hipMemcpyDeviceToHost));
             const double wt = (double)(hd[3] ? hd[3] : 1);  // wave-tiles
-            fprintf(stderr, "[kz stamp] per wave-tile cycles: slices %.0f  epilogue %.0f (shfl %.0f, groups %.0f)  init %.0f  (wave-tiles %llu)\n",
-                    hd[0] / wt, hd[1] / wt, hd[4] / wt, hd[5] / wt, hd[2] / wt, hd[3]);
-            fprintf(stderr, "[kz stamp]   inside slices, per wave-tile: query-frag wait %.0f  index-slice wait %.0f  barrier %.0f\n",
-                    hd[6] / wt, hd[7] / wt, hd[8] / wt);
-            if (tier_bf)
-                fprintf(stderr, "[kz stamp]   bf16 kernel, per wave-tile: merge cycles %.0f, merge passes %.4f, max-lane inserts %.3f, dma wait %.0f, barrier wait %.0f\n",
-                        hd[4] / wt, hd[5] / wt, hd[6] / wt, hd[7] / wt, hd[8] / wt);
-            if (tier_bf) fprintf(stderr, "[kz stamp]   bf16 epilogue: masks phase %.0f, first scan pass %.0f\n", hd[2] / wt, hd[9] / wt);
+            if (tier == KZ_TIER_F32) {
+                fprintf(stderr, "[kz stamp] f32 kernel, per wave-tile cycles: slices %.0f  epilogue %.0f  init %.0f  (wave-tiles %llu)\n",
+                        hd[0] / wt, hd[1] / wt, hd[2] / wt, hd[3]);
+                fprintf(stderr, "[kz stamp]   inside slices, per wave-tile: query-frag wait %.0f  index-slice wait %.0f  barrier %.0f\n",
+                        hd[6] / wt, hd[7] / wt, hd[8] / wt);
+            } else {
+                fprintf(stderr, "[kz stamp] %s kernel, per wave-tile cycles: slices %.0f (dma wait %.0f, barrier wait %.0f)  epilogue %.0f "
+                        "(masks %.0f, first scan pass %.0f, merges %.0f; merge passes %.4f, max-lane inserts %.3f)  (wave-tiles %llu)\n",
+                        tier == KZ_TIER_H ? "fp16" : "bf16", hd[0] / wt, hd[7] / wt, hd[8] / wt, hd[1] / wt, hd[2] / wt, hd[9] / wt,
+                        hd[4] / wt, hd[5] / wt, hd[6] / wt, hd[3]);
+            }
         }
 #endif
         float ms = 0;
@@ -1275,14 +1138,14 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         fin_ms += ms;
         last_splits = lay.pieces[0];
         last_blocks = W;
-        if (tier_bf && (int64_t)n_fail * 4 > cq_count) {
-            // more than a quarter of the chunk's rows could not be certified under the split-bf16 margin: this data
-            // needs the float32 operands; redo the chunk (and run the rest of the call) with the float32-MFMA kernel
-            tier_bf = false;
+        if (tier != KZ_TIER_F32 && (int64_t)n_fail * 4 > cq_count) {
+            // more than a quarter of the chunk's rows could not be certified under this tier's margin: this data needs the
+            // float32 operands; redo the chunk (and run the rest of the call) with the float32-MFMA kernel
+            tier = KZ_TIER_F32;
             n_escalated += cq_count;
             continue;
         }
-        if (tier_bf && n_fail > 0) {
+        if (tier != KZ_TIER_F32 && n_fail > 0) {
             // Escalate only the uncertified rows: gather them into a dense query block, run the float32-operand kernel
             // on it (its own uncertified rows go on to the exact float64 kernels), scatter the results back.
             KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -1321,10 +1184,8 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
                 kz_set_error("kz_knn: gathering the escalated rows failed: %s", hipGetErrorString(e));
                 return KZ_ERR_HIP;
             }
-            if (exclude_self && d_self_ids) {
-                // (an escalated subset of an escalated subset cannot happen: the inner call runs with float32 operands)
-            }
-            rc = kz_matrix_create(ctx, sub_raw, 1, n_fail, query->d, query->dtype, query->metric, &qsub);
+            // (an escalated subset of an escalated subset cannot happen: the inner call runs with float32 operands)
+            rc = kz_matrix_create(ctx, sub_raw, 2, n_fail, query->d, query->dtype, query->metric, &qsub);
             kz_knn_stats st2;
             memset(&st2, 0, sizeof(st2));
             if (rc == KZ_OK)
@@ -1408,7 +1269,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
         stats->list_len = KP;
         stats->n_splits = last_splits;
         stats->n_blocks = last_blocks;
-        stats->first_pass = tier_bf ? 1 : 0;
+        stats->first_pass = first_tier;
         stats->n_escalated_rows = n_escalated;
         stats->max_err_ratio = max_err_ratio;
     }
@@ -1417,5 +1278,7 @@ static int kz_knn_impl(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int
 
 extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index, int k,
                       int exclude_self, double* d_dist, int64_t* d_ind, kz_knn_stats* stats) {
-    return kz_knn_impl(ctx, query, q_begin, q_count, index, k, exclude_self, nullptr, -1, d_dist, d_ind, stats);
+    // (the matrices are logically const for the caller: kz_knn only attaches lazily built operand images to them)
+    return kz_knn_impl(ctx, const_cast<kz_matrix*>(query), q_begin, q_count, const_cast<kz_matrix*>(index), k, exclude_self, nullptr,
+                       -1, d_dist, d_ind, stats);
 }

@@ -1,5 +1,5 @@
 // Per-list-length translation unit of the split-bf16 kernels (included by kz_knn_bf_kp{16,32,64,128}.hip with KZ_BF_KP
-// defined): the 23 slice counts x 2 kernels of one list length compile in parallel with the other list lengths.
+// defined): the slice counts of one list length compile in parallel with the other list lengths.
 #include "kz_common.h"
 #include "kz_knn_device.h"
 #include "kz_knn_bf16.h"
@@ -14,12 +14,7 @@ constexpr int KZ_TWM = KZ_BF_TWO_WAVE_MAX;
 #define KZ_BF_CAT(a, b) KZ_BF_CAT2(a, b)
 
 template <int KP, int NSR>
-static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad, int variant) {
-    if (NSR == 8 && KP == 16 && variant == 7) {
-        KZ_HIP(hipFuncSetAttribute((const void*)kz_knn_cand_bf_ov_kernel<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, KZ_OV_LDS + lds_pad));
-        *blocks_per_cu = 1;
-        return KZ_OK;
-    }
+static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad) {
     const void* kern = NSR <= KZ_TWM ? (const void*)kz_knn_cand_bf_kernel<KP, (NSR <= KZ_TWM ? NSR : KZ_TWM), 2>
                                      : (const void*)kz_knn_cand_bf_ov_kernel<KP, (NSR > KZ_TWM ? NSR : KZ_TWM + 1)>;
     const int lds = (NSR <= KZ_TWM ? KZ_BF_LDS : KZ_OV_LDS) + lds_pad;
@@ -32,9 +27,7 @@ static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad, int variant) {
 
 template <int KP, int NSR>
 static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
-    if (NSR == 8 && KP == 16 && ctx->kernel_variant == 7)   // experiment: one wave per SIMD with the overlapped scan on C1
-        hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<16, 8>), dim3(n_blocks), dim3(256), KZ_OV_LDS + ctx->lds_pad, ctx->stream, p);
-    else if (NSR <= KZ_TWM)
+    if (NSR <= KZ_TWM)
         hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, (NSR <= KZ_TWM ? NSR : KZ_TWM), 2>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad,
                            ctx->stream, p);
     else
@@ -73,9 +66,9 @@ static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
         }                                                 \
     } while (0)
 
-int KZ_BF_CAT(kz_bf_occupancy_kp, KZ_BF_KP)(int n_slices_bf, int* blocks_per_cu, int lds_pad, int variant) {
+int KZ_BF_CAT(kz_bf_occupancy_kp, KZ_BF_KP)(int n_slices_bf, int* blocks_per_cu, int lds_pad) {
     int rc;
-    KZ_DISPATCH_BF_NSR(rc, kz_bf_occupancy, (blocks_per_cu, lds_pad, variant), KZ_BF_KP);
+    KZ_DISPATCH_BF_NSR(rc, kz_bf_occupancy, (blocks_per_cu, lds_pad), KZ_BF_KP);
     return rc;
 }
 

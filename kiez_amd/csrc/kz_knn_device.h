@@ -1,5 +1,5 @@
-// Device-side building blocks shared by the fused distance + candidate-selection kernels (kz_knn.hip and the
-// experimental variants in kz_knn_variants.h): parameter block, candidate list / log state, tile epilogue.
+// Device-side building blocks shared by the fused distance + candidate-selection kernels (kz_knn.hip: float32 operands,
+// kz_knn_bf16.h: split-bf16, kz_knn_h16.h: fp16): parameter block, candidate list / log state, tile epilogues.
 #pragma once
 #include "kz_common.h"
 
@@ -15,12 +15,6 @@ __device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-tempora
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// Diagnostic builds only (tools/ablate.sh): -DKZ_ABLATE=n removes parts of the fused kernel to price them
-// (1: no list inserts, 2: + no epilogue max, 3: + no LDS refill / barrier, 4: + no global prefetch).  Results are
-// wrong in those builds; the shipped library is built with KZ_ABLATE undefined (= 0).
-#ifndef KZ_ABLATE
-#define KZ_ABLATE 0
-#endif
 // -DKZ_STAMP: in-kernel s_memtime stamps per section, summed into p.dbg (diagnostic build, never shipped/timed).
 #ifdef KZ_STAMP
 #define KZ_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -80,11 +74,6 @@ struct KnnCandParams {
     int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
     float* out_key;       // per region: [query rows][pieces][2 lane halves][KP]
     int* out_idx;
-    int stagger_cycles;   // start-up delay unit: workgroup b sleeps ((b / n_cus) % 3) * stagger_cycles (phase-shifts co-resident groups)
-    int n_cus;
-    int* cu_tickets;      // [16*256] zeroed per launch
-    int* err;             // device error word (ring kernel: spin time-out)
-    int phase_tiles;      // ring kernel: > 0 enables the circular sweep with per-workgroup start offsets
     unsigned long long* dbg;  // diagnostic stamp build only (-DKZ_STAMP): cycle sums {slices, epilogue, init, waves}
 };
 
@@ -150,7 +139,7 @@ struct KzCandState {
 // half's K'-th best cannot be in the merged top-K' either, so both halves prune with the larger of the two thresholds.
 template <int KP, int CAP = KZ_LOG_CAP>
 __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& st, const int tile, const bool last_tile,
-                                                 const int h, const float never) {
+                                                 const int h) {
     float tau_eff = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
     const int rowbase = tile * KZ_TILE + 4 * h;
     ++st.tiles_done;
@@ -160,22 +149,12 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
         bool ovf = false;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-#if KZ_ABLATE >= 2 && KZ_ABLATE <= 4
-#pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[mt][r]));
-            float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#else
             float m4[4];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
                 m4[g4] = fmaxf(fmaxf(acc[mt][4 * g4], acc[mt][4 * g4 + 1]), fmaxf(acc[mt][4 * g4 + 2], acc[mt][4 * g4 + 3]));
-#endif
             const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-#if KZ_ABLATE >= 1 && KZ_ABLATE <= 4
-            if (m > tau_eff + 1e30f * never) {  // runtime-impossible: keeps the max tree, drops the logging
-#else
             if (m > tau_eff) {
-#endif
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     if (m4[g4] > tau_eff) {
@@ -323,6 +302,8 @@ __device__ __forceinline__ void kz_merge_logs_shared(KzCandState& st, KzBlockMin
 //     in LDS (sync[tile & 3]); every wave reads it at the start of the NEXT tile's epilogue and merges then, together.
 //     (The flag of tile t is written during epilogue t, read during epilogue t+1, cleared during epilogue t+2; waves of
 //     a workgroup are never more than one tile apart, and a workgroup barrier lies between any two epilogues.)
+// a wave asks for a workgroup-wide merge at the next tile once its fullest log passes this many rows
+#define KZ_MERGE_FLAG(CAP) ((CAP) >= 16 ? (CAP) - 8 : (CAP) / 2)
 template <int KP, int CAP>
 __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, KzBlockMin<KP>& bs, const int tile,
                                                   const bool last_tile, const int h, int* sync, const int resume0 KZ_EPI2_STAMP_ARGS) {
@@ -348,7 +329,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
     }
     if (resume0 >= 16 && !sched) {
         // nothing left to scan (an overlapped scan covered all 16 groups) and no merge due: only the bookkeeping
-        if (__any(st.cnt > CAP - 8) && (threadIdx.x & 63) == 0) sync[st.tiles_done & 3] = 1;
+        if (__any(st.cnt > KZ_MERGE_FLAG(CAP)) && (threadIdx.x & 63) == 0) sync[st.tiles_done & 3] = 1;
 #ifdef KZ_STAMP
         __builtin_amdgcn_sched_barrier(0);
         c_e1 += __builtin_amdgcn_s_memtime() - te0;
@@ -431,7 +412,7 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         if (!need_room) break;
         tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));  // fresher threshold for the rest of the tile
     }
-    if (__any(st.cnt > CAP - 8) && (threadIdx.x & 63) == 0) sync[st.tiles_done & 3] = 1;
+    if (__any(st.cnt > KZ_MERGE_FLAG(CAP)) && (threadIdx.x & 63) == 0) sync[st.tiles_done & 3] = 1;
     if (st.tiles_done == st.next_merge) {
         const int step = st.tiles_done * CAP / KP;
         st.next_merge = st.tiles_done + (step > 0 ? step : 1);

@@ -1,0 +1,87 @@
+// Per-list-length translation unit of the fp16 fused kernels (included by kz_knn_h_kp{16,32,64,128}.hip with KZ_H_KP
+// defined): the slice counts of one list length compile in parallel with the other list lengths.
+#include "kz_common.h"
+#include "kz_knn_device.h"
+#include "kz_knn_h16.h"
+
+#define KZ_H_CAT2(a, b) a##b
+#define KZ_H_CAT(a, b) KZ_H_CAT2(a, b)
+
+// Occupancy class of a slice count: three workgroups per CU (168 VGPRs, 53 KiB of LDS each: log of 8 rows per lane) while
+// the stationary query tile fits, two (256 VGPRs, 80 KiB: 20 rows) beyond.  wps_override (tuning knob "h_wps") forces
+// the two-workgroup build.
+constexpr int KZ_H_WPS3_MAX = 8;    // d <= 128 (beyond it the 168-VGPR budget of three waves per SIMD spills)
+constexpr int KZ_H_CAP3 = 8, KZ_H_CAP2 = 20;
+
+template <int KP, int NSR>
+static const void* kz_h_kernel(int wps, int* lds) {
+    if (NSR <= KZ_H_WPS3_MAX && wps != 2) {
+        *lds = kz_h_lds_bytes<KZ_H_CAP3>();
+        return (const void*)kz_knn_cand_h_kernel<KP, (NSR <= KZ_H_WPS3_MAX ? NSR : 1), 3, KZ_H_CAP3>;
+    }
+    *lds = kz_h_lds_bytes<KZ_H_CAP2>();
+    return (const void*)kz_knn_cand_h_kernel<KP, NSR, 2, KZ_H_CAP2>;
+}
+
+template <int KP, int NSR>
+static int kz_h_occupancy(int* blocks_per_cu, int wps, int lds_pad) {
+    int lds = 0;
+    const void* kern = kz_h_kernel<KP, NSR>(wps, &lds);
+    KZ_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds + lds_pad));
+    int nb = 0;
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds + lds_pad));
+    *blocks_per_cu = nb < 1 ? 1 : nb;
+    return KZ_OK;
+}
+
+template <int KP, int NSR>
+static int kz_launch_h(kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps) {
+    int lds = 0;
+    const void* kern = kz_h_kernel<KP, NSR>(wps, &lds);
+    KnnCandParams pc = p;
+    void* args[] = {&pc};
+    KZ_HIP(hipLaunchKernel(kern, dim3(n_blocks), dim3(256), args, (size_t)(lds + ctx->lds_pad), ctx->stream));
+    return KZ_OK;
+}
+
+#define KZ_DISPATCH_H_NSR(rc, fn, args, KPV)              \
+    do {                                                  \
+        switch (n_slices) {                               \
+            case 1: rc = fn<KPV, 1> args; break;          \
+            case 2: rc = fn<KPV, 2> args; break;          \
+            case 3: rc = fn<KPV, 3> args; break;          \
+            case 4: rc = fn<KPV, 4> args; break;          \
+            case 5: rc = fn<KPV, 5> args; break;          \
+            case 6: rc = fn<KPV, 6> args; break;          \
+            case 7: rc = fn<KPV, 7> args; break;          \
+            case 8: rc = fn<KPV, 8> args; break;          \
+            case 9: rc = fn<KPV, 9> args; break;          \
+            case 10: rc = fn<KPV, 10> args; break;        \
+            case 11: rc = fn<KPV, 11> args; break;        \
+            case 12: rc = fn<KPV, 12> args; break;        \
+            case 13: rc = fn<KPV, 13> args; break;        \
+            case 14: rc = fn<KPV, 14> args; break;        \
+            case 15: rc = fn<KPV, 15> args; break;        \
+            case 16: rc = fn<KPV, 16> args; break;        \
+            case 17: rc = fn<KPV, 17> args; break;        \
+            case 18: rc = fn<KPV, 18> args; break;        \
+            case 19: rc = fn<KPV, 19> args; break;        \
+            case 20: rc = fn<KPV, 20> args; break;        \
+            case 21: rc = fn<KPV, 21> args; break;        \
+            case 22: rc = fn<KPV, 22> args; break;        \
+            case 23: rc = fn<KPV, 23> args; break;        \
+            default: rc = fn<KPV, 24> args; break;        \
+        }                                                 \
+    } while (0)
+
+int KZ_H_CAT(kz_h_occupancy_kp, KZ_H_KP)(int n_slices, int* blocks_per_cu, int wps, int lds_pad) {
+    int rc;
+    KZ_DISPATCH_H_NSR(rc, kz_h_occupancy, (blocks_per_cu, wps, lds_pad), KZ_H_KP);
+    return rc;
+}
+
+int KZ_H_CAT(kz_h_launch_kp, KZ_H_KP)(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps) {
+    int rc;
+    KZ_DISPATCH_H_NSR(rc, kz_launch_h, (ctx, p, n_blocks, wps), KZ_H_KP);
+    return rc;
+}

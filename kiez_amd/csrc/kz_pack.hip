@@ -1,15 +1,20 @@
-// kz_matrix: HBM-resident embedding matrix = exact rows + float64 norms + MFMA-packed float32 tile image.
+// kz_matrix: HBM-resident embedding matrix = exact rows + float64 norms + MFMA operand images (built on first use).
 //
-// Packed image layout (the layout the fused distance kernel streams, DESIGN.md "Data layout in HBM"):
-//     packed[tile][kgroup][row_in_tile][4]      tile = row / 128, kgroup = k / 4, d padded to a multiple of 16
-// One 16-k slice of one tile is 4 consecutive kgroups = a contiguous 8 KiB block, and consecutive slices
-// (also across tile boundaries) are consecutive in memory, so the kernel's HBM stream is purely linear.
-// Inside a kgroup the 128 rows x 16 B are exactly the conflict-free ds_read_b128 image of the MFMA A/B operand.
+// kz_matrix_create only touches the rows once: float64 norms, the accumulator-init row (bias) and the maxima the
+// certification needs.  The operand images of the fused distance kernel are built by the first kz_knn call that needs
+// them (kz_matrix_image_*), all with the same geometry (DESIGN.md "Data layout in HBM"): tile = 128 rows, slice = 16 k,
+// d padded with zeros to a multiple of 16, rows padded to a multiple of 128; one slice of one tile is ONE contiguous
+// block and consecutive slices (also across tiles) are consecutive in memory, so the kernel's stream is linear and
+// every wave-load is 1 KiB coalesced.  Inside a block the bytes are exactly the conflict-free ds_read_b128 image of the
+// MFMA A/B operand, which is why the kernels copy them to LDS with a linear LDS-DMA.
 //
-// Split-bf16 image (first-pass operand of the bf16x2 kernel, same geometry and size): x = hi + lo + r with
-// hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-16 |x| (1 + 2^-7).  One 16-k slice = four 2 KiB planes
-//     packed_bf[tile][slice][plane][row_in_tile][8]     plane 0/1 = hi of k 0-7 / 8-15, plane 2/3 = lo of the same
-// i.e. plane p of lane-half h is the 16-byte fragment v_mfma_f32_32x32x16_bf16 expects (lane l: row l&31, k 8(l>>5)+j).
+//   fp16   (first pass, kz_knn_h16.h)   packed_h[tile][slice][plane][row][8]      4 KiB per slice
+//          plane p = k 8p..8p+7: the 16-byte fragment of lane-half p of v_mfma_f32_32x32x16_f16 (lane l: row l&31,
+//          k 8(l>>5)+j).  Values are x_h = fp16(S (x - mu)): centred with the pair's common shift mu and scaled by a
+//          power of two S (kz_center); per row the image keeps |x_c|^2, |x_h| and the MEASURED residual |x_c - x_h|.
+//   bf16x2 (second tier, kz_knn_bf16.h) packed_bf[tile][slice][plane][row][8]     8 KiB per slice
+//          planes hi(k 0-7), hi(k 8-15), lo(k 0-7), lo(k 8-15) with hi = bf16(x), lo = bf16(x - hi).
+//   fp32   (third tier, kz_knn.hip)     packed[tile][kgroup][row][4]              8 KiB per slice (4 kgroups)
 #include "kz_common.h"
 
 // round-to-nearest-even float32 -> bf16 bits (finite inputs)
@@ -19,32 +24,25 @@ __device__ __forceinline__ unsigned short kz_bf16_rn(float f) {
 }
 __device__ __forceinline__ float kz_bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
+// operand value of element k of a row: the raw value (euclidean family) or the row-normalised one (cosine), in float64
 template <typename T>
-__global__ __launch_bounds__(256) void kz_pack_kernel(const T* __restrict__ raw, int64_t n, int d, int metric, int kg,
-                                                      int kg_bf, int64_t n_pad, float* __restrict__ packed,
-                                                      unsigned short* __restrict__ packed_bf,
-                                                      float* __restrict__ bias, double* __restrict__ sqn,
-                                                      unsigned long long* __restrict__ maxnorm_bits,
-                                                      int* __restrict__ bad_flag) {
-    __shared__ double s_max[4];
+__device__ __forceinline__ double kz_operand(const T* x, int k, int d, int metric, double nrm) {
+    if (k >= d) return 0.0;
+    return metric == KZ_COSINE ? (double)x[k] / nrm : (double)x[k];
+}
+
+// ---- create: norms, bias, maxima, finiteness ------------------------------------------------------------------
+// stats[0] = max row norm, stats[1] = max |operand element| (bits of non-negative doubles order as integers)
+template <typename T>
+__global__ __launch_bounds__(256) void kz_norms_kernel(const T* __restrict__ raw, int64_t n, int d, int metric, int64_t n_pad,
+                                                       float* __restrict__ bias, double* __restrict__ sqn,
+                                                       unsigned long long* __restrict__ stats, int* __restrict__ bad_flag) {
+    __shared__ double s_max[4], s_abs[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int d_pad = kg * 4;
-    const int d_pad_bf = kg_bf * 4;
-    double wmax = 0.0;
+    double wmax = 0.0, amax = 0.0;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_pad; row += (int64_t)gridDim.x * 4) {
-        const int64_t tile = row >> 7;
-        const int r = (int)(row & 127);
-        float* dst = packed + (tile * kg) * (int64_t)(KZ_TILE * 4) + r * 4;
-        // bf16 image: element k of this row -> slice k/16, plane (k/8)&1 (+2 for lo), 8 values per row and plane
-        unsigned short* dbf = packed_bf + (tile * kg_bf) * (int64_t)(KZ_TILE * 8) + r * 8;
-        auto bf_off = [](int k) { return (int64_t)(k >> 4) * (4 * KZ_TILE * 8) + ((k >> 3) & 1) * (KZ_TILE * 8) + (k & 7); };
         if (row >= n) {
-            for (int k = lane; k < d_pad_bf; k += 64) {
-                if (k < d_pad) dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = 0.0f;
-                dbf[bf_off(k)] = 0;
-                dbf[bf_off(k) + 2 * KZ_TILE * 8] = 0;
-            }
             if (lane == 0) bias[row] = -INFINITY;
             continue;
         }
@@ -53,11 +51,10 @@ __global__ __launch_bounds__(256) void kz_pack_kernel(const T* __restrict__ raw,
         if (!(sq <= 1e30)) {  // NaN, inf, or too large for the float32 operand image
             if (lane == 0) atomicOr(bad_flag, 1);
         }
-        double scale_div = 1.0;
+        double nrm = 1.0;
         if (metric == KZ_COSINE) {
-            double nrm = sqrt(sq);
+            nrm = sqrt(sq);
             if (nrm == 0.0) nrm = 1.0;  // sklearn normalize(): zero rows stay zero
-            scale_div = nrm;
             if (lane == 0) {
                 sqn[row] = nrm;
                 bias[row] = 0.0f;
@@ -70,26 +67,356 @@ __global__ __launch_bounds__(256) void kz_pack_kernel(const T* __restrict__ raw,
             }
             wmax = fmax(wmax, sqrt(sq));
         }
-        for (int k = lane; k < d_pad_bf; k += 64) {
-            double vd = 0.0;
-            if (k < d) vd = (metric == KZ_COSINE) ? (double)x[k] / scale_div : (double)x[k];
-            if (k < d_pad) dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = (float)vd;
-            const unsigned short hi = kz_bf16_rn((float)vd);
-            const unsigned short lo = kz_bf16_rn((float)(vd - (double)kz_bf16_to_f32(hi)));
-            dbf[bf_off(k)] = hi;
-            dbf[bf_off(k) + 2 * KZ_TILE * 8] = lo;
+        for (int k = lane; k < d; k += 64) {
+            const double v = fabs(kz_operand(x, k, d, metric, nrm));
+            if (v <= 1e300) amax = fmax(amax, v);
         }
     }
-    if (lane == 0) s_max[wave] = wmax;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
+    if (lane == 0) {
+        s_max[wave] = wmax;
+        s_abs[wave] = amax;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         double m = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
-        atomicMax(maxnorm_bits, (unsigned long long)__double_as_longlong(m));  // non-negative doubles order as integers
+        if (m <= 1e300) atomicMax(stats, (unsigned long long)__double_as_longlong(m));
+        m = fmax(fmax(s_abs[0], s_abs[1]), fmax(s_abs[2], s_abs[3]));
+        atomicMax(stats + 1, (unsigned long long)__double_as_longlong(m));
     }
+}
+
+// ---- float32 and split-bf16 images (lower tiers) ---------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void kz_pack_f32_kernel(const T* __restrict__ raw, const double* __restrict__ sqn, int64_t n,
+                                                          int d, int metric, int kg, int64_t n_pad, float* __restrict__ packed) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int d_pad = kg * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_pad; row += (int64_t)gridDim.x * 4) {
+        const int64_t tile = row >> 7;
+        const int r = (int)(row & 127);
+        float* dst = packed + (tile * kg) * (int64_t)(KZ_TILE * 4) + r * 4;
+        const T* x = raw + row * (int64_t)d;
+        const double nrm = (row < n && metric == KZ_COSINE) ? sqn[row] : 1.0;
+        for (int k = lane; k < d_pad; k += 64) {
+            const double vd = row < n ? kz_operand(x, k, d, metric, nrm) : 0.0;
+            dst[(int64_t)(k >> 2) * (KZ_TILE * 4) + (k & 3)] = (float)vd;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kz_pack_bf_kernel(const T* __restrict__ raw, const double* __restrict__ sqn, int64_t n,
+                                                         int d, int metric, int kg_bf, int64_t n_pad,
+                                                         unsigned short* __restrict__ packed_bf) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int d_pad = kg_bf * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_pad; row += (int64_t)gridDim.x * 4) {
+        const int64_t tile = row >> 7;
+        const int r = (int)(row & 127);
+        // element k of this row -> slice k/16, plane (k/8)&1 (+2 for lo), 8 values per row and plane
+        unsigned short* dbf = packed_bf + (tile * kg_bf) * (int64_t)(KZ_TILE * 8) + r * 8;
+        const T* x = raw + row * (int64_t)d;
+        const double nrm = (row < n && metric == KZ_COSINE) ? sqn[row] : 1.0;
+        for (int k = lane; k < d_pad; k += 64) {
+            const double vd = row < n ? kz_operand(x, k, d, metric, nrm) : 0.0;
+            const unsigned short hi = kz_bf16_rn((float)vd);
+            const unsigned short lo = kz_bf16_rn((float)(vd - (double)kz_bf16_to_f32(hi)));
+            const int64_t off = (int64_t)(k >> 4) * (4 * KZ_TILE * 8) + ((k >> 3) & 1) * (KZ_TILE * 8) + (k & 7);
+            dbf[off] = hi;
+            dbf[off + 2 * KZ_TILE * 8] = lo;
+        }
+    }
+}
+
+// ---- fp16 image: centre (two-stage deterministic column mean), scale, pack ---------------------------------------
+constexpr int KZ_COLSUM_BLOCKS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void kz_colsum_kernel(const T* __restrict__ raw, const double* __restrict__ sqn, int64_t n, int d,
+                                                        int metric, double* __restrict__ partial) {
+    // block b sums rows b, b + B, ...; thread t the columns t, t + 256, ...  (row-major rows: consecutive threads read
+    // consecutive elements); four independent rows in flight per thread
+    const int64_t B = gridDim.x;
+    for (int k = threadIdx.x; k < d; k += 256) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int64_t row = blockIdx.x;
+        for (; row + 3 * B < n; row += 4 * B) {
+            const double n0 = metric == KZ_COSINE ? sqn[row] : 1.0, n1 = metric == KZ_COSINE ? sqn[row + B] : 1.0;
+            const double n2 = metric == KZ_COSINE ? sqn[row + 2 * B] : 1.0, n3 = metric == KZ_COSINE ? sqn[row + 3 * B] : 1.0;
+            a0 += (double)raw[row * (int64_t)d + k] / n0;
+            a1 += (double)raw[(row + B) * (int64_t)d + k] / n1;
+            a2 += (double)raw[(row + 2 * B) * (int64_t)d + k] / n2;
+            a3 += (double)raw[(row + 3 * B) * (int64_t)d + k] / n3;
+        }
+        for (; row < n; row += B) a0 += (double)raw[row * (int64_t)d + k] / (metric == KZ_COSINE ? sqn[row] : 1.0);
+        partial[(int64_t)blockIdx.x * d + k] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+// One block per column k: mu[k] = float32(mean_k), summed in a fixed order (the images, and with them which rows need a
+// lower tier, are reproducible from run to run).  Block 0 also fixes the scale S = 2^(13 - ceil(log2(max |operand|))):
+// S |x - mu| <= 2^14 for the matrix the centre was taken from, and a partner matrix with elements up to four times
+// larger still fits the fp16 range (beyond that the pack kernel clamps, and the clamped part shows up in the measured
+// residual, i.e. in the certification bound).
+__global__ __launch_bounds__(256) void kz_center_finish_kernel(const double* __restrict__ partial, int blocks, int64_t n, int d,
+                                                               const double* __restrict__ stats, float* __restrict__ mu,
+                                                               double* __restrict__ scale) {
+    __shared__ double red[256];
+    const int k = blockIdx.x;
+    double s = 0.0;
+    if (k < d)
+        for (int b = threadIdx.x; b < blocks; b += 256) s += partial[(int64_t)b * d + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        mu[k] = k < d ? (float)(red[0] / (double)n) : 0.0f;
+        if (k == 0) {
+            const double amax = stats[1];
+            double S = 1.0;
+            if (amax > 0.0 && amax < 1e300) {
+                int e;
+                frexp(amax, &e);        // amax = f 2^e, f in [0.5, 1): amax <= 2^e
+                int se = 13 - e;
+                if (se > 100) se = 100;    // S and S^2 |x|^2 stay far inside the float32 range
+                if (se < -100) se = -100;
+                S = ldexp(1.0, se);
+            }
+            scale[0] = S;
+            scale[1] = 1.0 / (S * S);
+        }
+    }
+}
+
+// One wave per row.  v = float32(x - mu) is the centred operand (the "exact" vector of the certification: its distance
+// to another centred row differs from the true distance only by float32 centring round-off, accounted for in the bound),
+// x_h = fp16(S v) / S the operand the matrix pipe multiplies.  Values below the fp16 normal range are stored as zero
+// (no dependence on the denormal mode of the matrix pipe), values beyond it are clamped; both end up in the residual.
+template <typename T>
+__global__ __launch_bounds__(256) void kz_pack_h_kernel(const T* __restrict__ raw, const double* __restrict__ sqn, int64_t n, int d,
+                                                        int metric, int nsr, int64_t n_pad, const float* __restrict__ mu,
+                                                        const double* __restrict__ scale, unsigned short* __restrict__ packed,
+                                                        float* __restrict__ bias, double* __restrict__ rowq,
+                                                        unsigned long long* __restrict__ dmax) {
+    __shared__ double s_m[3][4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int d_pad = nsr * 16;
+    const double S = scale[0];
+    const float Sf = (float)S;
+    double m_h = 0.0, m_r = 0.0, m_c = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_pad; row += (int64_t)gridDim.x * 4) {
+        const int64_t tile = row >> 7;
+        const int r = (int)(row & 127);
+        _Float16* dst = reinterpret_cast<_Float16*>(packed) + (tile * nsr) * (int64_t)(2 * KZ_TILE * 8) + r * 8;
+        auto off = [](int k) { return (int64_t)(k >> 4) * (2 * KZ_TILE * 8) + ((k >> 3) & 1) * (KZ_TILE * 8) + (k & 7); };
+        if (row >= n) {
+            for (int k = lane; k < d_pad; k += 64) dst[off(k)] = (_Float16)0.0f;
+            if (lane == 0) bias[row] = -INFINITY;
+            continue;
+        }
+        const T* x = raw + row * (int64_t)d;
+        const double nrm = metric == KZ_COSINE ? sqn[row] : 1.0;
+        double c2 = 0.0, h2 = 0.0, r2 = 0.0;
+        for (int k = lane; k < d_pad; k += 64) {
+            float v = 0.0f;
+            if (k < d) v = (float)(kz_operand(x, k, d, metric, nrm) - (double)mu[k]);
+            float vs = v * Sf;                                       // exact: S is a power of two
+            if (fabsf(vs) < 6.103515625e-05f) vs = 0.0f;             // below the fp16 normal range
+            vs = fminf(fmaxf(vs, -65504.0f), 65504.0f);
+            const _Float16 hv = (_Float16)vs;                        // round to nearest even
+            dst[off(k)] = hv;
+            const double xh = (double)(float)hv / S;
+            const double res = (double)v - xh;
+            c2 = fma((double)v, (double)v, c2);
+            h2 = fma(xh, xh, h2);
+            r2 = fma(res, res, r2);
+        }
+        c2 = kz_wave_sum(c2);
+        h2 = kz_wave_sum(h2);
+        r2 = kz_wave_sum(r2);
+        const double nh = sqrt(h2), nr = sqrt(r2);
+        if (lane == 0) {
+            rowq[row * 3 + 0] = c2;
+            rowq[row * 3 + 1] = nh;
+            rowq[row * 3 + 2] = nr;
+            bias[row] = (float)(-0.5 * c2 * S * S);
+        }
+        m_h = fmax(m_h, nh);
+        m_r = fmax(m_r, nr);
+        m_c = fmax(m_c, c2);
+    }
+    if (lane == 0) {
+        s_m[0][wave] = m_h;
+        s_m[1][wave] = m_r;
+        s_m[2][wave] = m_c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double m = fmax(fmax(s_m[threadIdx.x][0], s_m[threadIdx.x][1]), fmax(s_m[threadIdx.x][2], s_m[threadIdx.x][3]));
+        atomicMax(dmax + threadIdx.x, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+static int kz_pack_blocks(int64_t n_pad) {
+    const int64_t b = (n_pad + 3) / 4;
+    return (int)(b < 4096 ? b : 4096);
+}
+
+// ---- lazy images ----------------------------------------------------------------------------------------------
+int kz_matrix_image_f32(kz_matrix* m) {
+    if (m->packed) return KZ_OK;
+    kz_ctx* ctx = m->ctx;
+    const int64_t n_pad = m->n_tiles * KZ_TILE;
+    if (kz_pool_alloc(ctx, (size_t)n_pad * (size_t)m->kg * 16, (void**)&m->packed) != KZ_OK) return KZ_ERR_NOMEM;
+    if (m->dtype == KZ_F32)
+        hipLaunchKernelGGL(kz_pack_f32_kernel<float>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const float*)m->raw,
+                           m->sqn, m->n, (int)m->d, m->metric, m->kg, n_pad, m->packed);
+    else
+        hipLaunchKernelGGL(kz_pack_f32_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw,
+                           m->sqn, m->n, (int)m->d, m->metric, m->kg, n_pad, m->packed);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+int kz_matrix_image_bf(kz_matrix* m) {
+    if (m->packed_bf) return KZ_OK;
+    kz_ctx* ctx = m->ctx;
+    const int64_t n_pad = m->n_tiles * KZ_TILE;
+    if (kz_pool_alloc(ctx, (size_t)n_pad * (size_t)m->kg_bf * 16, (void**)&m->packed_bf) != KZ_OK) return KZ_ERR_NOMEM;
+    if (m->dtype == KZ_F32)
+        hipLaunchKernelGGL(kz_pack_bf_kernel<float>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const float*)m->raw,
+                           m->sqn, m->n, (int)m->d, m->metric, m->kg_bf, n_pad, m->packed_bf);
+    else
+        hipLaunchKernelGGL(kz_pack_bf_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw,
+                           m->sqn, m->n, (int)m->d, m->metric, m->kg_bf, n_pad, m->packed_bf);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+static void kz_center_release(kz_ctx* ctx, kz_center* c) {
+    if (!c) return;
+    if (--c->refs > 0) return;
+    kz_pool_free(ctx, c->d_mu, 0);
+    kz_pool_free(ctx, c->d_scale, 0);
+    delete c;
+}
+
+void kz_himage_free(kz_matrix* m) {
+    kz_himage* im = m->himg;
+    if (!im) return;
+    kz_pool_free(m->ctx, im->packed, 0);
+    kz_pool_free(m->ctx, im->bias, 0);
+    kz_pool_free(m->ctx, im->rowq, 0);
+    kz_pool_free(m->ctx, im->d_max, 0);
+    kz_center_release(m->ctx, im->center);
+    delete im;
+    m->himg = nullptr;
+}
+
+// centre taken from matrix `from`: column mean (of the normalised rows for cosine) and the fp16 scale
+static int kz_center_create(kz_ctx* ctx, const kz_matrix* from, kz_center** out) {
+    kz_center* c = new kz_center();
+    memset(c, 0, sizeof(*c));
+    c->refs = 1;
+    const int d = (int)from->d, d_pad = from->kg * 4;
+    double* partial = nullptr;
+    if (kz_pool_alloc(ctx, (size_t)d_pad * 4, (void**)&c->d_mu) != KZ_OK || kz_pool_alloc(ctx, 16, (void**)&c->d_scale) != KZ_OK ||
+        kz_pool_alloc(ctx, (size_t)KZ_COLSUM_BLOCKS * d * 8, (void**)&partial) != KZ_OK) {
+        kz_pool_free(ctx, partial, 0);
+        kz_center_release(ctx, c);
+        return KZ_ERR_NOMEM;
+    }
+    const int blocks = (int)(from->n < KZ_COLSUM_BLOCKS ? from->n : KZ_COLSUM_BLOCKS);
+    if (from->dtype == KZ_F32)
+        hipLaunchKernelGGL(kz_colsum_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)from->raw, from->sqn,
+                           from->n, d, from->metric, partial);
+    else
+        hipLaunchKernelGGL(kz_colsum_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)from->raw, from->sqn,
+                           from->n, d, from->metric, partial);
+    hipLaunchKernelGGL(kz_center_finish_kernel, dim3(d_pad), dim3(256), 0, ctx->stream, partial, blocks, from->n, d, from->d_stats,
+                       c->d_mu, c->d_scale);
+    const hipError_t e = hipGetLastError();
+    kz_pool_free(ctx, partial, 0);   // stream-ordered pool: reuse is ordered behind the kernels above
+    if (e != hipSuccess) {
+        kz_center_release(ctx, c);
+        kz_set_error("kz_knn: centre kernels failed: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    *out = c;
+    return KZ_OK;
+}
+
+static int kz_himage_build(kz_matrix* m, kz_center* center) {
+    kz_ctx* ctx = m->ctx;
+    kz_himage_free(m);
+    kz_himage* im = new kz_himage();
+    memset(im, 0, sizeof(*im));
+    im->center = center;
+    ++center->refs;
+    m->himg = im;
+    const int nsr = m->kg / 4;
+    const int64_t n_pad = m->n_tiles * KZ_TILE;
+    if (kz_pool_alloc(ctx, (size_t)n_pad * (size_t)nsr * 32, (void**)&im->packed) != KZ_OK ||
+        kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&im->bias) != KZ_OK ||
+        kz_pool_alloc(ctx, (size_t)m->n * 24, (void**)&im->rowq) != KZ_OK || kz_pool_alloc(ctx, 32, (void**)&im->d_max) != KZ_OK) {
+        kz_himage_free(m);
+        return KZ_ERR_NOMEM;
+    }
+    hipError_t e = hipMemsetAsync(im->d_max, 0, 32, ctx->stream);
+    if (e == hipSuccess) {
+        if (m->dtype == KZ_F32)
+            hipLaunchKernelGGL(kz_pack_h_kernel<float>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const float*)m->raw,
+                               m->sqn, m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, im->packed, im->bias,
+                               im->rowq, (unsigned long long*)im->d_max);
+        else
+            hipLaunchKernelGGL(kz_pack_h_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw,
+                               m->sqn, m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, im->packed, im->bias,
+                               im->rowq, (unsigned long long*)im->d_max);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        kz_himage_free(m);
+        kz_set_error("kz_knn: fp16 pack kernel failed: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    return KZ_OK;
+}
+
+// Make sure query and index carry fp16 images with ONE common centre.  The centre of an existing image wins (index
+// first), so the two passes of a fit (target -> source, then source -> target) pack every matrix once.
+int kz_himage_ensure(kz_matrix* query, kz_matrix* index) {
+    kz_ctx* ctx = index->ctx;
+    if (index->himg && query->himg && index->himg->center == query->himg->center) return KZ_OK;
+    kz_center* c = nullptr;
+    if (index->himg)
+        c = index->himg->center;
+    else if (query->himg)
+        c = query->himg->center;
+    int rc = KZ_OK;
+    bool created = false;
+    if (!c) {
+        rc = kz_center_create(ctx, index, &c);
+        if (rc != KZ_OK) return rc;
+        created = true;
+    }
+    if (!index->himg || index->himg->center != c) rc = kz_himage_build(index, c);
+    if (rc == KZ_OK && query != index && (!query->himg || query->himg->center != c)) rc = kz_himage_build(query, c);
+    if (created) kz_center_release(ctx, c);   // the images hold their own references
+    return rc;
 }
 
 extern "C" {
 
+// rows_on_device: 0 = host rows (copied), 1 = device rows (copied), 2 = device rows BORROWED: the matrix keeps the
+// caller's pointer, the caller keeps the buffer alive and unchanged until kz_matrix_destroy (zero-copy fit)
 int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t n, int64_t d, int dtype, int metric,
                      kz_matrix** out) {
     KZ_REQUIRE(ctx && rows && out, "kz_matrix_create: null argument");
@@ -99,6 +426,7 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     KZ_REQUIRE(dtype == KZ_F32 || dtype == KZ_F64, "kz_matrix_create: dtype must be KZ_F32 or KZ_F64");
     KZ_REQUIRE(metric == KZ_EUCLIDEAN || metric == KZ_SQEUCLIDEAN || metric == KZ_COSINE,
                "kz_matrix_create: unknown metric %d", metric);
+    KZ_REQUIRE(rows_on_device >= 0 && rows_on_device <= 2, "kz_matrix_create: rows_on_device must be 0, 1 or 2");
     KZ_HIP(hipSetDevice(ctx->device));
     kz_matrix* m = new kz_matrix();
     memset(m, 0, sizeof(*m));
@@ -110,61 +438,55 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     m->n_tiles = (n + KZ_TILE - 1) / KZ_TILE;
     const int64_t d_pad = ((d + KZ_KSLICE - 1) / KZ_KSLICE) * KZ_KSLICE;
     m->kg = (int)(d_pad / 4);
-    const int64_t d_pad_bf = d_pad;  // (kept separate from d_pad: the bf16 kernel is free to use its own slice count)
-    m->kg_bf = (int)(d_pad_bf / 4);
-    const size_t packed_bf_bytes = (size_t)(m->n_tiles * KZ_TILE) * (size_t)d_pad_bf * 4;
+    m->kg_bf = m->kg;
     const int64_t n_pad = m->n_tiles * KZ_TILE;
     const size_t esz = dtype == KZ_F32 ? 4 : 8;
     const size_t raw_bytes = (size_t)n * (size_t)d * esz;
-    const size_t packed_bytes = (size_t)n_pad * (size_t)d_pad * 4;
     auto fail = [&](int code) {
         kz_matrix_destroy(m);
         return code;
     };
-    if (kz_pool_alloc(ctx, raw_bytes, &m->raw) != KZ_OK || kz_pool_alloc(ctx, packed_bytes, (void**)&m->packed) != KZ_OK ||
-        kz_pool_alloc(ctx, packed_bf_bytes, (void**)&m->packed_bf) != KZ_OK ||
-        kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&m->bias) != KZ_OK ||
-        kz_pool_alloc(ctx, (size_t)n * 8, (void**)&m->sqn) != KZ_OK) {
-        kz_set_error("kz_matrix_create: out of device memory (raw %zu B + 2 x packed %zu B)", raw_bytes, packed_bytes);
+    m->raw_borrowed = rows_on_device == 2;
+    if (m->raw_borrowed) m->raw = const_cast<void*>(rows);
+    if ((!m->raw_borrowed && kz_pool_alloc(ctx, raw_bytes, &m->raw) != KZ_OK) ||
+        kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&m->bias) != KZ_OK || kz_pool_alloc(ctx, (size_t)n * 8, (void**)&m->sqn) != KZ_OK ||
+        kz_pool_alloc(ctx, 64, (void**)&m->d_stats) != KZ_OK) {
+        kz_set_error("kz_matrix_create: out of device memory (%zu B of rows)", raw_bytes);
         return fail(KZ_ERR_NOMEM);
     }
-    hipError_t e = hipMemcpyAsync(m->raw, rows, raw_bytes, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                  ctx->stream);
+    hipError_t e = hipSuccess;
+    if (!m->raw_borrowed)
+        e = hipMemcpyAsync(m->raw, rows, raw_bytes, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) {
         kz_set_error("kz_matrix_create: copy failed: %s", hipGetErrorString(e));
         return fail(KZ_ERR_HIP);
     }
-    // counters[0..1] = max-norm bits (u64), counters[2] = bad flag
-    e = hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(int), ctx->stream);
+    // d_stats: [0] max row norm, [1] max |operand element|, int at byte 32: non-finite flag
+    e = hipMemsetAsync(m->d_stats, 0, 64, ctx->stream);
     if (e != hipSuccess) {
         kz_set_error("kz_matrix_create: memset failed: %s", hipGetErrorString(e));
         return fail(KZ_ERR_HIP);
     }
-    int64_t blocks64 = (n_pad + 3) / 4;
-    int blocks = (int)(blocks64 < 2048 ? blocks64 : 2048);
-    auto* mx = (unsigned long long*)ctx->d_counters;
-    int* bad = ctx->d_counters + 2;
+    auto* st = (unsigned long long*)m->d_stats;
+    int* bad = (int*)(m->d_stats + 4);
     if (dtype == KZ_F32)
-        hipLaunchKernelGGL(kz_pack_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)m->raw, n, (int)d,
-                           metric, m->kg, m->kg_bf, n_pad, m->packed, m->packed_bf, m->bias, m->sqn, mx, bad);
+        hipLaunchKernelGGL(kz_norms_kernel<float>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const float*)m->raw, n,
+                           (int)d, metric, n_pad, m->bias, m->sqn, st, bad);
     else
-        hipLaunchKernelGGL(kz_pack_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)m->raw, n,
-                           (int)d, metric, m->kg, m->kg_bf, n_pad, m->packed, m->packed_bf, m->bias, m->sqn, mx, bad);
+        hipLaunchKernelGGL(kz_norms_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw, n,
+                           (int)d, metric, n_pad, m->bias, m->sqn, st, bad);
     e = hipGetLastError();
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_counters, m->d_stats, 40, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-        kz_set_error("kz_matrix_create: pack kernel failed: %s", hipGetErrorString(e));
+        kz_set_error("kz_matrix_create: norm kernel failed: %s", hipGetErrorString(e));
         return fail(KZ_ERR_HIP);
     }
-    if (ctx->h_counters[2] != 0) {
+    if (ctx->h_counters[8] != 0) {
         kz_set_error("kz_matrix_create: input contains NaN, infinity or a value too large for float32");
         return fail(KZ_ERR_NONFINITE);
     }
-    unsigned long long bits;
-    memcpy(&bits, ctx->h_counters, 8);
-    memcpy(&m->max_norm, &bits, 8);
+    memcpy(&m->max_norm, ctx->h_counters, 8);
     *out = m;
     return KZ_OK;
 }
@@ -173,11 +495,13 @@ int kz_matrix_destroy(kz_matrix* m) {
     if (!m) return KZ_OK;
     if (m->ctx) {
         (void)hipSetDevice(m->ctx->device);
-        kz_pool_free(m->ctx, m->raw, 0);
+        kz_himage_free(m);
+        if (!m->raw_borrowed) kz_pool_free(m->ctx, m->raw, 0);
         kz_pool_free(m->ctx, m->packed, 0);
         kz_pool_free(m->ctx, m->packed_bf, 0);
         kz_pool_free(m->ctx, m->bias, 0);
         kz_pool_free(m->ctx, m->sqn, 0);
+        kz_pool_free(m->ctx, m->d_stats, 0);
     }
     delete m;
     return KZ_OK;

@@ -42,14 +42,12 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->device = device;
     c->eps_scale = 1.0;
     c->force_splits = 0;
-    c->force_nres = -1;
+    c->h_wps = 0;
     c->min_splits = 1;
     c->lds_pad = 0;
     c->precision = 0;
-    if (const char* pv = getenv("KZ_PRECISION")) c->precision = (strcmp(pv, "fp32") == 0 || strcmp(pv, "1") == 0) ? 1 : 0;  // A/B runs of the test-suite
-    c->stagger = 0;
-    c->kernel_variant = 0;
-    if (const char* kv = getenv("KZ_KERNEL_VARIANT")) c->kernel_variant = (kv[0] >= '0' && kv[0] <= '7') ? kv[0] - '0' : 0;  // A/B runs of the test-suite
+    if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
+        c->precision = (strcmp(pv, "fp32") == 0 || strcmp(pv, "1") == 0) ? 1 : ((strcmp(pv, "bf16") == 0 || strcmp(pv, "2") == 0) ? 2 : 0);
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -61,7 +59,6 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     for (int i = 0; i < 6; ++i) KZ_HIP(hipEventCreate(&c->ev[i]));
     KZ_HIP(hipMalloc((void**)&c->d_counters, 64 * sizeof(int)));
     KZ_HIP(hipHostMalloc((void**)&c->h_counters, 64 * sizeof(int), hipHostMallocDefault));
-    KZ_HIP(hipMalloc((void**)&c->d_tickets, 4096 * sizeof(int)));
     KZ_HIP(hipMemsetAsync(c->d_counters, 0, 64 * sizeof(int), c->stream));
     KZ_HIP(hipStreamSynchronize(c->stream));
     *out = c;
@@ -75,7 +72,6 @@ int kz_ctx_destroy(kz_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     for (int i = 0; i < c->pool_n; ++i) (void)hipFree(c->pool[i].ptr);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->d_tickets) (void)hipFree(c->d_tickets);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -98,17 +94,15 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "force_splits") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
         c->force_splits = (int)value;
-    } else if (strcmp(name, "kernel_variant") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 7 && value == (int)value, "kernel_variant must be 0..7");
-        c->kernel_variant = (int)value;
-    } else if (strcmp(name, "stagger") == 0) {
-        KZ_REQUIRE(value >= -1 && value <= 1e7, "stagger must be in [-1, 1e7] cycles");
-        c->stagger = (int)value;
+    } else if (strcmp(name, "h_wps") == 0) {
+        KZ_REQUIRE(value == 0 || value == 2 || value == 3, "h_wps must be 0 (automatic), 2 or 3");
+        c->h_wps = (int)value;
     } else if (strcmp(name, "chunk_rows") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 1e9, "chunk_rows must be >= 0");
         c->chunk_rows = (int)value;
     } else if (strcmp(name, "precision") == 0) {
-        KZ_REQUIRE(value == 0 || value == 1, "precision must be 0 (split-bf16 first pass) or 1 (float32 operands only)");
+        KZ_REQUIRE(value == 0 || value == 1 || value == 2,
+                   "precision must be 0 (fp16 first pass), 2 (split-bf16 first pass) or 1 (float32 operands only)");
         c->precision = (int)value;
     } else if (strcmp(name, "lds_pad") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
@@ -116,9 +110,6 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "min_splits") == 0) {
         KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
         c->min_splits = (int)value;
-    } else if (strcmp(name, "force_nres") == 0) {
-        KZ_REQUIRE(value == -1 || value == 0 || value == 4 || value == 8, "force_nres must be -1, 0, 4 or 8");
-        c->force_nres = (int)value;
     } else {
         kz_set_error("kz_ctx_set_option: unknown option '%s'", name);
         return KZ_ERR_INVALID;
