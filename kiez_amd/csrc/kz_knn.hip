@@ -886,8 +886,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // ---- tier of this call ------------------------------------------------------------------------------------------
     const int precision = precision_override >= 0 ? precision_override : ctx->precision;
     int tier = KZ_TIER_F32;
-    if (precision != 1 && n_slices >= 1 && n_slices <= 24 && query->kg == index->kg) tier = precision == 2 ? KZ_TIER_BF : KZ_TIER_H;
-    if (tier == KZ_TIER_BF && n_slices < 2) tier = KZ_TIER_F32;
+    if (precision != 1 && n_slices >= 2 && n_slices <= 24 && query->kg == index->kg) tier = precision == 2 ? KZ_TIER_BF : KZ_TIER_H;
     if (tier == KZ_TIER_H) {
         const int rc = kz_himage_ensure(query, index);
         if (rc != KZ_OK) return rc;

@@ -1,0 +1,263 @@
+// Tile epilogue of the fp16 fused kernel (kz_knn_h16.h), third form: instruction count first.
+//
+// With one MFMA product per multiply-add a tile of d = 128 is 1024 matrix-pipe cycles per wave, so every VALU / SALU
+// instruction of the candidate scan is on the critical path (the second form, kz_tile_epilogue2, executes ~225
+// instructions per tile before it has found a single candidate).  What changed:
+//   * plain C++ max trees: this translation unit is compiled with -fno-honor-nans (keys are never NaN: operands are
+//     finite and clamped, pad rows carry -inf), so fmaxf() is v_max_f32 / v_max3_f32 with the MFMA hazards handled by
+//     the compiler -- no canonicalisation, no inline asm, no s_nop padding;
+//   * tile-level early out: 16 group maxima -> one tile maximum -> one compare: a tile without an event costs ~45
+//     instructions;
+//   * BLIND group appends: a lane that has an event in a group of four keys appends all four keys (one ds_write_b128)
+//     and {code, next} to the wave's event pool (below); which of the four really beat the threshold is decided at merge
+//     time.  No per-key compare / select / counter chain in the scan;
+//   * capacity is checked ONCE per tile with scalar arithmetic (pool fill + 16 x lanes with an event): the common path
+//     carries no per-group room / resume bookkeeping; tiles that might overflow the pool (the first tiles of a sweep)
+//     take a resumable slow path;
+//   * for K' <= 32 the candidate lists live in LDS for the whole sweep (16-32 KiB per workgroup) and are written to the
+//     output arrays once at the end: a merge insert is a few LDS round trips instead of L2 round trips (~1.2k cycles).
+#pragma once
+
+typedef __attribute__((address_space(3))) float kz_lds_f32;
+typedef __attribute__((address_space(3))) int kz_lds_i32;
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+typedef int i32x2e __attribute__((ext_vector_type(2)));
+
+// list storage: LDS ([entry][128 queries of the workgroup]) or the output arrays (wave-interleaved, KZ_LSTRIDE)
+template <bool IN_LDS>
+struct KzListRef;
+template <>
+struct KzListRef<true> {
+    kz_lds_f32* k;
+    kz_lds_i32* i;
+    static constexpr int STRIDE = 128;
+};
+template <>
+struct KzListRef<false> {
+    float* k;
+    int* i;
+    static constexpr int STRIDE = KZ_LSTRIDE;
+};
+
+// Per-lane candidate state (one lane = one (query, lane-half) pair) ...
+template <bool IN_LDS>
+struct KzCandState3 {
+    KzListRef<IN_LDS> list;   // this query's list (lanes < 32 own it)
+    float tau;                // K'-th best key of the list as of the last merge (same value in both lane halves)
+    int head;                 // newest entry of this lane's chain in the wave's event pool, -1 = empty
+};
+
+// ... and the wave's EVENT POOL: one shared log per wave instead of one log per lane.  An entry = the four keys of a group
+// in which a lane had an event (16 B) + {code, next} (8 B): code = 16 tile + group, next = the lane's previous entry.
+// Lanes append at pool positions handed out by ballot + mbcnt (consecutive 16-byte slots: conflict-free ds_write_b128)
+// and link the entry in front of their own chain; a merge lets every lane walk its chain.  Sharing the capacity is the
+// point: per-lane logs must be sized for the UNLUCKIEST lane (events are rare and Poisson: with room for 4 events per
+// lane a merge was triggered every ~4 tiles by one lane out of 256, and every merge pass runs as long as its fullest
+// lane), a pool is sized for the wave's total, its fill level is a scalar, and a merge processes ~100 events at once.
+struct KzWavePool {
+    __attribute__((address_space(3))) f32x4e* keys;   // [CAP]
+    __attribute__((address_space(3))) i32x2e* meta;     // [CAP] {code, next}
+    int cnt;                  // entries in use (wave-uniform)
+    int tiles_done, next_merge;
+};
+
+// Two-level minimum of an unsorted K'-entry list: the list is cut into NB blocks whose minima are kept in registers
+// (values only: the position of a block's minimum is found again when the block is re-read for the insert).
+template <int KP>
+struct KzBlockMin3 {
+    static constexpr int NB = KP >= 64 ? 8 : 4;
+    static constexpr int BS = KP / NB;
+    float bm[NB];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bm[i] = -INFINITY;
+    }
+};
+
+// Insert (v, idx) over the current minimum of the list (caller guarantees v > tau); returns the new minimum in tau.
+// Replacing the global minimum touches ONE block: read its K'/NB keys (one round trip), overwrite the first key equal to
+// the block minimum, refresh the block minimum -- instead of re-scanning all K' keys.
+template <int KP, bool IN_LDS>
+__device__ __forceinline__ void kz_list_insert3(const KzListRef<IN_LDS>& L, KzBlockMin3<KP>& bs, float v, int idx, float& tau) {
+    constexpr int NB = KzBlockMin3<KP>::NB, BS = KzBlockMin3<KP>::BS, S = KzListRef<IN_LDS>::STRIDE;
+    float m = bs.bm[0];
+    int b = 0;
+#pragma unroll
+    for (int i = 1; i < NB; ++i) {
+        if (bs.bm[i] < m) {
+            m = bs.bm[i];
+            b = i;
+        }
+    }
+    auto* blk = L.k + (b * BS) * S;
+    float kk[BS];
+#pragma unroll
+    for (int jj = 0; jj < BS; ++jj) kk[jj] = blk[jj * S];
+    int pos = BS - 1;
+#pragma unroll
+    for (int jj = BS - 2; jj >= 0; --jj) pos = (kk[jj] == m) ? jj : pos;   // first key equal to the block minimum
+    blk[pos * S] = v;
+    L.i[(b * BS + pos) * S] = idx;
+    float nm = INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < BS; ++jj) nm = fminf(nm, (jj == pos) ? v : kk[jj]);
+    float t = INFINITY;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        bs.bm[i] = (b == i) ? nm : bs.bm[i];
+        t = fminf(t, bs.bm[i]);
+    }
+    tau = t;
+}
+
+// Merge: lane l < 32 walks its own chain, then its partner's (lane l + 32: the other half of the same query), inserting
+// every key that still beats the list's threshold.  code = 16 tile + 4 mt + g4; the keys of an entry are index rows
+// 128 tile + 32 mt + 8 g4 + 4 half + 0..3 (C layout of the 32x32 MFMA).
+template <int KP, bool IN_LDS>
+__device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWavePool& pool, KzBlockMin3<KP>& bs) {
+    const int lane = threadIdx.x & 63;
+    const int other = __shfl_xor(st.head, 32, 64);
+    if (lane < 32) {
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            int e = half ? other : st.head;
+#pragma unroll 1
+            while (e >= 0) {
+                const f32x4e kv = pool.keys[e];
+                const i32x2e mt = pool.meta[e];
+                e = mt.y;
+                const int code = mt.x;
+                const int row0 = (code >> 4) * KZ_TILE + ((code >> 2) & 3) * 32 + (code & 3) * 8 + 4 * half;
+                if (kv.x > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.x, row0, st.tau);
+                if (kv.y > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.y, row0 + 1, st.tau);
+                if (kv.z > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.z, row0 + 2, st.tau);
+                if (kv.w > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.w, row0 + 3, st.tau);
+            }
+        }
+    }
+    st.head = -1;
+    pool.cnt = 0;
+    st.tau = __shfl(st.tau, lane & 31, 64);
+}
+
+#ifdef KZ_STAMP
+#define KZ_EPI3_STAMP_ARGS , unsigned long long& c_merge, unsigned long long& n_pass, unsigned long long& n_ins, unsigned long long& c_e1, unsigned long long& c_e2
+#define KZ_EPI3_MERGE()                                                  \
+    do {                                                                 \
+        const unsigned long long tm0_ = __builtin_amdgcn_s_memtime();    \
+        n_ins += pool.cnt;                                               \
+        kz_merge_pool3<KP, IN_LDS>(st, pool, bs);                        \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        c_merge += __builtin_amdgcn_s_memtime() - tm0_;                  \
+        n_pass += 1;                                                     \
+    } while (0)
+#else
+#define KZ_EPI3_STAMP_ARGS
+#define KZ_EPI3_MERGE() kz_merge_pool3<KP, IN_LDS>(st, pool, bs)
+#endif
+
+// One group of four keys: the lanes in `mask` append it to the pool (positions pool.cnt + rank of the lane in the mask)
+#define KZ_EPI3_APPEND(gi, ev, mask)                                                                                  \
+    do {                                                                                                              \
+        if (ev) {                                                                                                     \
+            const int pos = pool.cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)((mask) >> 32),                       \
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)(mask), 0u)); \
+            f32x4e kv;                                                                                                \
+            kv.x = acc[(gi) >> 2][4 * ((gi) & 3)];                                                                    \
+            kv.y = acc[(gi) >> 2][4 * ((gi) & 3) + 1];                                                                \
+            kv.z = acc[(gi) >> 2][4 * ((gi) & 3) + 2];                                                                \
+            kv.w = acc[(gi) >> 2][4 * ((gi) & 3) + 3];                                                                \
+            pool.keys[pos] = kv;                                                                                      \
+            { i32x2e mv_; mv_.x = tile * 16 + (gi); mv_.y = st.head; pool.meta[pos] = mv_; }                                                    \
+            st.head = pos;                                                                                            \
+        }                                                                                                             \
+        pool.cnt += __popcll(mask);                                                                                   \
+    } while (0)
+
+// CAP = pool capacity (entries per wave).  sync = 4 LDS words of the workgroup (merge flags: a wave whose pool passes
+// CAP / 2 asks every wave of the workgroup to merge at the start of the next tile, so that no wave merges alone while
+// its siblings wait for it at the slice barrier; the flag of tile t is written during epilogue t, read during epilogue
+// t+1, cleared during epilogue t+2, and a workgroup barrier lies between any two epilogues).
+template <int KP, int CAP, bool IN_LDS>
+__device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3<IN_LDS>& st, KzWavePool& pool, KzBlockMin3<KP>& bs,
+                                                  const int tile, const bool last_tile, kz_lds_i32* sync KZ_EPI3_STAMP_ARGS) {
+    KZ_T(te0);
+    const int t = ++pool.tiles_done;
+    const bool sched = (t == pool.next_merge) || last_tile;  // block-uniform
+    if (t == pool.next_merge) {
+        // geometric schedule: the expected number of events until the next scheduled merge stays near 4 per query
+        const int step = t * 4 / KP;
+        pool.next_merge = t + (step > 0 ? step : 1);
+    }
+    {
+        const bool together = __builtin_amdgcn_readfirstlane(sync[(t - 1) & 3]) != 0;
+        if ((threadIdx.x & 63) == 0) {
+            int zero = 0;
+            asm volatile("" : "+v"(zero));   // materialised here: hipcc otherwise keeps a zero VGPR live across the whole tile loop
+            sync[(t + 1) & 3] = zero;
+        }
+        if (together) KZ_EPI3_MERGE();
+    }
+    // 16 group maxima, tile maximum
+    float gm[16];
+#pragma unroll
+    for (int gi = 0; gi < 16; ++gi) {
+        const int mt = gi >> 2, g4 = gi & 3;
+        gm[gi] = fmaxf(fmaxf(acc[mt][4 * g4], acc[mt][4 * g4 + 1]), fmaxf(acc[mt][4 * g4 + 2], acc[mt][4 * g4 + 3]));
+    }
+    float m = gm[0];
+#pragma unroll
+    for (int gi = 1; gi < 16; ++gi) m = fmaxf(m, gm[gi]);
+    float tau_a = st.tau;
+    const unsigned long long anym = __builtin_amdgcn_ballot_w64(m > tau_a);
+#ifdef KZ_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long te1 = __builtin_amdgcn_s_memtime();
+    c_e1 += te1 - te0;
+#endif
+    if (anym != 0ull) {
+        if (pool.cnt + 16 * (int)__popcll(anym) <= CAP) {
+            // common path: even if every lane with an event had one in all 16 groups the pool would hold them -- no checks
+#pragma unroll
+            for (int gi = 0; gi < 16; ++gi) {
+                const bool ev = gm[gi] > tau_a;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(ev);
+                if (mask != 0ull) KZ_EPI3_APPEND(gi, ev, mask);
+            }
+        } else {
+            // slow path (first tiles of a sweep, bursts, a pool that is nearly full): merge when a group does not fit and
+            // resume at that group with the fresher threshold
+            int resume = 0;
+            for (;;) {
+                bool need_room = false;
+#pragma unroll
+                for (int gi = 0; gi < 16; ++gi) {
+                    const bool ev = gm[gi] > tau_a;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(ev);
+                    if (gi >= resume && !need_room && mask != 0ull) {
+                        if (pool.cnt + (int)__popcll(mask) > CAP) {
+                            need_room = true;
+                            resume = gi;
+                        } else {
+                            KZ_EPI3_APPEND(gi, ev, mask);
+                        }
+                    }
+                }
+                if (!need_room) break;
+                KZ_EPI3_MERGE();
+                tau_a = st.tau;
+            }
+        }
+        if (pool.cnt > CAP / 2 && (threadIdx.x & 63) == 0) {
+            int one = 1;
+            asm volatile("" : "+v"(one));
+            sync[t & 3] = one;
+        }
+    }
+#ifdef KZ_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::"v"(st.head));
+    c_e2 += __builtin_amdgcn_s_memtime() - te1;
+#endif
+    if (sched) KZ_EPI3_MERGE();
+}

@@ -9,26 +9,49 @@
 // distances are translation invariant, the rounding error scales with |q_c||y_c|, and embeddings with a large common
 // mean (rng.rand: |x|^2 = d/3, |x - mu|^2 = d/12) lose a factor four of it.
 //
-// Structure: the stationary-query / LDS-DMA-ring design of the split-bf16 kernel with half the bytes per slice
-// (one 16-k slice of 128 index rows = 4 KiB: two planes k 0-7 / 8-15 of 128 rows x 16 B), a ring of eight slots filled
-// two barrier periods ahead and a counted vmcnt in front of the slice barrier.  Registers per lane: 64 accumulators +
-// 4 NSR query + 2 x 16 fragment VGPRs, so three workgroups per CU fit up to d = 208 and two up to d = 384.
+// Structure: 4 waves x 32 queries per workgroup, the query tile STATIONARY in registers (4 VGPRs per 16-k slice), the
+// index image streamed global -> LDS by LDS-DMA (one 16-k slice of 128 index rows = 4 KiB: two planes k 0-7 / 8-15 of
+// 128 rows x 16 B, copied linearly because the image already is the conflict-free ds_read_b128 layout) through a ring of
+// R = 2 P slots with one workgroup barrier per P slices; fragments of slice g+1 are read under the MFMAs of slice g.
+// Candidate selection: kz_knn_epi3.h.  Three workgroups per CU (168 VGPRs) up to d = 128, two beyond.
 #pragma once
 #include <type_traits>
 
+#include "kz_knn_epi3.h"
+
 typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int KZ_H_RING = 8;                                       // 4 KiB slots
-constexpr int KZ_H_LDS_BASE = KZ_H_RING * 4096 + 1024 + 256;       // ring + 2 x 128 bias floats + merge flags
-template <int CAP>
-constexpr int kz_h_lds_bytes() { return KZ_H_LDS_BASE + (CAP + 1) * 256 * 8; }   // log rows 0..CAP-1 + one scratch row
+// Per (list length, occupancy class) configuration: ring slots, event-pool capacity per wave and where the lists live.  LDS per workgroup: 53.3 KiB at three workgroups per CU, 80 KiB at two.
+// (Every tile must contain a slice barrier -- the bias double buffer and the merge flags rely on it -- so the barrier
+// period RING / 2 never exceeds the slice count; NSR >= 2 is required by the host.)
+template <int KP, int WPS, int NSR>
+struct KzHCfg {
+    static constexpr bool LDS_LIST = KP <= 32;
+    static constexpr int RING = (WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8;
+    static constexpr int CAP = WPS == 3 ? (KP == 16 ? 192 : 256) : 256;     // event-pool entries per wave (24 B each)
+    static constexpr bool LISTS_FIT = WPS == 2 || KP == 16;           // K' = 32 lists do not fit beside the ring at 3 per CU
+    static constexpr bool IN_LDS = LDS_LIST && LISTS_FIT;
+    static constexpr int RING_BYTES = RING * 4096;
+    static constexpr int BIAS_OFF = RING_BYTES;                        // 2 x 128 floats
+    static constexpr int SYNC_OFF = BIAS_OFF + 1024;                   // 4 merge flags (+ padding)
+    static constexpr int POOLK_OFF = SYNC_OFF + 256;                   // [4 waves][CAP] x 4 floats
+    static constexpr int POOLM_OFF = POOLK_OFF + 4 * CAP * 16;         // [4 waves][CAP] x {code, next}
+    static constexpr int LIST_OFF = POOLM_OFF + 4 * CAP * 8;           // keys [KP][128], then rows [KP][128]
+    static constexpr int LDS_BYTES = LIST_OFF + (IN_LDS ? KP * 128 * 8 : 0);
+};
 
-template <int KP, int NSR, int WPS, int CAP>
+template <int KP, int NSR, int WPS>
 __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p) {
+    using Cfg = KzHCfg<KP, WPS, NSR>;
+    constexpr int R = Cfg::RING, P = R / 2, CAP = Cfg::CAP;
+    constexpr bool IN_LDS = Cfg::IN_LDS;
+    // at three waves per SIMD (168 VGPRs) the first fragments of the next tile are NOT fetched across the epilogue: the 16
+    // registers they would occupy there are what keeps the stationary query tile out of scratch memory
+    constexpr bool CARRY = WPS != 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ybuf = reinterpret_cast<float*>(smem);          // KZ_H_RING slots x 1024 floats
-    float* bbuf = ybuf + KZ_H_RING * 1024;                 // 2 x 128 bias floats
-    int* msync = reinterpret_cast<int*>(bbuf + 256);       // 4 merge flags (kz_tile_epilogue2)
+    float* ybuf = reinterpret_cast<float*>(smem);                       // R slots x 1024 floats
+    float* bbuf = reinterpret_cast<float*>(smem + Cfg::BIAS_OFF);       // 2 x 128 bias floats
+    kz_lds_i32* msync = (kz_lds_i32*)(smem + Cfg::SYNC_OFF);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -38,38 +61,56 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
 
-    const int64_t listoff = kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + j;  // ONE list per query
-    KzCandState st;
-    st.lk = p.out_key + listoff;
-    st.li = p.out_idx + listoff;
-    st.sk = reinterpret_cast<float*>(smem + KZ_H_LDS_BASE) + tid;
-    st.si = reinterpret_cast<int*>(smem + KZ_H_LDS_BASE + (CAP + 1) * 256 * 4) + tid;
-    if (h == 0) {  // the list belongs to the query: lane-half 0 owns it (kz_merge_logs_shared)
+    // this query's list in the output arrays (ONE list per query: halves = 1)
+    auto out_list_offset = [&]() { return kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + j; };
+    KzCandState3<IN_LDS> st;
+    if constexpr (IN_LDS) {
+        st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF) + 32 * (tid >> 6) + j;
+        st.list.i = (kz_lds_i32*)(smem + Cfg::LIST_OFF + KP * 128 * 4) + 32 * (tid >> 6) + j;
+    } else {
+        const int64_t listoff = out_list_offset();
+        st.list.k = p.out_key + listoff;
+        st.list.i = p.out_idx + listoff;
+    }
+    KzWavePool pool;
+    pool.keys = (__attribute__((address_space(3))) f32x4e*)(smem + Cfg::POOLK_OFF) + wave * CAP;
+    pool.meta = (__attribute__((address_space(3))) i32x2e*)(smem + Cfg::POOLM_OFF) + wave * CAP;
+    if (h == 0) {  // the list belongs to the query: lane-half 0 owns it (kz_merge_logs3)
 #pragma unroll 4
         for (int e = 0; e < KP; ++e) {
-            st.lk[e * KZ_LSTRIDE] = -INFINITY;
-            st.li[e * KZ_LSTRIDE] = -1;
+            st.list.k[e * KzListRef<IN_LDS>::STRIDE] = -INFINITY;
+            st.list.i[e * KzListRef<IN_LDS>::STRIDE] = -1;
         }
     }
+    if (total <= 0) {
+        if constexpr (IN_LDS) {
+            const int64_t listoff = out_list_offset();
+            if (h == 0)
+                for (int e = 0; e < KP; ++e) {
+                    p.out_key[listoff + e * KZ_LSTRIDE] = -INFINITY;
+                    p.out_idx[listoff + e * KZ_LSTRIDE] = -1;
+                }
+        }
+        return;
+    }
     st.tau = -INFINITY;
-    st.minpos = 0;
-    KzBlockMin<KP> bmin;
+    KzBlockMin3<KP> bmin;
     bmin.init();
-    st.cnt = 0;
-    st.tiles_done = 0;
-    st.next_merge = 1;
-    if (total <= 0) return;
+    st.head = -1;
+    pool.cnt = 0;
+    pool.tiles_done = 0;
+    pool.next_merge = 1;
 
-    // LDS-DMA of one 4 KiB slice: lane l of wave w copies 16 B from src + (64 w + l) * 16 to the same offset of the slot
-    // (the image is copied linearly: it already is the LDS layout); one wave-instruction per wave and slice
+    // LDS-DMA of one 4 KiB slice: lane l of wave w copies 16 B from src + (64 w + l) * 16 to the same offset of the slot;
+    // one wave-instruction per wave and slice
     const float* ysrc = p.ypack + ((int64_t)t_begin * NSR) * 1024 + tid * 4;
     auto dma_slice = [&](int gi) {
         const float* src = ysrc + (int64_t)min(gi, total - 1) * 1024;
-        float* dst = ybuf + (gi & (KZ_H_RING - 1)) * 1024 + wave * 256;  // wave-uniform LDS base (floats)
+        float* dst = ybuf + (gi & (R - 1)) * 1024 + wave * 256;  // wave-uniform LDS base (floats)
         kz_glds16(src, dst);
     };
 #pragma unroll
-    for (int i = 0; i < KZ_H_RING; ++i) dma_slice(i);
+    for (int i = 0; i < R; ++i) dma_slice(i);
     bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
     if (tid < 4) msync[tid] = 0;
     // stationary query fragments: lane (j, h) holds k = 16 u + 8 h + 0..7 of query row 32 wave + j
@@ -83,11 +124,11 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     // two static fragment sets selected by the parity of the global slice counter (no register copies)
     kz_f16x8 f0[4], f1[4];
     auto fetch_frags = [&](kz_f16x8 (&f)[4], const int gi) {
-        const float* fb = fbase + (gi & (KZ_H_RING - 1)) * 1024;
+        const float* fb = fbase + (gi & (R - 1)) * 1024;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) f[mt] = *reinterpret_cast<const kz_f16x8*>(fb + 128 * mt);
     };
-    fetch_frags(f0, 0);
+    if (CARRY) fetch_frags(f0, 0);
     int g = 0;
     f32x16 acc[4];
 #ifdef KZ_STAMP
@@ -117,33 +158,39 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         // above the init this fresh load would be waited for at every tile start)
         __builtin_amdgcn_sched_barrier(0);
         const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
+        if (!CARRY) {
+            if (P0)
+                fetch_frags(f1, g);
+            else
+                fetch_frags(f0, g);
+        }
 #pragma unroll
         for (int u = 0; u < NSR; ++u) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const bool odd = ((P0 + u) & 1) != 0;
             kz_f16x8 (&cur)[4] = odd ? f1 : f0;
             // fragments of the next slice, under this slice's MFMAs (it landed at least one barrier ago)
             __builtin_amdgcn_sched_barrier(0);
-            if (odd)
-                fetch_frags(f0, g + 1);
-            else
-                fetch_frags(f1, g + 1);
+            if (CARRY || u + 1 < NSR) {
+                if (odd)
+                    fetch_frags(f0, g + 1);
+                else
+                    fetch_frags(f1, g + 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[mt], qf[u], acc[mt], 0, 0, 0);
             if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
-            if (odd) {
-                // Slices g-1 and g are consumed by every wave once it passes this barrier (their fragments were read one
-                // slice ago); their slots take slices g-1+RING and g+RING.  Until the NEXT barrier this wave reads slices
-                // g+2 (now prefetching g+1 is done) and g+3: both were issued two barriers ago, so only the two
-                // wave-loads of the LAST barrier (slices g+5, g+6) may still be in flight -- vmcnt counts in issue order,
-                // and any younger operation (bias load, list traffic of a merge) only makes the wait stricter.
+            // One barrier per P slices, after the slices g with (g + 2) % P == 0.  Every wave that passes it has the
+            // fragments of all slices <= g + 1 in registers (lgkmcnt(0)), so the slots of slices g-P+2 .. g+1 take
+            // slices g+P+2 .. g+2P+1.  The next period prefetches slices g+2 .. g+P+1: those were issued at the PREVIOUS
+            // barrier and are this wave's youngest DMAs, hence vmcnt(0) (any other outstanding operation -- bias load,
+            // list traffic of a merge -- only has to finish too).
+            if (!odd && (P == 2 || ((g + 2) & (P - 1)) == 0)) {
 #ifdef KZ_STAMP
                 {
                     __builtin_amdgcn_sched_barrier(0);
                     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     const unsigned long long w1 = __builtin_amdgcn_s_memtime();
                     asm volatile("s_barrier" ::: "memory");
                     c_dma += w1 - w0;
@@ -151,22 +198,22 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #else
-                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
-                dma_slice(g - 1 + KZ_H_RING);
-                dma_slice(g + KZ_H_RING);
+#pragma unroll
+                for (int i = 0; i < P; ++i) dma_slice(g + P + 2 + i);
             }
             ++g;
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef KZ_STAMP
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        kz_tile_epilogue2<KP, CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync, 0, c_merge, n_pass, n_ins, c_e1, c_e2);
+        kz_tile_epilogue3<KP, CAP, IN_LDS>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, c_merge, n_pass, n_ins, c_e1, c_e2);
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
 #else
-        kz_tile_epilogue2<KP, CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync, 0);
+        kz_tile_epilogue3<KP, CAP, IN_LDS>(acc, st, pool, bmin, tile, tile == t_end - 1, msync);
 #endif
     };
 
@@ -176,6 +223,17 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         if (++tile >= t_end) break;
         run_tile(tile, std::integral_constant<int, (NSR & 1)>{});
         if (++tile >= t_end) break;
+    }
+    if constexpr (IN_LDS) {
+        // the sweep is over: the list goes to the output arrays in the layout kz_knn_finalize_kernel reads
+        const int64_t listoff = out_list_offset();
+        if (h == 0) {
+#pragma unroll 4
+            for (int e = 0; e < KP; ++e) {
+                p.out_key[listoff + e * KZ_LSTRIDE] = st.list.k[e * 128];
+                p.out_idx[listoff + e * KZ_LSTRIDE] = st.list.i[e * 128];
+            }
+        }
     }
 #ifdef KZ_STAMP
     if (lane == 0 && p.dbg) {

@@ -7,20 +7,18 @@
 #define KZ_H_CAT2(a, b) a##b
 #define KZ_H_CAT(a, b) KZ_H_CAT2(a, b)
 
-// Occupancy class of a slice count: three workgroups per CU (168 VGPRs, 53 KiB of LDS each: log of 8 rows per lane) while
-// the stationary query tile fits, two (256 VGPRs, 80 KiB: 20 rows) beyond.  wps_override (tuning knob "h_wps") forces
-// the two-workgroup build.
+// Occupancy class of a slice count: three workgroups per CU (168 VGPRs, 53 KiB of LDS each) while the stationary query
+// tile fits, two (256 VGPRs, 80 KiB) beyond.  wps (tuning knob "h_wps") = 2 forces the two-workgroup build.
 constexpr int KZ_H_WPS3_MAX = 8;    // d <= 128 (beyond it the 168-VGPR budget of three waves per SIMD spills)
-constexpr int KZ_H_CAP3 = 8, KZ_H_CAP2 = 20;
 
 template <int KP, int NSR>
 static const void* kz_h_kernel(int wps, int* lds) {
     if (NSR <= KZ_H_WPS3_MAX && wps != 2) {
-        *lds = kz_h_lds_bytes<KZ_H_CAP3>();
-        return (const void*)kz_knn_cand_h_kernel<KP, (NSR <= KZ_H_WPS3_MAX ? NSR : 1), 3, KZ_H_CAP3>;
+        *lds = KzHCfg<KP, 3, NSR>::LDS_BYTES;
+        return (const void*)kz_knn_cand_h_kernel<KP, (NSR <= KZ_H_WPS3_MAX ? NSR : 2), 3>;
     }
-    *lds = kz_h_lds_bytes<KZ_H_CAP2>();
-    return (const void*)kz_knn_cand_h_kernel<KP, NSR, 2, KZ_H_CAP2>;
+    *lds = KzHCfg<KP, 2, NSR>::LDS_BYTES;
+    return (const void*)kz_knn_cand_h_kernel<KP, NSR, 2>;
 }
 
 template <int KP, int NSR>
@@ -47,7 +45,6 @@ static int kz_launch_h(kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wp
 #define KZ_DISPATCH_H_NSR(rc, fn, args, KPV)              \
     do {                                                  \
         switch (n_slices) {                               \
-            case 1: rc = fn<KPV, 1> args; break;          \
             case 2: rc = fn<KPV, 2> args; break;          \
             case 3: rc = fn<KPV, 3> args; break;          \
             case 4: rc = fn<KPV, 4> args; break;          \
