@@ -819,14 +819,16 @@ extern "C" int kz_knn_plan(int64_t n_query_rows, int64_t n_index_rows, int k_eff
 // Rows of a query matrix gathered into a dense block (escalation of uncertified rows to the float32-operand kernel)
 __global__ __launch_bounds__(256) void kz_gather_rows_kernel(const char* __restrict__ raw, const int* __restrict__ rows,
                                                              int64_t row0, int n_rows, int64_t row_bytes,
-                                                             char* __restrict__ out, int64_t* __restrict__ self_ids) {
+                                                             char* __restrict__ out, int64_t* __restrict__ self_ids,
+                                                             const int64_t* __restrict__ parent_self) {
     const int r = blockIdx.x;
     if (r >= n_rows) return;
     const int64_t src = row0 + rows[r];
     const char* sp = raw + src * row_bytes;
     char* dp = out + (int64_t)r * row_bytes;
     for (int64_t b = threadIdx.x * 4; b < row_bytes; b += 256 * 4) *reinterpret_cast<int*>(dp + b) = *reinterpret_cast<const int*>(sp + b);
-    if (self_ids && threadIdx.x == 0) self_ids[r] = src;
+    // index row to strip for this query: its own row, or (subset of a subset) what its parent recorded for it
+    if (self_ids && threadIdx.x == 0) self_ids[r] = parent_self ? parent_self[src] : src;
 }
 
 __global__ __launch_bounds__(256) void kz_scatter_rows_kernel(const double* __restrict__ sd, const int64_t* __restrict__ si,
@@ -846,9 +848,12 @@ enum { KZ_TIER_F32 = 0, KZ_TIER_BF = 1, KZ_TIER_H = 2 };
 
 // d_self_ids (device, optional): index row to strip per query when exclude_self is set and the query matrix is not the
 // index matrix itself (escalated subsets).  precision_override: -1 = the context's setting, 1 = float32 operands only.
+// kp_min: smallest list length to use (escalated subsets of the fp16 tier are first re-done with LONGER lists on the same
+// operand images: the certification compares the K'-th approximate key with the k-th exact one, so more margin in ranks
+// is usually all a failed row needs, and unlike the float32 tier it costs no new image of the index).
 static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q_count, kz_matrix* index, int k,
-                       int exclude_self, const int64_t* d_self_ids, int precision_override, double* d_dist, int64_t* d_ind,
-                       kz_knn_stats* stats) {
+                       int exclude_self, const int64_t* d_self_ids, int precision_override, int kp_min, double* d_dist,
+                       int64_t* d_ind, kz_knn_stats* stats) {
     KZ_REQUIRE(ctx && query && index && d_dist && d_ind, "kz_knn: null argument");
     KZ_REQUIRE(query->ctx == ctx && index->ctx == ctx, "kz_knn: matrices belong to a different context");
     KZ_REQUIRE(query->d == index->d, "kz_knn: feature dimensions differ (%lld vs %lld)", (long long)query->d,
@@ -862,11 +867,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                exclude_self ? "<" : "<=", k, (long long)index->n);
     if (exclude_self && !d_self_ids)
         KZ_REQUIRE(query->n == index->n, "kz_knn: exclude_self needs query and index of equal length");
-    const int KP = kz_pick_list_len(k_eff);
+    int KP = kz_pick_list_len(k_eff);
     if (KP == 0) {
         kz_set_error("kz_knn: k=%d exceeds the supported maximum of 110 neighbours per query", k_eff);
         return KZ_ERR_UNSUPPORTED;
     }
+    if (KP < kp_min) KP = kp_min;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (q_count == 0) return KZ_OK;
     KZ_HIP(hipSetDevice(ctx->device));
@@ -1145,8 +1151,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             continue;
         }
         if (tier != KZ_TIER_F32 && n_fail > 0) {
-            // Escalate only the uncertified rows: gather them into a dense query block, run the float32-operand kernel
-            // on it (its own uncertified rows go on to the exact float64 kernels), scatter the results back.
+            // Escalate only the uncertified rows: gather them into a dense query block and search it again -- fp16 tier
+            // with lists shorter than 128: same operands, lists four times as long (no new image of the index: 14 rows
+            // of a 1M-row index cost 0.4 ms this way against 7 ms for packing its float32 image); otherwise the
+            // float32-operand kernel.  The inner call sends its own uncertified rows further down (float32 operands,
+            // exact float64 kernels).  Results are scattered back.
+            const bool widen = tier == KZ_TIER_H && KP < 128;
             KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
             const size_t row_bytes = (size_t)query->d * (query->dtype == KZ_F32 ? 4 : 8);
             int* fl = nullptr;
@@ -1175,7 +1185,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             hipError_t e = hipMemcpyAsync(fl, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(kz_gather_rows_kernel, dim3(n_fail), dim3(256), 0, ctx->stream, (const char*)query->raw, fl,
-                                   cq_begin, n_fail, (int64_t)row_bytes, (char*)sub_raw, sub_self);
+                                   cq_begin, n_fail, (int64_t)row_bytes, (char*)sub_raw, sub_self, d_self_ids);
                 e = hipGetLastError();
             }
             if (e != hipSuccess) {
@@ -1183,12 +1193,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 kz_set_error("kz_knn: gathering the escalated rows failed: %s", hipGetErrorString(e));
                 return KZ_ERR_HIP;
             }
-            // (an escalated subset of an escalated subset cannot happen: the inner call runs with float32 operands)
             rc = kz_matrix_create(ctx, sub_raw, 2, n_fail, query->d, query->dtype, query->metric, &qsub);
             kz_knn_stats st2;
             memset(&st2, 0, sizeof(st2));
             if (rc == KZ_OK)
-                rc = kz_knn_impl(ctx, qsub, 0, n_fail, index, k, exclude_self, sub_self, 1, sub_dist, sub_ind, &st2);
+                rc = kz_knn_impl(ctx, qsub, 0, n_fail, index, k, exclude_self, sub_self, widen ? 0 : 1,
+                                 widen ? (KP * 4 < 128 ? KP * 4 : 128) : 0, sub_dist, sub_ind, &st2);
             if (rc == KZ_OK) {
                 hipLaunchKernelGGL(kz_scatter_rows_kernel, dim3((unsigned)(((int64_t)n_fail * k + 255) / 256)), dim3(256), 0,
                                    ctx->stream, sub_dist, sub_ind, fl, n_fail, k, fp.out_dist, fp.out_ind);
@@ -1204,7 +1214,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             if (rc != KZ_OK) return rc;
             KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
             fb_ms += ms;
-            n_escalated += n_fail;
+            n_escalated += n_fail + st2.n_escalated_rows;
             n_fail_total += st2.n_fallback_rows;
             if (st2.max_err_ratio > max_err_ratio) max_err_ratio = st2.max_err_ratio;
             c0 += max_rows_per_chunk;
@@ -1279,5 +1289,5 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
                       int exclude_self, double* d_dist, int64_t* d_ind, kz_knn_stats* stats) {
     // (the matrices are logically const for the caller: kz_knn only attaches lazily built operand images to them)
     return kz_knn_impl(ctx, const_cast<kz_matrix*>(query), q_begin, q_count, const_cast<kz_matrix*>(index), k, exclude_self, nullptr,
-                       -1, d_dist, d_ind, stats);
+                       -1, 0, d_dist, d_ind, stats);
 }

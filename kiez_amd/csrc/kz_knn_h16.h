@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     constexpr int R = Cfg::RING, P = R / 2, CAP = Cfg::CAP;
     constexpr bool IN_LDS = Cfg::IN_LDS;
     // at three waves per SIMD (168 VGPRs) the first fragments of the next tile are NOT fetched across the epilogue: the 16
-    // registers they would occupy there are what keeps the stationary query tile out of scratch memory
+    // registers they would occupy there are what keeps the stationary query tile out of scratch memory.  Exception: a tile
+    // whose LAST slice carries the barrier (even global slice index: odd NSR, tile starting at parity 0) must have read
+    // slice g+1 before that barrier hands its slot to the DMA engine -- that tile carries, and its successor does not re-fetch.
     constexpr bool CARRY = WPS != 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);                       // R slots x 1024 floats
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         // above the init this fresh load would be waited for at every tile start)
         __builtin_amdgcn_sched_barrier(0);
         const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
-        if (!CARRY) {
+        constexpr bool carry_in = CARRY || (P0 == 1 && (NSR & 1));
+        constexpr bool carry_out = CARRY || (((P0 + NSR) & 1) != 0);
+        if (!carry_in) {
             if (P0)
                 fetch_frags(f1, g);
             else
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
             kz_f16x8 (&cur)[4] = odd ? f1 : f0;
             // fragments of the next slice, under this slice's MFMAs (it landed at least one barrier ago)
             __builtin_amdgcn_sched_barrier(0);
-            if (CARRY || u + 1 < NSR) {
+            if (carry_out || u + 1 < NSR) {
                 if (odd)
                     fetch_frags(f0, g + 1);
                 else

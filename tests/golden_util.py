@@ -62,3 +62,45 @@ def tie_tolerant_index_equal(dist_ref, ind_ref, dist_got, ind_got, rtol=1e-9):
             if set(ind_ref[r][tied]) != set(ind_got[r][tied]):
                 return False
     return True
+
+
+def knife_edge_rows(ind):
+    """Rows whose candidate list holds the query's own id i.  For such a row MP-empiric (mutual_proximity.py:202-212) looks the
+    target id i up in the reverse lists (of SOURCE ids) of the candidates c_j; where it is found the reference compares
+    d(s_i, t_cj) from the forward pass with the SAME pair's value from the reverse pass -- equal in exact arithmetic, so the
+    strict '>' is decided by last-bit rounding inside the reference's BLAS.  Affected: the candidates whose reverse list
+    contains i, each by exactly one count (1/K)."""
+    n = ind.shape[0]
+    return (ind == np.arange(n)[:, None]).any(axis=1)
+
+
+def _affected(ind_row, row_id, ind_t2s):
+    return np.array([row_id in ind_t2s[c] for c in ind_row])
+
+
+def knife_edge_transform_ok(ref_row, got_row, ind_row, row_id, K, ind_t2s, rtol=1e-5):
+    """Unsorted transform output of a knife-edge row: candidates whose reverse list does not contain the query id must
+    agree; the others may differ by one count."""
+    aff = _affected(ind_row, row_id, ind_t2s)
+    if not np.allclose(got_row[~aff], ref_row[~aff], rtol=rtol, atol=1e-9):
+        return False
+    return bool(np.all(np.abs(got_row[aff] - ref_row[aff]) <= 1.0 / K + 1e-9))
+
+
+def knife_edge_topk_ok(ref_d, ref_i, got_d, got_i, row_id, K, ind_t2s, rtol=1e-5):
+    """Final (sorted) result of a knife-edge row, compared tie-tolerantly: ids returned by both sides carry the same value
+    (affected candidates: within one count), at most as many ids are swapped in / out as there are affected candidates,
+    and neither side's worst value beats the other's by more than one count."""
+    step = 1.0 / K + 1e-9
+    ref = dict(zip(ref_i.tolist(), ref_d.tolist()))
+    got = dict(zip(got_i.tolist(), got_d.tolist()))
+    ids = sorted(set(ref) | set(got))
+    aff = dict(zip(ids, _affected(np.array(ids), row_id, ind_t2s).tolist()))
+    for idx in set(ref) & set(got):
+        tol = step if aff[idx] else rtol * abs(ref[idx]) + 1e-9
+        if abs(ref[idx] - got[idx]) > tol:
+            return False
+    n_aff = max(1, sum(aff.values()))
+    if len(set(ref) - set(got)) > n_aff or len(set(got) - set(ref)) > n_aff:
+        return False
+    return bool(got_d.max() <= ref_d.max() + step and ref_d.max() <= got_d.max() + step)

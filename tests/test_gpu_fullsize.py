@@ -141,13 +141,13 @@ def test_long_index_keeps_the_dma_ring_honest():
 
 
 @pytest.mark.parametrize("n_s,n_t,d,metric,k", [
-    (100_000, 100_000, 128, "euclidean", 10),     # C1: two-wave split-bf16 kernel
-    (30_000, 300_000, 300, "euclidean", 10),      # C4-shaped: one-workgroup-per-CU overlapped kernel, 19 slices
-    (40_000, 200_000, 200, "cosine", 50),         # C3-shaped: list length 64, 13 slices
+    (100_000, 100_000, 128, "euclidean", 10),     # C1: fp16 kernel at three workgroups per CU, lists in LDS
+    (30_000, 300_000, 300, "euclidean", 10),      # C4-shaped: two workgroups per CU, 19 slices
+    (40_000, 200_000, 200, "cosine", 50),         # C3-shaped: list length 64 (lists in the output arrays), 13 slices
 ])
 def test_two_independent_kernels_agree_on_every_row(n_s, n_t, d, metric, k):
-    """The split-bf16 kernels and the float32-operand kernel share no synchronisation structure (LDS-DMA ring + counted
-    waits vs register staging + one barrier per slice).  At full length they must agree on EVERY row, bit for bit; a
+    """The fp16 kernel (default first pass) and the float32-operand kernel share no synchronisation structure (LDS-DMA ring
+    + event pool vs register staging + one barrier per slice).  At full length they must agree on EVERY row, bit for bit; a
     race in either shows up here even when it only drops a true neighbour (which the bound self-check cannot see)."""
     from kiez_amd import _native as N
     rng = np.random.default_rng(d)
@@ -171,3 +171,57 @@ def test_two_independent_kernels_agree_on_every_row(n_s, n_t, d, metric, k):
             ctx.set_option("precision", 0)
     np.testing.assert_array_equal(res[0][1], res[1][1])
     np.testing.assert_array_equal(res[0][0], res[1][0])
+
+
+def test_c3_full_size_mp_empiric_properties_and_oracle_sample():
+    """BASELINE config 3 at FULL size through the drop-in API: 500k x 500k, d=200, cosine, k=50, MutualProximity empiric.
+    The oracle cannot run this size (the reference's own loop is ~2.5e7 allocations of 4 MB), so:
+      * size-independent properties of the full result;
+      * a 256-row sample of BOTH kNN passes against the oracle's exact float64 search;
+      * the oracle's MP-empiric transform + final sort on a row sample, fed with the (sample-verified) reverse lists."""
+    from kiez_amd import Kiez
+    from oracle import kiez_oracle as O
+    from tests.golden_util import knife_edge_rows, knife_edge_topk_ok
+    n, d, K = 500_000, 200, 50
+    rng = np.random.RandomState(0)
+    s = rng.rand(n, d).astype(np.float32)
+    t = rng.rand(n, d).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = Kiez(n_candidates=K, algorithm="SklearnNN", algorithm_kwargs={"metric": "cosine"}, hubness="MutualProximity",
+                  hubness_kwargs={"method": "empiric"})
+        kz.fit(s, t)
+        dist, ind = kz.kneighbors(K)
+    # properties
+    assert dist.shape == (n, K) and ind.shape == (n, K) and dist.dtype == np.float32 and ind.dtype == np.int64
+    assert ind.min() >= 0 and ind.max() < n
+    assert (np.diff(dist, axis=1) >= 0).all()                       # ascending
+    assert dist.min() >= 0.0 and dist.max() <= 1.0                  # 1 - count / K
+    assert np.allclose(dist * K, np.round(dist * K), atol=1e-4)     # multiples of 1/K
+    srt = np.sort(ind, axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()                        # distinct neighbours per row
+    # both passes on a row sample (float64 casts: the oracle's convention for cosine + float32, DESIGN.md section 5)
+    nn = kz.algorithm
+    rows = np.arange(0, n, n // 256)[:256]
+    s64, t64 = s.astype(np.float64), None
+    fd, fi = nn.kneighbors_device(k=K)
+    fd, fi = fd.numpy(), fi.numpy()
+    rd_dev, ri_dev = kz.hubness._dist_t2s_dev.numpy(), kz.hubness._ind_t2s_dev.numpy()
+    t64 = t.astype(np.float64)
+    od, oi = O.knn_exact(s64[rows], t64, K, "cosine")
+    np.testing.assert_array_equal(fi[rows], oi)
+    np.testing.assert_allclose(fd[rows], od, rtol=1e-6, atol=1e-7)
+    od, oi = O.knn_exact(t64[rows], s64, K, "cosine")
+    np.testing.assert_array_equal(ri_dev[rows], oi)
+    np.testing.assert_allclose(rd_dev[rows], od, rtol=1e-6, atol=1e-7)
+    # transform + sort on a (smaller) sample: the oracle loop allocates n floats per candidate
+    sub = rows[:48]
+    hr = O.mp_empiric_transform(fd[sub], fi[sub], rd_dev, ri_dev)
+    sd, si = O.sort_topk(hr, fi[sub], K)
+    ke = (fi[sub] == sub[:, None]).any(axis=1)
+    for a, r in enumerate(sub):
+        if ke[a]:
+            assert knife_edge_topk_ok(sd[a], si[a], dist[r].astype(np.float64), ind[r], r, K, ri_dev), r
+        else:
+            np.testing.assert_array_equal(ind[r], si[a])
+            np.testing.assert_allclose(dist[r], sd[a], rtol=1e-5, atol=1e-6)

@@ -33,7 +33,7 @@ def main():
         if metric == "cosine":
             s, t = s.astype(np.float64), (s if single else t).astype(np.float64)
         res = {}
-        for prec in (0, 1):
+        for prec in (0, 2, 1):   # fp16 first pass (default), split-bf16, float32 operands only
             ctx.set_option("precision", prec)
             try:
                 ym = N.DeviceMatrix(ctx, t, metric)
@@ -42,7 +42,7 @@ def main():
                 res[prec] = (dd.numpy(), ii.numpy(), st)
             finally:
                 ctx.set_option("precision", 0)
-        ok = np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
+        ok = all(np.array_equal(res[0][1], res[p][1]) and np.array_equal(res[0][0], res[p][0]) for p in (1, 2))
         if len(s) * n_t <= 2_000_000:
             od, oi = O.knn_exact(s, t, k, O.canonical_metric(metric), exclude_self=single)
             ok = ok and np.array_equal(res[0][1], oi)
