@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: source queries/s over fit + kneighbors (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c2_mp|c3s]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c1|c2|c3|c3s|c4s|c1g] [--no-others]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
 A "step" is one full `fit(source, target)` + `kneighbors(k)` over synthetic embeddings that are already resident in
-HBM (the reference's `rng.rand` data, float32).  Default workload = BASELINE.json configs[1]:
-100k x 100k, d=128, euclidean, k=10, hubness=None.  With N > 1 every rank owns a 100k-row source shard (weak
-scaling); the target lives on rank 0 and is RCCL-broadcast inside `fit`.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+HBM (the reference's `rng.rand` data, float32).  Default workload = the shape BASELINE.json quotes its target on, one
+GPU's share of it: 250k source rows x 1M targets, d=200, k=10, CSLS ("ns"); with N > 1 every rank owns a 250k-row source
+shard (weak scaling, 8 GPUs = 2M x 1M); the target lives on rank 0 and is RCCL-broadcast inside `fit`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects; at N = 1 the
+other BASELINE configurations (C1, C2, C3 full size, C4's per-GPU share) are run briefly too and reported under
+`other_workloads` (each with step time, main-kernel time, roofline fraction, fallback counts and a result check).
 """
 import argparse
 import json
@@ -38,91 +40,167 @@ WORKLOADS = {
     "c4s": (250_000, 1_000_000, 300, "euclidean", 10, 10, "CSLS", {},
             "C4 per-GPU share: 250k source rows x 1M target, d=300, k=10, CSLS"),
     "ns": (250_000, 1_000_000, 200, "euclidean", 10, 10, "CSLS", {},
-           "north-star target shape, per-GPU share: 250k source rows x 1M target, d=200, k=10, CSLS"),
+           "north-star target shape (BASELINE.json), per-GPU share: 250k source rows x 1M target, d=200, k=10, CSLS"),
     "c1g": (100_000, 100_000, 128, "euclidean", 10, 10, None, {},
             "C1 on gaussian data (rng.randn) for contrast with uniform: 100k x 100k, d=128, euclidean, k=10, hubness=None"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, 'Peak BF16/FP16 MFMA ~2.5 PF dense'
+TIER_NAME = {0: "f32", 1: "bf16x2", 2: "f16"}
+TIER_PRODUCTS = {0: 1, 1: 3, 2: 1}
+TIER_KERNEL = {
+    2: "kz_knn_cand_h_kernel (fp16 MFMA 32x32x16 on centred operands, 1 product per multiply-add, fused distance+top-k)",
+    1: "kz_knn_cand_bf_kernel (split-bf16 MFMA 32x32x16, 3 products per multiply-add, fused distance+top-k)",
+    0: "kz_knn_cand_kernel (fp32 MFMA 32x32x2 fused distance+top-k)"}
 
 
-def cpu_baseline(source, target, metric, k, budget_rows=10_000):
-    """CPU leg, timed on this host's cores on a bounded query-row sample against the FULL index:
-    value       = scikit-learn's brute-force kNN, i.e. the third-party routine the reference's SklearnNN._kneighbors
-                  delegates to (kiez/neighbors/exact/sklearn_nearest_neighbors.py:98-101) — the reference's real CPU path;
-    port_value  = the oracle's numpy restatement of the same algorithm (oracle/kiez_oracle.py: knn_exact)."""
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(source, target, metric, K, k, hub, hub_kw, budget_flop=6e11):
+    """CPU leg on this host's cores: the reference's own CPU path = scikit-learn's brute-force kNN
+    (what SklearnNN._kneighbors delegates to, kiez/neighbors/exact/sklearn_nearest_neighbors.py:98-101) for both distance
+    passes + the oracle's restatement of the rescale / final sort (oracle/kiez_oracle.py), timed on a bounded ROW SAMPLE
+    against the full index, one discarded warm-up, median of 3, and extrapolated linearly in rows (every stage is
+    row-independent given the fit state).  value = n_source / (t_fit + t_kneighbors)."""
     from oracle import kiez_oracle as O
-    rows = min(budget_rows, len(source))
-    q = source[:rows]
-    t0 = time.perf_counter()
-    O.knn_exact(q, target, k, metric)
-    t_oracle = time.perf_counter() - t0
-    out = {"value": rows / t_oracle, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
-           "sample": f"hubness=None forward pass: first {rows} source rows x all {len(target)} target rows, d={source.shape[1]}, "
-                     f"{metric}, k={k}",
-           "port_value": rows / t_oracle, "port_seconds": t_oracle}
+    n_s, d = source.shape
+    n_t = target.shape[0]
+    rows_f = int(max(256, min(n_s, budget_flop / (2.0 * n_t * d))))   # forward sample: source rows vs ALL targets
+    rows_r = int(max(256, min(n_t, budget_flop / (2.0 * n_s * d))))   # reverse sample: target rows vs ALL source rows
+    out = {"unit": "queries/s", "cores": os.cpu_count(), "kind": "port"}
+    metric_c = O.canonical_metric(metric)
     try:
         from sklearn.neighbors import NearestNeighbors
-        nn = NearestNeighbors(n_neighbors=k, algorithm="brute", metric=metric).fit(target)
-        nn.kneighbors(q[:256])  # thread-pool warm-up
-        t0 = time.perf_counter()
-        nn.kneighbors(q)
-        t_sk = time.perf_counter() - t0
-        out.update(value=rows / t_sk, kind="reference", seconds=t_sk,
-                   note="value = sklearn.neighbors.NearestNeighbors(algorithm='brute').kneighbors (what kiez's SklearnNN calls); "
-                        "port_value = oracle/kiez_oracle.py knn_exact (numpy, mostly single-threaded selection)")
+
+        def knn(q, index, kk):
+            nn = NearestNeighbors(n_neighbors=kk, algorithm="brute", metric=metric_c).fit(index)
+            nn.kneighbors(q[:128])  # thread-pool warm-up, discarded
+            ts, res = [], None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                res = nn.kneighbors(q)
+                ts.append(time.perf_counter() - t0)
+            return _median(ts), res
+        out["kind"] = "reference"
     except Exception as e:  # pragma: no cover
-        out["note"] = f"sklearn timing failed ({e}); value = oracle port"
+        out["note_sklearn"] = f"sklearn unavailable ({e}); distance passes timed with the oracle's numpy search"
+
+        def knn(q, index, kk):
+            O.knn_exact(q[:64], index, kk, metric_c)
+            ts, res = [], None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                res = O.knn_exact(q, index, kk, metric_c)
+                ts.append(time.perf_counter() - t0)
+            return _median(ts), res
+    t_rev = t_resc = 0.0
+    if hub is None:
+        t_fwd, _ = knn(source[:rows_f], target, k)
+        sample = f"forward pass: first {rows_f} source rows x all {n_t} target rows"
+    else:
+        t_rev_s, (rd, ri) = knn(target[:rows_r], source, K)
+        t_fwd, (fd, fi) = knn(source[:rows_f], target, K)
+        t_rev = t_rev_s * n_t / rows_r
+        # rescale + final sort (oracle) on the forward sample; the fit state of the sampled candidates comes from a reverse
+        # pass of exactly those target rows (timed above per row), here replaced by the sampled reverse rows tiled
+        reps = -(-n_t // rows_r)
+        rd_full = np.tile(rd, (reps, 1))[:n_t]
+        ri_full = np.tile(ri, (reps, 1))[:n_t]
+        rows_x = min(rows_f, 2000 if hub.lower().startswith("mutual") and hub_kw.get("method") == "empiric" else rows_f)
+        h = hub.lower()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            if h == "csls":
+                hr = O.csls_transform(fd[:rows_x], fi[:rows_x], rd_full)
+            elif h in ("localscaling", "ls"):
+                hr = O.ls_transform(fd[:rows_x], fi[:rows_x], rd_full, hub_kw.get("method", "standard"))
+            elif h in ("mutualproximity", "mp") and hub_kw.get("method", "normal") in ("exact", "empiric"):
+                hr = O.mp_empiric_transform(fd[:rows_x], fi[:rows_x], rd_full, ri_full)
+            elif h in ("mutualproximity", "mp"):
+                hr = O.mp_normal_transform(fd[:rows_x], fi[:rows_x], rd_full)
+            else:
+                hr = fd[:rows_x]
+            O.sort_topk(hr, fi[:rows_x], k)
+            ts.append(time.perf_counter() - t0)
+        t_resc = _median(ts) * n_s / rows_x
+        sample = (f"reverse pass: first {rows_r} target rows x all {n_s} source rows; forward pass: first {rows_f} source rows x all "
+                  f"{n_t} target rows; rescale + sort (oracle): {rows_x} rows; each extrapolated linearly in rows")
+    t_fwd_full = t_fwd * n_s / rows_f
+    t_fit, t_kn = t_rev, t_fwd_full + t_resc
+    out.update(value=n_s / (t_fit + t_kn), sample=sample + f", d={d}, {metric}, K={K}, k={k}",
+               fit_seconds_extrapolated=t_fit, kneighbors_seconds_extrapolated=t_kn,
+               measured_seconds={"reverse_sample": t_rev * rows_r / n_t if hub else 0.0, "forward_sample": t_fwd},
+               protocol="one discarded warm-up, median of 3 per stage",
+               note="distance passes = sklearn.neighbors.NearestNeighbors(algorithm='brute') (the reference's CPU path); "
+                    "rescale/sort = oracle/kiez_oracle.py")
     return out
 
 
-def main():
-    # Keep stdout clean for the ONE JSON line: librccl prints a start-up banner to fd 1 when the communicator is created.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="verify 2000 rows of the result against the oracle (default: 256 rows, hubness=None only)")
-    ap.add_argument("--no-check", action="store_true", help="skip the default oracle spot check")
-    ap.add_argument("--opt", action="append", default=[], help="context option name=value (tuning experiments)")
-    args = ap.parse_args()
+def sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, rows=128):
+    """Result check that also works where the oracle cannot run the whole fit (1M-row reverse pass): a row sample of BOTH
+    kNN passes against the oracle's exact float64 search, then the oracle's rescale + final sort on the sampled source rows
+    fed with the (sample-verified) fit state of this run."""
+    from oracle import kiez_oracle as O
+    metric_c = O.canonical_metric(metric)
+    n_s, n_t = len(source_h), len(target_h)
+    rows = min(rows, n_s, n_t)
+    sel_s = np.arange(0, n_s, max(1, n_s // rows))[:rows]
+    s64 = source_h[sel_s].astype(np.float64) if metric_c == "cosine" else source_h[sel_s]
+    t_all = target_h.astype(np.float64) if metric_c == "cosine" else target_h
+    dd, ii = res
+    got_d, got_i = dd.cpu().numpy()[sel_s], ii.cpu().numpy()[sel_s]
+    out = {"rows": int(rows)}
+    if hub is None:
+        od, oi = O.knn_exact(s64, t_all, k, metric_c)
+    else:
+        fd, fi = O.knn_exact(s64, t_all, K, metric_c)
+        st = sk.state
+        # verify the fit state on a sample of target rows
+        sel_t = np.arange(0, n_t, max(1, n_t // rows))[:rows]
+        s_all = source_h.astype(np.float64) if metric_c == "cosine" else source_h
+        rd, ri = O.knn_exact(t_all[sel_t], s_all, min(K, n_s), metric_c)
+        h = hub.lower()
+        if h == "csls":
+            r_t = st["r_t"].cpu().numpy()
+            out["fit_state_max_rel_err"] = float(np.max(np.abs(r_t[sel_t] - rd.mean(axis=1)) / np.abs(rd.mean(axis=1))))
+            r_s = fd.mean(axis=1)
+            hr = 2.0 * fd - r_s[:, None] - r_t[fi]
+        elif h in ("mutualproximity", "mp") and hub_kw.get("method") in ("exact", "empiric"):
+            d_t2s, i_t2s = st["dist_t2s"].cpu().numpy(), st["ind_t2s"].cpu().numpy()
+            out["fit_state_rows_identical"] = int((i_t2s[sel_t] == ri).all(axis=1).sum())
+            sub = min(rows, 32)   # the oracle loop allocates n_t floats per candidate
+            fd, fi, got_d, got_i, sel_s = fd[:sub], fi[:sub], got_d[:sub], got_i[:sub], sel_s[:sub]
+            out["rows"] = int(sub)
+            hr = O.mp_empiric_transform(fd, fi, d_t2s, i_t2s)
+        else:
+            return None
+        od, oi = O.sort_topk(hr, fi, k)
+    same = (got_i == oi).all(axis=1)
+    if hub and hub.lower().startswith("mutual"):
+        # MP-empiric values are multiples of 1/K: rows whose candidates include the query id are knife-edge (DESIGN.md section 5)
+        same |= (fi == sel_s[:, None]).any(axis=1)
+    out.update(index_rows_identical=int(same.sum()),
+               recall_at_k=float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got_i, oi)])),
+               max_rel_dist_err=float(np.max(np.abs(got_d - od) / np.maximum(np.abs(od), 1e-12))))
+    return out
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    import torch.distributed as dist
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # started through torch.distributed.run
-    if world > 1 or launched:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from kiez_amd.distributed import Comm, HipEngine, ShardedKiez
-    n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[args.workload]
-    eng = HipEngine(local_rank)
-    comm = Comm()
-    for o in args.opt:
-        name, val = o.split("=")
-        eng.ctx.set_option(name, float(val))
-
+def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, min_seconds=0.0):
+    """Generate the data, run warm-up + timed steps, return (summary dict, host arrays) on every rank."""
+    from kiez_amd.distributed import ShardedKiez
+    n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[name]
     # synthetic data in the reference's style (kiez/kiez.py:50-52): rng.rand, source first, then target
     rng = np.random.RandomState(0 if rank == 0 else 1000 + rank)
-    gen = rng.randn if args.workload.endswith("g") else rng.rand
+    gen = rng.randn if name.endswith("g") else rng.rand
     source_h = gen(n_s, d).astype(np.float32)
     target_h = gen(n_t, d).astype(np.float32) if rank == 0 else None
     source = eng.to_engine(source_h)
     target = eng.to_engine(target_h) if rank == 0 else None
     eng.sync()
-
     sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": metric}, hubness=hub, hubness_kwargs=hub_kw,
                      engine=eng, comm=comm)
     knn_log = []
@@ -144,110 +222,180 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    knn_log.clear()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    try:
+        res = None
+        for _ in range(warmup):
+            res = step()
+        knn_log.clear()
+        comm.reset_timers()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    finally:
+        eng.knn = orig_knn
     if dist.is_initialized():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.cpu()[0])
-
     # roofline of the dominant kernel (fused distance + top-k): algorithmic flops 2*n_q*n_i*d per launch
     flops = sum(2.0 * q * n * d for q, n, _ in knn_log)
     kernel_s = sum(st["main_kernel_ms"] for _, _, st in knn_log) * 1e-3
     n_launch = len(knn_log)
     achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
-    # which fused kernel did (most of) the work: split-bf16 first pass (3 bf16 MFMA products per multiply-add) or float32 MFMA
     tier_ms = {t: sum(st["main_kernel_ms"] for _, _, st in knn_log if st.get("first_pass") == t) for t in (0, 1, 2)}
     tier = max(tier_ms, key=tier_ms.get)       # 0 float32 operands, 1 split-bf16 (3 products), 2 fp16 (1 product)
-    tier_bf = tier != 0                        # a 16-bit MFMA tier did the work: price against the bf16/fp16 dense peak
-    products = {0: 1, 1: 3, 2: 1}[tier]
-    tier_name = {0: "f32", 1: "bf16x2", 2: "f16"}[tier]
-    peak = PEAK_BF16_MFMA_TFLOPS if tier_bf else PEAK_F32_MFMA_TFLOPS
-    traffic = None
-    pmc = ROOT / "profiles" / "pmc_traffic.json"   # HBM bytes per launch from separate rocprofv3 --pmc passes
-    if pmc.exists():
-        try:
-            key = args.workload + "_" + tier_name
-            traffic = json.loads(pmc.read_text()).get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    fallback_rows = sum(st["n_fallback_rows"] for _, _, st in knn_log)
+    peak = PEAK_F32_MFMA_TFLOPS if tier == 0 else PEAK_BF16_MFMA_TFLOPS
+    summary = {
+        "name": name, "desc": desc, "n_s": n_s, "n_t": n_t, "d": d, "metric": metric, "K": K, "k": k, "hub": hub, "hub_kw": hub_kw,
+        "elapsed": elapsed, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": n_s * world * steps / elapsed,
+        "tier": tier, "peak": peak, "achieved": achieved, "n_launch": n_launch, "kernel_s": kernel_s, "flops": flops,
+        "fallback_rows": int(sum(st["n_fallback_rows"] for _, _, st in knn_log)),
+        "escalated_rows": int(sum(st.get("n_escalated_rows", 0) for _, _, st in knn_log)),
+        "max_err_ratio": max((st.get("max_err_ratio", 0.0) for _, _, st in knn_log), default=0.0),
+        "finalize_avg_ms": sum(st["finalize_ms"] for _, _, st in knn_log) / max(n_launch, 1),
+        "fallback_total_ms": sum(st["fallback_ms"] for _, _, st in knn_log),
+        "collective_ms_per_step": comm.timers_ms(steps),
+    }
+    chk = None
+    if check and rank == 0 and world == 1:
+        chk = sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw)
+    summary["check"] = chk
+    return summary, (source_h, target_h), res
 
-    check = None
-    do_check = args.check or (not args.no_check and hub is None and world == 1 and n_t <= 200_000)
-    if do_check and rank == 0:
-        from oracle import kiez_oracle as O
-        rows = 2000 if args.check else 256
-        dd, ii = res
-        od, oi = O.kiez_pipeline(source_h, target_h, K, k, metric, 2, hub, hub_kw, query_rows=rows)
-        got_i = ii[:len(oi)].cpu().numpy()
-        check = {"rows": int(len(oi)), "index_rows_identical": int((got_i == oi).all(axis=1).sum()),
-                 "recall_at_k": float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got_i, oi)])),
-                 "max_rel_dist_err": float(np.max(np.abs(dd[:len(od)].cpu().numpy() - od) / np.maximum(np.abs(od), 1e-12)))}
 
+def short(summary):
+    """Compact per-workload record for `other_workloads`."""
+    s = summary
+    return {"workload": s["desc"], "ms_per_step": s["ms_per_step"], "value": s["value"], "unit": "queries/s",
+            "main_kernel_avg_ms": s["kernel_s"] / max(s["n_launch"], 1) * 1e3, "dtype": TIER_NAME[s["tier"]],
+            "roofline_frac": s["achieved"] / s["peak"], "achieved_tflops": s["achieved"],
+            "finalize_avg_ms": s["finalize_avg_ms"], "certification_fallback_rows": s["fallback_rows"],
+            "escalated_rows": s["escalated_rows"], "fallback_total_ms": s["fallback_total_ms"],
+            "max_err_over_eps": s["max_err_ratio"], "steps": s["steps"], "check": s["check"]}
+
+
+def main():
+    # Keep stdout clean for the ONE JSON line: librccl prints a start-up banner to fd 1 when the communicator is created.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle sample check")
+    ap.add_argument("--no-others", action="store_true", help="do not run the other BASELINE configurations after the main workload")
+    ap.add_argument("--opt", action="append", default=[], help="context option name=value (tuning experiments)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    import torch.distributed as dist
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # started through torch.distributed.run
+    if world > 1 or launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from kiez_amd.distributed import Comm, HipEngine
+    eng = HipEngine(local_rank)
+    comm = Comm(time_collectives=True)
+    for o in args.opt:
+        name, val = o.split("=")
+        eng.ctx.set_option(name, float(val))
+
+    main_s, (source_h, target_h), _ = run_workload(args.workload, eng, comm, dist, rank, world, args.steps, args.warmup,
+                                                   check=not args.no_check)
+    n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[args.workload]
+
+    line = None
     if rank == 0:
-        total_queries = n_s * world * args.steps
+        s = main_s
+        tier = s["tier"]
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"   # HBM bytes per launch from separate rocprofv3 --pmc passes
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get(args.workload + "_" + TIER_NAME[tier], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         line = {
             "metric": "source queries/sec (fit+kneighbors) + recall@k vs reference, 1/2/4/8 GPU",  # BASELINE.json's metric
-            "recall_at_k": (check or {}).get("recall_at_k"),   # against the oracle on a row sample (None if not checked)
-            "value": total_queries / elapsed,
+            "recall_at_k": (s["check"] or {}).get("recall_at_k"),   # against the oracle on a row sample (None if not checked)
+            "value": s["value"],
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": s["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": tier_name,
+            "dtype": TIER_NAME[tier],
             "data": "synthetic",
             "config": {"workload": desc, "n_source_per_gpu": n_s, "n_target": n_t, "d": d, "metric": metric,
                        "n_candidates": K, "k": k, "hubness": hub, "hubness_kwargs": hub_kw,
                        "inputs": "float32 rng.rand, resident in HBM; results left in HBM",
-                       "parallelism": f"source row-sharded x{world}, target replicated (RCCL broadcast)"},
-            "roofline": {"bound": "mfma",
-                         "kernel": {2: "kz_knn_cand_h_kernel (fp16 MFMA 32x32x16 on centred operands, 1 product per multiply-add, fused distance+top-k)",
-                                    1: "kz_knn_cand_bf_kernel (split-bf16 MFMA 32x32x16, 3 products per multiply-add, fused distance+top-k)",
-                                    0: "kz_knn_cand_kernel (fp32 MFMA 32x32x2 fused distance+top-k)"}[tier],
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "launches": n_launch, "avg_launch_ms": kernel_s / max(n_launch, 1) * 1e3,
-                         "algorithmic_flop_per_launch": flops / max(n_launch, 1),
-                         "mfma_products_per_mac": products,
-                         "executed_mfma_frac": achieved * products / peak,
-                         "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS},
-            "certification_fallback_rows": int(fallback_rows),
-            "escalated_rows": int(sum(st.get("n_escalated_rows", 0) for _, _, st in knn_log)),
-            "rounding_bound_self_check": {"max_err_over_eps": max((st.get("max_err_ratio", 0.0) for _, _, st in knn_log), default=0.0),
+                       "parallelism": f"source row-sharded x{world}, target replicated"
+                                      + (" (RCCL broadcast; fit state RCCL all-gather)" if world > 1 else " (single rank: no collective runs)")},
+            "roofline": {"bound": "mfma", "kernel": TIER_KERNEL[tier],
+                         "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s",
+                         "frac": s["achieved"] / s["peak"], "traffic": traffic,
+                         "launches": s["n_launch"], "avg_launch_ms": s["kernel_s"] / max(s["n_launch"], 1) * 1e3,
+                         "algorithmic_flop_per_launch": s["flops"] / max(s["n_launch"], 1),
+                         "mfma_products_per_mac": TIER_PRODUCTS[tier],
+                         "executed_mfma_frac": s["achieved"] * TIER_PRODUCTS[tier] / s["peak"],
+                         "vs_fp32_mfma_peak": s["achieved"] / PEAK_F32_MFMA_TFLOPS},
+            "certification_fallback_rows": s["fallback_rows"],
+            "escalated_rows": s["escalated_rows"],
+            "rounding_bound_self_check": {"max_err_over_eps": s["max_err_ratio"],
                                           "note": "max |approximate key - exact key| / eps over all re-ranked candidates; the certification needs < 1"},
-            "other_kernels_ms": {"finalize_avg": sum(st["finalize_ms"] for _, _, st in knn_log) / max(n_launch, 1),
-                                 "fallback_total": sum(st["fallback_ms"] for _, _, st in knn_log)},
+            "other_kernels_ms": {"finalize_avg": s["finalize_avg_ms"], "fallback_total": s["fallback_total_ms"]},
+            "collective_ms_per_step": s["collective_ms_per_step"],
         }
-        if check is not None:
-            line["check"] = check
-        if world == 1:
-            # PCIe-inclusive rate of the drop-in API (numpy in -> numpy out); reported beside `value`, never as `value`
-            import warnings
-            from kiez_amd import Kiez
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                kz = Kiez(n_candidates=K, algorithm="SklearnNN", algorithm_kwargs={"metric": metric}, hubness=hub,
-                          hubness_kwargs=dict(hub_kw))
-                kz.fit(source_h, target_h).kneighbors(k)  # warm-up
-                t0 = time.perf_counter()
-                kz.fit(source_h, target_h).kneighbors(k)
-                t_host = time.perf_counter() - t0
-            line["host_api"] = {"value": n_s / t_host, "unit": "queries/s", "ms": t_host * 1e3,
-                                "note": "Kiez(...).fit(numpy, numpy).kneighbors(k) -> numpy: includes H2D of both matrices and D2H of the result"}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(source_h, target_h, metric, k)
+        if s["check"] is not None:
+            line["check"] = s["check"]
+    if world == 1 and rank == 0:
+        # PCIe-inclusive rate of the drop-in API (numpy in -> numpy out); reported beside `value`, never as `value`
+        import warnings
+        from kiez_amd import Kiez
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            kz = Kiez(n_candidates=K, algorithm="SklearnNN", algorithm_kwargs={"metric": metric}, hubness=hub,
+                      hubness_kwargs=dict(hub_kw))
+            kz.fit(source_h, target_h).kneighbors(k)  # warm-up
+            t0 = time.perf_counter()
+            kz.fit(source_h, target_h).kneighbors(k)
+            t_host = time.perf_counter() - t0
+            del kz
+        line["host_api"] = {"value": n_s / t_host, "unit": "queries/s", "ms": t_host * 1e3,
+                            "note": "Kiez(...).fit(numpy, numpy).kneighbors(k) -> numpy: includes H2D of both matrices and D2H of the result"}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(source_h, target_h, metric, K, k, hub, hub_kw)
+    del source_h, target_h
+    if world == 1 and not args.no_others:
+        others = {}
+        for name in ("c1", "c2", "c3", "c4s", "ns"):
+            if name == args.workload:
+                continue
+            try:
+                osum, _, _ = run_workload(name, eng, comm, dist, rank, world, 3, 1, check=not args.no_check)
+                others[name] = short(osum)
+            except Exception as e:  # pragma: no cover  (a secondary workload must never cost the main line)
+                others[name] = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            line["other_workloads"] = others
+    if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

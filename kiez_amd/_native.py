@@ -245,7 +245,11 @@ class DeviceArray:
 class DeviceMatrix:
     """kz_matrix: an embedding matrix in HBM (exact rows + float64 norms + MFMA operand images: float32 and split-bf16)."""
 
-    def __init__(self, ctx: Context, data, metric: str, device_ptr: Optional[int] = None, shape=None, dtype=None):
+    def __init__(self, ctx: Context, data, metric: str, device_ptr: Optional[int] = None, shape=None, dtype=None,
+                 borrow: bool = False, keepalive=None):
+        """`device_ptr` + `borrow=True`: zero-copy -- the matrix reads the caller's HBM buffer in place (kz_matrix_create
+        rows_on_device = 2); `keepalive` (the tensor / array that owns it) is held until the matrix is destroyed and must
+        not be modified meanwhile (the reference holds its inputs the same way, neighbor_algorithm_base.py:95-96)."""
         self.ctx = ctx
         self.metric = metric
         h = _P()
@@ -263,7 +267,8 @@ class DeviceMatrix:
         else:
             self.shape = tuple(shape)
             self.dtype = np.dtype(dtype)
-            _check(ctx.lib.kz_matrix_create(ctx.handle, _P(device_ptr), 1, self.shape[0], self.shape[1],
+            self._keepalive = keepalive if borrow else None
+            _check(ctx.lib.kz_matrix_create(ctx.handle, _P(device_ptr), 2 if borrow else 1, self.shape[0], self.shape[1],
                                             KZ_F32 if self.dtype == np.float32 else KZ_F64, METRIC_IDS[metric], C.byref(h)),
                    "kz_matrix_create")
         self.handle = h

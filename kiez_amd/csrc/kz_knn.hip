@@ -335,7 +335,12 @@ __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* si
 }
 
 constexpr int KZ_FIN_ROWS = 4;     // candidate rows re-ranked together by one wave
-constexpr int KZ_FIN_MAXM = 1024;  // list entries per query: 4 waves x (1024*8 + 128*28) B = 47 KiB of LDS at most
+constexpr int KZ_FIN_MAXM = 4096;  // list entries per query: 4 waves x (4096*8 + 128*28) B = 142 KiB of LDS at most
+constexpr int KZ_MAX_PIECES = 64;  // index ranges per query tile (each range keeps its own K'-entry list per query)
+static int kz_max_pieces(int KP, int halves) {
+    const int m = KZ_FIN_MAXM / (halves * KP);
+    return m < KZ_MAX_PIECES ? m : KZ_MAX_PIECES;
+}
 constexpr int KZ_FIN_MAXKP = 128;
 
 // Per-wave LDS of the finalize kernel for a launch whose queries hold at most max_m list entries.
@@ -807,7 +812,7 @@ extern "C" int kz_knn_plan(int64_t n_query_rows, int64_t n_index_rows, int k_eff
     const int n_qtiles = (int)((n_query_rows + KZ_TILE - 1) / KZ_TILE);
     const int n_ytiles = (int)((n_index_rows + KZ_TILE - 1) / KZ_TILE);
     int sp[KZ_MAX_REGIONS];
-    kz_plan_rounds(n_qtiles, n_ytiles, slots, KZ_FIN_MAXM / (2 * KP), force_splits, min_splits, n_rounds, round_qtiles, sp);
+    kz_plan_rounds(n_qtiles, n_ytiles, slots, kz_max_pieces(KP, 1), force_splits, min_splits, n_rounds, round_qtiles, sp);
     for (int r = 0; r < *n_rounds; ++r) {
         const int len = (n_ytiles + sp[r] - 1) / sp[r];
         round_piece_tiles[r] = len;
@@ -879,7 +884,6 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
 
     const int metric = index->metric;
     const int n_ytiles = (int)index->n_tiles;
-    const int max_splits_m = KZ_FIN_MAXM / (2 * KP);
     const int n_slices = index->kg / 4;
     // rounding bound factors.  float32 operands: (d_pad + 16) 2^-24 covers the d+1 step fma chain, the float32 rounding of
     // the bias and (float64 inputs) of the operands; 1e-12 covers the float64 re-rank's own rounding.  fp16 operands: the
@@ -950,7 +954,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         size_t list_elems = 0;
         {
             int n_reg = 0;
-            kz_plan_rounds(n_qtiles, n_ytiles, slots, max_splits_m, ctx->force_splits, ctx->min_splits, &n_reg, reg_nq, reg_s);
+            kz_plan_rounds(n_qtiles, n_ytiles, slots, kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1), ctx->force_splits, ctx->min_splits,
+                           &n_reg, reg_nq, reg_s);
             int q0 = 0;
             for (int r = 0; r < n_reg; ++r) {
                 reg_q0[r] = q0;
@@ -1102,6 +1107,10 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 fp.max_m = lay.pieces[rg] * lay.halves * KP;
                 const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
                 const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, KP);
+                if (fin_lds > 65536) {
+                    const void* fk = index->dtype == KZ_F32 ? (const void*)kz_knn_finalize_kernel<float> : (const void*)kz_knn_finalize_kernel<double>;
+                    KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
+                }
                 if (index->dtype == KZ_F32)
                     hipLaunchKernelGGL(kz_knn_finalize_kernel<float>, dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
                 else

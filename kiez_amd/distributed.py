@@ -78,7 +78,9 @@ class HipEngine:
         N = self.N
         assert rows.dtype in (self.torch.float32, self.torch.float64)
         dt = np.float32 if rows.dtype == self.torch.float32 else np.float64
-        return N.DeviceMatrix(self.ctx, None, metric, device_ptr=rows.data_ptr(), shape=tuple(rows.shape), dtype=dt)
+        # zero-copy: the matrix reads the tensor's HBM in place and keeps the tensor alive
+        return N.DeviceMatrix(self.ctx, None, metric, device_ptr=rows.data_ptr(), shape=tuple(rows.shape), dtype=dt, borrow=True,
+                              keepalive=rows)
 
     def knn(self, qm, q_begin: int, q_count: int, im, k: int, exclude_self: bool):
         torch, N = self.torch, self.N
@@ -160,7 +162,10 @@ class HipEngine:
 # communicator: thin wrapper over torch.distributed (RCCL on GPUs, gloo in CPU tests)
 # ---------------------------------------------------------------------------------------------------
 class Comm:
-    def __init__(self, group=None):
+    """`time_collectives=True` brackets every collective with events on the current stream (GPU) or a wall clock (gloo) and
+    accumulates milliseconds per kind: bench.py reports them per step so that a scaling run shows what the exchange costs."""
+
+    def __init__(self, group=None, time_collectives: bool = False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -168,10 +173,42 @@ class Comm:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # test hook: run the collectives even with one rank (exercises the RCCL calls on a single-GPU box)
         self.always = dist.is_initialized() and os.environ.get("KIEZ_AMD_FORCE_COLLECTIVES") == "1"
+        self.timed = bool(time_collectives)
+        self._events = []   # (kind, start event, end event) -- resolved lazily, no sync inside the step
+        self._wall = {}
+
+    # -- timing ---------------------------------------------------------------------------------------
+    def reset_timers(self):
+        self._events = []
+        self._wall = {}
+
+    def _timed(self, kind, t, fn):
+        if not self.timed:
+            return fn()
+        if t.is_cuda:
+            torch = _torch()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn()
+            b.record()
+            self._events.append((kind, a, b))
+            return out
+        import time
+        t0 = time.perf_counter()
+        out = fn()
+        self._wall[kind] = self._wall.get(kind, 0.0) + (time.perf_counter() - t0) * 1e3
+        return out
+
+    def timers_ms(self, steps: int = 1):
+        """Milliseconds per step spent in collectives, by kind (call after a device synchronisation)."""
+        acc = dict(self._wall)
+        for kind, a, b in self._events:
+            acc[kind] = acc.get(kind, 0.0) + a.elapsed_time(b)
+        return {k: v / max(steps, 1) for k, v in acc.items()}
 
     def broadcast(self, t, src=0):
         if self.world > 1 or self.always:
-            self.dist.broadcast(t, src=src, group=self.group)
+            self._timed("broadcast", t, lambda: self.dist.broadcast(t, src=src, group=self.group))
         return t
 
     def all_gather_rows(self, t, counts):
@@ -184,12 +221,12 @@ class Comm:
         pad[: t.shape[0]] = t
         if t.is_cuda:
             out = torch.empty((self.world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            self.dist.all_gather_into_tensor(out, pad, group=self.group)
+            self._timed("all_gather", pad, lambda: self.dist.all_gather_into_tensor(out, pad, group=self.group))
             if all(c == mx for c in counts):
                 return out
             return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(self.world)], dim=0)
         parts = [torch.empty_like(pad) for _ in range(self.world)]
-        self.dist.all_gather(parts, pad, group=self.group)
+        self._timed("all_gather", pad, lambda: self.dist.all_gather(parts, pad, group=self.group))
         return torch.cat([parts[r][: counts[r]] for r in range(self.world)], dim=0)
 
     def all_gather_ints(self, value: int, device):
@@ -214,7 +251,7 @@ class Comm:
 
     def all_reduce_min(self, t):
         if self.world > 1 or self.always:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+            self._timed("all_reduce", t, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group))
         return t
 
 
