@@ -151,6 +151,9 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
         c_merge += __builtin_amdgcn_s_memtime() - tm0_;                  \
         n_pass += 1;                                                     \
     } while (0)
+#elif defined(KZ_EXP) && KZ_EXP == 3
+#define KZ_EPI3_STAMP_ARGS
+#define KZ_EPI3_MERGE() do { st.head = -1; pool.cnt = 0; } while (0)   /* diagnostic build: scan without merges (threshold never rises) */
 #else
 #define KZ_EPI3_STAMP_ARGS
 #define KZ_EPI3_MERGE() kz_merge_pool3<KP, IN_LDS>(st, pool, bs)

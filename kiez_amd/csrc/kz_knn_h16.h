@@ -50,6 +50,10 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     // whose LAST slice carries the barrier (even global slice index: odd NSR, tile starting at parity 0) must have read
     // slice g+1 before that barrier hands its slot to the DMA engine -- that tile carries, and its successor does not re-fetch.
     constexpr bool CARRY = WPS != 3;
+    // beyond 8 slices the stationary query tile leaves no room for a second fragment set at three waves per SIMD: the
+    // fragments of a slice are then fetched right before its MFMAs (two other waves of the SIMD cover the LDS latency)
+    constexpr bool ONE_SET = WPS == 3 && NSR > 8;
+    constexpr int LAG = ONE_SET ? 1 : 2;   // slices between a barrier and the oldest slot it may hand to the DMA engine
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);                       // R slots x 1024 floats
     float* bbuf = reinterpret_cast<float*>(smem + Cfg::BIAS_OFF);       // 2 x 128 bias floats
@@ -160,9 +164,9 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         // above the init this fresh load would be waited for at every tile start)
         __builtin_amdgcn_sched_barrier(0);
         const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
-        constexpr bool carry_in = CARRY || (P0 == 1 && (NSR & 1));
-        constexpr bool carry_out = CARRY || (((P0 + NSR) & 1) != 0);
-        if (!carry_in) {
+        constexpr bool carry_in = !ONE_SET && (CARRY || (P0 == 1 && (NSR & 1)));
+        constexpr bool carry_out = !ONE_SET && (CARRY || (((P0 + NSR) & 1) != 0));
+        if (!carry_in && !ONE_SET) {
             if (P0)
                 fetch_frags(f1, g);
             else
@@ -171,10 +175,12 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
 #pragma unroll
         for (int u = 0; u < NSR; ++u) {
             const bool odd = ((P0 + u) & 1) != 0;
-            kz_f16x8 (&cur)[4] = odd ? f1 : f0;
+            kz_f16x8 (&cur)[4] = (odd && !ONE_SET) ? f1 : f0;
             // fragments of the next slice, under this slice's MFMAs (it landed at least one barrier ago)
             __builtin_amdgcn_sched_barrier(0);
-            if (carry_out || u + 1 < NSR) {
+            if (ONE_SET) {
+                fetch_frags(f0, g);
+            } else if (carry_out || u + 1 < NSR) {
                 if (odd)
                     fetch_frags(f0, g + 1);
                 else
@@ -189,7 +195,13 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
             // slices g+P+2 .. g+2P+1.  The next period prefetches slices g+2 .. g+P+1: those were issued at the PREVIOUS
             // barrier and are this wave's youngest DMAs, hence vmcnt(0) (any other outstanding operation -- bias load,
             // list traffic of a merge -- only has to finish too).
-            if (!odd && (P == 2 || ((g + 2) & (P - 1)) == 0)) {
+#if defined(KZ_EXP) && KZ_EXP == 2
+            if (false) {   // diagnostic build: no slice barrier, no DMA after the prologue (stale LDS data; timing only)
+#else
+            // (ONE_SET: nothing is prefetched, a wave at the barrier has read the slices <= g only: the barrier sits one
+            //  slice later in the period -- (g + 1) % P == 0 -- and hands out the slots of slices g-P+1 .. g.)
+            if ((ONE_SET ? odd : !odd) && (P == 2 || ((g + LAG) & (P - 1)) == 0)) {
+#endif
 #ifdef KZ_STAMP
                 {
                     __builtin_amdgcn_sched_barrier(0);
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 #pragma unroll
-                for (int i = 0; i < P; ++i) dma_slice(g + P + 2 + i);
+                for (int i = 0; i < P; ++i) dma_slice(g + P + LAG + i);
             }
             ++g;
         }
@@ -216,6 +228,9 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
+#elif defined(KZ_EXP) && (KZ_EXP == 1 || KZ_EXP == 2)
+        // diagnostic build (tools/ablate.sh, never shipped): no candidate scan at all -- the accumulators are only kept alive
+        asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
 #else
         kz_tile_epilogue3<KP, CAP, IN_LDS>(acc, st, pool, bmin, tile, tile == t_end - 1, msync);
 #endif

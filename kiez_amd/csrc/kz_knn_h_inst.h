@@ -9,13 +9,18 @@
 
 // Occupancy class of a slice count: three workgroups per CU (168 VGPRs, 53 KiB of LDS each) while the stationary query
 // tile fits, two (256 VGPRs, 80 KiB) beyond.  wps (tuning knob "h_wps") = 2 forces the two-workgroup build.
-constexpr int KZ_H_WPS3_MAX = 8;    // d <= 128 (beyond it the 168-VGPR budget of three waves per SIMD spills)
+// Measured (MI355X, rocprof): d = 128, K' = 16: 2.93 ms at three per CU against 3.51 ms at two; d = 200, K' = 16 (single
+// fragment set, kz_knn_h16.h: ONE_SET): 96.8 against 102.2 ms; d = 200, K' = 64 (lists in the output arrays, 13 spilled
+// VGPRs at three per CU): 132 against 127 ms -- so beyond 8 slices only the K' = 16 build runs three per CU.
+constexpr int KZ_H_WPS3_MAX = 8;        // d <= 128: every list length
+constexpr int KZ_H_WPS3_MAX_KP16 = 13;  // d <= 208: K' = 16 only
 
 template <int KP, int NSR>
 static const void* kz_h_kernel(int wps, int* lds) {
-    if (NSR <= KZ_H_WPS3_MAX && wps != 2) {
+    constexpr bool three = NSR <= KZ_H_WPS3_MAX || (KP == 16 && NSR <= KZ_H_WPS3_MAX_KP16);
+    if (three && wps != 2) {
         *lds = KzHCfg<KP, 3, NSR>::LDS_BYTES;
-        return (const void*)kz_knn_cand_h_kernel<KP, (NSR <= KZ_H_WPS3_MAX ? NSR : 2), 3>;
+        return (const void*)kz_knn_cand_h_kernel<KP, (three ? NSR : 2), 3>;
     }
     *lds = KzHCfg<KP, 2, NSR>::LDS_BYTES;
     return (const void*)kz_knn_cand_h_kernel<KP, NSR, 2>;
