@@ -145,6 +145,9 @@ int kz_select_topk(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int6
 /* ---- "next" row (f-1): kiez.analysis.hubness_score on the neighbour index matrix (kiez/analysis/estimation.py:197-351) */
 /* min / max of an int64 device array (validation + bincount length). */
 int kz_minmax_i64(kz_ctx* ctx, const int64_t* d_in, int64_t count, int64_t* h_min, int64_t* h_max);
+/* the same over the first k columns of a row-major [rows, cols] matrix: the reference slices nn_ind[:, :k] BEFORE
+ * np.bincount(minlength=n_train) (estimation.py:276-292), so ids in the dropped columns must not size the histogram. */
+int kz_minmax_i64_2d(kz_ctx* ctx, const int64_t* d_in, int64_t rows, int cols, int k, int64_t* h_min, int64_t* h_max);
 /* k-occurrence: np.bincount(nn_ind[:, :k].ravel(), minlength=n_bins) with negative ids dropped (estimation.py:283-292).
  * d_ind: [n_rows, cols] int64; d_kocc: [n_bins] int64. */
 int kz_k_occurrence(kz_ctx* ctx, const int64_t* d_ind, int64_t n_rows, int cols, int k, int64_t n_bins, int64_t* d_kocc);

@@ -26,7 +26,10 @@ _lock = threading.Lock()
 KZ_F32, KZ_F64 = 0, 1
 KZ_EUCLIDEAN, KZ_SQEUCLIDEAN, KZ_COSINE = 0, 1, 2
 METRIC_IDS = {"euclidean": KZ_EUCLIDEAN, "sqeuclidean": KZ_SQEUCLIDEAN, "cosine": KZ_COSINE}
-MAX_NEIGHBORS = 110  # list length 128 minus the certification margin (kz_knn.hip: kz_pick_list_len)
+MAX_FUSED_NEIGHBORS = 110   # neighbours per query the fused kernels keep (list length 128 minus the certification margin);
+                            # beyond it kz_knn runs on the exact float64 kernels only (correct, slow), up to MAX_NEIGHBORS
+MAX_NEIGHBORS = 4096
+MAX_HUBNESS_CANDIDATES = 128  # n_candidates the device hubness kernels (transform, final sort) handle
 
 _ERR_TYPES = {1: ValueError, 2: RuntimeError, 3: NotImplementedError, 4: MemoryError, 5: ValueError}
 
@@ -82,6 +85,7 @@ SYMBOLS = [
     ("kz_select_topk", C.c_int, [_P, _P, _P, _I64, C.c_int, C.c_int, _P, _P]),
     ("kz_cast_f64_f32", C.c_int, [_P, _P, _P, _I64]),
     ("kz_minmax_i64", C.c_int, [_P, _P, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
+    ("kz_minmax_i64_2d", C.c_int, [_P, _P, _I64, C.c_int, C.c_int, C.POINTER(_I64), C.POINTER(_I64)]),
     ("kz_k_occurrence", C.c_int, [_P, _P, _I64, C.c_int, C.c_int, _I64, _P]),
     ("kz_kocc_stats", C.c_int, [_P, _P, _I64, C.c_double, C.c_int, C.POINTER(C.c_double)]),
     ("kz_kocc_select", C.c_int, [_P, _P, _I64, C.c_int, C.c_double, _P, C.POINTER(_I64)]),

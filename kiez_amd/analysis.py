@@ -63,8 +63,10 @@ def hubness_score(nn_ind, target_samples: int, *, k: Optional[int] = None, hub_s
         warnings.warn(f"k > nn_ind.shape[1], k will be set to {k}", stacklevel=2)
     lib = ctx.lib
     lo, hi = C.c_int64(0), C.c_int64(0)
-    N._check(lib.kz_minmax_i64(ctx.handle, ind.ptr, n_train * cols, C.byref(lo), C.byref(hi)), "kz_minmax_i64")
-    n_bins = max(n_train, int(hi.value) + 1)          # np.bincount(..., minlength=n_train)
+    # the histogram is sized by the ids of the first k columns only: the reference slices nn_ind[:, :k] before
+    # np.bincount(..., minlength=n_train) (estimation.py:276-292)
+    N._check(lib.kz_minmax_i64_2d(ctx.handle, ind.ptr, n_train, cols, int(k), C.byref(lo), C.byref(hi)), "kz_minmax_i64_2d")
+    n_bins = max(n_train, int(hi.value) + 1)
     kocc = ctx.empty((n_bins,), np.int64)
     N._check(lib.kz_k_occurrence(ctx.handle, ind.ptr, n_train, cols, int(k), n_bins, kocc.ptr), "kz_k_occurrence")
 

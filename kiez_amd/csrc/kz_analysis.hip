@@ -38,6 +38,28 @@ __global__ void kz_minmax_i64_kernel(const int64_t* __restrict__ in, int64_t cou
     }
 }
 
+// the same over the first k columns of a row-major [rows, cols] matrix (element e of the rows x k sub-matrix)
+__global__ void kz_minmax_i64_2d_kernel(const int64_t* __restrict__ in, int64_t rows, int cols, int k, long long* __restrict__ mn,
+                                        long long* __restrict__ mx) {
+    long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+    const int64_t count = rows * k;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / k;
+        const long long v = in[r * cols + (e - r * k)];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const long long ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(mn, lo);
+        atomicMax(mx, hi);
+    }
+}
+
 // pass 1 (exact integer reductions): sum, max, #zeros, sum and count of entries >= hub threshold
 __global__ void kz_kocc_int_stats_kernel(const long long* __restrict__ kocc, int64_t n, double thr,
                                          unsigned long long* __restrict__ out) {
@@ -175,6 +197,24 @@ int kz_minmax_i64(kz_ctx* ctx, const int64_t* d_in, int64_t count, int64_t* h_mi
     KZ_HIP(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
     const int blocks = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
     hipLaunchKernelGGL(kz_minmax_i64_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_in, count, d, d + 1);
+    KZ_HIP(hipGetLastError());
+    long long h[2];
+    KZ_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    KZ_HIP(hipStreamSynchronize(ctx->stream));
+    *h_min = h[0];
+    *h_max = h[1];
+    return KZ_OK;
+}
+
+int kz_minmax_i64_2d(kz_ctx* ctx, const int64_t* d_in, int64_t rows, int cols, int k, int64_t* h_min, int64_t* h_max) {
+    KZ_REQUIRE(ctx && d_in && h_min && h_max && rows > 0 && cols >= 1 && k >= 1 && k <= cols, "kz_minmax_i64_2d: bad argument");
+    KZ_HIP(hipSetDevice(ctx->device));
+    long long* d = (long long*)(ctx->d_counters + 32);
+    const long long init[2] = {0x7fffffffffffffffLL, -0x7fffffffffffffffLL - 1};
+    KZ_HIP(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    const int64_t count = rows * k;
+    const int blocks = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+    hipLaunchKernelGGL(kz_minmax_i64_2d_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_in, rows, cols, k, d, d + 1);
     KZ_HIP(hipGetLastError());
     long long h[2];
     KZ_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

@@ -324,82 +324,73 @@ __global__ void kz_dsl_finalize_kernel(double* __restrict__ out, int64_t count, 
     out[e] = v;
 }
 
-// HubnessReduction._sort (base.py:81-86): selection sort with swaps of the first k positions; wave per row.
-// Position p lives in lane p & 63, slot p >> 6 (K <= 128 -> 2 slots).
-__global__ __launch_bounds__(256) void kz_select_topk_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind,
-                                                             int64_t n, int K, int k, double* __restrict__ odist,
-                                                             int64_t* __restrict__ oind) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
-    if (r >= n) return;
-    const double* a = dist + r * (int64_t)K;
-    const int64_t* id = ind + r * (int64_t)K;
-    double v0 = INFINITY, v1 = INFINITY;
-    int64_t i0 = -1, i1 = -1;
-    if (lane < K) {
-        v0 = a[lane];
-        i0 = id[lane];
+// HubnessReduction._sort (base.py:81-86): np.argpartition(kth=arange(k)) == selection sort with swaps of the first k
+// positions: for i < k pick the FIRST minimum of positions [i, K) and swap it into position i.  The swap
+// history decides the order of tied values (MP-empiric rows are full of ties), so the sort is emulated step by step --
+// but by ONE LANE PER ROW on a transposed copy of 64 rows in LDS (values [pos][row], original positions as bytes):
+// ~5 instructions per compared element and no cross-lane traffic, against a 6-step shuffle butterfly per selection in the
+// wave-per-row form (C3, 500k x 50: 6.4 ms -> see profiles/).  Loads and stores are coalesced through the LDS copy;
+// neighbour ids are gathered at the end through the sorted positions.  NaN sorts last (numpy's order), so a row with NaN
+// (MP-normal with sd = 0, LS / NICDM with radius 0) stays a permutation.
+constexpr int KZ_SEL_ROWS = 64;                      // rows per workgroup (one wave)
+constexpr int KZ_SEL_LD = KZ_SEL_ROWS + 1;           // padded leading dimension of the value image (doubles)
+__host__ __device__ constexpr int kz_sel_lds_bytes(int K) { return K * KZ_SEL_LD * 8 + K * KZ_SEL_ROWS; }
+
+__global__ __launch_bounds__(64) void kz_select_topk_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind,
+                                                            int64_t n, int K, int k, double* __restrict__ odist,
+                                                            int64_t* __restrict__ oind) {
+    extern __shared__ __attribute__((aligned(16))) char sel_smem[];
+    double* v = reinterpret_cast<double*>(sel_smem);                            // v[pos * LD + row]
+    unsigned char* ps = reinterpret_cast<unsigned char*>(sel_smem + (size_t)K * KZ_SEL_LD * 8);   // ps[pos * 64 + row]
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * KZ_SEL_ROWS;
+    const int rows = (int)((n - row0) < KZ_SEL_ROWS ? (n - row0) : KZ_SEL_ROWS);
+    // coalesced load of rows x K values, transposed into LDS
+    const double* src = dist + row0 * (int64_t)K;
+    const int total = rows * K;
+    for (int e = lane; e < total; e += 64) {
+        const int r = e / K, j = e - r * K;
+        v[j * KZ_SEL_LD + r] = src[e];
     }
-    if (lane + 64 < K) {
-        v1 = a[lane + 64];
-        i1 = id[lane + 64];
-    }
-    for (int i = 0; i < k; ++i) {
-        // first strict minimum among positions [i, K)
-        double bv = INFINITY;
-        int bp = 0x7fffffff;
-        if (lane >= i && lane < K) {
-            bv = v0;
-            bp = lane;
-        }
-        if (lane + 64 >= i && lane + 64 < K) {
-            if (bp == 0x7fffffff || v1 < bv) {
-                bv = v1;
-                bp = lane + 64;
+    for (int j = 0; j < K; ++j) ps[j * KZ_SEL_ROWS + lane] = (unsigned char)j;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < rows) {
+        double* vr = v + lane;
+        unsigned char* pr = ps + lane;
+        for (int i = 0; i < k; ++i) {
+            double m = vr[i * KZ_SEL_LD];
+            int mp = i;
+            for (int j = i + 1; j < K; ++j) {
+                const double x = vr[j * KZ_SEL_LD];
+                // total order with NaN last; strict: the first minimum wins
+                const bool less = (x < m) || ((m != m) && (x == x));
+                m = less ? x : m;
+                mp = less ? j : mp;
             }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(bv, off, 64);
-            const int op = __shfl_xor(bp, off, 64);
-            if (op != 0x7fffffff && (bp == 0x7fffffff || ov < bv || (ov == bv && op < bp))) {
-                bv = ov;
-                bp = op;
-            }
-        }
-        // fetch entry at position i and at position bp, swap
-        const int li = i & 63, lb = bp & 63;
-        const double vi = __shfl((i >> 6) ? v1 : v0, li, 64);
-        const int64_t ii = __shfl((i >> 6) ? i1 : i0, li, 64);
-        const double vb = __shfl((bp >> 6) ? v1 : v0, lb, 64);
-        const int64_t ib = __shfl((bp >> 6) ? i1 : i0, lb, 64);
-        if (lane == lb) {
-            if (bp >> 6) {
-                v1 = vi;
-                i1 = ii;
-            } else {
-                v0 = vi;
-                i0 = ii;
-            }
-        }
-        if (lane == li) {
-            if (i >> 6) {
-                v1 = vb;
-                i1 = ib;
-            } else {
-                v0 = vb;
-                i0 = ib;
+            if (mp != i) {
+                const double vi = vr[i * KZ_SEL_LD];
+                vr[mp * KZ_SEL_LD] = vi;
+                vr[i * KZ_SEL_LD] = m;
+                const unsigned char a = pr[i * KZ_SEL_ROWS], b = pr[mp * KZ_SEL_ROWS];
+                pr[i * KZ_SEL_ROWS] = b;
+                pr[mp * KZ_SEL_ROWS] = a;
             }
         }
     }
-    if (lane < k) {
-        odist[r * (int64_t)k + lane] = v0;
-        oind[r * (int64_t)k + lane] = i0;
-    }
-    if (lane + 64 < k) {
-        odist[r * (int64_t)k + lane + 64] = v1;
-        oind[r * (int64_t)k + lane + 64] = i1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // coalesced store of rows x k results; ids gathered through the sorted positions
+    const int out_total = rows * k;
+    double* od = odist + row0 * (int64_t)k;
+    int64_t* oi = oind + row0 * (int64_t)k;
+    const int64_t* id = ind + row0 * (int64_t)K;
+    for (int e = lane; e < out_total; e += 64) {
+        const int r = e / k, i = e - r * k;
+        od[e] = v[i * KZ_SEL_LD + r];
+        oi[e] = id[(int64_t)r * K + ps[i * KZ_SEL_ROWS + r]];
     }
 }
 
@@ -513,7 +504,10 @@ int kz_select_topk(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int6
     KZ_CHECK_NK("kz_select_topk");
     KZ_REQUIRE(d_dist && d_ind && d_odist && d_oind, "kz_select_topk: null argument");
     KZ_REQUIRE(k >= 1 && k <= K, "kz_select_topk: k=%d must be in [1, K=%d]", k, K);
-    hipLaunchKernelGGL(kz_select_topk_kernel, kz_grid1d(n, 4), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K, k, d_odist, d_oind);
+    const int lds = kz_sel_lds_bytes(K);
+    if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kz_select_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kz_select_topk_kernel, kz_grid1d(n, KZ_SEL_ROWS), dim3(64), lds, ctx->stream, d_dist, d_ind, n, K, k, d_odist,
+                       d_oind);
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }

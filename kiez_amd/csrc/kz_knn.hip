@@ -643,13 +643,14 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
                                                               int64_t* __restrict__ out_ind) {
     __shared__ double s_v[4];
     __shared__ int s_i[4];
-    __shared__ double s_sv[KZ_FIN_MAXKP];
-    __shared__ int s_si[KZ_FIN_MAXKP];
+    extern __shared__ __attribute__((aligned(16))) char sel_sm[];   // k_eff doubles + k_eff ints (any k the host admits)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int q = fail_list[batch0 + b];
     const double* v = vals + (int64_t)b * n_i;
     const int k_eff = (int)min((int64_t)(k + (exclude_self ? 1 : 0)), n_i);
+    double* s_sv = reinterpret_cast<double*>(sel_sm);
+    int* s_si = reinterpret_cast<int*>(s_sv + k_eff);
     double pv = -1.0;  // values are >= 0
     int pi = -1;
     for (int r = 0; r < k_eff; ++r) {
@@ -836,6 +837,11 @@ __global__ __launch_bounds__(256) void kz_gather_rows_kernel(const char* __restr
     if (self_ids && threadIdx.x == 0) self_ids[r] = parent_self ? parent_self[src] : src;
 }
 
+__global__ void kz_iota_kernel(int* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 __global__ __launch_bounds__(256) void kz_scatter_rows_kernel(const double* __restrict__ sd, const int64_t* __restrict__ si,
                                                               const int* __restrict__ rows, int n_rows, int k,
                                                               double* __restrict__ od, int64_t* __restrict__ oi) {
@@ -850,6 +856,7 @@ __global__ __launch_bounds__(256) void kz_scatter_rows_kernel(const double* __re
 // candidate set cannot be certified under that tier's bound go down: fp16 / split-bf16 -> float32 operands (gathered into
 // a dense query block) -> exact float64 brute force.  The result is the float64 neighbour order at every tier.
 enum { KZ_TIER_F32 = 0, KZ_TIER_BF = 1, KZ_TIER_H = 2 };
+constexpr int KZ_EXACT_MAX_K = 4096;   // neighbours per query on the exact-only route (selection state: 48 KiB of LDS)
 
 // d_self_ids (device, optional): index row to strip per query when exclude_self is set and the query matrix is not the
 // index matrix itself (escalated subsets).  precision_override: -1 = the context's setting, 1 = float32 operands only.
@@ -872,10 +879,17 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                exclude_self ? "<" : "<=", k, (long long)index->n);
     if (exclude_self && !d_self_ids)
         KZ_REQUIRE(query->n == index->n, "kz_knn: exclude_self needs query and index of equal length");
+    // More than 110 neighbours per query: no fused kernel keeps lists that long; the call runs entirely on the exact float64
+    // kernels (k selection rounds over the full distance row per query: correct for any k <= n, and slow -- the reference's
+    // scikit-learn path has no such limit either, sklearn_nearest_neighbors.py:51-65; INTEGRATION.md "Deviations").
     int KP = kz_pick_list_len(k_eff);
-    if (KP == 0) {
-        kz_set_error("kz_knn: k=%d exceeds the supported maximum of 110 neighbours per query", k_eff);
-        return KZ_ERR_UNSUPPORTED;
+    const bool exact_only = KP == 0;
+    if (exact_only) {
+        if (k_eff > KZ_EXACT_MAX_K) {
+            kz_set_error("kz_knn: k=%d exceeds the supported maximum of %d neighbours per query", k_eff, KZ_EXACT_MAX_K);
+            return KZ_ERR_UNSUPPORTED;
+        }
+        KP = 128;   // (list geometry of the scratch block only; no list kernel runs)
     }
     if (KP < kp_min) KP = kp_min;
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -897,6 +911,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     const int precision = precision_override >= 0 ? precision_override : ctx->precision;
     int tier = KZ_TIER_F32;
     if (precision != 1 && n_slices >= 2 && n_slices <= 24 && query->kg == index->kg) tier = precision == 2 ? KZ_TIER_BF : KZ_TIER_H;
+    if (exact_only) tier = KZ_TIER_F32;   // (nothing is packed or launched for it below)
     if (tier == KZ_TIER_H) {
         const int rc = kz_himage_ensure(query, index);
         if (rc != KZ_OK) return rc;
@@ -929,7 +944,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             int rc = kz_matrix_image_bf(query);
             if (rc == KZ_OK) rc = kz_matrix_image_bf(index);
             if (rc != KZ_OK) return rc;
-        } else if (tier == KZ_TIER_F32) {
+        } else if (tier == KZ_TIER_F32 && !exact_only) {
             int rc = kz_matrix_image_f32(query);
             if (rc == KZ_OK) rc = kz_matrix_image_f32(index);
             if (rc != KZ_OK) return rc;
@@ -1053,7 +1068,11 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         KZ_HIP(hipMemsetAsync(cp.dbg, 0, 10 * sizeof(unsigned long long), ctx->stream));
 #endif
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-        if (tier == KZ_TIER_H)
+        if (exact_only) {
+            // every row of the chunk goes to the exact kernels: the "fail list" is 0 .. cq_count-1
+            hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((cq_count + 255) / 256)), dim3(256), 0, ctx->stream, fail_list, (int)cq_count);
+            KZ_HIP(hipGetLastError());
+        } else if (tier == KZ_TIER_H)
             KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps));
         else if (tier == KZ_TIER_BF)
             KZ_DISPATCH_KP(rc, kz_bf_launch, (n_slices, ctx, cp, W));
@@ -1098,7 +1117,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
         {
             // one launch per list region: the dynamic LDS follows the region's entry count (occupancy of the gather)
-            for (int rg = 0; rg < lay.n_regions; ++rg) {
+            for (int rg = 0; rg < (exact_only ? 0 : lay.n_regions); ++rg) {
                 const int64_t lo = (int64_t)(rg > 0 ? lay.qt_end[rg - 1] : 0) * KZ_TILE - fp.list_row0;
                 const int64_t hi = (int64_t)lay.qt_end[rg] * KZ_TILE - fp.list_row0;
                 fp.q_first = lo < 0 ? 0 : lo;
@@ -1121,7 +1140,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         KZ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
         KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         KZ_HIP(hipStreamSynchronize(ctx->stream));
-        const int n_fail = ctx->h_counters[8];
+        const int n_fail = exact_only ? (int)cq_count : ctx->h_counters[8];
         {
             double ratio;
             memcpy(&ratio, ctx->h_counters + 10, 8);
@@ -1250,19 +1269,25 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 return rc;
             }
             const int dist_blocks = (int)((index->n + 3) / 4);
+            const size_t sel_lds = (size_t)(k_eff < index->n ? k_eff : (int)index->n) * 12 + 16;
+            if (sel_lds > 65536) {
+                kz_pool_free(ctx, fl, 0);
+                kz_set_error("kz_knn: k=%d is too large for the exact selection kernel", k_eff);
+                return KZ_ERR_UNSUPPORTED;
+            }
             for (int b0 = 0; b0 < n_fail; b0 += (int)batch) {
                 const int nb = (n_fail - b0 < batch) ? (n_fail - b0) : (int)batch;
                 if (index->dtype == KZ_F32) {
                     hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
                                        cq_begin, (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn,
                                        index->n, (int)index->d, metric, (double*)vals);
-                    hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(nb), dim3(256), 0, ctx->stream, fl, b0, cq_begin,
+                    hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
                                        (const double*)vals, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, fp.out_dist, fp.out_ind);
                 } else {
                     hipLaunchKernelGGL(kz_exact_dist_kernel<double>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
                                        cq_begin, (const double*)query->raw, (const double*)index->raw, query->sqn, index->sqn,
                                        index->n, (int)index->d, metric, (double*)vals);
-                    hipLaunchKernelGGL(kz_exact_select_kernel<double>, dim3(nb), dim3(256), 0, ctx->stream, fl, b0, cq_begin,
+                    hipLaunchKernelGGL(kz_exact_select_kernel<double>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
                                        (const double*)vals, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, fp.out_dist, fp.out_ind);
                 }
             }

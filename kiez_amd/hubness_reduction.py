@@ -34,6 +34,12 @@ class HubnessReduction(ABC):
         self._use_torch = False
         if nn_algo.n_candidates == 1:
             raise ValueError("Cannot perform hubness reduction with a single candidate per query!")
+        # known at construction, so say it at construction (not after a long fit): the device transforms and the final
+        # sort handle up to 128 candidates per query (INTEGRATION.md "Deviations"); NoHubnessReduction has no such limit
+        if (self._device_native and type(self).__name__ != "NoHubnessReduction" and isinstance(nn_algo.n_candidates, (int, np.integer))
+                and nn_algo.n_candidates > N.MAX_HUBNESS_CANDIDATES):
+            raise NotImplementedError(f"n_candidates={nn_algo.n_candidates}: the MI355X hubness reductions support up to "
+                                      f"{N.MAX_HUBNESS_CANDIDATES} candidates per query")
 
     # Subclasses shipped here consume device arrays; a user-written subclass (docs/source/using_your_own.rst:11-19)
     # gets numpy arrays exactly as in the reference.
@@ -128,8 +134,10 @@ class HubnessReduction(ABC):
             if _is_tensor(src):   # tensors in -> tensors out, on the source's device
                 torch = _torch_if_loaded()
                 self.ctx.sync()
-                return (torch.as_tensor(od, device="cuda").clone().to(src.device),
-                        torch.as_tensor(oi, device="cuda").clone().to(src.device))
+                out = (torch.as_tensor(od, device="cuda").clone().to(src.device),
+                       torch.as_tensor(oi, device="cuda").clone().to(src.device))
+                torch.cuda.current_stream().synchronize()   # before od / oi go back to our stream-ordered pool
+                return out
             return od.numpy(), oi.numpy()
         n_neighbors = self._set_k_if_needed(k)
         query_dist, query_ind = self.nn_algo.kneighbors(query=None, k=self.nn_algo.n_candidates, return_distance=True)

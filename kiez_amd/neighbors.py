@@ -31,7 +31,14 @@ def check_is_fitted(obj, attributes, all_or_any=all):
 
 
 class NNAlgorithm(ABC):
-    """Base class for nearest neighbor algorithms (kiez/neighbors/neighbor_algorithm_base.py:13-136)."""
+    """The reference's plugin interface for nearest-neighbour backends (kiez/neighbors/neighbor_algorithm_base.py:13-136).
+
+    A backend implements `_fit(data, is_source) -> index` and `_kneighbors(k, query, index, return_distance,
+    is_self_querying)`; this base class keeps the two fitted sides and does the argument checking.  Attributes after `fit`
+    are the reference's: `source_`, `target_` (the caller's arrays), `source_index`, `target_index`,
+    `source_equals_target`.  Organisation is this repository's own: one table of the two search directions
+    (`_direction`) instead of branches, checks as small helpers.
+    """
 
     _ALLOWED_INPUT_TYPES: Tuple[Any, ...] = (np.ndarray,)
 
@@ -40,11 +47,7 @@ class NNAlgorithm(ABC):
         self.metric = metric
         self.n_jobs = n_jobs
 
-    def _describe_source_target_fitted(self):
-        if hasattr(self, "source_"):
-            return f" is fitted with: source.shape={self.source_.shape} and target.shape={self.target_.shape}"
-        return " is unfitted"
-
+    # ---- what a backend provides --------------------------------------------------------------------
     @property
     @abstractmethod
     def valid_metrics(self):
@@ -54,68 +57,84 @@ class NNAlgorithm(ABC):
     def _fit(self, data, is_source: bool) -> Any:
         pass  # pragma: no cover
 
-    def _check_input_types(self, value):
-        if not isinstance(value, tuple):
-            value = (value,)
-        if not all(isinstance(x, self.__class__._ALLOWED_INPUT_TYPES) for x in value if x is not None):
-            found_types = [type(x) for x in value]
-            raise ValueError(
-                f"Not implemented for input type(s) {found_types}! Only {self.__class__._ALLOWED_INPUT_TYPES} allowed!")
+    @abstractmethod
+    def _kneighbors(self, k, query, index, return_distance, is_self_querying):
+        pass  # pragma: no cover
 
-    def fit(self, source, target=None, only_fit_target: bool = False):
-        """Index the data (neighbor_algorithm_base.py:53-96)."""
-        self._check_input_types((source, target))
-        self.source_equals_target = target is None
-        if self.source_equals_target:
-            self.source_index = self._fit(source, True)
-            self.target_index = self.source_index
-            target = source
-        else:
-            if target is not None and source.shape[1] != target.shape[1]:
-                raise ValueError(
-                    "Expected source and target to have the same number of features,"
-                    f" but got source.shape: {source.shape} and target.shape: {target.shape}")
-            if only_fit_target:
-                self.target_index = self._fit(target, True)
-            else:
-                self.source_index = self._fit(source, True)
-                self.target_index = self._fit(target, False)
-        self.source_ = source
-        self.target_ = target
+    # ---- checks -------------------------------------------------------------------------------------
+    def _check_input_types(self, value):
+        values = value if isinstance(value, tuple) else (value,)
+        allowed = type(self)._ALLOWED_INPUT_TYPES
+        if any(x is not None and not isinstance(x, allowed) for x in values):
+            found_types = [type(x) for x in values]
+            raise ValueError(f"Not implemented for input type(s) {found_types}! Only {allowed} allowed!")
+
+    @staticmethod
+    def _same_width(source, target):
+        if source.shape[1] != target.shape[1]:
+            raise ValueError("Expected source and target to have the same number of features,"
+                             f" but got source.shape: {source.shape} and target.shape: {target.shape}")
 
     def _check_k_value(self, k: int, needed_space) -> int:
         if not np.issubdtype(type(k), np.integer):
             raise TypeError(f"k does not take {type(k)} value, enter integer value")
         if k <= 0:
             raise ValueError(f"Expected k > 0. Got {k}")
-        if k > needed_space:
-            warnings.warn(
-                f"k={k} is larger than number of samples in indexed space.\n" + f"Setting to k={needed_space}",
-                stacklevel=2)
-            return needed_space
-        return k
+        if k <= needed_space:
+            return k
+        warnings.warn(f"k={k} is larger than number of samples in indexed space.\n" + f"Setting to k={needed_space}",
+                      stacklevel=2)
+        return needed_space
 
-    @abstractmethod
-    def _kneighbors(self, k, query, index, return_distance, is_self_querying):
-        pass  # pragma: no cover
+    def _describe_source_target_fitted(self):
+        if not hasattr(self, "source_"):
+            return " is unfitted"
+        return f" is fitted with: source.shape={self.source_.shape} and target.shape={self.target_.shape}"
+
+    # ---- fit ----------------------------------------------------------------------------------------
+    def fit(self, source, target=None, only_fit_target: bool = False):
+        """Index the data.  One argument: a single-source search (the index serves both directions).  Two arguments: both
+        sides are indexed, or only the target when the caller never searches target -> source (`only_fit_target`, used by
+        NoHubnessReduction).  An index that this call does not rebuild is dropped, never left over from an earlier fit."""
+        self._check_input_types((source, target))
+        single = target is None
+        if not single:
+            self._same_width(source, target)
+        for stale in ("source_index", "target_index"):
+            if hasattr(self, stale):
+                delattr(self, stale)
+        if single:
+            self.source_index = self.target_index = self._fit(source, True)
+            target = source
+        elif only_fit_target:
+            self.target_index = self._fit(target, True)
+        else:
+            self.source_index = self._fit(source, True)
+            self.target_index = self._fit(target, False)
+        self.source_equals_target = single
+        self.source_, self.target_ = source, target
+
+    # ---- search -------------------------------------------------------------------------------------
+    def _direction(self, s_to_t: bool):
+        """(default query array, index searched, its size) of a search direction."""
+        if s_to_t:
+            return self.source_, getattr(self, "target_index", None), self.target_.shape[0]
+        return self.target_, getattr(self, "source_index", None), self.source_.shape[0]
 
     def _select_direction(self, k, query, s_to_t):
         check_is_fitted(self, ["source_index", "target_index"], all_or_any=any)
-        k = self.n_candidates if k is None else k
+        default_query, index, index_size = self._direction(s_to_t)
+        if index is None:   # e.g. target -> source after fit(..., only_fit_target=True)
+            raise NotFittedError(f"'{type(self).__name__}' object has no attribute "
+                                 f"'{'target_index' if s_to_t else 'source_index'}'")
+        # only the implicit query of a single-source fit searches "itself" (the explicit reverse pass of
+        # HubnessReduction.fit keeps each row as its own first neighbour, base.py:37-42)
         is_self_querying = query is None and self.source_equals_target
-        if s_to_t:
-            query = self.source_ if query is None else query
-            index = self.target_index
-            needed_space = self.target_.shape[0]
-        else:
-            query = self.target_ if query is None else query
-            index = self.source_index
-            needed_space = self.source_.shape[0]
-        k = self._check_k_value(k, needed_space)
-        return k, query, index, is_self_querying
+        k = self._check_k_value(self.n_candidates if k is None else k, index_size)
+        return k, (default_query if query is None else query), index, is_self_querying
 
     def kneighbors(self, k=None, query=None, s_to_t=True, return_distance=True):
-        """neighbor_algorithm_base.py:116-136."""
+        """k nearest neighbours of `query` (default: the fitted source, or target when `s_to_t` is False)."""
         k, query, index, is_self_querying = self._select_direction(k, query, s_to_t)
         return self._kneighbors(k=k, query=query, index=index, return_distance=return_distance,
                                 is_self_querying=is_self_querying)
@@ -170,8 +189,11 @@ class SklearnNN(NNAlgorithm):
         self.metric_params = metric_params
         self.device = device
         self._metric_c = canonical_metric(metric, p)
+        if isinstance(n_candidates, (int, np.integer)) and n_candidates > N.MAX_NEIGHBORS - 1:
+            raise NotImplementedError(f"n_candidates={n_candidates} exceeds the {N.MAX_NEIGHBORS - 1} neighbours per query the "
+                                      "MI355X exact backend supports")
         self._ctx = None
-        self._aux = {}  # id(array) -> (array, DeviceMatrix) for query matrices that are not an index
+        self._aux = None  # (array, DeviceMatrix) of the most recent query array that is not a fitted side
         self.last_stats = None
 
     def __repr__(self):
@@ -217,17 +239,17 @@ class SklearnNN(NNAlgorithm):
             if t.device.index != self.ctx.device:
                 raise ValueError(f"tensor lives on cuda:{t.device.index}, the NN backend on device {self.ctx.device}")
             torch.cuda.current_stream(t.device).synchronize()   # the producer stream is not ours
-            m = N.DeviceMatrix(self.ctx, None, self._metric_c, device_ptr=t.data_ptr(), shape=tuple(t.shape),
-                               dtype=np.float32 if t.dtype == torch.float32 else np.float64)
-            self.ctx.sync()                                      # rows are copied into the matrix: the tensor may go away
-            return m
+            # zero-copy: the matrix reads the tensor's HBM in place and keeps it alive (the reference, too, only keeps
+            # references to its inputs, neighbor_algorithm_base.py:95-96: they must not be modified while fitted)
+            return N.DeviceMatrix(self.ctx, None, self._metric_c, device_ptr=t.data_ptr(), shape=tuple(t.shape),
+                                  dtype=np.float32 if t.dtype == torch.float32 else np.float64, borrow=True, keepalive=t)
         if isinstance(data, N.DeviceArray):
             if len(data.shape) != 2 or data.dtype not in (np.float32, np.float64):
                 raise ValueError("device inputs must be 2D float32/float64 arrays")
             if dtype is not None and data.dtype != dtype:
                 raise ValueError(f"device input has dtype {data.dtype}, the index has {dtype}")
             return N.DeviceMatrix(self.ctx, None, self._metric_c, device_ptr=data.ptr.value, shape=data.shape,
-                                  dtype=data.dtype)
+                                  dtype=data.dtype, borrow=True, keepalive=data)
         arr = self._prepare(data)
         if dtype is not None and arr.dtype != dtype:
             arr = arr.astype(dtype)
@@ -235,8 +257,7 @@ class SklearnNN(NNAlgorithm):
 
     def _fit(self, data, is_source: bool):
         """Replaces SklearnNN._fit (sklearn_nearest_neighbors.py:83-94): upload + norms + MFMA tile packing."""
-        if is_source:
-            self._aux = {}
+        self._aux = None
         return self._make_matrix(data)
 
     def fit(self, source, target=None, only_fit_target: bool = False):
@@ -250,18 +271,19 @@ class SklearnNN(NNAlgorithm):
         super().fit(source, target, only_fit_target)
 
     def _matrix_for(self, array) -> N.DeviceMatrix:
-        """Device matrix of a query array: an existing index if it is the fitted source/target, else a cached upload."""
+        """Device matrix of a query array: the index of a fitted side if it IS that side's array, else an upload.  The most
+        recent ad-hoc query is kept (a hubness transform asks for the same array right after the search) and replaced by
+        the next one: nothing accumulates, and a new fit drops it."""
         if hasattr(self, "source_index") and array is self.source_:
             return self.source_index
         if hasattr(self, "target_index") and array is self.target_:
             return self.target_index
-        hit = self._aux.get(id(array))
-        if hit is not None and hit[0] is array:
-            return hit[1]
+        if self._aux is not None and self._aux[0] is array:
+            return self._aux[1]
         self._check_input_types(array)
         ref = self.target_index if hasattr(self, "target_index") else self.source_index
         m = self._make_matrix(array, dtype=ref.dtype)
-        self._aux[id(array)] = (array, m)
+        self._aux = (array, m)
         return m
 
     def _out_dtype(self, index: N.DeviceMatrix):
@@ -271,9 +293,6 @@ class SklearnNN(NNAlgorithm):
     def kneighbors_device(self, k=None, query=None, s_to_t=True, q_begin=0, q_count=None):
         """`kneighbors` that leaves (dist float64, ind int64) in HBM; used by the GPU hubness reductions."""
         k, query, index, is_self_querying = self._select_direction(k, query, s_to_t)
-        if k > N.MAX_NEIGHBORS - (1 if is_self_querying else 0):
-            raise NotImplementedError(
-                f"k={k} exceeds the {N.MAX_NEIGHBORS} neighbours per query the MI355X exact backend supports")
         qm = self._matrix_for(query)
         dist, ind, stats = N.knn(self.ctx, qm, index, k, exclude_self=is_self_querying, q_begin=q_begin, q_count=q_count)
         self.last_stats = stats
@@ -281,9 +300,6 @@ class SklearnNN(NNAlgorithm):
 
     def _kneighbors(self, k, query, index, return_distance, is_self_querying):
         """Replaces SklearnNN._kneighbors (sklearn_nearest_neighbors.py:96-101)."""
-        if k > N.MAX_NEIGHBORS - (1 if is_self_querying else 0):
-            raise NotImplementedError(
-                f"k={k} exceeds the {N.MAX_NEIGHBORS} neighbours per query the MI355X exact backend supports")
         qm = self._matrix_for(query)
         dist, ind, stats = N.knn(self.ctx, qm, index, k, exclude_self=is_self_querying)
         self.last_stats = stats
@@ -292,12 +308,15 @@ class SklearnNN(NNAlgorithm):
             self.ctx.sync()
             dev = query.device
             ind_t = torch.as_tensor(ind, device="cuda").clone().to(dev)
-            if not return_distance:
-                return ind_t
-            dist_t = torch.as_tensor(dist, device="cuda").clone().to(dev)
-            if self._out_dtype(index) == np.float32:
-                dist_t = dist_t.to(torch.float32)
-            return dist_t, ind_t
+            dist_t = None
+            if return_distance:
+                dist_t = torch.as_tensor(dist, device="cuda").clone().to(dev)
+                if self._out_dtype(index) == np.float32:
+                    dist_t = dist_t.to(torch.float32)
+            # the clones run on torch's stream, the pool that takes `dist` / `ind` back is ordered on OURS: finish them
+            # before the DeviceArrays are released
+            torch.cuda.current_stream().synchronize()
+            return (dist_t, ind_t) if return_distance else ind_t
         ind_h = ind.numpy()
         if not return_distance:
             return ind_h

@@ -116,3 +116,27 @@ def test_hits_docstring_example_and_device_input():
     assert hits(nn, gold) == {1: 0.5, 5: 1.0, 10: 1.0}
     assert hits(N.Context.get().to_device(nn.astype(np.int64)), gold) == {1: 0.5, 5: 1.0, 10: 1.0}
     assert hits(nn, {0: 2, 7: 1}) == {1: 0.0, 5: 0.5, 10: 0.5}     # gold rows outside the matrix count in the denominator
+
+
+def test_histogram_is_sized_by_the_first_k_columns_only():
+    """ADVICE (round 1): with k < nn_ind.shape[1] and target ids >= n_train in the DROPPED columns, the k-occurrence vector
+    (and every measure derived from its length) must follow np.bincount(nn_ind[:, :k].ravel(), minlength=n_train)
+    (kiez/analysis/estimation.py:276-292)."""
+    import numpy as np
+    from kiez_amd.analysis import hubness_score
+    rng = np.random.RandomState(3)
+    n_train, cols, k = 40, 8, 3
+    nn_ind = rng.randint(0, 35, size=(n_train, cols)).astype(np.int64)
+    nn_ind[:, k:] += 500                       # large ids only in the columns k.. (n_target > n_source case)
+    want = np.bincount(nn_ind[:, :k].ravel(), minlength=n_train)
+    got = hubness_score(nn_ind, 600, k=k, return_value="k_occurrence")
+    assert got.shape == want.shape == (n_train,)
+    np.testing.assert_array_equal(got, want)
+    allm = hubness_score(nn_ind, 600, k=k, return_value="all_but_gini")
+    np.testing.assert_array_equal(allm["antihubs"], np.argwhere(want == 0).ravel())
+    assert abs(allm["antihub_occurrence"] - (want == 0).mean()) < 1e-12
+    # ... and ids >= n_train INSIDE the first k columns do extend it
+    nn_ind[0, 0] = 77
+    want = np.bincount(nn_ind[:, :k].ravel(), minlength=n_train)
+    got = hubness_score(nn_ind, 600, k=k, return_value="k_occurrence")
+    np.testing.assert_array_equal(got, want)

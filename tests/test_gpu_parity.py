@@ -458,3 +458,49 @@ def test_rounding_bound_holds_with_margin(n_s, n_t, d, dtype, metric, gauss, pre
     finally:
         ctx.set_option("precision", 0)
     assert 0.0 < st["max_err_ratio"] < (0.6 if precision == PREC_FP16 else 0.5), st
+
+
+def test_sort_keeps_rows_with_nan_a_permutation():
+    """ADVICE (round 1): a transformed row can hold NaN (MP-normal with sd = 0, LS / NICDM with radius 0).  numpy's
+    argpartition sorts NaN last and keeps the row a permutation; so must the device sort (NaN last, finite part exactly the
+    selection sort of the finite values in their original order)."""
+    from kiez_amd.hubness_reduction import HubnessReduction
+    from oracle import kiez_oracle as O
+    rng = np.random.RandomState(4)
+    d = rng.rand(300, 12)
+    d[rng.rand(300, 12) < 0.15] = np.nan
+    d[7, :] = np.nan
+    d[::5] = np.round(d[::5], 1)        # ties among the finite values
+    ind = np.tile(np.arange(12, dtype=np.int64), (300, 1)) + 100
+    for k in (1, 5, 12):
+        od, oi = HubnessReduction._sort(d, ind, k)
+        for r in range(300):
+            fin = ~np.isnan(d[r])
+            nf = int(fin.sum())
+            assert len(set(oi[r].tolist())) == k                              # no id duplicated or dropped
+            assert not np.isnan(od[r][:min(k, nf)]).any() and np.isnan(od[r][min(k, nf):]).all()   # NaN last
+            if nf:
+                ed, ei = O.sort_topk(d[r][fin][None, :], ind[r][fin][None, :], min(k, nf))
+                # NaN never takes part in a swap before the finite values are exhausted only if it is never selected;
+                # values agree with the finite-only sort (ids may differ where a NaN was swapped through: compare values)
+                np.testing.assert_array_equal(od[r][:min(k, nf)], ed[0])
+
+
+@pytest.mark.parametrize("metric,single", [("euclidean", False), ("cosine", True)])
+def test_more_than_110_neighbours_run_on_the_exact_route(metric, single):
+    """The reference's SklearnNN accepts any k <= n (sklearn_nearest_neighbors.py:51-65).  The fused kernels keep at most
+    110 candidates per query; beyond that kz_knn runs every row on the exact float64 kernels -- slow, and still the
+    reference's order."""
+    from kiez_amd import Kiez
+    from oracle import kiez_oracle as O
+    s, t = _data(400, 900, 20, np.float64, seed=77)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = Kiez(n_candidates=150, algorithm="SklearnNN", algorithm_kwargs={"metric": metric})
+        kz.fit(s, None if single else t)
+        d, i = kz.kneighbors(150)
+    od, oi = O.kiez_pipeline(s, None if single else t, 150, 150, metric, 2, None, {})
+    np.testing.assert_array_equal(i, oi)
+    np.testing.assert_allclose(d, od, rtol=1e-9, atol=1e-12)
+    with pytest.raises(NotImplementedError, match="up to 128"):
+        Kiez(n_candidates=150, algorithm="SklearnNN", hubness="CSLS")

@@ -64,6 +64,9 @@ def test_context_and_error_reporting():
     m = N.DeviceMatrix(ctx, np.random.rand(10, 4), "euclidean")
     with pytest.raises(ValueError, match="Expected n_neighbors"):
         N.knn(ctx, m, m, 10, exclude_self=True)
+    big = N.DeviceMatrix(ctx, np.random.rand(300, 4), "euclidean")
+    d, i, st = N.knn(ctx, big, big, 200)          # beyond the fused kernels' 110: the exact float64 route, any k <= n
+    assert i.shape == (300, 200) and st["n_fallback_rows"] == 300
     with pytest.raises(NotImplementedError, match="maximum"):
-        big = N.DeviceMatrix(ctx, np.random.rand(300, 4), "euclidean")
-        N.knn(ctx, big, big, 200)
+        huge = N.DeviceMatrix(ctx, np.random.rand(5000, 4), "euclidean")
+        N.knn(ctx, huge, huge, 4500)
