@@ -6,7 +6,7 @@ from .hubness_reduction import (CSLS, DisSimLocal, HubnessReduction, LocalScalin
                                 NoHubnessReduction)
 from .kiez import Kiez, hubness_reduction_resolver, nn_algorithm_resolver
 from .neighbors import NNAlgorithm, NotFittedError, SklearnNN
-from . import analysis, evaluate  # noqa: F401  (hubness_score, hits: "next" rows of SURVEY.md §8 f)
+from . import analysis, evaluate, io  # noqa: F401  (hubness_score, hits, from_openea: "next" rows of SURVEY.md §8 f)
 
 __version__ = "0.1.0"
 __all__ = ["Kiez", "NNAlgorithm", "SklearnNN", "HubnessReduction", "NoHubnessReduction", "CSLS", "LocalScaling",
