@@ -77,7 +77,8 @@ struct kz_matrix {
                                 // (NULL until kz_matrix_image_bf)
     float* bias;      // [n_tiles*128] accumulator init: -|y|^2/2 (euclidean family), 0 (cosine), -inf (pad rows)
     double* sqn;      // [n] float64: squared norms (euclidean family) or norms with 0 -> 1 (cosine)
-    double max_norm;  // max_j |y_j|  (host copy)
+    double max_norm;  // max_j |y_j|  (host copy, valid once `checked`)
+    bool checked;     // the norm kernel's verdict (finite input, max_norm) has been read back (kz_matrix_check)
     double* d_stats;  // device [4]: max |y_j| (as max_norm), max |operand element| (normalised rows for cosine)
     kz_himage* himg;  // fp16 image (NULL until a kz_knn call builds it)
     size_t raw_bytes, packed_bytes, bias_bytes, sqn_bytes;
@@ -87,6 +88,7 @@ struct kz_matrix {
 int kz_matrix_image_f32(kz_matrix* m);
 int kz_matrix_image_bf(kz_matrix* m);
 int kz_himage_ensure(kz_matrix* query, kz_matrix* index);
+int kz_matrix_check(kz_matrix* m);
 void kz_himage_free(kz_matrix* m);
 
 void kz_set_error(const char* fmt, ...);

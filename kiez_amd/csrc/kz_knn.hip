@@ -268,7 +268,7 @@ struct KnnFinParams {
     int exclude_self;
     const int64_t* self_ids;  // optional: index row to strip per local query (escalated subsets); NULL = q_begin + q
     double gamma;         // rounding-bound factor (already multiplied by eps_scale)
-    double ymax;          // max index-row norm
+    const double* ystats; // index matrix: [0] max row norm (device)
     // fp16 first pass (kz_knn_h16.h): keys are in centred, scaled units; the bound uses the measured operand residuals
     int tier_h;
     double eps_mult;      // eps_scale (test knob)
@@ -535,7 +535,8 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         const double Yh = p.y_hmax[0], Ry = p.y_hmax[1], Yc2 = p.y_hmax[2];
         const double qc = sqrt(qc2), yc = sqrt(Yc2);
         // (the float64 re-rank evaluates |q|^2 + |y|^2 - 2 q.y on the UNCENTRED rows: its own round-off scales with those)
-        const double raw2 = p.metric == KZ_COSINE ? 2.0 : qs + p.ymax * p.ymax;
+        const double ymax = p.ystats[0];
+        const double raw2 = p.metric == KZ_COSINE ? 2.0 : qs + ymax * ymax;
         eps_q = p.eps_mult * (qr * Yh + qh * Ry + qr * Ry + p.gamma_acc * (0.5 * Yc2 + qh * Yh) +
                               1.1920928955078125e-07 * (qc + yc) * (qc + yc) + 1e-12 * (0.5 * Yc2 + qc2) + 1e-14 * raw2);
         key_scale = p.hscale[1];
@@ -543,7 +544,8 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     } else if (p.metric == KZ_COSINE) {
         eps_q = p.gamma * 1.001;
     } else {
-        const double scale = 0.5 * p.ymax * p.ymax + sqrt(qs) * p.ymax;
+        const double ymax = p.ystats[0];
+        const double scale = 0.5 * ymax * ymax + sqrt(qs) * ymax;
         eps_q = p.gamma * scale;
         // the relative bound assumes the products stay in the normal float32 range (data at the 1e-19 scale and below
         // underflows in the matrix pipe): such rows are left to the exact float64 kernels
@@ -1101,7 +1103,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fp.exclude_self = exclude_self ? 1 : 0;
         fp.self_ids = d_self_ids;
         fp.gamma = tier == KZ_TIER_BF ? gamma_bf : gamma_f32;
-        fp.ymax = index->max_norm;
+        fp.ystats = index->d_stats;
         fp.tier_h = tier == KZ_TIER_H ? 1 : 0;
         if (fp.tier_h) {
             fp.eps_mult = ctx->eps_scale;
@@ -1139,7 +1141,22 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         KZ_HIP(hipGetLastError());
         KZ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
         KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        // matrices created from device rows have not had their finiteness verdict read yet (kz_matrix_create waits for
+        // nothing): it rides on this call's read-back
+        kz_matrix* unchecked[2] = {query->checked ? nullptr : query, (index->checked || index == query) ? nullptr : index};
+        for (int u = 0; u < 2; ++u)
+            if (unchecked[u])
+                KZ_HIP(hipMemcpyAsync(ctx->h_counters + 44 + 10 * u, unchecked[u]->d_stats, 40, hipMemcpyDeviceToHost, ctx->stream));
         KZ_HIP(hipStreamSynchronize(ctx->stream));
+        for (int u = 0; u < 2; ++u) {
+            if (!unchecked[u]) continue;
+            if (ctx->h_counters[44 + 10 * u + 8] != 0) {
+                kz_set_error("kz_matrix_create: input contains NaN, infinity or a value too large for float32");
+                return KZ_ERR_NONFINITE;
+            }
+            memcpy(&unchecked[u]->max_norm, ctx->h_counters + 44 + 10 * u, 8);
+            unchecked[u]->checked = true;
+        }
         const int n_fail = exact_only ? (int)cq_count : ctx->h_counters[8];
         {
             double ratio;

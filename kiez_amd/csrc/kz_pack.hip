@@ -413,6 +413,22 @@ int kz_himage_ensure(kz_matrix* query, kz_matrix* index) {
     return rc;
 }
 
+// Wait for the matrix' norm kernel and read its verdict: max row norm (host copy for the lower tiers' bound) and the
+// non-finite flag.  Idempotent; called by kz_matrix_create (host rows) or by the first kz_knn that uses the matrix.
+int kz_matrix_check(kz_matrix* m) {
+    if (m->checked) return KZ_OK;
+    kz_ctx* ctx = m->ctx;
+    KZ_HIP(hipMemcpyAsync(ctx->h_counters, m->d_stats, 40, hipMemcpyDeviceToHost, ctx->stream));
+    KZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_counters[8] != 0) {
+        kz_set_error("kz_matrix_create: input contains NaN, infinity or a value too large for float32");
+        return KZ_ERR_NONFINITE;
+    }
+    memcpy(&m->max_norm, ctx->h_counters, 8);
+    m->checked = true;
+    return KZ_OK;
+}
+
 extern "C" {
 
 // rows_on_device: 0 = host rows (copied), 1 = device rows (copied), 2 = device rows BORROWED: the matrix keeps the
@@ -476,17 +492,19 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
         hipLaunchKernelGGL(kz_norms_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw, n,
                            (int)d, metric, n_pad, m->bias, m->sqn, st, bad);
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_counters, m->d_stats, 40, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         kz_set_error("kz_matrix_create: norm kernel failed: %s", hipGetErrorString(e));
         return fail(KZ_ERR_HIP);
     }
-    if (ctx->h_counters[8] != 0) {
-        kz_set_error("kz_matrix_create: input contains NaN, infinity or a value too large for float32");
-        return fail(KZ_ERR_NONFINITE);
+    // Host rows: the copy above was synchronous anyway, so the finiteness verdict is checked here and the caller gets
+    // KZ_ERR_NONFINITE from the call that passed the data (scikit-learn rejects such input in fit, too).  Device rows:
+    // NOTHING is waited for -- the matrix is usable at once, the verdict stays in d_stats and is checked by the first kz_knn
+    // that searches the matrix (its result read-back synchronises anyway): fit() enqueues both matrices and the reverse
+    // pass back to back.
+    if (rows_on_device == 0) {
+        const int rc = kz_matrix_check(m);
+        if (rc != KZ_OK) return fail(rc);
     }
-    memcpy(&m->max_norm, ctx->h_counters, 8);
     *out = m;
     return KZ_OK;
 }

@@ -29,6 +29,15 @@ for hub in (None, "CSLS", "DisSimLocal"):
         assert d.device.type == dev and i.dtype == torch.int64
         assert np.array_equal(i.cpu().numpy(), oi), (hub, dev)
         assert np.allclose(d.cpu().numpy(), od, rtol=1e-5, atol=5e-6), (hub, dev)
+# device-resident rows are indexed without waiting for anything (zero-copy, asynchronous kz_matrix_create): a non-finite
+# value is reported by the first search instead of by fit's index construction
+bad = torch.from_numpy(s).to("cuda").clone()
+bad[3, 2] = float("nan")
+try:
+    Kiez(n_candidates=10, algorithm="SklearnNN", algorithm_kwargs={"metric": "euclidean"}).fit(bad, torch.from_numpy(t).to("cuda")).kneighbors(5)
+    raise SystemExit("NaN input was not rejected")
+except ValueError as e:
+    assert "NaN" in str(e), e
 print("TORCH_INPUTS_OK")
 """
 
