@@ -107,16 +107,22 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     pool.tiles_done = 0;
     pool.next_merge = 1;
 
-    // LDS-DMA of one 4 KiB slice: lane l of wave w copies 16 B from src + (64 w + l) * 16 to the same offset of the slot;
-    // one wave-instruction per wave and slice
-    const float* ysrc = p.ypack + ((int64_t)t_begin * NSR) * 1024 + tid * 4;
-    auto dma_slice = [&](int gi) {
-        const float* src = ysrc + (int64_t)min(gi, total - 1) * 1024;
-        float* dst = ybuf + (gi & (R - 1)) * 1024 + wave * 256;  // wave-uniform LDS base (floats)
-        kz_glds16(src, dst);
+    // LDS-DMA of one 4 KiB slice: lane l of wave w copies 16 B from slice base + (64 w + l) * 16 to the same offset of the
+    // slot; one wave-instruction per wave and slice.  The source is a wave-uniform running pointer (scalar base + lane
+    // offset: two scalar adds per slice instead of a clamped 64-bit index computation); slices are issued strictly in
+    // order, and the ring runs up to R + P slices past the end of the sweep -- into the next tiles of the image or into
+    // the padding kz_himage_build allocates behind it (those slots are never read).
+    const char* dma_src = reinterpret_cast<const char*>(p.ypack) + ((int64_t)t_begin * NSR) * 4096;   // uniform
+    const int lane_off = tid * 16;
+    int dma_slot = 0;   // uniform: slot of the next slice to issue
+    auto dma_next = [&]() {
+        float* dst = ybuf + dma_slot * 1024 + wave * 256;  // wave-uniform LDS base (floats)
+        kz_glds16(reinterpret_cast<const float*>(dma_src + lane_off), dst);
+        dma_src += 4096;
+        dma_slot = (dma_slot + 1) & (R - 1);
     };
 #pragma unroll
-    for (int i = 0; i < R; ++i) dma_slice(i);
+    for (int i = 0; i < R; ++i) dma_next();
     bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
     if (tid < 4) msync[tid] = 0;
     // stationary query fragments: lane (j, h) holds k = 16 u + 8 h + 0..7 of query row 32 wave + j
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 #pragma unroll
-                for (int i = 0; i < P; ++i) dma_slice(g + P + LAG + i);
+                for (int i = 0; i < P; ++i) dma_next();   // slices g+P+LAG .. g+2P+LAG-1, in order
             }
             ++g;
         }

@@ -364,7 +364,8 @@ static int kz_himage_build(kz_matrix* m, kz_center* center) {
     m->himg = im;
     const int nsr = m->kg / 4;
     const int64_t n_pad = m->n_tiles * KZ_TILE;
-    if (kz_pool_alloc(ctx, (size_t)n_pad * (size_t)nsr * 32, (void**)&im->packed) != KZ_OK ||
+    // (+ 32 slices of padding: the kernel's DMA ring runs a few slices past the end of a sweep, kz_knn_h16.h)
+    if (kz_pool_alloc(ctx, (size_t)n_pad * (size_t)nsr * 32 + 32 * 4096, (void**)&im->packed) != KZ_OK ||
         kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&im->bias) != KZ_OK ||
         kz_pool_alloc(ctx, (size_t)m->n * 24, (void**)&im->rowq) != KZ_OK || kz_pool_alloc(ctx, 32, (void**)&im->d_max) != KZ_OK) {
         kz_himage_free(m);
