@@ -10,6 +10,11 @@ __device__ __forceinline__ void kz_glds16(const float* gsrc, float* lds_wave_bas
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// ... and the 4-byte form: lane l copies one dword to (wave-uniform LDS base) + l*4
+__device__ __forceinline__ void kz_glds4(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
 __device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-temporal 16-byte load (streaming cache policy)
     const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
     return make_float4(v.x, v.y, v.z, v.w);

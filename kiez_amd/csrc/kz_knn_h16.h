@@ -165,11 +165,13 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
                 }
             }
         }
-        // bias rows of the next tile: one 4-byte load per thread and tile, parked in LDS after the first slice; pinned
-        // BEHIND the accumulator init (hipcc orders every ds_read after an LDS-DMA behind s_waitcnt vmcnt(0): hoisted
-        // above the init this fresh load would be waited for at every tile start)
+        // bias rows of the next tile: 128 floats by LDS-DMA (waves 0 and 1, one dword per lane), issued at the start of this
+        // tile -- every tile contains a slice barrier behind this point, whose vmcnt(0) + s_barrier make them visible to
+        // all waves before the next tile reads them.  No VGPR round trip, no extra wait.  Pinned BEHIND the accumulator
+        // init (hipcc orders every ds_read after an LDS-DMA behind s_waitcnt vmcnt(0)).
         __builtin_amdgcn_sched_barrier(0);
-        const float bn = p.ybias[(int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + (tid & 127)];
+        if (wave < 2)
+            kz_glds4(p.ybias + (int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + tid, bbuf + ((tile + 1) & 1) * 128 + wave * 64);
         constexpr bool carry_in = !ONE_SET && (CARRY || (P0 == 1 && (NSR & 1)));
         constexpr bool carry_out = !ONE_SET && (CARRY || (((P0 + NSR) & 1) != 0));
         if (!carry_in && !ONE_SET) {
@@ -195,7 +197,6 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[mt], qf[u], acc[mt], 0, 0, 0);
-            if (u == 0) bbuf[((tile + 1) & 1) * 128 + (tid & 127)] = bn;
             // One barrier per P slices, after the slices g with (g + 2) % P == 0.  Every wave that passes it has the
             // fragments of all slices <= g + 1 in registers (lgkmcnt(0)), so the slots of slices g-P+2 .. g+1 take
             // slices g+P+2 .. g+2P+1.  The next period prefetches slices g+2 .. g+P+1: those were issued at the PREVIOUS
