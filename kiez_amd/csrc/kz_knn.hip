@@ -401,15 +401,24 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     const int halves = p.lay.halves;
     const int M = n_pieces * halves * KP;
     // entry e of this query: piece e / (halves KP), lane-half (e / KP) % halves, list entry e % KP  (kz_list_wave_base)
-    const int64_t lwave = kz_list_wave_base(lrow, p.lay, KP, 0) + (lrow & 31);
-    for (int e = lane; e < M; e += 64) {
-        const int piece = e / (halves * KP);
-        const int rem = e - piece * halves * KP;
-        const int hh = rem / KP;
-        const int ee = rem - hh * KP;
-        const int64_t off = lwave + ((int64_t)piece * KP + ee) * KZ_LSTRIDE + hh * 32;
-        ekey[e] = p.in_key[off];
-        eidx[e] = p.in_idx[off];
+    if (p.lay.contig) {
+        // fp16 kernel: the query's pieces x K' entries are one contiguous run
+        const int64_t l0 = kz_list_contig_off(lrow, p.lay, KP, 0);
+        for (int e = lane; e < M; e += 64) {
+            ekey[e] = p.in_key[l0 + e];
+            eidx[e] = p.in_idx[l0 + e];
+        }
+    } else {
+        const int64_t lwave = kz_list_wave_base(lrow, p.lay, KP, 0) + (lrow & 31);
+        for (int e = lane; e < M; e += 64) {
+            const int piece = e / (halves * KP);
+            const int rem = e - piece * halves * KP;
+            const int hh = rem / KP;
+            const int ee = rem - hh * KP;
+            const int64_t off = lwave + ((int64_t)piece * KP + ee) * KZ_LSTRIDE + hh * 32;
+            ekey[e] = p.in_key[off];
+            eidx[e] = p.in_idx[off];
+        }
     }
     kz_wave_sync();
 
@@ -980,12 +989,15 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 lay.qt_end[r] = q0 + reg_nq[r];
                 lay.pieces[r] = split_cnt(reg_s[r]);
                 lay.base[r] = (long long)list_elems;
-                list_elems += (size_t)reg_nq[r] * KZ_TILE * (size_t)(lay.pieces[r] * 2 * KP);
+                // entries per (query, index range): K' in the contiguous layout, 2 K' in the interleaved one (two lane-half
+                // columns per list block, also where only one is used)
+                list_elems += (size_t)reg_nq[r] * KZ_TILE * (size_t)(lay.pieces[r] * (tier == KZ_TIER_H ? 1 : 2) * KP);
                 W += reg_nq[r] * lay.pieces[r];
                 q0 += reg_nq[r];
             }
             lay.n_regions = n_reg;
             lay.halves = tier == KZ_TIER_F32 ? 2 : 1;
+            lay.contig = tier == KZ_TIER_H ? 1 : 0;
         }
         const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
         const size_t fail_bytes = ((size_t)cq_count * 4 + 255) & ~(size_t)255;

@@ -48,6 +48,8 @@ struct KzListLayout {
     int pieces[KZ_MAX_REGIONS];      // index-range pieces per query tile
     int halves;                      // lists per (query, piece): 2 = one per lane half (float32 kernels), 1 = one shared
                                      // by both lane halves (split-bf16 kernels; column h = 1 of a list block is unused)
+    int contig;                      // 1: every list is K' CONTIGUOUS entries (fp16 kernel, kz_list_contig_off); 0: the
+                                     // wave-interleaved layout below
     long long base[KZ_MAX_REGIONS];  // element offset of the region's first list
 };
 __host__ __device__ __forceinline__ int kz_list_region(int64_t list_row, const KzListLayout& L) {
@@ -66,6 +68,16 @@ __host__ __device__ __forceinline__ int64_t kz_list_wave_base(int64_t list_row, 
     const int64_t row0 = r > 0 ? (int64_t)L.qt_end[r - 1] * KZ_TILE : 0;
     const int64_t wb = (list_row - row0) >> 5;  // 32 queries per wave
     return L.base[r] + ((wb * L.pieces[r] + piece) * (int64_t)KP) * KZ_LSTRIDE;
+}
+
+// Contiguous layout (fp16 kernel): offset(list_row, piece, entry e) = kz_list_contig_off(...) + e.  With the event pool a
+// merge inserts for a FEW lanes at a time; an insert re-reads one block of K'/8 keys: 32 contiguous bytes here, against
+// eight 128-byte lines in the interleaved layout (C3, K' = 64, lists in the output arrays: 337 GB of fabric reads per
+// launch, profiles/r02_c3_pmc.jsonl) -- and the finalize kernel gathers a query's entries as one contiguous run.
+__host__ __device__ __forceinline__ int64_t kz_list_contig_off(int64_t list_row, const KzListLayout& L, int KP, int piece) {
+    const int r = kz_list_region(list_row, L);
+    const int64_t row0 = r > 0 ? (int64_t)L.qt_end[r - 1] * KZ_TILE : 0;
+    return L.base[r] + ((list_row - row0) * L.pieces[r] + piece) * (int64_t)KP;
 }
 
 struct KnnCandParams {

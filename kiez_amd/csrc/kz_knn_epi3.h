@@ -23,7 +23,7 @@ typedef __attribute__((address_space(3))) int kz_lds_i32;
 typedef float f32x4e __attribute__((ext_vector_type(4)));
 typedef int i32x2e __attribute__((ext_vector_type(2)));
 
-// list storage: LDS ([entry][128 queries of the workgroup]) or the output arrays (wave-interleaved, KZ_LSTRIDE)
+// list storage: LDS ([entry][128 queries of the workgroup]) or the output arrays (K' contiguous entries per list)
 template <bool IN_LDS>
 struct KzListRef;
 template <>
@@ -36,7 +36,7 @@ template <>
 struct KzListRef<false> {
     float* k;
     int* i;
-    static constexpr int STRIDE = KZ_LSTRIDE;
+    static constexpr int STRIDE = 1;
 };
 
 // Per-lane candidate state (one lane = one (query, lane-half) pair) ...

@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
 
-    // this query's list in the output arrays (ONE list per query: halves = 1)
-    auto out_list_offset = [&]() { return kz_list_wave_base((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s) + j; };
+    // this query's list in the output arrays (ONE list per query and index range, K' contiguous entries)
+    auto out_list_offset = [&]() { return kz_list_contig_off((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s); };
     KzCandState3<IN_LDS> st;
     if constexpr (IN_LDS) {
         st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF) + 32 * (tid >> 6) + j;
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
             const int64_t listoff = out_list_offset();
             if (h == 0)
                 for (int e = 0; e < KP; ++e) {
-                    p.out_key[listoff + e * KZ_LSTRIDE] = -INFINITY;
-                    p.out_idx[listoff + e * KZ_LSTRIDE] = -1;
+                    p.out_key[listoff + e] = -INFINITY;
+                    p.out_idx[listoff + e] = -1;
                 }
         }
         return;
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         if (h == 0) {
 #pragma unroll 4
             for (int e = 0; e < KP; ++e) {
-                p.out_key[listoff + e * KZ_LSTRIDE] = st.list.k[e * 128];
-                p.out_idx[listoff + e * KZ_LSTRIDE] = st.list.i[e * 128];
+                p.out_key[listoff + e] = st.list.k[e * 128];
+                p.out_idx[listoff + e] = st.list.i[e * 128];
             }
         }
     }
