@@ -124,10 +124,42 @@ __device__ __forceinline__ double kz_wave_sum(double acc) {
     return acc;
 }
 
+// Order of the canonical dot product: the row is cut into chunks of 256 elements; inside a chunk lane l owns elements
+// 4l .. 4l+3 (one 16-byte load for float32 rows), accumulated in increasing k by an fma chain per lane; then the butterfly
+// sum.  kz_row4 fetches a lane's four elements of a chunk (vector load when the row allows it, scalar loads with zero fill
+// at the tail: the fma of a zero leaves the chain unchanged, so both paths give identical bits).
+template <typename T>
+__device__ __forceinline__ void kz_row4(const T* __restrict__ row, int k0, int d, bool vec, double (&out)[4]) {
+    if (vec && k0 + 3 < d) {
+        if (sizeof(T) == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(row + k0);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else {
+            const double2 v0 = *reinterpret_cast<const double2*>(row + k0), v1 = *reinterpret_cast<const double2*>(row + k0 + 2);
+            out[0] = v0.x; out[1] = v0.y; out[2] = v1.x; out[3] = v1.y;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[u] = k0 + u < d ? (double)row[k0 + u] : 0.0;
+    }
+}
+// a row may be read with 16-byte loads when its start and its pitch are 16-byte aligned
+template <typename T>
+__device__ __forceinline__ bool kz_row_vec_ok(const T* base, int d) {
+    return ((reinterpret_cast<uintptr_t>(base) | ((uintptr_t)d * sizeof(T))) & 15u) == 0;
+}
+
 template <typename T>
 __device__ __forceinline__ double kz_wave_dot(const T* __restrict__ a, const T* __restrict__ b, int d, int lane) {
+    const bool vec = kz_row_vec_ok(a, d) && kz_row_vec_ok(b, d);
     double acc = 0.0;
-    for (int k = lane; k < d; k += 64) acc = fma((double)a[k], (double)b[k], acc);
+    for (int k0 = 4 * lane; k0 < d; k0 += 256) {
+        double x[4], y[4];
+        kz_row4(a, k0, d, vec, x);
+        kz_row4(b, k0, d, vec, y);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = fma(x[u], y[u], acc);
+    }
     return kz_wave_sum(acc);
 }
 
@@ -135,7 +167,14 @@ __device__ __forceinline__ double kz_wave_dot(const T* __restrict__ a, const T* 
 template <typename T>
 __device__ __forceinline__ double kz_wave_dot_normalized(const T* __restrict__ a, double na, const T* __restrict__ b,
                                                          double nb, int d, int lane) {
+    const bool vec = kz_row_vec_ok(a, d) && kz_row_vec_ok(b, d);
     double acc = 0.0;
-    for (int k = lane; k < d; k += 64) acc = fma((double)a[k] / na, (double)b[k] / nb, acc);
+    for (int k0 = 4 * lane; k0 < d; k0 += 256) {
+        double x[4], y[4];
+        kz_row4(a, k0, d, vec, x);
+        kz_row4(b, k0, d, vec, y);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = fma(x[u] / na, y[u] / nb, acc);
+    }
     return kz_wave_sum(acc);
 }

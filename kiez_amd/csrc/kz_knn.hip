@@ -334,14 +334,13 @@ __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* si
     }
 }
 
-constexpr int KZ_FIN_ROWS = 4;     // candidate rows re-ranked together by one wave
+constexpr int KZ_FIN_ROWS = 4;     // candidate rows re-ranked together by one wave (same-box A/B: 4 rows at 5 waves per SIMD beat 8 rows at 4)
 constexpr int KZ_FIN_MAXM = 4096;  // list entries per query: 4 waves x (4096*8 + 128*28) B = 142 KiB of LDS at most
 constexpr int KZ_MAX_PIECES = 64;  // index ranges per query tile (each range keeps its own K'-entry list per query)
 static int kz_max_pieces(int KP, int halves) {
     const int m = KZ_FIN_MAXM / (halves * KP);
     return m < KZ_MAX_PIECES ? m : KZ_MAX_PIECES;
 }
-constexpr int KZ_FIN_MAXKP = 128;
 
 // Per-wave LDS of the finalize kernel for a launch whose queries hold at most max_m list entries.
 __host__ __device__ __forceinline__ int kz_fin_wave_bytes(int max_m, int KP) {
@@ -473,60 +472,6 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     const T* qptr = reinterpret_cast<const T*>(p.qraw) + qrow * (int64_t)p.d;
     const double qs = p.qsqn[qrow];
 
-    // exact float64 re-rank of the V candidates, KZ_FIN_ROWS rows in flight per pass (independent gathers and butterfly sums overlap) (the per-candidate arithmetic is exactly
-    // kz_wave_dot: per-lane fma chain over k = lane, lane+64, ... then the butterfly sum)
-    const T* yraw = reinterpret_cast<const T*>(p.yraw);
-    for (int c0 = 0; c0 < V; c0 += KZ_FIN_ROWS) {
-        const T* yp[KZ_FIN_ROWS];
-        double ys[KZ_FIN_ROWS], acc[KZ_FIN_ROWS];
-#pragma unroll
-        for (int u = 0; u < KZ_FIN_ROWS; ++u) {
-            const int yi = ci[min(c0 + u, V - 1)];
-            yp[u] = yraw + (int64_t)yi * p.d;
-            ys[u] = p.ysqn[yi];
-            acc[u] = 0.0;
-        }
-        if (p.metric == KZ_COSINE) {
-            for (int k = lane; k < p.d; k += 64) {
-                const double qk = (double)qptr[k] / qs;
-#pragma unroll
-                for (int u = 0; u < KZ_FIN_ROWS; ++u) acc[u] = fma(qk, (double)yp[u][k] / ys[u], acc[u]);
-            }
-        } else {
-            for (int k = lane; k < p.d; k += 64) {
-                const double qk = (double)qptr[k];
-#pragma unroll
-                for (int u = 0; u < KZ_FIN_ROWS; ++u) acc[u] = fma(qk, (double)yp[u][k], acc[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < KZ_FIN_ROWS; ++u) {
-            const double dot = kz_wave_sum(acc[u]);
-            double v;
-            if (p.metric == KZ_COSINE) {
-                v = fmin(fmax(1.0 - dot, 0.0), 2.0);  // sklearn cosine_distances: S *= -1; S += 1; clip(0, 2)
-            } else {
-                v = fmax((qs + ys[u]) - 2.0 * dot, 0.0);  // |x|^2 - 2 x.y + |y|^2, clamped (_argkmin.pyx.tp:494-502)
-            }
-            if (lane == 0 && c0 + u < V) cv[c0 + u] = v;
-        }
-    }
-    kz_wave_sync();
-    // rank by (value asc, idx asc) and scatter into sorted order
-    for (int c = lane; c < V; c += 64) {
-        const double v = cv[c];
-        const int id = ci[c];
-        int rank = 0;
-        for (int o = 0; o < V; ++o) {
-            const double ov = cv[o];
-            const int oid = ci[o];
-            rank += (ov < v || (ov == v && oid < id)) ? 1 : 0;
-        }
-        sv[rank] = v;
-        si[rank] = id;
-    }
-    kz_wave_sync();
-
     // Rounding bound of this query's approximate keys and the exact key of a candidate from its exact value.
     //   float32 / split-bf16 operands: |key~ - key| <= gamma (|y|max^2 / 2 + |q| |y|max), key = (|q|^2 - d^2) / 2 (euclidean
     //   family) or 1 - dist (cosine);
@@ -565,12 +510,88 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         return 0.5 * (qref - (p.metric == KZ_COSINE ? 2.0 * v : v));
     };
 
+    // Which candidates need an exact distance?  Those that can still be among the exact top-k: a candidate c with
+    // key~_c < key~_(k) - 2 eps has key_c <= key~_c + eps < key~_(k) - eps <= (k-th best exact key of the re-ranked ones),
+    // so it is out.  The list is ordered by approximate key: the re-rank covers a prefix of Vr >= k_eff candidates (K' = 64,
+    // k = 50: ~52 gathered rows instead of 64).  The certification below re-checks the first pruned candidate.
+    int Vr = V;
+    if (V > k_eff && eps_q < INFINITY) {
+        const double thr = (double)ck[k_eff - 1] * key_scale - 2.0 * eps_q;
+        int cnt = 0;
+        for (int c = lane; c < V; c += 64) cnt += ((double)ck[c] * key_scale >= thr) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        Vr = cnt < k_eff ? k_eff : cnt;
+    }
+
+    // exact float64 re-rank of the Vr candidates, KZ_FIN_ROWS rows in flight per pass (independent gathers and butterfly sums
+    // overlap); the per-candidate arithmetic is exactly kz_wave_dot / kz_wave_dot_normalized (kz_common.h)
+    const T* yraw = reinterpret_cast<const T*>(p.yraw);
+    const bool vec = kz_row_vec_ok(qptr, p.d) && kz_row_vec_ok(yraw, p.d);
+    for (int c0 = 0; c0 < Vr; c0 += KZ_FIN_ROWS) {
+        const T* yp[KZ_FIN_ROWS];
+        double ys[KZ_FIN_ROWS], acc[KZ_FIN_ROWS];
+#pragma unroll
+        for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+            const int yi = ci[min(c0 + u, Vr - 1)];
+            yp[u] = yraw + (int64_t)yi * p.d;
+            ys[u] = p.ysqn[yi];
+            acc[u] = 0.0;
+        }
+        for (int k0 = 4 * lane; k0 < p.d; k0 += 256) {
+            double qk[4];
+            kz_row4(qptr, k0, p.d, vec, qk);
+            if (p.metric == KZ_COSINE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qk[e] = qk[e] / qs;
+            }
+#pragma unroll
+            for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+                double yk[4];
+                kz_row4(yp[u], k0, p.d, vec, yk);
+                if (p.metric == KZ_COSINE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[u] = fma(qk[e], yk[e] / ys[u], acc[u]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[u] = fma(qk[e], yk[e], acc[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+            const double dot = kz_wave_sum(acc[u]);
+            double v;
+            if (p.metric == KZ_COSINE) {
+                v = fmin(fmax(1.0 - dot, 0.0), 2.0);  // sklearn cosine_distances: S *= -1; S += 1; clip(0, 2)
+            } else {
+                v = fmax((qs + ys[u]) - 2.0 * dot, 0.0);  // |x|^2 - 2 x.y + |y|^2, clamped (_argkmin.pyx.tp:494-502)
+            }
+            if (lane == 0 && c0 + u < Vr) cv[c0 + u] = v;
+        }
+    }
+    kz_wave_sync();
+    // rank by (value asc, idx asc) and scatter into sorted order
+    for (int c = lane; c < Vr; c += 64) {
+        const double v = cv[c];
+        const int id = ci[c];
+        int rank = 0;
+        for (int o = 0; o < Vr; ++o) {
+            const double ov = cv[o];
+            const int oid = ci[o];
+            rank += (ov < v || (ov == v && oid < id)) ? 1 : 0;
+        }
+        sv[rank] = v;
+        si[rank] = id;
+    }
+    kz_wave_sync();
+
     // Self-check of the bound the certification rests on: for every candidate both the approximate key (ck, from the
     // fused kernel) and the exact key (from the float64 re-rank) are known here.
     bool bound_violated = false;
     if (eps_q > 0.0 && eps_q < INFINITY && p.err_ratio_bits) {
         double worst = 0.0;
-        for (int c = lane; c < V; c += 64) {
+        for (int c = lane; c < Vr; c += 64) {
             const double v = cv[c];
             if (v > 0.0)  // (a distance clamped at 0 no longer carries the exact key)
                 worst = fmax(worst, fabs((double)ck[c] * key_scale - exact_key(v)) / eps_q);
@@ -594,6 +615,8 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         certified = (V >= min((int64_t)k_eff, p.n_i));
     else
         certified = (double)ck[KP - 1] * key_scale + eps_q < exact_key(sv[k_eff - 1]);
+    // ... and the candidates that were not re-ranked are out by the same argument (implied by how Vr was chosen; re-checked)
+    if (Vr < V && !((double)ck[Vr] * key_scale + eps_q < exact_key(sv[k_eff - 1]))) certified = false;
     // An approximate key further than eps from its exact value contradicts the bound everything above rests on (a kernel
     // or hardware fault, not a property of the data): do not trust this row's candidate set, send it down a tier.
     if (bound_violated) certified = false;
@@ -604,7 +627,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         }
         return;
     }
-    kz_emit_sorted<T>(sv, si, V, p.k, p.exclude_self, p.self_ids ? p.self_ids[q] : qrow, p.metric,
+    kz_emit_sorted<T>(sv, si, Vr, p.k, p.exclude_self, p.self_ids ? p.self_ids[q] : qrow, p.metric,
                       p.out_dist + q * (int64_t)p.k, p.out_ind + q * (int64_t)p.k, lane);
 }
 
@@ -612,7 +635,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 // cache lines of one wave-interleaved block) measured 2x SLOWER than 4: finalize is latency-bound and wants many workgroups.
 constexpr int KZ_FIN_QPB = 4;
 #ifndef KZ_FIN_WAVES
-#define KZ_FIN_WAVES 8  // waves per SIMD the finalize kernel is compiled for (latency-bound gathers: occupancy matters)
+#define KZ_FIN_WAVES 4  // minimum waves per SIMD the finalize kernel is compiled for: the 16-byte row loads need ~86 VGPRs (5 waves); at 8 waves / 64 VGPRs they spill
 #endif
 template <typename T>
 __global__ __launch_bounds__(256, KZ_FIN_WAVES) void kz_knn_finalize_kernel(KnnFinParams p) {
