@@ -10,10 +10,25 @@ __device__ __forceinline__ void kz_glds16(const float* gsrc, float* lds_wave_bas
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-// ... and the 4-byte form: lane l copies one dword to (wave-uniform LDS base) + l*4
-__device__ __forceinline__ void kz_glds4(const float* gsrc, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+// The same with the address split the way the instruction takes it -- scalar 64-bit base + 32-bit per-lane byte offset
+// (saddr form) -- and the LDS base placed in M0 by hand.  hipcc otherwise materialises base + offset as a 64-bit VGPR pair
+// per lane and keeps it alive (and, at 168 VGPRs, spills and reloads it at every barrier).  Inline asm is invisible to
+// hipcc's waitcnt pass: it only ever under-counts the wave's outstanding operations, which makes its own vmcnt waits
+// stricter, never looser; completion of these copies is awaited explicitly (vmcnt(0) in front of the slice barrier).
+__device__ __forceinline__ void kz_glds16_s(const void* sbase_uniform, unsigned lane_byte_off, float* lds_wave_base) {
+    const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :
+                 : "s"(lds), "v"(lane_byte_off), "s"(sbase_uniform)
+                 : "memory", "m0");
+}
+// ... and the 4-byte form: lane l copies one dword from scalar base + its byte offset to (wave-uniform LDS base) + l*4
+__device__ __forceinline__ void kz_glds4_s(const void* sbase_uniform, unsigned lane_byte_off, float* lds_wave_base) {
+    const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                 :
+                 : "s"(lds), "v"(lane_byte_off), "s"(sbase_uniform)
+                 : "memory", "m0");
 }
 __device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-temporal 16-byte load (streaming cache policy)
     const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));

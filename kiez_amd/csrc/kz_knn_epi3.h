@@ -31,12 +31,17 @@ struct KzListRef<true> {
     kz_lds_f32* k;
     kz_lds_i32* i;
     static constexpr int STRIDE = 128;
+    __device__ __forceinline__ kz_lds_f32* kp() const { return k; }
+    __device__ __forceinline__ kz_lds_i32* ip() const { return i; }
 };
 template <>
 struct KzListRef<false> {
-    float* k;
-    int* i;
+    float* kb;      // wave-uniform bases of the output arrays ...
+    int* ib;
+    unsigned off;   // ... and this query's first list entry (element offset)
     static constexpr int STRIDE = 1;
+    __device__ __forceinline__ float* kp() const { return kb + off; }
+    __device__ __forceinline__ int* ip() const { return ib + off; }
 };
 
 // Per-lane candidate state (one lane = one (query, lane-half) pair) ...
@@ -89,7 +94,7 @@ __device__ __forceinline__ void kz_list_insert3(const KzListRef<IN_LDS>& L, KzBl
             b = i;
         }
     }
-    auto* blk = L.k + (b * BS) * S;
+    auto* blk = L.kp() + (b * BS) * S;
     float kk[BS];
 #pragma unroll
     for (int jj = 0; jj < BS; ++jj) kk[jj] = blk[jj * S];
@@ -97,7 +102,7 @@ __device__ __forceinline__ void kz_list_insert3(const KzListRef<IN_LDS>& L, KzBl
 #pragma unroll
     for (int jj = BS - 2; jj >= 0; --jj) pos = (kk[jj] == m) ? jj : pos;   // first key equal to the block minimum
     blk[pos * S] = v;
-    L.i[(b * BS + pos) * S] = idx;
+    L.ip()[(b * BS + pos) * S] = idx;
     float nm = INFINITY;
 #pragma unroll
     for (int jj = 0; jj < BS; ++jj) nm = fminf(nm, (jj == pos) ? v : kk[jj]);

@@ -74,9 +74,11 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF) + 32 * (tid >> 6) + j;
         st.list.i = (kz_lds_i32*)(smem + Cfg::LIST_OFF + KP * 128 * 4) + 32 * (tid >> 6) + j;
     } else {
-        const int64_t listoff = out_list_offset();
-        st.list.k = p.out_key + listoff;
-        st.list.i = p.out_idx + listoff;
+        // (uniform bases + a 32-bit per-lane element offset: no 64-bit per-lane pointers to keep alive; a launch's lists stay
+        //  far below 2^32 elements: <= 524288 rows x 64 ranges x K')
+        st.list.kb = p.out_key;
+        st.list.ib = p.out_idx;
+        st.list.off = (unsigned)out_list_offset();
     }
     KzWavePool pool;
     pool.keys = (__attribute__((address_space(3))) f32x4e*)(smem + Cfg::POOLK_OFF) + wave * CAP;
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     if (h == 0) {  // the list belongs to the query: lane-half 0 owns it (kz_merge_logs3)
 #pragma unroll 4
         for (int e = 0; e < KP; ++e) {
-            st.list.k[e * KzListRef<IN_LDS>::STRIDE] = -INFINITY;
-            st.list.i[e * KzListRef<IN_LDS>::STRIDE] = -1;
+            st.list.kp()[e * KzListRef<IN_LDS>::STRIDE] = -INFINITY;
+            st.list.ip()[e * KzListRef<IN_LDS>::STRIDE] = -1;
         }
     }
     if (total <= 0) {
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     int dma_slot = 0;   // uniform: slot of the next slice to issue
     auto dma_next = [&]() {
         float* dst = ybuf + dma_slot * 1024 + wave * 256;  // wave-uniform LDS base (floats)
-        kz_glds16(reinterpret_cast<const float*>(dma_src + lane_off), dst);
+        kz_glds16_s(dma_src, (unsigned)lane_off, dst);
         dma_src += 4096;
         dma_slot = (dma_slot + 1) & (R - 1);
     };
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         // init (hipcc orders every ds_read after an LDS-DMA behind s_waitcnt vmcnt(0)).
         __builtin_amdgcn_sched_barrier(0);
         if (wave < 2)
-            kz_glds4(p.ybias + (int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE + tid, bbuf + ((tile + 1) & 1) * 128 + wave * 64);
+            kz_glds4_s(p.ybias + (int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE, (unsigned)tid * 4u, bbuf + ((tile + 1) & 1) * 128 + wave * 64);
         constexpr bool carry_in = !ONE_SET && (CARRY || (P0 == 1 && (NSR & 1)));
         constexpr bool carry_out = !ONE_SET && (CARRY || (((P0 + NSR) & 1) != 0));
         if (!carry_in && !ONE_SET) {
@@ -256,8 +258,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         if (h == 0) {
 #pragma unroll 4
             for (int e = 0; e < KP; ++e) {
-                p.out_key[listoff + e] = st.list.k[e * 128];
-                p.out_idx[listoff + e] = st.list.i[e * 128];
+                p.out_key[listoff + e] = st.list.kp()[e * 128];
+                p.out_idx[listoff + e] = st.list.ip()[e * 128];
             }
         }
     }

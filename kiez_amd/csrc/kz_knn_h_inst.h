@@ -12,6 +12,8 @@
 // Measured (MI355X, rocprof): d = 128, K' = 16: 2.93 ms at three per CU against 3.51 ms at two; d = 200, K' = 16 (single
 // fragment set, kz_knn_h16.h: ONE_SET): 96.8 against 102.2 ms; d = 200, K' = 64 (lists in the output arrays, 13 spilled
 // VGPRs at three per CU): 132 against 127 ms -- so beyond 8 slices only the K' = 16 build runs three per CU.
+// Tried and dropped: a long-sweep build at three per CU with an 8-slot ring / one barrier per four slices and the lists in
+// the output arrays instead of LDS (same-box A/B on ns: 98.0 against 88.7 ms).
 constexpr int KZ_H_WPS3_MAX = 8;        // d <= 128: every list length
 constexpr int KZ_H_WPS3_MAX_KP16 = 13;  // d <= 208: K' = 16 only
 

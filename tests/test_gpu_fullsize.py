@@ -225,3 +225,31 @@ def test_c3_full_size_mp_empiric_properties_and_oracle_sample():
         else:
             np.testing.assert_array_equal(ind[r], si[a])
             np.testing.assert_allclose(dist[r], sd[a], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("d", [64, 200, 72])
+def test_long_sweeps_of_the_fp16_kernel_at_three_workgroups_per_cu(d):
+    """1563 index tiles per sweep through the three-workgroups-per-CU builds (4-slot DMA ring with hand-issued saddr-form
+    LDS-DMA; d = 200: single fragment set): must agree with the float32-operand kernel (a different synchronisation
+    structure) on every row and with the oracle -- even, odd and 13 slice counts."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.default_rng(d)
+    t = rng.random((200_000, d), dtype=np.float32)
+    s = rng.random((6000, d), dtype=np.float32)
+    ctx = N.Context.get()
+    ym, qm = N.DeviceMatrix(ctx, t, "euclidean"), N.DeviceMatrix(ctx, s, "euclidean")
+    res = {}
+    try:
+        for name, prec in (("fp16", 0), ("f32", 1)):
+            ctx.set_option("precision", prec)
+            for _ in range(2):   # races are timing dependent
+                dd, ii, st = N.knn(ctx, qm, ym, 10)
+                assert st["max_err_ratio"] < 0.6, (name, st)
+            res[name] = (dd.numpy(), ii.numpy())
+    finally:
+        ctx.set_option("precision", 0)
+    np.testing.assert_array_equal(res["fp16"][1], res["f32"][1])
+    np.testing.assert_array_equal(res["fp16"][0], res["f32"][0])
+    od, oi = O.knn_exact(s[:256], t, 10, "euclidean")
+    np.testing.assert_array_equal(res["fp16"][1][:256], oi)
