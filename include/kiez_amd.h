@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 2
+#define KZ_ABI_VERSION 3
 
 /* status codes */
 enum { KZ_OK = 0, KZ_ERR_INVALID = 1, KZ_ERR_HIP = 2, KZ_ERR_UNSUPPORTED = 3, KZ_ERR_NOMEM = 4, KZ_ERR_NONFINITE = 5 };
@@ -49,12 +49,16 @@ typedef struct kz_knn_stats {
     int32_t list_len;        /* K' = per-list candidate count kept by the fused kernel                     */
     int32_t n_splits;        /* index range splits (grid.y)                                                */
     int32_t n_blocks;        /* workgroups launched                                                        */
-    int32_t first_pass;      /* operand precision of the fused kernel that produced the result of the last
-                                chunk: 0 = float32 MFMA, 1 = split-bf16 (bf16x2) MFMA                        */
-    int64_t n_escalated_rows; /* query rows first tried with the split-bf16 pass and re-done with float32
-                                operands because they (or too many rows of their chunk) failed its certification */
+    int32_t first_pass;      /* operand precision of the fused kernel the call started with: 0 = float32 MFMA,
+                                1 = split-bf16 (bf16x2) MFMA, 2 = fp16 MFMA on centred operands               */
+    int64_t n_escalated_rows; /* query rows whose candidate set the first pass could not certify and that were
+                                searched again one tier down (longer lists -> float32 operands -> exact float64) */
     double max_err_ratio;    /* self-check: max over all re-ranked candidates of |approximate key - exact key| / eps,
                                 eps = the rounding bound the certification uses; must stay below 1          */
+    int32_t dual;            /* kz_knn_dual: 1 = this direction came out of the shared sweep, 0 = ordinary search */
+    int32_t reserved_;
+    int64_t n_events;        /* kz_knn_dual, reverse direction: events filed for the rows of b                */
+    int64_t n_overflow_rows; /* kz_knn_dual, reverse direction: rows of b whose event buffer overflowed (searched again) */
 } kz_knn_stats;
 
 /* ---- library / context -------------------------------------------------------------------------------- */
@@ -65,11 +69,12 @@ int kz_device_count(int* n);
 int kz_ctx_create(int device, void* stream, kz_ctx** out);
 int kz_ctx_destroy(kz_ctx* ctx);
 int kz_ctx_sync(kz_ctx* ctx);
-/* Options.  "precision": 0 (default) = split-bf16 first pass where the query tile fits in registers (d <= 128),
- * escalating to float32 operands / exact float64 per chunk as certification demands; 1 = float32 operands only.
- * The neighbour order is the float64 one either way.  Test/diagnostic knobs: "eps_scale" multiplies the
- * certification bound (huge value => every row takes the exact fallback); "force_splits" fixes the index split
- * count (0 = automatic); "kernel_variant" selects experimental float32 kernels. */
+/* Options.  "precision": 0 (default) = fp16 first pass on centred operands (16 <= d_pad <= 384), uncertified rows go
+ * down the tiers (longer lists -> float32 operands -> exact float64); 2 = split-bf16 first pass; 1 = float32 operands
+ * only.  The neighbour order is the float64 one either way.  "dual_stride": kz_knn_dual samples every n-th tile of a
+ * for its thresholds (default 10; 0 = always two ordinary searches).  Test/diagnostic knobs: "eps_scale" multiplies the
+ * certification bound (huge value => every row takes the exact fallback); "force_splits" fixes the index split count
+ * (0 = automatic); "min_splits", "chunk_rows", "h_wps", "lds_pad": scheduling / occupancy knobs. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 
 int kz_malloc(kz_ctx* ctx, size_t bytes, void** d_ptr);
@@ -79,9 +84,11 @@ int kz_memcpy_d2h(kz_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int kz_memcpy_d2d(kz_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 
 /* ---- index construction: replaces SklearnNN._fit (sklearn_nearest_neighbors.py:83-94) ------------------ */
-/* Copies rows [n, d] (host or device memory) into HBM, computes float64 row norms, and writes the
- * MFMA-packed float32 tile image used by the distance kernel.  Fails with KZ_ERR_NONFINITE on NaN/inf
- * (scikit-learn rejects those inputs too). */
+/* rows [n, d]: rows_on_device = 0 host memory (copied into HBM), 1 device memory (copied), 2 device memory BORROWED
+ * (read in place; the caller keeps the buffer alive and unchanged until kz_matrix_destroy).  Computes the float64 row
+ * norms; the MFMA operand images (fp16 / split-bf16 / float32 tiles) are built by the first kz_knn that needs them.
+ * NaN/inf input is an error (KZ_ERR_NONFINITE; scikit-learn rejects those inputs too): reported here for host rows, by
+ * the first kz_knn / kz_knn_dual that searches the matrix for device rows (this call then waits for nothing). */
 int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t n, int64_t d, int dtype,
                      int metric, kz_matrix** out);
 int kz_matrix_destroy(kz_matrix* m);
@@ -95,6 +102,15 @@ int kz_matrix_shape(const kz_matrix* m, int64_t* n, int64_t* d, int* dtype, int*
  * (float32 inputs + euclidean: (double)sqrtf((float)d2)). */
 int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index,
            int k, int exclude_self, double* d_dist, int64_t* d_ind, kz_knn_stats* stats);
+
+/* Both directions between two matrices from ONE sweep of the distance matrix: what HubnessReduction.fit (target ->
+ * source neighbours, kiez/hubness_reduction/base.py:48-58) and .kneighbors (source -> target, base.py:95-112) compute
+ * with two brute-force searches.  d_dist_ab / d_ind_ab: [a.n, k] = for every row of a its k nearest rows of b;
+ * d_dist_ba / d_ind_ba: [b.n, k] the reverse.  Results are identical to kz_knn(a, b) and kz_knn(b, a) (same float64
+ * order, same tie rule); pass the LARGER matrix as a (fewer rows get event buffers).  Falls back to two ordinary
+ * searches where the shared sweep does not apply (precision != 0, tiny inputs, k > 110).  stats_* may be NULL. */
+int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a, const kz_matrix* b, int k, double* d_dist_ab, int64_t* d_ind_ab,
+                double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba);
 
 /* Host-only (no GPU needed): the work schedule kz_knn builds for a launch with `slots` resident workgroups
  * (DESIGN.md section 3.1 "greedy rounds").  Round r covers round_qtiles[r] query tiles of 128 rows, each swept as

@@ -46,6 +46,10 @@ class KnnStats(C.Structure):
         ("first_pass", C.c_int32),
         ("n_escalated_rows", C.c_int64),
         ("max_err_ratio", C.c_double),
+        ("dual", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("n_events", C.c_int64),
+        ("n_overflow_rows", C.c_int64),
     ]
 
     def as_dict(self):
@@ -72,6 +76,7 @@ SYMBOLS = [
     ("kz_matrix_destroy", C.c_int, [_P]),
     ("kz_matrix_shape", C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("kz_knn", C.c_int, [_P, _P, _I64, _I64, _P, C.c_int, C.c_int, _P, _P, C.POINTER(KnnStats)]),
+    ("kz_knn_dual", C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(KnnStats), C.POINTER(KnnStats)]),
     ("kz_knn_plan", C.c_int, [_I64, _I64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                               C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("kz_row_stats", C.c_int, [_P, _P, _I64, C.c_int, _P, _P, _P]),
@@ -118,8 +123,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.kz_abi_version() != 2:
-            raise RuntimeError(f"{path}: ABI version {lib.kz_abi_version()} != 2")
+        if lib.kz_abi_version() != 3:
+            raise RuntimeError(f"{path}: ABI version {lib.kz_abi_version()} != 3")
         _lib = lib
     return _lib
 
@@ -298,6 +303,19 @@ def knn(ctx: Context, query: DeviceMatrix, index: DeviceMatrix, k: int, exclude_
     _check(ctx.lib.kz_knn(ctx.handle, query.handle, q_begin, q_count, index.handle, int(k), int(bool(exclude_self)),
                           dist.ptr, ind.ptr, C.byref(st)), "kz_knn")
     return dist, ind, st.as_dict()
+
+
+def knn_dual(ctx: Context, a: DeviceMatrix, b: DeviceMatrix, k: int):
+    """kz_knn_dual: both directions between two matrices from one sweep of the distance matrix.
+    Returns ((dist, ind, stats) of a -> b [a.n, k], (dist, ind, stats) of b -> a [b.n, k])."""
+    d_ab = ctx.empty((a.shape[0], k), np.float64)
+    i_ab = ctx.empty((a.shape[0], k), np.int64)
+    d_ba = ctx.empty((b.shape[0], k), np.float64)
+    i_ba = ctx.empty((b.shape[0], k), np.int64)
+    s_ab, s_ba = KnnStats(), KnnStats()
+    _check(ctx.lib.kz_knn_dual(ctx.handle, a.handle, b.handle, int(k), d_ab.ptr, i_ab.ptr, d_ba.ptr, i_ba.ptr,
+                               C.byref(s_ab), C.byref(s_ba)), "kz_knn_dual")
+    return (d_ab, i_ab, s_ab.as_dict()), (d_ba, i_ba, s_ba.as_dict())
 
 
 def row_stats(ctx: Context, dist: DeviceArray, mean=False, std=False, last=False):

@@ -17,13 +17,15 @@ struct kz_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
-    hipEvent_t ev[6];
+    hipEvent_t ev[8];
     double eps_scale;
     int force_splits;
     int h_wps;        // tuning knob: 2 = run the fp16 kernel's two-workgroups-per-CU build also where three would fit
     int chunk_rows;   // test knob: query rows per chunk (0 = default 524288)
     int min_splits;   // tuning knob: minimum index splits per query tile in the large-item region
     int precision;    // 0: fp16 first pass where eligible (default), 2: split-bf16 first pass, 1: float32 operands only
+    int dual_stride;  // kz_knn_dual: every dual_stride-th tile of the query side is in the threshold sample (0 / 1: no dual pass)
+    int dual_force;   // test knob: run the dual pass also where it does not pay (few query rows)
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)
     void* scratch;
@@ -33,6 +35,7 @@ struct kz_ctx {
     int n_cus;        // compute units of the device
     void* h_stage;    // pinned host staging for the per-call work table
     size_t h_stage_bytes;
+    int h_stage_flip; // which half of h_stage the last pass used (kz_prepare_pass)
     // stream-ordered free list: buffers released by kz_free / kz_matrix_destroy are reused by later allocations of a
     // similar size instead of going through hipFree (device-wide sync) + hipMalloc on every fit()
     struct { void* ptr; size_t bytes; } pool[64];

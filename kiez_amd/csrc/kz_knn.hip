@@ -276,6 +276,10 @@ struct KnnFinParams {
     const double* q_rowq; // query image: [n][3] = |x_c|^2, |x_h|, |x_c - x_h|
     const double* y_hmax; // index image: max |y_h|, max |y_c - y_h|, max |y_c|^2
     const double* hscale; // {S, 1 / S^2}
+    // dual pass, reverse direction (kz_knn_dual.h): the list holds the K' best EVENTS of the row; rows outside the events
+    // have an approximate key below excl_floor[q] (+inf: the row's events are incomplete, it must fail)
+    const float* excl_floor;
+    int dual_col;
     double* out_dist;     // [q_count][k]
     int64_t* out_ind;
     int* fail_count;
@@ -493,6 +497,9 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         const double raw2 = p.metric == KZ_COSINE ? 2.0 : qs + ymax * ymax;
         eps_q = p.eps_mult * (qr * Yh + qh * Ry + qr * Ry + p.gamma_acc * (0.5 * Yc2 + qh * Yh) +
                               1.1920928955078125e-07 * (qc + yc) * (qc + yc) + 1e-12 * (0.5 * Yc2 + qc2) + 1e-14 * raw2);
+        // reverse direction of a dual pass: the key was accumulated on top of THIS row's bias (|q_c|^2 / 2 joins the
+        // accumulation term) and went through one more float32 rounding when it was filed as key' = acc - bias(t) + bias(q)
+        if (p.dual_col) eps_q += p.eps_mult * (p.gamma_acc * 0.5 * qc2 + 1.1920928955078125e-07 * (0.5 * Yc2 + 0.5 * qc2 + qh * Yh));
         key_scale = p.hscale[1];
         qref = qc2;
     } else if (p.metric == KZ_COSINE) {
@@ -611,7 +618,13 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     // The exact key of the k-th re-ranked candidate is known.  If it is strictly larger, no outside row can enter -- or
     // tie with -- the exact top-k.  V < KP means no list ever evicted anything: the set is complete.
     bool certified;
-    if (V < KP)
+    if (p.excl_floor) {
+        // dual pass: outside the list are events that lost the selection (key~ <= ck[KP-1], full lists only) and the rows
+        // that never were events (key~ < floor)
+        double bound = (double)p.excl_floor[qrow];
+        if (V == KP) bound = fmax(bound, (double)ck[KP - 1]);
+        certified = V >= k_eff && bound * key_scale + eps_q < exact_key(sv[k_eff - 1]);
+    } else if (V < KP)
         certified = (V >= min((int64_t)k_eff, p.n_i));
     else
         certified = (double)ck[KP - 1] * key_scale + eps_q < exact_key(sv[k_eff - 1]);
@@ -779,6 +792,14 @@ int kz_h_launch_kp16(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_bl
 int kz_h_launch_kp32(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
 int kz_h_launch_kp64(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
 int kz_h_launch_kp128(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
+int kz_hd_occupancy_kp16(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
+int kz_hd_occupancy_kp32(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
+int kz_hd_occupancy_kp64(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
+int kz_hd_occupancy_kp128(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
+int kz_hd_launch_kp16(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
+int kz_hd_launch_kp32(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
+int kz_hd_launch_kp64(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
+int kz_hd_launch_kp128(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
 int kz_bf_occupancy_kp16(int n_slices_bf, int* blocks_per_cu, int lds_pad);
 int kz_bf_occupancy_kp32(int n_slices_bf, int* blocks_per_cu, int lds_pad);
 int kz_bf_occupancy_kp64(int n_slices_bf, int* blocks_per_cu, int lds_pad);
@@ -892,6 +913,212 @@ __global__ __launch_bounds__(256) void kz_scatter_rows_kernel(const double* __re
 enum { KZ_TIER_F32 = 0, KZ_TIER_BF = 1, KZ_TIER_H = 2 };
 constexpr int KZ_EXACT_MAX_K = 4096;   // neighbours per query on the exact-only route (selection state: 48 KiB of LDS)
 
+// The finalize launches of one pass: one per list region (the dynamic LDS follows the region's entry count: occupancy of
+// the gather).  fp.q_first / q_last / max_m are filled here.
+static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout& lay, int KP, int64_t q_count, int dtype) {
+    for (int rg = 0; rg < lay.n_regions; ++rg) {
+        const int64_t lo = (int64_t)(rg > 0 ? lay.qt_end[rg - 1] : 0) * KZ_TILE - fp.list_row0;
+        const int64_t hi = (int64_t)lay.qt_end[rg] * KZ_TILE - fp.list_row0;
+        fp.q_first = lo < 0 ? 0 : lo;
+        fp.q_last = hi > q_count ? q_count : hi;
+        if (fp.q_last <= fp.q_first) continue;
+        fp.max_m = lay.pieces[rg] * lay.halves * KP;
+        const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
+        const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, KP);
+        if (fin_lds > 65536) {
+            const void* fk = dtype == KZ_F32 ? (const void*)kz_knn_finalize_kernel<float> : (const void*)kz_knn_finalize_kernel<double>;
+            KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
+        }
+        if (dtype == KZ_F32)
+            hipLaunchKernelGGL(kz_knn_finalize_kernel<float>, dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
+        else
+            hipLaunchKernelGGL(kz_knn_finalize_kernel<double>, dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
+    }
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+// One launch of a fused kernel: list layout, scratch carve-up and the uploaded work table.
+struct KzPass {
+    KzListLayout lay;
+    int W;            // workgroups
+    float* out_key;   // candidate lists (scratch)
+    int* out_idx;
+    int* fail_list;   // [fail_rows] (scratch)
+    int4* d_work;     // [W] (scratch)
+};
+
+// Plans the rounds (kz_plan_rounds), carves the context's scratch block and uploads the work table.  tier decides the
+// list layout (fp16: K' contiguous entries per list; float32 kernels: two lane-half lists per query and range).
+static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, int max_pieces, int KP, int tier, int64_t fail_rows,
+                           KzPass* out) {
+    auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
+    auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
+    KzListLayout lay;
+    memset(&lay, 0, sizeof(lay));
+    int reg_q0[KZ_MAX_REGIONS], reg_nq[KZ_MAX_REGIONS], reg_s[KZ_MAX_REGIONS], reg_w0[KZ_MAX_REGIONS];
+    int W = 0;
+    size_t list_elems = 0;
+    {
+        int n_reg = 0;
+        kz_plan_rounds(n_qtiles, n_ytiles, slots, max_pieces, ctx->force_splits, ctx->min_splits, &n_reg, reg_nq, reg_s);
+        int q0 = 0;
+        for (int r = 0; r < n_reg; ++r) {
+            reg_q0[r] = q0;
+            reg_w0[r] = W;
+            lay.qt_end[r] = q0 + reg_nq[r];
+            lay.pieces[r] = split_cnt(reg_s[r]);
+            lay.base[r] = (long long)list_elems;
+            // entries per (query, index range): K' in the contiguous layout, 2 K' in the interleaved one (two lane-half
+            // columns per list block, also where only one is used)
+            list_elems += (size_t)reg_nq[r] * KZ_TILE * (size_t)(lay.pieces[r] * (tier == KZ_TIER_H ? 1 : 2) * KP);
+            W += reg_nq[r] * lay.pieces[r];
+            q0 += reg_nq[r];
+        }
+        lay.n_regions = n_reg;
+        lay.halves = tier == KZ_TIER_F32 ? 2 : 1;
+        lay.contig = tier == KZ_TIER_H ? 1 : 0;
+    }
+    const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
+    const size_t fail_bytes = ((size_t)fail_rows * 4 + 255) & ~(size_t)255;
+    const size_t work_bytes = ((size_t)W * sizeof(int4) + 255) & ~(size_t)255;
+    void* scratch = nullptr;
+    int rc = kz_scratch(ctx, key_bytes * 2 + fail_bytes + work_bytes, &scratch);
+    if (rc != KZ_OK) return rc;
+    out->lay = lay;
+    out->W = W;
+    out->out_key = (float*)scratch;
+    out->out_idx = (int*)((char*)scratch + key_bytes);
+    out->fail_list = (int*)((char*)scratch + 2 * key_bytes);
+    out->d_work = (int4*)((char*)scratch + 2 * key_bytes + fail_bytes);
+    {
+        // host-side table (pinned staging grows on demand)
+        const size_t need = work_bytes;
+        if (need * 2 > ctx->h_stage_bytes) {
+            KZ_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->h_stage) KZ_HIP(hipHostFree(ctx->h_stage));
+            ctx->h_stage = nullptr;
+            ctx->h_stage_bytes = 0;
+            KZ_HIP(hipHostMalloc(&ctx->h_stage, need * 4, hipHostMallocDefault));
+            ctx->h_stage_bytes = need * 4;
+        }
+        // The table of the PREVIOUS pass may still be in flight out of h_stage when two passes follow each other without a
+        // read-back in between (dual pass: sample sweep, then the main sweep): passes alternate between the two halves of
+        // the staging buffer, and every second pass is followed by a stream synchronisation in any case (kz_knn_impl's
+        // fail-counter read).
+        ctx->h_stage_flip ^= 1;
+        int4* hw = (int4*)((char*)ctx->h_stage + (ctx->h_stage_flip ? ctx->h_stage_bytes / 2 : 0));
+        // Logical order inside a region: groups of KZ_QGROUP query tiles, inside a group split-major.  The workgroups
+        // resident on one XCD then cover few query tiles (their fragments stay in the 4 MiB L2) times a few index
+        // ranges (each index tile is fetched once and hit by the whole group); items are spread over block ids so that
+        // blocks with equal (id % 8) -- one XCD -- take consecutive items.
+        auto fill_region = [&](int off, int cnt, int q0, int nq, int sp) {
+            if (cnt == 0) return;
+            const int len = split_len(sp);
+            const int nsp = split_cnt(sp);
+            const int G = KZ_QGROUP < nq ? KZ_QGROUP : nq;
+            int next = 0;
+            for (int label = 0; label < 8; ++label) {
+                for (int i = 0; i < cnt; ++i) {
+                    if (((off + i) & 7) != label) continue;
+                    const int grp = next / (G * nsp);
+                    const int gq0 = grp * G;
+                    const int gsz = (nq - gq0) < G ? (nq - gq0) : G;  // last group may be smaller
+                    const int within = next - grp * G * nsp;
+                    const int sidx = within / gsz, qt = q0 + gq0 + within % gsz;
+                    ++next;
+                    int4 w4;
+                    w4.x = qt;
+                    w4.y = sidx * len;
+                    w4.z = (sidx + 1) * len < n_ytiles ? (sidx + 1) * len : n_ytiles;
+                    w4.w = sidx;
+                    hw[off + i] = w4;
+                }
+            }
+        };
+        for (int r = 0; r < lay.n_regions; ++r) fill_region(reg_w0[r], reg_nq[r] * lay.pieces[r], reg_q0[r], reg_nq[r], reg_s[r]);
+        KZ_HIP(hipMemcpyAsync(out->d_work, hw, (size_t)W * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    }
+    return KZ_OK;
+}
+
+// Escalation of uncertified rows: gather rows cq_begin + fail_list[0 .. n_fail) of `query` into a dense block, search it
+// again (kz_knn_impl with the given precision / minimum list length; that call sends ITS uncertified rows further down)
+// and scatter the results into out_dist / out_ind at the rows' positions.  Ends with a stream synchronisation.
+// Dual pass (kz_knn_dual.h): what the main sweep needs to report the events of the index rows besides its own lists.
+struct KzDualPass {
+    const float* theta;            // [index tiles * 128]
+    const float* qnbias;           // [query tiles * 128]
+    void* log_keys;
+    void* log_meta;
+    unsigned long long* log_cnt;   // device counter
+    long long log_cap;
+    int broken;                    // set by kz_knn_impl when a chunk did not run the dual build (tier change): events incomplete
+    double main_ms;
+};
+static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q_count, kz_matrix* index, int k,
+                       int exclude_self, const int64_t* d_self_ids, int precision_override, int kp_min, double* d_dist,
+                       int64_t* d_ind, kz_knn_stats* stats, KzDualPass* dual);
+static int kz_escalate_rows(kz_ctx* ctx, kz_matrix* query, int64_t cq_begin, const int* fail_list, int n_fail, kz_matrix* index, int k,
+                            int exclude_self, const int64_t* d_self_ids, int precision_override, int kp_min, double* out_dist,
+                            int64_t* out_ind, kz_knn_stats* st2, float* ms_out) {
+    KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    const size_t row_bytes = (size_t)query->d * (query->dtype == KZ_F32 ? 4 : 8);
+    int* fl = nullptr;
+    void* sub_raw = nullptr;
+    int64_t* sub_self = nullptr;
+    double* sub_dist = nullptr;
+    int64_t* sub_ind = nullptr;
+    kz_matrix* qsub = nullptr;
+    auto release = [&]() {
+        if (qsub) kz_matrix_destroy(qsub);
+        kz_pool_free(ctx, fl, 0);
+        kz_pool_free(ctx, sub_raw, 0);
+        kz_pool_free(ctx, sub_self, 0);
+        kz_pool_free(ctx, sub_dist, 0);
+        kz_pool_free(ctx, sub_ind, 0);
+    };
+    int rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&fl);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * row_bytes, &sub_raw);
+    if (rc == KZ_OK && exclude_self) rc = kz_pool_alloc(ctx, (size_t)n_fail * 8, (void**)&sub_self);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * k * 8, (void**)&sub_dist);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * k * 8, (void**)&sub_ind);
+    if (rc != KZ_OK) {
+        release();
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(fl, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(kz_gather_rows_kernel, dim3(n_fail), dim3(256), 0, ctx->stream, (const char*)query->raw, fl, cq_begin,
+                           n_fail, (int64_t)row_bytes, (char*)sub_raw, sub_self, d_self_ids);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        release();
+        kz_set_error("kz_knn: gathering the escalated rows failed: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    rc = kz_matrix_create(ctx, sub_raw, 2, n_fail, query->d, query->dtype, query->metric, &qsub);
+    memset(st2, 0, sizeof(*st2));
+    if (rc == KZ_OK)
+        rc = kz_knn_impl(ctx, qsub, 0, n_fail, index, k, exclude_self, sub_self, precision_override, kp_min, sub_dist, sub_ind, st2, nullptr);
+    if (rc == KZ_OK) {
+        hipLaunchKernelGGL(kz_scatter_rows_kernel, dim3((unsigned)(((int64_t)n_fail * k + 255) / 256)), dim3(256), 0, ctx->stream,
+                           sub_dist, sub_ind, fl, n_fail, k, out_dist, out_ind);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev[4], ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            kz_set_error("kz_knn: scattering the escalated rows failed: %s", hipGetErrorString(e));
+            rc = KZ_ERR_HIP;
+        }
+    }
+    release();
+    if (rc != KZ_OK) return rc;
+    KZ_HIP(hipEventElapsedTime(ms_out, ctx->ev[3], ctx->ev[4]));
+    return KZ_OK;
+}
+
 // d_self_ids (device, optional): index row to strip per query when exclude_self is set and the query matrix is not the
 // index matrix itself (escalated subsets).  precision_override: -1 = the context's setting, 1 = float32 operands only.
 // kp_min: smallest list length to use (escalated subsets of the fp16 tier are first re-done with LONGER lists on the same
@@ -899,7 +1126,7 @@ constexpr int KZ_EXACT_MAX_K = 4096;   // neighbours per query on the exact-only
 // is usually all a failed row needs, and unlike the float32 tier it costs no new image of the index).
 static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q_count, kz_matrix* index, int k,
                        int exclude_self, const int64_t* d_self_ids, int precision_override, int kp_min, double* d_dist,
-                       int64_t* d_ind, kz_knn_stats* stats) {
+                       int64_t* d_ind, kz_knn_stats* stats, KzDualPass* dual) {
     KZ_REQUIRE(ctx && query && index && d_dist && d_ind, "kz_knn: null argument");
     KZ_REQUIRE(query->ctx == ctx && index->ctx == ctx, "kz_knn: matrices belong to a different context");
     KZ_REQUIRE(query->d == index->d, "kz_knn: feature dimensions differ (%lld vs %lld)", (long long)query->d,
@@ -955,7 +1182,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (slots_cache[t] == 0) {
             int blocks_per_cu = 1;
             int rc0;
-            if (t == KZ_TIER_H)
+            if (t == KZ_TIER_H && dual)
+                KZ_DISPATCH_KP(rc0, kz_hd_occupancy, (n_slices, &blocks_per_cu, ctx->h_wps, ctx->lds_pad));
+            else if (t == KZ_TIER_H)
                 KZ_DISPATCH_KP(rc0, kz_h_occupancy, (n_slices, &blocks_per_cu, ctx->h_wps, ctx->lds_pad));
             else if (t == KZ_TIER_BF)
                 KZ_DISPATCH_KP(rc0, kz_bf_occupancy, (n_slices, &blocks_per_cu, ctx->lds_pad));
@@ -993,94 +1222,18 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         const int qt0 = (int)(cq_begin / KZ_TILE);
         const int qt1 = (int)((cq_begin + cq_count - 1) / KZ_TILE);
         const int n_qtiles = qt1 - qt0 + 1;
-        // ---- schedule: which workgroup sweeps which (query tile, index-tile range): kz_plan_rounds above ---------
-        auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
-        auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
-        KzListLayout lay;
-        memset(&lay, 0, sizeof(lay));
-        int reg_q0[KZ_MAX_REGIONS], reg_nq[KZ_MAX_REGIONS], reg_s[KZ_MAX_REGIONS], reg_w0[KZ_MAX_REGIONS];
-        int W = 0;
-        size_t list_elems = 0;
-        {
-            int n_reg = 0;
-            kz_plan_rounds(n_qtiles, n_ytiles, slots, kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1), ctx->force_splits, ctx->min_splits,
-                           &n_reg, reg_nq, reg_s);
-            int q0 = 0;
-            for (int r = 0; r < n_reg; ++r) {
-                reg_q0[r] = q0;
-                reg_w0[r] = W;
-                lay.qt_end[r] = q0 + reg_nq[r];
-                lay.pieces[r] = split_cnt(reg_s[r]);
-                lay.base[r] = (long long)list_elems;
-                // entries per (query, index range): K' in the contiguous layout, 2 K' in the interleaved one (two lane-half
-                // columns per list block, also where only one is used)
-                list_elems += (size_t)reg_nq[r] * KZ_TILE * (size_t)(lay.pieces[r] * (tier == KZ_TIER_H ? 1 : 2) * KP);
-                W += reg_nq[r] * lay.pieces[r];
-                q0 += reg_nq[r];
-            }
-            lay.n_regions = n_reg;
-            lay.halves = tier == KZ_TIER_F32 ? 2 : 1;
-            lay.contig = tier == KZ_TIER_H ? 1 : 0;
-        }
-        const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
-        const size_t fail_bytes = ((size_t)cq_count * 4 + 255) & ~(size_t)255;
-        const size_t work_bytes = ((size_t)W * sizeof(int4) + 255) & ~(size_t)255;
-        void* scratch = nullptr;
-        int rc = kz_scratch(ctx, key_bytes * 2 + fail_bytes + work_bytes, &scratch);
+        // ---- schedule: which workgroup sweeps which (query tile, index-tile range): kz_prepare_pass above --------------
+        KzPass ps;
+        int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1), KP, tier, cq_count, &ps);
         if (rc != KZ_OK) return rc;
-        float* out_key = (float*)scratch;
-        int* out_idx = (int*)((char*)scratch + key_bytes);
-        int* fail_list = (int*)((char*)scratch + 2 * key_bytes);
-        int4* d_work = (int4*)((char*)scratch + 2 * key_bytes + fail_bytes);
+        const KzListLayout& lay = ps.lay;
+        const int W = ps.W;
+        float* out_key = ps.out_key;
+        int* out_idx = ps.out_idx;
+        int* fail_list = ps.fail_list;
+        int4* d_work = ps.d_work;
         int* fail_count = ctx->d_counters + 8;
         KZ_HIP(hipMemsetAsync(fail_count, 0, 4 * sizeof(int), ctx->stream));  // fail counter, (unused), error-ratio bits
-        {
-            // host-side table (pinned staging grows on demand)
-            const size_t need = work_bytes;
-            if (need > ctx->h_stage_bytes) {
-                KZ_HIP(hipStreamSynchronize(ctx->stream));
-                if (ctx->h_stage) KZ_HIP(hipHostFree(ctx->h_stage));
-                ctx->h_stage = nullptr;
-                ctx->h_stage_bytes = 0;
-                KZ_HIP(hipHostMalloc(&ctx->h_stage, need * 2, hipHostMallocDefault));
-                ctx->h_stage_bytes = need * 2;
-            }
-            // (No wait otherwise: every pass over this point is followed by a stream synchronisation before the table
-            //  is written again -- the fail-counter read below -- so the previous async copy out of h_stage has drained;
-            //  waiting here would only stall the host behind the pack kernels.)
-            int4* hw = (int4*)ctx->h_stage;
-            // Logical order inside a region: groups of KZ_QGROUP query tiles, inside a group split-major.  The workgroups
-            // resident on one XCD then cover few query tiles (their fragments stay in the 4 MiB L2) times a few index
-            // ranges (each index tile is fetched once and hit by the whole group); items are spread over block ids so that
-            // blocks with equal (id % 8) -- one XCD -- take consecutive items.
-            auto fill_region = [&](int off, int cnt, int q0, int nq, int sp) {
-                if (cnt == 0) return;
-                const int len = split_len(sp);
-                const int nsp = split_cnt(sp);
-                const int G = KZ_QGROUP < nq ? KZ_QGROUP : nq;
-                int next = 0;
-                for (int label = 0; label < 8; ++label) {
-                    for (int i = 0; i < cnt; ++i) {
-                        if (((off + i) & 7) != label) continue;
-                        const int grp = next / (G * nsp);
-                        const int gq0 = grp * G;
-                        const int gsz = (nq - gq0) < G ? (nq - gq0) : G;  // last group may be smaller
-                        const int within = next - grp * G * nsp;
-                        const int sidx = within / gsz, qt = q0 + gq0 + within % gsz;
-                        ++next;
-                        int4 w4;
-                        w4.x = qt;
-                        w4.y = sidx * len;
-                        w4.z = (sidx + 1) * len < n_ytiles ? (sidx + 1) * len : n_ytiles;
-                        w4.w = sidx;
-                        hw[off + i] = w4;
-                    }
-                }
-            };
-            for (int r = 0; r < lay.n_regions; ++r) fill_region(reg_w0[r], reg_nq[r] * lay.pieces[r], reg_q0[r], reg_nq[r], reg_s[r]);
-            KZ_HIP(hipMemcpyAsync(d_work, hw, (size_t)W * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-        }
-
         KnnCandParams cp;
         memset(&cp, 0, sizeof(cp));
         if (tier == KZ_TIER_H) {
@@ -1109,6 +1262,14 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             // every row of the chunk goes to the exact kernels: the "fail list" is 0 .. cq_count-1
             hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((cq_count + 255) / 256)), dim3(256), 0, ctx->stream, fail_list, (int)cq_count);
             KZ_HIP(hipGetLastError());
+        } else if (tier == KZ_TIER_H && dual) {
+            cp.theta = dual->theta;
+            cp.qnbias = dual->qnbias;
+            cp.log_keys = dual->log_keys;
+            cp.log_meta = dual->log_meta;
+            cp.log_cnt = dual->log_cnt;
+            cp.log_cap = dual->log_cap;
+            KZ_DISPATCH_KP(rc, kz_hd_launch, (n_slices, ctx, cp, W, ctx->h_wps));
         } else if (tier == KZ_TIER_H)
             KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps));
         else if (tier == KZ_TIER_BF)
@@ -1116,6 +1277,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         else
             KZ_DISPATCH_CAND(rc, kz_launch_cand, (ctx, cp, W));
         if (rc != KZ_OK) return rc;
+        if (dual && tier != KZ_TIER_H) dual->broken = 1;   // this chunk's pairs were not scanned for events
         KZ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
 
         KnnFinParams fp;
@@ -1152,26 +1314,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fp.fail_count = fail_count;
         fp.fail_list = fail_list;
         fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
-        {
-            // one launch per list region: the dynamic LDS follows the region's entry count (occupancy of the gather)
-            for (int rg = 0; rg < (exact_only ? 0 : lay.n_regions); ++rg) {
-                const int64_t lo = (int64_t)(rg > 0 ? lay.qt_end[rg - 1] : 0) * KZ_TILE - fp.list_row0;
-                const int64_t hi = (int64_t)lay.qt_end[rg] * KZ_TILE - fp.list_row0;
-                fp.q_first = lo < 0 ? 0 : lo;
-                fp.q_last = hi > cq_count ? cq_count : hi;
-                if (fp.q_last <= fp.q_first) continue;
-                fp.max_m = lay.pieces[rg] * lay.halves * KP;
-                const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
-                const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, KP);
-                if (fin_lds > 65536) {
-                    const void* fk = index->dtype == KZ_F32 ? (const void*)kz_knn_finalize_kernel<float> : (const void*)kz_knn_finalize_kernel<double>;
-                    KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
-                }
-                if (index->dtype == KZ_F32)
-                    hipLaunchKernelGGL(kz_knn_finalize_kernel<float>, dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
-                else
-                    hipLaunchKernelGGL(kz_knn_finalize_kernel<double>, dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
-            }
+        if (!exact_only) {
+            rc = kz_launch_finalize(ctx, fp, lay, KP, cq_count, index->dtype);
+            if (rc != KZ_OK) return rc;
         }
         KZ_HIP(hipGetLastError());
         KZ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -1237,62 +1382,10 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             // float32-operand kernel.  The inner call sends its own uncertified rows further down (float32 operands,
             // exact float64 kernels).  Results are scattered back.
             const bool widen = tier == KZ_TIER_H && KP < 128;
-            KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
-            const size_t row_bytes = (size_t)query->d * (query->dtype == KZ_F32 ? 4 : 8);
-            int* fl = nullptr;
-            void* sub_raw = nullptr;
-            int64_t* sub_self = nullptr;
-            double* sub_dist = nullptr;
-            int64_t* sub_ind = nullptr;
-            kz_matrix* qsub = nullptr;
-            auto release = [&]() {
-                if (qsub) kz_matrix_destroy(qsub);
-                kz_pool_free(ctx, fl, 0);
-                kz_pool_free(ctx, sub_raw, 0);
-                kz_pool_free(ctx, sub_self, 0);
-                kz_pool_free(ctx, sub_dist, 0);
-                kz_pool_free(ctx, sub_ind, 0);
-            };
-            rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&fl);
-            if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * row_bytes, &sub_raw);
-            if (rc == KZ_OK && exclude_self) rc = kz_pool_alloc(ctx, (size_t)n_fail * 8, (void**)&sub_self);
-            if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * k * 8, (void**)&sub_dist);
-            if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * k * 8, (void**)&sub_ind);
-            if (rc != KZ_OK) {
-                release();
-                return rc;
-            }
-            hipError_t e = hipMemcpyAsync(fl, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(kz_gather_rows_kernel, dim3(n_fail), dim3(256), 0, ctx->stream, (const char*)query->raw, fl,
-                                   cq_begin, n_fail, (int64_t)row_bytes, (char*)sub_raw, sub_self, d_self_ids);
-                e = hipGetLastError();
-            }
-            if (e != hipSuccess) {
-                release();
-                kz_set_error("kz_knn: gathering the escalated rows failed: %s", hipGetErrorString(e));
-                return KZ_ERR_HIP;
-            }
-            rc = kz_matrix_create(ctx, sub_raw, 2, n_fail, query->d, query->dtype, query->metric, &qsub);
             kz_knn_stats st2;
-            memset(&st2, 0, sizeof(st2));
-            if (rc == KZ_OK)
-                rc = kz_knn_impl(ctx, qsub, 0, n_fail, index, k, exclude_self, sub_self, widen ? 0 : 1,
-                                 widen ? (KP * 4 < 128 ? KP * 4 : 128) : 0, sub_dist, sub_ind, &st2);
-            if (rc == KZ_OK) {
-                hipLaunchKernelGGL(kz_scatter_rows_kernel, dim3((unsigned)(((int64_t)n_fail * k + 255) / 256)), dim3(256), 0,
-                                   ctx->stream, sub_dist, sub_ind, fl, n_fail, k, fp.out_dist, fp.out_ind);
-                e = hipGetLastError();
-                if (e == hipSuccess) e = hipEventRecord(ctx->ev[4], ctx->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-                if (e != hipSuccess) {
-                    kz_set_error("kz_knn: scattering the escalated rows failed: %s", hipGetErrorString(e));
-                    rc = KZ_ERR_HIP;
-                }
-            }
-            release();
+            rc = kz_escalate_rows(ctx, query, cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids, widen ? 0 : 1,
+                                  widen ? (KP * 4 < 128 ? KP * 4 : 128) : 0, fp.out_dist, fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
-            KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
             fb_ms += ms;
             n_escalated += n_fail + st2.n_escalated_rows;
             n_fail_total += st2.n_fallback_rows;
@@ -1375,5 +1468,7 @@ extern "C" int kz_knn(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int6
                       int exclude_self, double* d_dist, int64_t* d_ind, kz_knn_stats* stats) {
     // (the matrices are logically const for the caller: kz_knn only attaches lazily built operand images to them)
     return kz_knn_impl(ctx, const_cast<kz_matrix*>(query), q_begin, q_count, const_cast<kz_matrix*>(index), k, exclude_self, nullptr,
-                       -1, 0, d_dist, d_ind, stats);
+                       -1, 0, d_dist, d_ind, stats, nullptr);
 }
+
+#include "kz_knn_dual.h"

@@ -30,6 +30,8 @@ __device__ __forceinline__ void kz_glds4_s(const void* sbase_uniform, unsigned l
                  : "s"(lds), "v"(lane_byte_off), "s"(sbase_uniform)
                  : "memory", "m0");
 }
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+typedef int i32x2e __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-temporal 16-byte load (streaming cache policy)
     const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
@@ -107,6 +109,13 @@ struct KnnCandParams {
     float* out_key;       // per region: [query rows][pieces][2 lane halves][KP]
     int* out_idx;
     unsigned long long* dbg;  // diagnostic stamp build only (-DKZ_STAMP): cycle sums {slices, epilogue, init, waves}
+    // dual pass (fp16 kernel, DUAL build; kz_knn_epi3.h "Dual pass")
+    const float* theta;            // [n_ytiles * 128] event threshold per index row (+inf on pad rows)
+    const float* qnbias;           // [query rows incl. padding, global row numbers] -bias(q) (+inf on pad rows)
+    void* log_keys;                // [log_cap] x 16 B
+    void* log_meta;                // [log_cap] x 8 B
+    unsigned long long* log_cnt;
+    long long log_cap;
 };
 
 constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows

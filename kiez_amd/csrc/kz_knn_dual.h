@@ -1,0 +1,472 @@
+// Dual pass: both directions of a kNN search between two matrices from ONE sweep of the distance matrix
+// (included by kz_knn.hip).
+//
+// The hubness reductions need the neighbours of every target among the sources (fit, kiez/hubness_reduction/base.py:
+// 48-58) AND of every source among the targets (kneighbors, base.py:95-112): the reference runs two brute-force searches
+// over the same n_s x n_t distances.  Here the fused fp16 kernel sweeps  A (queries) x B (index)  once and reports
+//   * per row of A its K' best rows of B -- the candidate lists it always keeps -- and
+//   * per row t of B every row q of A whose key for the REVERSE direction,
+//         key'(t, q) = q_h.t_h + bias(q) = acc(q, t) - bias(t) + bias(q),
+//     reaches a threshold tau(t): the "events" of t (kz_knn_epi3.h "Dual pass").
+// tau(t) is fixed before the sweep: the K'-th best key of t against a SAMPLE of A (every s-th tile of A's fp16 image,
+// copied into a small image and swept by the ordinary kernel with B as the query side: 1/s of a full sweep).  By
+// construction about K' s rows of A pass tau(t), whatever the data looks like (the count of population members above
+// the K'-th order statistic of a sample is negative binomial: mean K' (s - 1), deviation sqrt(K') s), so the event
+// buffers are small and of predictable size.
+//
+// After the sweep: kz_dual_scatter_kernel files the logged groups per index row (per-key test, atomic slot),
+// kz_dual_select_kernel keeps the K' best events of every row as an ordinary candidate list, and the ordinary finalize
+// kernel certifies and re-ranks it in float64 with B as the query side -- with one change: rows of A outside the list are
+// bounded by max(K'-th list key, tau(t)) instead of the K'-th list key alone.  Rows of B whose event buffer overflowed or
+// whose list cannot be certified are searched again the ordinary way (kz_escalate_rows).  The result is the float64
+// neighbour order in both directions, as from two separate kz_knn calls.
+#pragma once
+
+// ---- thresholds from the sample sweep --------------------------------------------------------------------------------
+// One wave per row t of B.  The row's lists from the sample sweep hold pieces x K' <= 256 entries; tau = the K'-th best of
+// them (by key, ties by entry order).  theta(t) = tau + bias(t) - margin, rounded DOWN to float32: an event is
+// fl(acc - theta) >= -bias(q), so a NON-event has acc - theta < -bias(q) + 2^-24 |acc - theta|, and with
+// margin = 2^-22 S^2 (Ah Bh + Ac2 + Bc2) >= 2^-24 (|acc| + |theta|) that gives  acc - bias(t) + bias(q) < tau  in exact
+// arithmetic on the float32 values: every row outside the events has key' < tau.
+__global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restrict__ in_key, const int* __restrict__ in_idx,
+                                                            KzListLayout lay, int KP, int64_t n_b, int64_t n_b_pad,
+                                                            const float* __restrict__ bias_b, const double* __restrict__ a_hmax,
+                                                            const double* __restrict__ b_hmax, const double* __restrict__ hscale,
+                                                            float* __restrict__ theta, float* __restrict__ floor_) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_b_pad) return;
+    if (t >= n_b) {
+        if (lane == 0) theta[t] = INFINITY;
+        return;
+    }
+    const int M = lay.pieces[kz_list_region(t, lay)] * KP;
+    const int64_t l0 = kz_list_contig_off(t, lay, KP, 0);
+    float x[4];
+    int valid[4], rank[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = lane + 64 * u;
+        x[u] = e < M ? in_key[l0 + e] : -INFINITY;
+        valid[u] = e < M && in_idx[l0 + e] >= 0;
+        rank[u] = 0;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int lim = min(64, M - 64 * v);
+        for (int jj = 0; jj < lim; ++jj) {
+            const float ox = __shfl(x[v], jj, 64);
+            const int ov = __shfl(valid[v], jj, 64);
+            const int oe = jj + 64 * v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rank[u] += (ov && (ox > x[u] || (ox == x[u] && oe < lane + 64 * u))) ? 1 : 0;
+        }
+    }
+    float tau = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (valid[u] && rank[u] == KP - 1) tau = x[u];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tau = fmaxf(tau, __shfl_xor(tau, off, 64));
+    if (lane == 0) {
+        const double S2 = hscale[0] * hscale[0];
+        const double margin = 2.384185791015625e-07 * S2 * (a_hmax[0] * b_hmax[0] + a_hmax[2] + b_hmax[2]);
+        const double th = (double)tau + (double)bias_b[t] - margin;
+        float tf = (float)th;
+        if ((double)tf > th) tf = nextafterf(tf, -INFINITY);
+        theta[t] = tf;
+        floor_[t] = tau;
+    }
+}
+
+// -bias of the query side (pad rows: +inf, never an event)
+__global__ void kz_dual_negbias_kernel(const float* __restrict__ bias, int64_t n, int64_t n_pad, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pad) out[i] = i < n ? -bias[i] : INFINITY;
+}
+
+// ---- logged groups -> per-row event buffers --------------------------------------------------------------------------
+// One thread per logged group of four keys: the kernel's test again per key (the same float32 expression), an atomic slot
+// in the row's buffer, one 8-byte store.  A row with more events than its buffer holds keeps counting (kz_dual_select_kernel
+// sees the overflow and sends the row to the ordinary search).
+__global__ __launch_bounds__(256) void kz_dual_scatter_kernel(const f32x4e* __restrict__ log_keys, const i32x2e* __restrict__ log_meta,
+                                                              const unsigned long long* __restrict__ log_cnt, long long log_cap,
+                                                              const float* __restrict__ theta, const float* __restrict__ qnb,
+                                                              int* __restrict__ ev_cnt, uint2* __restrict__ ev, int ev_cap) {
+    const unsigned long long filled = *log_cnt;
+    // (an overflowed or poisoned log holds entries that were never written: nothing is filed, the host falls back)
+    const long long n = filled <= (unsigned long long)log_cap ? (long long)filled : 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4e kv = log_keys[i];
+        const i32x2e mt = log_meta[i];
+        const int ql = mt.x & 63, tg = mt.x >> 6;   // lane of the wave, 16 tile + group
+        const int row0 = (tg >> 4) * KZ_TILE + ((tg >> 2) & 3) * 32 + (tg & 3) * 8 + 4 * (ql >> 5);
+        const float nb = qnb[mt.y];
+        const float4 th = *reinterpret_cast<const float4*>(theta + row0);
+        const float kk[4] = {kv.x, kv.y, kv.z, kv.w};
+        const float tt[4] = {th.x, th.y, th.z, th.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (kk[u] - tt[u] >= nb) {
+                const int slot = atomicAdd(ev_cnt + row0 + u, 1);
+                if (slot < ev_cap) ev[(int64_t)(row0 + u) * ev_cap + slot] = make_uint2(__float_as_uint(kk[u]), (unsigned)mt.y);
+            }
+        }
+    }
+}
+
+// ---- the K' best events of a row -> an ordinary candidate list ---------------------------------------------------------
+// One wave per row t of B.  key'(t, q) = acc - bias(t) + bias(q) is evaluated in float64 on the float32 values (exact) and
+// rounded once to float32 (the list format); selection by (key' descending, q ascending) is a total order, so the list
+// does not depend on the order the atomics filed the events in.  K'-th key by radix select on the sortable bit pattern.
+__global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restrict__ ev_cnt, const uint2* __restrict__ ev, int ev_cap,
+                                                             int64_t n_b, const float* __restrict__ bias_b,
+                                                             const float* __restrict__ bias_a, int KP, float* __restrict__ out_key,
+                                                             int* __restrict__ out_idx, float* __restrict__ floor_,
+                                                             unsigned long long* __restrict__ totals) {
+    extern __shared__ __attribute__((aligned(16))) char ssm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t >= n_b) return;
+    unsigned* su = reinterpret_cast<unsigned*>(ssm) + (size_t)wave * 2 * ev_cap;   // sortable key bits
+    int* sq = reinterpret_cast<int*>(su + ev_cap);
+    const int filed = ev_cnt[t];
+    const int n = filed < ev_cap ? filed : ev_cap;
+    if (lane == 0) {
+        atomicAdd(totals + 0, (unsigned long long)filed);
+        if (filed > ev_cap) {
+            floor_[t] = INFINITY;   // incomplete events: the certification must fail, the row is searched again
+            atomicAdd(totals + 1, 1ull);
+        }
+    }
+    const double bt = (double)bias_b[t];
+    for (int e = lane; e < n; e += 64) {
+        const uint2 v = ev[t * (int64_t)ev_cap + e];
+        const float kf = (float)(((double)__uint_as_float(v.x) - bt) + (double)bias_a[v.y]);
+        const unsigned b = __float_as_uint(kf);
+        su[e] = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+        sq[e] = (int)v.y;
+    }
+    kz_wave_sync();
+    float* ok = out_key + t * (int64_t)KP;
+    int* oi = out_idx + t * (int64_t)KP;
+    auto key_of = [](unsigned u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); };
+    if (n <= KP) {
+        for (int e = lane; e < KP; e += 64) {
+            ok[e] = e < n ? key_of(su[e]) : -INFINITY;
+            oi[e] = e < n ? sq[e] : -1;
+        }
+        return;
+    }
+    // thr = the largest value with at least K' entries >= it
+    unsigned thr = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = thr | (1u << bit);
+        int c = 0;
+        for (int e0 = 0; e0 < n; e0 += 64) c += (int)__popcll(__ballot(e0 + lane < n && su[e0 + lane] >= cand));
+        if (c >= KP) thr = cand;
+    }
+    int base = 0;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        const bool sel = e < n && su[e] > thr;
+        const unsigned long long mask = __ballot(sel);
+        if (sel) {
+            const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            ok[pos] = key_of(su[e]);
+            oi[pos] = sq[e];
+        }
+        base += (int)__popcll(mask);
+    }
+    // the remaining slots go to the entries equal to thr with the smallest query rows
+    int last = -1;
+    for (; base < KP; ++base) {
+        int best = 0x7fffffff;
+        for (int e = lane; e < n; e += 64)
+            if (su[e] == thr && sq[e] > last && sq[e] < best) best = sq[e];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+        if (lane == 0) {
+            ok[base] = key_of(thr);
+            oi[base] = best;
+        }
+        last = best;
+    }
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------
+static void kz_dual_fill_stats(kz_knn_stats* st, const kz_knn_stats& v) {
+    if (st) *st = v;
+}
+
+// Both directions by two ordinary searches (shapes or settings the dual pass does not cover)
+static int kz_knn_dual_separately(kz_ctx* ctx, kz_matrix* a, kz_matrix* b, int k, double* d_dist_ab, int64_t* d_ind_ab,
+                                  double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba) {
+    int rc = kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, -1, 0, d_dist_ab, d_ind_ab, stats_ab, nullptr);
+    if (rc == KZ_OK) rc = kz_knn_impl(ctx, b, 0, b->n, a, k, 0, nullptr, -1, 0, d_dist_ba, d_ind_ba, stats_ba, nullptr);
+    return rc;
+}
+
+extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b_c, int k, double* d_dist_ab, int64_t* d_ind_ab,
+                           double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba) {
+    kz_matrix* a = const_cast<kz_matrix*>(a_c);
+    kz_matrix* b = const_cast<kz_matrix*>(b_c);
+    KZ_REQUIRE(ctx && a && b && d_dist_ab && d_ind_ab && d_dist_ba && d_ind_ba, "kz_knn_dual: null argument");
+    KZ_REQUIRE(a != b, "kz_knn_dual: the two matrices must be different objects (a single matrix is searched with kz_knn)");
+    KZ_REQUIRE(a->ctx == ctx && b->ctx == ctx, "kz_knn_dual: matrices belong to a different context");
+    KZ_REQUIRE(a->d == b->d, "kz_knn_dual: feature dimensions differ (%lld vs %lld)", (long long)a->d, (long long)b->d);
+    KZ_REQUIRE(a->dtype == b->dtype, "kz_knn_dual: the matrices must have the same dtype");
+    KZ_REQUIRE(a->metric == b->metric, "kz_knn_dual: the matrices were packed for different metrics");
+    KZ_REQUIRE(k >= 1, "kz_knn_dual: Expected k > 0. Got %d", k);
+    KZ_REQUIRE((int64_t)k <= a->n && (int64_t)k <= b->n,
+               "kz_knn_dual: Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k,
+               (long long)(a->n < b->n ? a->n : b->n));
+    if (stats_ab) memset(stats_ab, 0, sizeof(*stats_ab));
+    if (stats_ba) memset(stats_ba, 0, sizeof(*stats_ba));
+    KZ_HIP(hipSetDevice(ctx->device));
+
+    const int KP = kz_pick_list_len(k);
+    const int n_slices = b->kg / 4;
+    const int stride = ctx->dual_stride;                        // every stride-th tile of A is in the sample
+    const int64_t a_tiles = a->n_tiles, b_tiles = b->n_tiles;
+    const int64_t s_tiles = stride > 0 ? (a_tiles + stride - 1) / stride : 0;
+    // rows of A in the sample (the last tile of A may be partial and may or may not be part of it)
+    int64_t s_rows = s_tiles * KZ_TILE;
+    if (stride > 0 && (a_tiles - 1) % stride == 0) s_rows -= a_tiles * KZ_TILE - a->n;
+    // The column scan pays while events are rare: a (wave, tile) pair covers 4096 (query, index row) pairs, each an event
+    // with probability K' stride / |A|; beyond ~2 expected events per wave-tile the rescans and appends cost more than the
+    // second sweep they save (measured: 100k x 100k, K' = 16: 12.3 ms dual against 6.9 ms separately).  "dual_force" (test
+    // knob) skips this gate.
+    const bool pays = ctx->dual_force || (int64_t)KP * stride * 2048 <= a->n;
+    const bool eligible = pays && ctx->dual_stride >= 2 && ctx->precision == 0 && KP > 0 && n_slices >= 2 && n_slices <= 24 && a->kg == b->kg &&
+                          s_rows >= (int64_t)8 * KP && b->n >= 1024 && b_tiles < (1 << 20);
+    if (!eligible) return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
+
+    int rc = kz_himage_ensure(a, b);
+    if (rc != KZ_OK) return rc;
+    const kz_himage* ia = a->himg;
+    const kz_himage* ib = b->himg;
+    const int64_t b_pad = b_tiles * KZ_TILE, a_pad = a_tiles * KZ_TILE;
+
+    // expected events per row of B: K' (stride - 1), deviation sqrt(K') stride; the buffer takes mean + ~5 deviations
+    const int ev_cap = (int)(((int64_t)KP * stride + (int64_t)(5.0 * sqrt((double)KP) * stride) + 63) & ~(int64_t)63);
+    // logged groups: one per event (rarely two events share a group) + the groups whose keys fail the per-key test
+    // (none: a group is logged only if one of its keys passes) -- twice the expectation, plus slack for small inputs
+    const long long log_cap = (long long)b->n * KP * stride * 2 + (1 << 16);
+
+    unsigned short* s_packed = nullptr;
+    float *s_bias = nullptr, *theta = nullptr, *floor_ = nullptr, *qnb = nullptr, *col_key = nullptr;
+    int *ev_cnt = nullptr, *col_idx = nullptr, *fail_list = nullptr;
+    uint2* ev = nullptr;
+    void *log_keys = nullptr, *log_meta = nullptr;
+    unsigned long long* d_cnt = nullptr;   // [0] log counter, [1] events filed, [2] rows with an overflowing buffer
+    auto release = [&]() {
+        kz_pool_free(ctx, s_packed, 0);
+        kz_pool_free(ctx, s_bias, 0);
+        kz_pool_free(ctx, theta, 0);
+        kz_pool_free(ctx, floor_, 0);
+        kz_pool_free(ctx, qnb, 0);
+        kz_pool_free(ctx, col_key, 0);
+        kz_pool_free(ctx, ev_cnt, 0);
+        kz_pool_free(ctx, col_idx, 0);
+        kz_pool_free(ctx, fail_list, 0);
+        kz_pool_free(ctx, ev, 0);
+        kz_pool_free(ctx, log_keys, 0);
+        kz_pool_free(ctx, log_meta, 0);
+        kz_pool_free(ctx, d_cnt, 0);
+    };
+    const size_t tile_bytes = (size_t)n_slices * 4096;
+    rc = kz_pool_alloc(ctx, (size_t)s_tiles * tile_bytes + 32 * 4096, (void**)&s_packed);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)s_tiles * KZ_TILE * 4, (void**)&s_bias);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&theta);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&floor_);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&qnb);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * KP * 4, (void**)&col_key);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * KP * 4, (void**)&col_idx);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&ev_cnt);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * 4, (void**)&fail_list);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * ev_cap * 8, (void**)&ev);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 16, &log_keys);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 8, &log_meta);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, 64, (void**)&d_cnt);
+    if (rc != KZ_OK) {
+        release();
+        // (not enough memory for the event buffers: the two ordinary searches need far less)
+        return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
+    }
+#define KZ_DUAL_HIP(call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            kz_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);   \
+            release();                                                                                 \
+            return KZ_ERR_HIP;                                                                         \
+        }                                                                                              \
+    } while (0)
+#define KZ_DUAL_RC(expr)      \
+    do {                      \
+        rc = (expr);          \
+        if (rc != KZ_OK) {    \
+            release();        \
+            return rc;        \
+        }                     \
+    } while (0)
+
+    // ---- sample image: every stride-th tile of A's fp16 image (tiles are contiguous runs of n_slices x 4 KiB) ----------
+    KZ_DUAL_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+    KZ_DUAL_HIP(hipMemcpy2DAsync(s_packed, tile_bytes, ia->packed, tile_bytes * stride, tile_bytes, (size_t)s_tiles,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    KZ_DUAL_HIP(hipMemcpy2DAsync(s_bias, KZ_TILE * 4, ia->bias, (size_t)KZ_TILE * 4 * stride, KZ_TILE * 4, (size_t)s_tiles,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    KZ_DUAL_HIP(hipMemsetAsync(ev_cnt, 0, (size_t)b_pad * 4, ctx->stream));
+    KZ_DUAL_HIP(hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(kz_dual_negbias_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, ia->bias, a->n, a_pad, qnb);
+
+    // ---- sample sweep: B x sample(A) with the ordinary kernel, lists of at most 256 entries per row -----------------------
+    {
+        int blocks_per_cu = 1;
+        KZ_DISPATCH_KP(rc, kz_h_occupancy, (n_slices, &blocks_per_cu, ctx->h_wps, ctx->lds_pad));
+        if (rc != KZ_OK) {
+            release();
+            return rc;
+        }
+        KzPass ps;
+        KZ_DUAL_RC(kz_prepare_pass(ctx, (int)b_tiles, (int)s_tiles, blocks_per_cu * ctx->n_cus, 256 / KP, KP, KZ_TIER_H, 0, &ps));
+        KnnCandParams cp;
+        memset(&cp, 0, sizeof(cp));
+        cp.qpack = (const float*)ib->packed;
+        cp.ypack = (const float*)s_packed;
+        cp.ybias = s_bias;
+        cp.work = ps.d_work;
+        cp.qt0 = 0;
+        cp.n_ytiles = (int)s_tiles;
+        cp.lay = ps.lay;
+        cp.kg = b->kg;
+        cp.out_key = ps.out_key;
+        cp.out_idx = ps.out_idx;
+        KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W, ctx->h_wps));
+        if (rc != KZ_OK) {
+            release();
+            return rc;
+        }
+        hipLaunchKernelGGL(kz_dual_theta_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, ctx->stream, ps.out_key, ps.out_idx,
+                           ps.lay, KP, b->n, b_pad, ib->bias, ia->d_max, ib->d_max, ib->center->d_scale, theta, floor_);
+        KZ_DUAL_HIP(hipGetLastError());
+    }
+    KZ_DUAL_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+    float sample_ms = 0;
+
+    // ---- main sweep: A x B, lists of A's rows + event log of B's rows ---------------------------------------------------------
+    KzDualPass dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.theta = theta;
+    dp.qnbias = qnb;
+    dp.log_keys = log_keys;
+    dp.log_meta = log_meta;
+    dp.log_cnt = d_cnt;
+    dp.log_cap = log_cap;
+    kz_knn_stats st_ab;
+    KZ_DUAL_RC(kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, -1, 0, d_dist_ab, d_ind_ab, &st_ab, &dp));
+    // (kz_knn_impl ends with a stream synchronisation: ev[5] and ev[6] around the sample sweep have completed)
+    KZ_DUAL_HIP(hipEventElapsedTime(&sample_ms, ctx->ev[5], ctx->ev[6]));
+    st_ab.dual = 1;
+    kz_dual_fill_stats(stats_ab, st_ab);
+
+    kz_knn_stats st_ba;
+    memset(&st_ba, 0, sizeof(st_ba));
+    if (!dp.broken) {
+        // ---- events -> lists -> ordinary finalize with B as the query side --------------------------------------------------
+        KZ_DUAL_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+        hipLaunchKernelGGL(kz_dual_scatter_kernel, dim3(ctx->n_cus * 8), dim3(256), 0, ctx->stream, (const f32x4e*)log_keys,
+                           (const i32x2e*)log_meta, d_cnt, log_cap, theta, qnb, ev_cnt, ev, ev_cap);
+        const size_t sel_lds = (size_t)4 * 2 * ev_cap * 4;
+        if (sel_lds > 65536)
+            KZ_DUAL_HIP(hipFuncSetAttribute((const void*)kz_dual_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+        hipLaunchKernelGGL(kz_dual_select_kernel, dim3((unsigned)((b->n + 3) / 4)), dim3(256), sel_lds, ctx->stream, ev_cnt, ev, ev_cap,
+                           b->n, ib->bias, ia->bias, KP, col_key, col_idx, floor_, d_cnt + 1);
+        KZ_DUAL_HIP(hipGetLastError());
+        KZ_DUAL_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        KzListLayout lay;
+        memset(&lay, 0, sizeof(lay));
+        lay.n_regions = 1;
+        lay.qt_end[0] = (int)b_tiles;
+        lay.pieces[0] = 1;
+        lay.halves = 1;
+        lay.contig = 1;
+        int* fail_count = ctx->d_counters + 8;
+        KZ_DUAL_HIP(hipMemsetAsync(fail_count, 0, 4 * sizeof(int), ctx->stream));
+        KnnFinParams fp;
+        memset(&fp, 0, sizeof(fp));
+        fp.in_key = col_key;
+        fp.in_idx = col_idx;
+        fp.lay = lay;
+        fp.KP = KP;
+        fp.list_row0 = 0;
+        fp.q_begin = 0;
+        fp.q_count = b->n;
+        fp.qraw = b->raw;
+        fp.yraw = a->raw;
+        fp.qsqn = b->sqn;
+        fp.ysqn = a->sqn;
+        fp.n_i = a->n;
+        fp.d = (int)a->d;
+        fp.metric = a->metric;
+        fp.k = k;
+        fp.ystats = a->d_stats;
+        fp.tier_h = 1;
+        fp.eps_mult = ctx->eps_scale;
+        fp.gamma_acc = 2.0 * (double)(a->kg * 4 + 16) * 5.9604644775390625e-08;
+        fp.q_rowq = ib->rowq;
+        fp.y_hmax = ia->d_max;
+        fp.hscale = ia->center->d_scale;
+        fp.excl_floor = floor_;
+        fp.dual_col = 1;
+        fp.out_dist = d_dist_ba;
+        fp.out_ind = d_ind_ba;
+        fp.fail_count = fail_count;
+        fp.fail_list = fail_list;
+        fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
+        KZ_DUAL_RC(kz_launch_finalize(ctx, fp, lay, KP, b->n, a->dtype));
+        KZ_DUAL_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        KZ_DUAL_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        KZ_DUAL_HIP(hipMemcpyAsync(ctx->h_counters + 16, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+        KZ_DUAL_HIP(hipStreamSynchronize(ctx->stream));
+        const int n_fail = ctx->h_counters[8];
+        unsigned long long hc[4];
+        memcpy(hc, ctx->h_counters + 16, 32);
+        memcpy(&st_ba.max_err_ratio, ctx->h_counters + 10, 8);
+        float ms = 0;
+        KZ_DUAL_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        st_ba.main_kernel_ms = sample_ms + ms;   // sample sweep + scatter + select: what this direction cost besides the shared sweep
+        KZ_DUAL_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+        st_ba.finalize_ms = ms;
+        st_ba.list_len = KP;
+        st_ba.n_splits = 1;
+        st_ba.first_pass = KZ_TIER_H;
+        st_ba.dual = 1;
+        st_ba.n_events = (int64_t)hc[1];
+        st_ba.n_overflow_rows = (int64_t)hc[2];
+        if (hc[0] > (unsigned long long)log_cap) {
+            dp.broken = 1;   // the log itself overflowed: events are missing for unknown rows
+        } else if (n_fail > 0) {
+            // rows of B with an overflowing buffer or an uncertified list: the ordinary search, longer lists when they are few
+            const int kp_min = ((int64_t)n_fail * 8 > b->n || KP >= 128) ? 0 : KP * 4;
+            kz_knn_stats st2;
+            KZ_DUAL_RC(kz_escalate_rows(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, -1, kp_min, d_dist_ba, d_ind_ba, &st2, &ms));
+            st_ba.fallback_ms = ms;
+            st_ba.n_escalated_rows = n_fail + st2.n_escalated_rows;
+            st_ba.n_fallback_rows = st2.n_fallback_rows;
+            if (st2.max_err_ratio > st_ba.max_err_ratio) st_ba.max_err_ratio = st2.max_err_ratio;
+        }
+    }
+    release();
+    if (dp.broken) {
+        // the sweep left the fp16 tier on the way, or the log overflowed: this direction the ordinary way
+        rc = kz_knn_impl(ctx, b, 0, b->n, a, k, 0, nullptr, -1, 0, d_dist_ba, d_ind_ba, &st_ba, nullptr);
+        if (rc != KZ_OK) return rc;
+    }
+    kz_dual_fill_stats(stats_ba, st_ba);
+    return KZ_OK;
+#undef KZ_DUAL_HIP
+#undef KZ_DUAL_RC
+}

@@ -20,8 +20,6 @@
 
 typedef __attribute__((address_space(3))) float kz_lds_f32;
 typedef __attribute__((address_space(3))) int kz_lds_i32;
-typedef float f32x4e __attribute__((ext_vector_type(4)));
-typedef int i32x2e __attribute__((ext_vector_type(2)));
 
 // list storage: LDS ([entry][128 queries of the workgroup]) or the output arrays (K' contiguous entries per list)
 template <bool IN_LDS>
@@ -29,10 +27,10 @@ struct KzListRef;
 template <>
 struct KzListRef<true> {
     kz_lds_f32* k;
-    kz_lds_i32* i;
+    int i_off;   // rows live i_off floats behind the keys (a constant of the build: one address register, not two)
     static constexpr int STRIDE = 128;
     __device__ __forceinline__ kz_lds_f32* kp() const { return k; }
-    __device__ __forceinline__ kz_lds_i32* ip() const { return i; }
+    __device__ __forceinline__ kz_lds_i32* ip() const { return (kz_lds_i32*)(k + i_off); }
 };
 template <>
 struct KzListRef<false> {
@@ -65,6 +63,57 @@ struct KzWavePool {
     int cnt;                  // entries in use (wave-uniform)
     int tiles_done, next_merge;
 };
+
+// Dual pass (kz_knn_dual, kz_dual.hip): besides the per-query lists the kernel reports, for every INDEX row t, the queries
+// q whose key for the reverse direction  key'(t, q) = acc(q, t) - bias(t) + bias(q)  reaches a threshold tau(t) fixed
+// before the launch (from a sample of the query rows) -- the "events" of t.  The test is  fl(acc - theta(t)) >= -bias(q)
+// with theta = tau + bias(t) (rounded down, minus a margin for the one float32 subtraction).  A lane with an event in a
+// group of four keys appends the group blindly to the wave's pool (code < 0: not linked into any chain); every merge also
+// FLUSHES those entries to a global log (one atomic per flush reserves the range, the entries go out as coalesced 16- and
+// 8-byte stores).  Which of the four keys really is an event, and of which index row, is decided by kz_dual_scatter_kernel
+// after the launch: the kernel itself carries no per-key test, no per-row atomics and no threshold re-reads.
+struct KzDualRef {
+    f32x4e* log_keys;              // [log_cap] the four accumulators of the group
+    i32x2e* log_meta;              // [log_cap] {(16 tile + group) << 6 | lane of the wave, query row of the lane}
+    unsigned long long* log_cnt;   // entries reserved so far (may pass log_cap: the launch's events are then incomplete)
+    long long log_cap;
+    int qrow0;                     // global row of this wave's query 0
+};
+constexpr int KZ_COL_FLAG = (int)0x80000000;
+
+__device__ __forceinline__ void kz_flush_col3(const KzWavePool& pool, const KzDualRef& du) {
+    const int lane = threadIdx.x & 63;
+    // how many of the pool's entries are column entries (wave-uniform), then one reservation for all of them
+    int n_col = 0;
+    for (int e0 = 0; e0 < pool.cnt; e0 += 64) {   // (uniform trip count)
+        const int e = e0 + lane;
+        const bool col = e < pool.cnt && pool.meta[e].x < 0;
+        n_col += (int)__popcll(__builtin_amdgcn_ballot_w64(col));
+    }
+    if (n_col == 0) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = __hip_atomic_fetch_add(du.log_cnt, (unsigned long long)n_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    for (int e0 = 0; e0 < pool.cnt; e0 += 64) {
+        const int e = e0 + lane;
+        i32x2e mt;
+        mt.x = 0;
+        if (e < pool.cnt) mt = pool.meta[e];
+        const bool col = mt.x < 0;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(col);
+        if (col) {
+            const unsigned long long pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if ((long long)pos < du.log_cap) {
+                du.log_keys[pos] = pool.keys[e];
+                i32x2e mo;
+                mo.x = mt.x & 0x7fffffff;
+                mo.y = du.qrow0 + (mt.x & 31);
+                du.log_meta[pos] = mo;
+            }
+        }
+        base += __popcll(mask);
+    }
+}
 
 // Two-level minimum of an unsorted K'-entry list: the list is cut into NB blocks whose minima are kept in registers
 // (values only: the position of a block's minimum is found again when the block is re-read for the insert).
@@ -118,11 +167,25 @@ __device__ __forceinline__ void kz_list_insert3(const KzListRef<IN_LDS>& L, KzBl
 // Merge: lane l < 32 walks its own chain, then its partner's (lane l + 32: the other half of the same query), inserting
 // every key that still beats the list's threshold.  code = 16 tile + 4 mt + g4; the keys of an entry are index rows
 // 128 tile + 32 mt + 8 g4 + 4 half + 0..3 (C layout of the 32x32 MFMA).
-template <int KP, bool IN_LDS>
-__device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWavePool& pool, KzBlockMin3<KP>& bs) {
+// RECOMP: the block minima are NOT carried from merge to merge but re-read from the list at the start of every merge
+// (K' reads per merge against K'/4 registers per lane for the whole sweep: what the dual-pass build lacks at three
+// workgroups per CU and 13 stationary slices).
+template <int KP, bool IN_LDS, bool DUAL, bool RECOMP>
+__device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWavePool& pool, KzBlockMin3<KP>& bs, const KzDualRef& du) {
     const int lane = threadIdx.x & 63;
+    if constexpr (DUAL) kz_flush_col3(pool, du);
     const int other = __shfl_xor(st.head, 32, 64);
     if (lane < 32) {
+        if constexpr (RECOMP) {
+            constexpr int NB = KzBlockMin3<KP>::NB, BS = KzBlockMin3<KP>::BS, S = KzListRef<IN_LDS>::STRIDE;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float m = INFINITY;
+#pragma unroll
+                for (int jj = 0; jj < BS; ++jj) m = fminf(m, st.list.kp()[(b * BS + jj) * S]);
+                bs.bm[b] = m;
+            }
+        }
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             int e = half ? other : st.head;
@@ -151,7 +214,7 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
     do {                                                                 \
         const unsigned long long tm0_ = __builtin_amdgcn_s_memtime();    \
         n_ins += pool.cnt;                                               \
-        kz_merge_pool3<KP, IN_LDS>(st, pool, bs);                        \
+        kz_merge_pool3<KP, IN_LDS, DUAL, RECOMP>(st, pool, bs, du);              \
         __builtin_amdgcn_sched_barrier(0);                               \
         c_merge += __builtin_amdgcn_s_memtime() - tm0_;                  \
         n_pass += 1;                                                     \
@@ -161,7 +224,7 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
 #define KZ_EPI3_MERGE() do { st.head = -1; pool.cnt = 0; } while (0)   /* diagnostic build: scan without merges (threshold never rises) */
 #else
 #define KZ_EPI3_STAMP_ARGS
-#define KZ_EPI3_MERGE() kz_merge_pool3<KP, IN_LDS>(st, pool, bs)
+#define KZ_EPI3_MERGE() kz_merge_pool3<KP, IN_LDS, DUAL, RECOMP>(st, pool, bs, du)
 #endif
 
 // One group of four keys: the lanes in `mask` append it to the pool (positions pool.cnt + rank of the lane in the mask)
@@ -182,13 +245,101 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
         pool.cnt += __popcll(mask);                                                                                   \
     } while (0)
 
+// Dual pass: events of the tile's index rows.  tp = this lane-half's view of the tile's theta rows in LDS (the layout the
+// accumulator init uses), nbq = -bias of this lane's query.  One max tree of (acc - theta) per 32-row block and one ballot;
+// a block with an event (rare: the expected number of events per index row is fixed by the sample rate) is rescanned per
+// group of four and the groups with an event are appended.  Runs BEFORE kz_tile_epilogue3 (whose merge on the last tile
+// flushes the pool for good).
+typedef float f32x2e __attribute__((ext_vector_type(2)));
+// max over the four keys of a group of (acc - theta): two packed subtractions (v_pk_add_f32 with negated operand) + a max tree
+__device__ __forceinline__ float kz_col3_group_max(const f32x16& a, const int g4, const float4& th) {
+    f32x2e a01, a23, t01, t23;
+    a01.x = a[4 * g4];
+    a01.y = a[4 * g4 + 1];
+    a23.x = a[4 * g4 + 2];
+    a23.y = a[4 * g4 + 3];
+    t01.x = th.x;
+    t01.y = th.y;
+    t23.x = th.z;
+    t23.y = th.w;
+    const f32x2e d01 = a01 - t01, d23 = a23 - t23;
+    return fmaxf(fmaxf(d01.x, d01.y), fmaxf(d23.x, d23.y));
+}
+#define KZ_COL3_GROUP_MAX(mt, g4) kz_col3_group_max(acc[mt], (g4), th)
+#define KZ_COL3_APPEND(mt, g4, ev, mask)                                                                                      \
+    do {                                                                                                                      \
+        if (ev) {                                                                                                             \
+            const int pos = pool.cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)((mask) >> 32),                               \
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)(mask), 0u));       \
+            f32x4e kv;                                                                                                        \
+            kv.x = acc[mt][4 * (g4)];                                                                                         \
+            kv.y = acc[mt][4 * (g4) + 1];                                                                                     \
+            kv.z = acc[mt][4 * (g4) + 2];                                                                                     \
+            kv.w = acc[mt][4 * (g4) + 3];                                                                                     \
+            pool.keys[pos] = kv;                                                                                              \
+            i32x2e mv_;                                                                                                       \
+            int lane_;   /* the lane number, made HERE (kept in a register for the whole sweep it was spilled) */              \
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));                      \
+            mv_.x = KZ_COL_FLAG | ((tile * 16 + 4 * (mt) + (g4)) << 6) | lane_;                                               \
+            mv_.y = -1;                                                                                                       \
+            pool.meta[pos] = mv_;                                                                                             \
+        }                                                                                                                     \
+        pool.cnt += (int)__popcll(mask);                                                                                      \
+    } while (0)
+
+template <int KP, int CAP, bool IN_LDS, bool RECOMP>
+__device__ __forceinline__ void kz_tile_col3(f32x16 (&acc)[4], const float* tp, const float nbq, KzCandState3<IN_LDS>& st,
+                                             KzWavePool& pool, KzBlockMin3<KP>& bs, const int tile, kz_lds_i32* sync, const KzDualRef& du) {
+    unsigned long long hit[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 th = *reinterpret_cast<const float4*>(tp + 32 * mt + 8 * g4);
+            m = fmaxf(m, KZ_COL3_GROUP_MAX(mt, g4));
+        }
+        hit[mt] = __builtin_amdgcn_ballot_w64(m >= nbq);
+        __builtin_amdgcn_sched_barrier(0);   // one block's thresholds in flight at a time (register budget at three workgroups per CU)
+    }
+    if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull) return;
+    const int worst = 4 * (int)(__popcll(hit[0]) + __popcll(hit[1]) + __popcll(hit[2]) + __popcll(hit[3]));
+    // make room first if the worst case (every lane with a hit has one in all four groups of the block) would not fit
+    if (pool.cnt + worst > CAP) kz_merge_pool3<KP, IN_LDS, true, RECOMP>(st, pool, bs, du);
+    if (worst <= CAP) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (hit[mt] == 0ull) continue;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 th = *reinterpret_cast<const float4*>(tp + 32 * mt + 8 * g4);
+                const bool ev = KZ_COL3_GROUP_MAX(mt, g4) >= nbq;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(ev);
+                if (mask != 0ull) KZ_COL3_APPEND(mt, g4, ev, mask);
+            }
+        }
+    } else {
+        // More than CAP / 4 (lane, block) pairs of ONE tile with an event: the thresholds are not doing their job (the
+        // expected number is below one).  The tile's events are dropped and the log is marked as overflowed: the host
+        // then searches the reverse direction the ordinary way (kz_knn_dual.h).  No resumable per-group loop here: it
+        // cost 89 spilled registers at three workgroups per CU.
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(du.log_cnt, 1ull << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (same merge-together request as the list events make, written into the flag slot of the epilogue that follows)
+    if (pool.cnt > CAP / 2 && (threadIdx.x & 63) == 0) {
+        int one = 1;
+        asm volatile("" : "+v"(one));
+        sync[(pool.tiles_done + 1) & 3] = one;
+    }
+}
+
 // CAP = pool capacity (entries per wave).  sync = 4 LDS words of the workgroup (merge flags: a wave whose pool passes
 // CAP / 2 asks every wave of the workgroup to merge at the start of the next tile, so that no wave merges alone while
 // its siblings wait for it at the slice barrier; the flag of tile t is written during epilogue t, read during epilogue
 // t+1, cleared during epilogue t+2, and a workgroup barrier lies between any two epilogues).
-template <int KP, int CAP, bool IN_LDS>
+template <int KP, int CAP, bool IN_LDS, bool DUAL, bool RECOMP>
 __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3<IN_LDS>& st, KzWavePool& pool, KzBlockMin3<KP>& bs,
-                                                  const int tile, const bool last_tile, kz_lds_i32* sync KZ_EPI3_STAMP_ARGS) {
+                                                  const int tile, const bool last_tile, kz_lds_i32* sync, const KzDualRef& du KZ_EPI3_STAMP_ARGS) {
     KZ_T(te0);
     const int t = ++pool.tiles_done;
     const bool sched = (t == pool.next_merge) || last_tile;  // block-uniform

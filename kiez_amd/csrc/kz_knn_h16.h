@@ -24,7 +24,8 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 // Per (list length, occupancy class) configuration: ring slots, event-pool capacity per wave and where the lists live.  LDS per workgroup: 53.3 KiB at three workgroups per CU, 80 KiB at two.
 // (Every tile must contain a slice barrier -- the bias double buffer and the merge flags rely on it -- so the barrier
 // period RING / 2 never exceeds the slice count; NSR >= 2 is required by the host.)
-template <int KP, int WPS, int NSR>
+// DUAL: the dual-pass build (kz_knn_epi3.h "Dual pass"): + 3 x 128 threshold floats.
+template <int KP, int WPS, int NSR, bool DUAL = false>
 struct KzHCfg {
     static constexpr bool LDS_LIST = KP <= 32;
     static constexpr int RING = (WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8;
@@ -34,15 +35,16 @@ struct KzHCfg {
     static constexpr int RING_BYTES = RING * 4096;
     static constexpr int BIAS_OFF = RING_BYTES;                        // 2 x 128 floats
     static constexpr int SYNC_OFF = BIAS_OFF + 1024;                   // 4 merge flags (+ padding)
-    static constexpr int POOLK_OFF = SYNC_OFF + 256;                   // [4 waves][CAP] x 4 floats
+    static constexpr int THETA_OFF = SYNC_OFF + 256;                   // dual pass: 3 x 128 threshold floats
+    static constexpr int POOLK_OFF = THETA_OFF + (DUAL ? 1536 : 0);    // [4 waves][CAP] x 4 floats
     static constexpr int POOLM_OFF = POOLK_OFF + 4 * CAP * 16;         // [4 waves][CAP] x {code, next}
     static constexpr int LIST_OFF = POOLM_OFF + 4 * CAP * 8;           // keys [KP][128], then rows [KP][128]
     static constexpr int LDS_BYTES = LIST_OFF + (IN_LDS ? KP * 128 * 8 : 0);
 };
 
-template <int KP, int NSR, int WPS>
+template <int KP, int NSR, int WPS, bool DUAL = false>
 __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p) {
-    using Cfg = KzHCfg<KP, WPS, NSR>;
+    using Cfg = KzHCfg<KP, WPS, NSR, DUAL>;
     constexpr int R = Cfg::RING, P = R / 2, CAP = Cfg::CAP;
     constexpr bool IN_LDS = Cfg::IN_LDS;
     // at three waves per SIMD (168 VGPRs) the first fragments of the next tile are NOT fetched across the epilogue: the 16
@@ -53,10 +55,12 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     // beyond 8 slices the stationary query tile leaves no room for a second fragment set at three waves per SIMD: the
     // fragments of a slice are then fetched right before its MFMAs (two other waves of the SIMD cover the LDS latency)
     constexpr bool ONE_SET = WPS == 3 && NSR > 8;
+    constexpr bool RECOMP = DUAL && ONE_SET;   // kz_merge_pool3: block minima re-read per merge instead of carried
     constexpr int LAG = ONE_SET ? 1 : 2;   // slices between a barrier and the oldest slot it may hand to the DMA engine
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);                       // R slots x 1024 floats
     float* bbuf = reinterpret_cast<float*>(smem + Cfg::BIAS_OFF);       // 2 x 128 bias floats
+    float* tbuf = reinterpret_cast<float*>(smem + Cfg::THETA_OFF);      // dual pass: 3 x 128 thresholds
     kz_lds_i32* msync = (kz_lds_i32*)(smem + Cfg::SYNC_OFF);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     KzCandState3<IN_LDS> st;
     if constexpr (IN_LDS) {
         st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF) + 32 * (tid >> 6) + j;
-        st.list.i = (kz_lds_i32*)(smem + Cfg::LIST_OFF + KP * 128 * 4) + 32 * (tid >> 6) + j;
+        st.list.i_off = KP * 128;
     } else {
         // (uniform bases + a 32-bit per-lane element offset: no 64-bit per-lane pointers to keep alive; a launch's lists stay
         //  far below 2^32 elements: <= 524288 rows x 64 ranges x K')
@@ -126,6 +130,17 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
 #pragma unroll
     for (int i = 0; i < R; ++i) dma_next();
     bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
+    KzDualRef du;
+    float nbq = 0.0f;
+    if constexpr (DUAL) {
+        tbuf[tid & 127] = p.theta[(int64_t)t_begin * KZ_TILE + (tid & 127)];
+        du.log_keys = (f32x4e*)p.log_keys;
+        du.log_meta = (i32x2e*)p.log_meta;
+        du.log_cnt = p.log_cnt;
+        du.log_cap = p.log_cap;
+        du.qrow0 = (p.qt0 + qt) * KZ_TILE + 32 * wave;
+        nbq = p.qnbias[du.qrow0 + j];
+    }
     if (tid < 4) msync[tid] = 0;
     // stationary query fragments: lane (j, h) holds k = 16 u + 8 h + 0..7 of query row 32 wave + j
     const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * NSR) * 1024 + (h * KZ_TILE + 32 * (tid >> 6) + j) * 4;
@@ -144,6 +159,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     };
     if (CARRY) fetch_frags(f0, 0);
     int g = 0;
+    int th_cur = 0;   // dual pass: threshold buffer of the current tile (uniform)
     f32x16 acc[4];
 #ifdef KZ_STAMP
     unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0;
@@ -172,8 +188,22 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         // all waves before the next tile reads them.  No VGPR round trip, no extra wait.  Pinned BEHIND the accumulator
         // init (hipcc orders every ds_read after an LDS-DMA behind s_waitcnt vmcnt(0)).
         __builtin_amdgcn_sched_barrier(0);
-        if (wave < 2)
-            kz_glds4_s(p.ybias + (int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE, (unsigned)tid * 4u, bbuf + ((tile + 1) & 1) * 128 + wave * 64);
+        {
+            // lane offset tid * 4 of the 4-byte copies: derived from the 16-byte one HERE, by an instruction the compiler cannot
+            // hoist -- kept alive across the tile it was spilled at three workgroups per CU and reloaded (scratch_load +
+            // s_waitcnt vmcnt(0): a wait for the whole DMA ring) at the top of every tile
+            unsigned off4;
+            asm volatile("v_lshrrev_b32 %0, 2, %1" : "=v"(off4) : "v"(lane_off));
+            if (wave < 2)
+                kz_glds4_s(p.ybias + (int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE, off4, bbuf + ((tile + 1) & 1) * 128 + wave * 64);
+            else if (DUAL)
+                // ... and its thresholds, by the other two waves (the -128 floats of their lane offset are folded into the
+                // scalar base).  THREE buffers: the thresholds are read at the END of a tile (kz_tile_col3), so a wave that is
+                // already here may not overwrite what a slower wave still reads for the previous tile; the buffer written
+                // here was last read two tiles ago, with a slice barrier in between.
+                kz_glds4_s(p.theta + ((int64_t)min(tile + 1, p.n_ytiles - 1) - 1) * KZ_TILE, off4,
+                           tbuf + (th_cur == 2 ? 0 : th_cur + 1) * 128 + (wave - 2) * 64);
+        }
         constexpr bool carry_in = !ONE_SET && (CARRY || (P0 == 1 && (NSR & 1)));
         constexpr bool carry_out = !ONE_SET && (CARRY || (((P0 + NSR) & 1) != 0));
         if (!carry_in && !ONE_SET) {
@@ -233,7 +263,11 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         __builtin_amdgcn_sched_barrier(0);
 #ifdef KZ_STAMP
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        kz_tile_epilogue3<KP, CAP, IN_LDS>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, c_merge, n_pass, n_ins, c_e1, c_e2);
+        if constexpr (DUAL) {
+            kz_tile_col3<KP, CAP, IN_LDS, RECOMP>(acc, tbuf + th_cur * 128 + 4 * h, nbq, st, pool, bmin, tile, msync, du);
+            th_cur = th_cur == 2 ? 0 : th_cur + 1;
+        }
+        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du, c_merge, n_pass, n_ins, c_e1, c_e2);
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
@@ -241,7 +275,11 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         // diagnostic build (tools/ablate.sh, never shipped): no candidate scan at all -- the accumulators are only kept alive
         asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
 #else
-        kz_tile_epilogue3<KP, CAP, IN_LDS>(acc, st, pool, bmin, tile, tile == t_end - 1, msync);
+        if constexpr (DUAL) {
+            kz_tile_col3<KP, CAP, IN_LDS, RECOMP>(acc, tbuf + th_cur * 128 + 4 * h, nbq, st, pool, bmin, tile, msync, du);
+            th_cur = th_cur == 2 ? 0 : th_cur + 1;
+        }
+        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du);
 #endif
     };
 

@@ -1,9 +1,17 @@
 // Per-list-length translation unit of the fp16 fused kernels (included by kz_knn_h_kp{16,32,64,128}.hip with KZ_H_KP
-// defined): the slice counts of one list length compile in parallel with the other list lengths.
+// defined): the slice counts of one list length compile in parallel with the other list lengths.  With KZ_H_DUAL
+// defined (kz_knn_hd_kp*.hip) the unit holds the dual-pass builds of the same kernels (kz_hd_* entry points).
 #include "kz_common.h"
 #include "kz_knn_device.h"
 #include "kz_knn_h16.h"
 
+#ifdef KZ_H_DUAL
+#define KZ_H_DUALV true
+#define KZ_H_NAME(base) KZ_H_CAT(kz_hd_##base##_kp, KZ_H_KP)
+#else
+#define KZ_H_DUALV false
+#define KZ_H_NAME(base) KZ_H_CAT(kz_h_##base##_kp, KZ_H_KP)
+#endif
 #define KZ_H_CAT2(a, b) a##b
 #define KZ_H_CAT(a, b) KZ_H_CAT2(a, b)
 
@@ -21,11 +29,11 @@ template <int KP, int NSR>
 static const void* kz_h_kernel(int wps, int* lds) {
     constexpr bool three = NSR <= KZ_H_WPS3_MAX || (KP == 16 && NSR <= KZ_H_WPS3_MAX_KP16);
     if (three && wps != 2) {
-        *lds = KzHCfg<KP, 3, NSR>::LDS_BYTES;
-        return (const void*)kz_knn_cand_h_kernel<KP, (three ? NSR : 2), 3>;
+        *lds = KzHCfg<KP, 3, NSR, KZ_H_DUALV>::LDS_BYTES;
+        return (const void*)kz_knn_cand_h_kernel<KP, (three ? NSR : 2), 3, KZ_H_DUALV>;
     }
-    *lds = KzHCfg<KP, 2, NSR>::LDS_BYTES;
-    return (const void*)kz_knn_cand_h_kernel<KP, NSR, 2>;
+    *lds = KzHCfg<KP, 2, NSR, KZ_H_DUALV>::LDS_BYTES;
+    return (const void*)kz_knn_cand_h_kernel<KP, NSR, 2, KZ_H_DUALV>;
 }
 
 template <int KP, int NSR>
@@ -78,13 +86,13 @@ static int kz_launch_h(kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wp
         }                                                 \
     } while (0)
 
-int KZ_H_CAT(kz_h_occupancy_kp, KZ_H_KP)(int n_slices, int* blocks_per_cu, int wps, int lds_pad) {
+int KZ_H_NAME(occupancy)(int n_slices, int* blocks_per_cu, int wps, int lds_pad) {
     int rc;
     KZ_DISPATCH_H_NSR(rc, kz_h_occupancy, (blocks_per_cu, wps, lds_pad), KZ_H_KP);
     return rc;
 }
 
-int KZ_H_CAT(kz_h_launch_kp, KZ_H_KP)(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps) {
+int KZ_H_NAME(launch)(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps) {
     int rc;
     KZ_DISPATCH_H_NSR(rc, kz_launch_h, (ctx, p, n_blocks, wps), KZ_H_KP);
     return rc;

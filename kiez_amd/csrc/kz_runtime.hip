@@ -44,6 +44,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->force_splits = 0;
     c->h_wps = 0;
     c->min_splits = 1;
+    c->dual_stride = 10;
     c->lds_pad = 0;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
@@ -56,7 +57,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
         KZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    for (int i = 0; i < 6; ++i) KZ_HIP(hipEventCreate(&c->ev[i]));
+    for (int i = 0; i < 8; ++i) KZ_HIP(hipEventCreate(&c->ev[i]));
     KZ_HIP(hipMalloc((void**)&c->d_counters, 64 * sizeof(int)));
     KZ_HIP(hipHostMalloc((void**)&c->h_counters, 64 * sizeof(int), hipHostMallocDefault));
     KZ_HIP(hipMemsetAsync(c->d_counters, 0, 64 * sizeof(int), c->stream));
@@ -74,7 +75,7 @@ int kz_ctx_destroy(kz_ctx* c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
-    for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return KZ_OK;
@@ -104,6 +105,11 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
         KZ_REQUIRE(value == 0 || value == 1 || value == 2,
                    "precision must be 0 (fp16 first pass), 2 (split-bf16 first pass) or 1 (float32 operands only)");
         c->precision = (int)value;
+    } else if (strcmp(name, "dual_stride") == 0) {
+        KZ_REQUIRE(value == 0 || (value >= 2 && value <= 64), "dual_stride must be 0 (no dual pass) or in [2, 64]");
+        c->dual_stride = (int)value;
+    } else if (strcmp(name, "dual_force") == 0) {
+        c->dual_force = value != 0;
     } else if (strcmp(name, "lds_pad") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
         c->lds_pad = (int)value;

@@ -8,7 +8,7 @@ objs=""
 pids=""
 for f in $(make -s -C kiez_amd/csrc print-srcs); do
   b=${f%.hip}
-  fl=""; case $f in kz_knn_h_kp*) fl="-fno-honor-nans";; esac
+  fl=""; case $f in kz_knn_h_kp*|kz_knn_hd_kp*) fl="-fno-honor-nans";; esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DKZ_STAMP $fl "$@" -c kiez_amd/csrc/$f -o /tmp/kz_stamp_obj/$b.o &
   pids="$pids $!"
   objs="$objs /tmp/kz_stamp_obj/$b.o"
