@@ -59,6 +59,7 @@ typedef struct kz_knn_stats {
     int32_t reserved_;
     int64_t n_events;        /* kz_knn_dual, reverse direction: events filed for the rows of b                */
     int64_t n_overflow_rows; /* kz_knn_dual, reverse direction: rows of b whose event buffer overflowed (searched again) */
+    int64_t n_logged_groups; /* kz_knn_dual, reverse direction: groups of four keys the sweep logged (>= n_events / 4)   */
 } kz_knn_stats;
 
 /* ---- library / context -------------------------------------------------------------------------------- */

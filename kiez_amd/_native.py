@@ -50,6 +50,7 @@ class KnnStats(C.Structure):
         ("reserved_", C.c_int32),
         ("n_events", C.c_int64),
         ("n_overflow_rows", C.c_int64),
+        ("n_logged_groups", C.c_int64),
     ]
 
     def as_dict(self):

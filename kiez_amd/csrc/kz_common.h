@@ -91,6 +91,9 @@ struct kz_matrix {
 int kz_matrix_image_f32(kz_matrix* m);
 int kz_matrix_image_bf(kz_matrix* m);
 int kz_himage_ensure(kz_matrix* query, kz_matrix* index);
+int kz_himage_pack_permuted(kz_matrix* m, const int* d_perm, unsigned short* packed, float* bias);
+// stable sort of (float key, int value) pairs on the context's stream (kz_sort.hip)
+int kz_sort_pairs_f32_i32(kz_ctx* ctx, const float* keys_in, float* keys_out, const int* vals_in, int* vals_out, int n, int descending);
 int kz_matrix_check(kz_matrix* m);
 void kz_himage_free(kz_matrix* m);
 

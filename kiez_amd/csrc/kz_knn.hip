@@ -280,6 +280,7 @@ struct KnnFinParams {
     // have an approximate key below excl_floor[q] (+inf: the row's events are incomplete, it must fail)
     const float* excl_floor;
     int dual_col;
+    const int* idx_map;   // dual pass, forward direction: list entry r stands for index row idx_map[r] (NULL: identity)
     double* out_dist;     // [q_count][k]
     int64_t* out_ind;
     int* fail_count;
@@ -409,7 +410,9 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         const int64_t l0 = kz_list_contig_off(lrow, p.lay, KP, 0);
         for (int e = lane; e < M; e += 64) {
             ekey[e] = p.in_key[l0 + e];
-            eidx[e] = p.in_idx[l0 + e];
+            int r = p.in_idx[l0 + e];
+            if (p.idx_map && r >= 0) r = p.idx_map[r];
+            eidx[e] = r;
         }
     } else {
         const int64_t lwave = kz_list_wave_base(lrow, p.lay, KP, 0) + (lrow & 31);
@@ -1047,7 +1050,10 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
 // and scatter the results into out_dist / out_ind at the rows' positions.  Ends with a stream synchronisation.
 // Dual pass (kz_knn_dual.h): what the main sweep needs to report the events of the index rows besides its own lists.
 struct KzDualPass {
-    const float* theta;            // [index tiles * 128]
+    const float* ypack;            // fp16 image of the index rows SORTED by their event threshold (kz_himage_pack_permuted) ...
+    const float* ybias;            // ... and its accumulator-init rows
+    const int* perm;               // [index rows] matrix row of image row r: list entries are translated by the finalize kernel
+    const float* theta;            // [index tiles * 128] per row of the sorted image: the smallest threshold of its tile
     const float* qnbias;           // [query tiles * 128]
     void* log_keys;
     void* log_meta;
@@ -1255,7 +1261,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         cp.dbg = nullptr;
 #ifdef KZ_STAMP
         cp.dbg = (unsigned long long*)(ctx->d_counters + 16);
-        KZ_HIP(hipMemsetAsync(cp.dbg, 0, 10 * sizeof(unsigned long long), ctx->stream));
+        KZ_HIP(hipMemsetAsync(cp.dbg, 0, 12 * sizeof(unsigned long long), ctx->stream));
 #endif
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         if (exact_only) {
@@ -1263,6 +1269,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((cq_count + 255) / 256)), dim3(256), 0, ctx->stream, fail_list, (int)cq_count);
             KZ_HIP(hipGetLastError());
         } else if (tier == KZ_TIER_H && dual) {
+            cp.ypack = dual->ypack;
+            cp.ybias = dual->ybias;
             cp.theta = dual->theta;
             cp.qnbias = dual->qnbias;
             cp.log_keys = dual->log_keys;
@@ -1309,6 +1317,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             fp.y_hmax = index->himg->d_max;
             fp.hscale = index->himg->center->d_scale;
         }
+        if (tier == KZ_TIER_H && dual) fp.idx_map = dual->perm;   // the lists hold rows of the sorted image
         fp.out_dist = d_dist + c0 * (int64_t)k;
         fp.out_ind = d_ind + c0 * (int64_t)k;
         fp.fail_count = fail_count;
@@ -1345,7 +1354,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         }
 #ifdef KZ_STAMP
         {
-            unsigned long long hd[10];
+            unsigned long long hd[12];
             KZ_HIP(hipMemcpy(hd, ctx->d_counters + 16, sizeof(hd), hipMemcpyDeviceToHost));
             const double wt = (double)(hd[3] ? hd[3] : 1);  // wave-tiles
             if (tier == KZ_TIER_F32) {
@@ -1355,9 +1364,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                         hd[6] / wt, hd[7] / wt, hd[8] / wt);
             } else {
                 fprintf(stderr, "[kz stamp] %s kernel, per wave-tile cycles: slices %.0f (dma wait %.0f, barrier wait %.0f)  epilogue %.0f "
-                        "(masks %.0f, first scan pass %.0f, merges %.0f; merge passes %.4f, max-lane inserts %.3f)  (wave-tiles %llu)\n",
+                        "(masks %.0f, first scan pass %.0f, merges %.0f; merge passes %.4f, max-lane inserts %.3f; column part %.0f in %.3f of the tiles)  (wave-tiles %llu)\n",
                         tier == KZ_TIER_H ? "fp16" : "bf16", hd[0] / wt, hd[7] / wt, hd[8] / wt, hd[1] / wt, hd[2] / wt, hd[9] / wt,
-                        hd[4] / wt, hd[5] / wt, hd[6] / wt, hd[3]);
+                        hd[4] / wt, hd[5] / wt, hd[6] / wt, hd[10] / wt, hd[11] / wt, hd[3]);
             }
         }
 #endif

@@ -73,11 +73,9 @@ struct KzWavePool {
 // 8-byte stores).  Which of the four keys really is an event, and of which index row, is decided by kz_dual_scatter_kernel
 // after the launch: the kernel itself carries no per-key test, no per-row atomics and no threshold re-reads.
 struct KzDualRef {
-    f32x4e* log_keys;              // [log_cap] the four accumulators of the group
-    i32x2e* log_meta;              // [log_cap] {(16 tile + group) << 6 | lane of the wave, query row of the lane}
-    unsigned long long* log_cnt;   // entries reserved so far (may pass log_cap: the launch's events are then incomplete)
-    long long log_cap;
-    int qrow0;                     // global row of this wave's query 0
+    int qrow0;   // global row of this wave's query 0
+    // (the log's pointers, counter and capacity are read from the kernel argument segment inside kz_flush_col3, per flush:
+    //  carried in scalar registers for the whole sweep they pushed the kernel into spilling SGPRs to a VGPR)
 };
 constexpr int KZ_COL_FLAG = (int)0x80000000;
 
@@ -91,8 +89,14 @@ __device__ __forceinline__ void kz_flush_col3(const KzWavePool& pool, const KzDu
         n_col += (int)__popcll(__builtin_amdgcn_ballot_w64(col));
     }
     if (n_col == 0) return;
+    typedef __attribute__((address_space(4))) const volatile unsigned long long kz_karg_u64;
+    const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    f32x4e* log_keys = (f32x4e*)*(kz_karg_u64*)(ka + offsetof(KnnCandParams, log_keys));
+    i32x2e* log_meta = (i32x2e*)*(kz_karg_u64*)(ka + offsetof(KnnCandParams, log_meta));
+    unsigned long long* log_cnt = (unsigned long long*)*(kz_karg_u64*)(ka + offsetof(KnnCandParams, log_cnt));
+    const long long log_cap = (long long)*(kz_karg_u64*)(ka + offsetof(KnnCandParams, log_cap));
     unsigned long long base = 0;
-    if (lane == 0) base = __hip_atomic_fetch_add(du.log_cnt, (unsigned long long)n_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) base = __hip_atomic_fetch_add(log_cnt, (unsigned long long)n_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
     for (int e0 = 0; e0 < pool.cnt; e0 += 64) {
         const int e = e0 + lane;
@@ -103,12 +107,12 @@ __device__ __forceinline__ void kz_flush_col3(const KzWavePool& pool, const KzDu
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(col);
         if (col) {
             const unsigned long long pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            if ((long long)pos < du.log_cap) {
-                du.log_keys[pos] = pool.keys[e];
+            if ((long long)pos < log_cap) {
+                log_keys[pos] = pool.keys[e];
                 i32x2e mo;
                 mo.x = mt.x & 0x7fffffff;
                 mo.y = du.qrow0 + (mt.x & 31);
-                du.log_meta[pos] = mo;
+                log_meta[pos] = mo;
             }
         }
         base += __popcll(mask);
@@ -209,7 +213,7 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
 }
 
 #ifdef KZ_STAMP
-#define KZ_EPI3_STAMP_ARGS , unsigned long long& c_merge, unsigned long long& n_pass, unsigned long long& n_ins, unsigned long long& c_e1, unsigned long long& c_e2
+#define KZ_EPI3_STAMP_ARGS , unsigned long long& c_merge, unsigned long long& n_pass, unsigned long long& n_ins, unsigned long long& c_e1, unsigned long long& c_e2, unsigned long long& c_col, unsigned long long& n_col
 #define KZ_EPI3_MERGE()                                                  \
     do {                                                                 \
         const unsigned long long tm0_ = __builtin_amdgcn_s_memtime();    \
@@ -245,93 +249,28 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
         pool.cnt += __popcll(mask);                                                                                   \
     } while (0)
 
-// Dual pass: events of the tile's index rows.  tp = this lane-half's view of the tile's theta rows in LDS (the layout the
-// accumulator init uses), nbq = -bias of this lane's query.  One max tree of (acc - theta) per 32-row block and one ballot;
-// a block with an event (rare: the expected number of events per index row is fixed by the sample rate) is rescanned per
-// group of four and the groups with an event are appended.  Runs BEFORE kz_tile_epilogue3 (whose merge on the last tile
-// flushes the pool for good).
-typedef float f32x2e __attribute__((ext_vector_type(2)));
-// max over the four keys of a group of (acc - theta): two packed subtractions (v_pk_add_f32 with negated operand) + a max tree
-__device__ __forceinline__ float kz_col3_group_max(const f32x16& a, const int g4, const float4& th) {
-    f32x2e a01, a23, t01, t23;
-    a01.x = a[4 * g4];
-    a01.y = a[4 * g4 + 1];
-    a23.x = a[4 * g4 + 2];
-    a23.y = a[4 * g4 + 3];
-    t01.x = th.x;
-    t01.y = th.y;
-    t23.x = th.z;
-    t23.y = th.w;
-    const f32x2e d01 = a01 - t01, d23 = a23 - t23;
-    return fmaxf(fmaxf(d01.x, d01.y), fmaxf(d23.x, d23.y));
-}
-#define KZ_COL3_GROUP_MAX(mt, g4) kz_col3_group_max(acc[mt], (g4), th)
-#define KZ_COL3_APPEND(mt, g4, ev, mask)                                                                                      \
+// Dual pass: a group whose maximum reaches the tile's column threshold goes to the pool as a column entry (code < 0, not
+// linked into any chain; kz_flush_col3)
+#define KZ_EPI3_APPEND_COL(gi, ev, mask)                                                                                      \
     do {                                                                                                                      \
         if (ev) {                                                                                                             \
             const int pos = pool.cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)((mask) >> 32),                               \
                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)(mask), 0u));       \
             f32x4e kv;                                                                                                        \
-            kv.x = acc[mt][4 * (g4)];                                                                                         \
-            kv.y = acc[mt][4 * (g4) + 1];                                                                                     \
-            kv.z = acc[mt][4 * (g4) + 2];                                                                                     \
-            kv.w = acc[mt][4 * (g4) + 3];                                                                                     \
+            kv.x = acc[(gi) >> 2][4 * ((gi) & 3)];                                                                            \
+            kv.y = acc[(gi) >> 2][4 * ((gi) & 3) + 1];                                                                        \
+            kv.z = acc[(gi) >> 2][4 * ((gi) & 3) + 2];                                                                        \
+            kv.w = acc[(gi) >> 2][4 * ((gi) & 3) + 3];                                                                        \
             pool.keys[pos] = kv;                                                                                              \
             i32x2e mv_;                                                                                                       \
             int lane_;   /* the lane number, made HERE (kept in a register for the whole sweep it was spilled) */              \
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));                      \
-            mv_.x = KZ_COL_FLAG | ((tile * 16 + 4 * (mt) + (g4)) << 6) | lane_;                                               \
+            mv_.x = KZ_COL_FLAG | ((tile * 16 + (gi)) << 6) | lane_;                                                          \
             mv_.y = -1;                                                                                                       \
             pool.meta[pos] = mv_;                                                                                             \
         }                                                                                                                     \
         pool.cnt += (int)__popcll(mask);                                                                                      \
     } while (0)
-
-template <int KP, int CAP, bool IN_LDS, bool RECOMP>
-__device__ __forceinline__ void kz_tile_col3(f32x16 (&acc)[4], const float* tp, const float nbq, KzCandState3<IN_LDS>& st,
-                                             KzWavePool& pool, KzBlockMin3<KP>& bs, const int tile, kz_lds_i32* sync, const KzDualRef& du) {
-    unsigned long long hit[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 th = *reinterpret_cast<const float4*>(tp + 32 * mt + 8 * g4);
-            m = fmaxf(m, KZ_COL3_GROUP_MAX(mt, g4));
-        }
-        hit[mt] = __builtin_amdgcn_ballot_w64(m >= nbq);
-        __builtin_amdgcn_sched_barrier(0);   // one block's thresholds in flight at a time (register budget at three workgroups per CU)
-    }
-    if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull) return;
-    const int worst = 4 * (int)(__popcll(hit[0]) + __popcll(hit[1]) + __popcll(hit[2]) + __popcll(hit[3]));
-    // make room first if the worst case (every lane with a hit has one in all four groups of the block) would not fit
-    if (pool.cnt + worst > CAP) kz_merge_pool3<KP, IN_LDS, true, RECOMP>(st, pool, bs, du);
-    if (worst <= CAP) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            if (hit[mt] == 0ull) continue;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const float4 th = *reinterpret_cast<const float4*>(tp + 32 * mt + 8 * g4);
-                const bool ev = KZ_COL3_GROUP_MAX(mt, g4) >= nbq;
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(ev);
-                if (mask != 0ull) KZ_COL3_APPEND(mt, g4, ev, mask);
-            }
-        }
-    } else {
-        // More than CAP / 4 (lane, block) pairs of ONE tile with an event: the thresholds are not doing their job (the
-        // expected number is below one).  The tile's events are dropped and the log is marked as overflowed: the host
-        // then searches the reverse direction the ordinary way (kz_knn_dual.h).  No resumable per-group loop here: it
-        // cost 89 spilled registers at three workgroups per CU.
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(du.log_cnt, 1ull << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // (same merge-together request as the list events make, written into the flag slot of the epilogue that follows)
-    if (pool.cnt > CAP / 2 && (threadIdx.x & 63) == 0) {
-        int one = 1;
-        asm volatile("" : "+v"(one));
-        sync[(pool.tiles_done + 1) & 3] = one;
-    }
-}
 
 // CAP = pool capacity (entries per wave).  sync = 4 LDS words of the workgroup (merge flags: a wave whose pool passes
 // CAP / 2 asks every wave of the workgroup to merge at the start of the next tile, so that no wave merges alone while
@@ -339,7 +278,8 @@ __device__ __forceinline__ void kz_tile_col3(f32x16 (&acc)[4], const float* tp, 
 // t+1, cleared during epilogue t+2, and a workgroup barrier lies between any two epilogues).
 template <int KP, int CAP, bool IN_LDS, bool DUAL, bool RECOMP>
 __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3<IN_LDS>& st, KzWavePool& pool, KzBlockMin3<KP>& bs,
-                                                  const int tile, const bool last_tile, kz_lds_i32* sync, const KzDualRef& du KZ_EPI3_STAMP_ARGS) {
+                                                  const int tile, const bool last_tile, kz_lds_i32* sync, const KzDualRef& du,
+                                                  const float cthr KZ_EPI3_STAMP_ARGS) {
     KZ_T(te0);
     const int t = ++pool.tiles_done;
     const bool sched = (t == pool.next_merge) || last_tile;  // block-uniform
@@ -364,41 +304,112 @@ __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3
         const int mt = gi >> 2, g4 = gi & 3;
         gm[gi] = fmaxf(fmaxf(acc[mt][4 * g4], acc[mt][4 * g4 + 1]), fmaxf(acc[mt][4 * g4 + 2], acc[mt][4 * g4 + 3]));
     }
-    float m = gm[0];
+    // ... four block maxima (one per 32-row block) on the way to the tile maximum: a tile with an event usually has it in
+    // ONE block, and only that block's four groups are then looked at (4 + 4 ballots instead of 16)
+    float bmx[4];
 #pragma unroll
-    for (int gi = 1; gi < 16; ++gi) m = fmaxf(m, gm[gi]);
+    for (int mt = 0; mt < 4; ++mt) bmx[mt] = fmaxf(fmaxf(gm[4 * mt], gm[4 * mt + 1]), fmaxf(gm[4 * mt + 2], gm[4 * mt + 3]));
+    const float m = fmaxf(fmaxf(bmx[0], bmx[1]), fmaxf(bmx[2], bmx[3]));
     float tau_a = st.tau;
     const unsigned long long anym = __builtin_amdgcn_ballot_w64(m > tau_a);
+    // Dual pass: the index rows of a tile are sorted by their event threshold, so ONE per-tile value (the tile's smallest
+    // theta, plus this query's own offset: cthr) tested against the same maxima finds the groups that may hold an event of
+    // an index row -- a second compare on the tile maximum, nothing per key.  Which of the four keys of such a group
+    // really is an event of its row is decided after the launch (kz_dual_scatter_kernel).
+    unsigned long long anyc = 0ull;
+    if constexpr (DUAL) anyc = __builtin_amdgcn_ballot_w64(m >= cthr);
 #ifdef KZ_STAMP
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long te1 = __builtin_amdgcn_s_memtime();
     c_e1 += te1 - te0;
 #endif
-    if (anym != 0ull) {
-        if (pool.cnt + 16 * (int)__popcll(anym) <= CAP) {
-            // common path: even if every lane with an event had one in all 16 groups the pool would hold them -- no checks
+    if ((anym | anyc) != 0ull) {
+        // room needed at most: four entries per (lane, block) pair with an event -- counted from the block maxima (a tile with
+        // an event usually has ONE such pair; the older bound, 16 entries per lane with an event, sent many tiles down the
+        // slow path once the pool carried the column entries of a dual pass)
+        int worst = 0;
+        if (anym != 0ull) {
 #pragma unroll
-            for (int gi = 0; gi < 16; ++gi) {
-                const bool ev = gm[gi] > tau_a;
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(ev);
-                if (mask != 0ull) KZ_EPI3_APPEND(gi, ev, mask);
+            for (int mt = 0; mt < 4; ++mt) worst += 4 * (int)__popcll(__builtin_amdgcn_ballot_w64(bmx[mt] > tau_a));
+        }
+        if constexpr (DUAL) {
+            if (anyc != 0ull) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) worst += 4 * (int)__popcll(__builtin_amdgcn_ballot_w64(bmx[mt] >= cthr));
+            }
+        }
+        if (pool.cnt + worst <= CAP) {
+            // common path: whatever the groups hold, the pool takes it -- no checks
+            if (anym != 0ull) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    if (__builtin_amdgcn_ballot_w64(bmx[mt] > tau_a) == 0ull) continue;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int gi = 4 * mt + g4;
+                        const bool ev = gm[gi] > tau_a;
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(ev);
+                        if (mask != 0ull) KZ_EPI3_APPEND(gi, ev, mask);
+                    }
+                }
+            }
+            if constexpr (DUAL) {
+                if (anyc != 0ull) {
+#ifdef KZ_STAMP
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        if (__builtin_amdgcn_ballot_w64(bmx[mt] >= cthr) == 0ull) continue;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int gi = 4 * mt + g4;
+                            const bool evc = gm[gi] >= cthr;
+                            const unsigned long long maskc = __builtin_amdgcn_ballot_w64(evc);
+                            if (maskc != 0ull) KZ_EPI3_APPEND_COL(gi, evc, maskc);
+                        }
+                    }
+#ifdef KZ_STAMP
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("" ::"v"(pool.cnt));
+                    c_col += __builtin_amdgcn_s_memtime() - tc0;
+                    n_col += 1;
+#endif
+                }
             }
         } else {
             // slow path (first tiles of a sweep, bursts, a pool that is nearly full): merge when a group does not fit and
-            // resume at that group with the fresher threshold
+            // resume at that step with the fresher threshold (step = 2 group + kind: list entry, then column entry)
             int resume = 0;
+            float cthr_l = cthr;
             for (;;) {
                 bool need_room = false;
+                // (opaque to the compiler: the 16 column masks are loop invariant, and hoisted out of this loop they held 32
+                //  scalar registers -- SGPRs spilled into a VGPR the kernel does not have at three workgroups per CU)
+                if constexpr (DUAL) asm volatile("" : "+v"(cthr_l));
 #pragma unroll
                 for (int gi = 0; gi < 16; ++gi) {
                     const bool ev = gm[gi] > tau_a;
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64(ev);
-                    if (gi >= resume && !need_room && mask != 0ull) {
+                    if (2 * gi >= resume && !need_room && mask != 0ull) {
                         if (pool.cnt + (int)__popcll(mask) > CAP) {
                             need_room = true;
-                            resume = gi;
+                            resume = 2 * gi;
                         } else {
                             KZ_EPI3_APPEND(gi, ev, mask);
+                        }
+                    }
+                    if constexpr (DUAL) {
+                        const bool evc = gm[gi] >= cthr_l;
+                        const unsigned long long maskc = __builtin_amdgcn_ballot_w64(evc);
+                        if (2 * gi + 1 >= resume && !need_room && maskc != 0ull) {
+                            if (pool.cnt + (int)__popcll(maskc) > CAP) {
+                                need_room = true;
+                                resume = 2 * gi + 1;
+                            } else {
+                                KZ_EPI3_APPEND_COL(gi, evc, maskc);
+                            }
                         }
                     }
                 }

@@ -24,7 +24,7 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 // Per (list length, occupancy class) configuration: ring slots, event-pool capacity per wave and where the lists live.  LDS per workgroup: 53.3 KiB at three workgroups per CU, 80 KiB at two.
 // (Every tile must contain a slice barrier -- the bias double buffer and the merge flags rely on it -- so the barrier
 // period RING / 2 never exceeds the slice count; NSR >= 2 is required by the host.)
-// DUAL: the dual-pass build (kz_knn_epi3.h "Dual pass"): + 3 x 128 threshold floats.
+// DUAL: the dual-pass build (kz_knn_epi3.h "Dual pass"): + 1.5 KiB (thresholds of three tiles, the queries' offsets).
 template <int KP, int WPS, int NSR, bool DUAL = false>
 struct KzHCfg {
     static constexpr bool LDS_LIST = KP <= 32;
@@ -35,7 +35,7 @@ struct KzHCfg {
     static constexpr int RING_BYTES = RING * 4096;
     static constexpr int BIAS_OFF = RING_BYTES;                        // 2 x 128 floats
     static constexpr int SYNC_OFF = BIAS_OFF + 1024;                   // 4 merge flags (+ padding)
-    static constexpr int THETA_OFF = SYNC_OFF + 256;                   // dual pass: 3 x 128 threshold floats
+    static constexpr int THETA_OFF = SYNC_OFF + 256;                   // dual pass: 3 x 64 threshold floats + 128 query offsets
     static constexpr int POOLK_OFF = THETA_OFF + (DUAL ? 1536 : 0);    // [4 waves][CAP] x 4 floats
     static constexpr int POOLM_OFF = POOLK_OFF + 4 * CAP * 16;         // [4 waves][CAP] x {code, next}
     static constexpr int LIST_OFF = POOLM_OFF + 4 * CAP * 8;           // keys [KP][128], then rows [KP][128]
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);                       // R slots x 1024 floats
     float* bbuf = reinterpret_cast<float*>(smem + Cfg::BIAS_OFF);       // 2 x 128 bias floats
-    float* tbuf = reinterpret_cast<float*>(smem + Cfg::THETA_OFF);      // dual pass: 3 x 128 thresholds
+    float* tbuf = reinterpret_cast<float*>(smem + Cfg::THETA_OFF);      // dual pass: 3 x 64 thresholds (first half of a tile's rows), then -bias of the 128 queries
     kz_lds_i32* msync = (kz_lds_i32*)(smem + Cfg::SYNC_OFF);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,15 +131,12 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     for (int i = 0; i < R; ++i) dma_next();
     bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
     KzDualRef du;
-    float nbq = 0.0f;
     if constexpr (DUAL) {
-        tbuf[tid & 127] = p.theta[(int64_t)t_begin * KZ_TILE + (tid & 127)];
-        du.log_keys = (f32x4e*)p.log_keys;
-        du.log_meta = (i32x2e*)p.log_meta;
-        du.log_cnt = p.log_cnt;
-        du.log_cap = p.log_cap;
+        if (tid < 64) tbuf[tid] = p.theta[(int64_t)t_begin * KZ_TILE + tid];
         du.qrow0 = (p.qt0 + qt) * KZ_TILE + 32 * wave;
-        nbq = p.qnbias[du.qrow0 + j];
+        // this query's own offset: read back from LDS in every epilogue (a register held for the whole sweep was spilled at
+        // three workgroups per CU, and reloaded behind a wait for the DMA ring)
+        if (h == 0) tbuf[192 + 32 * (tid >> 6) + j] = p.qnbias[du.qrow0 + j];
     }
     if (tid < 4) msync[tid] = 0;
     // stationary query fragments: lane (j, h) holds k = 16 u + 8 h + 0..7 of query row 32 wave + j
@@ -162,7 +159,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     int th_cur = 0;   // dual pass: threshold buffer of the current tile (uniform)
     f32x16 acc[4];
 #ifdef KZ_STAMP
-    unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0;
+    unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0, c_col = 0, n_col = 0;
 #endif
 
     // one tile whose first slice has global parity P0 (compile time: the parity alternates from tile to tile when NSR is odd)
@@ -170,7 +167,13 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         constexpr int P0 = decltype(start_parity)::value;
         KZ_T(t0);
         {
-            const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
+            int h_now = h;
+            if constexpr (WPS == 3) {
+                // (lane half re-made here: the base address below, kept in a register across the tile, is what gets spilled at
+                //  three workgroups per CU -- and reloaded behind a wait for the whole DMA ring)
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshrrev_b32 %0, 5, %0" : "=v"(h_now));
+            }
+            const float* bp = bbuf + (tile & 1) * 128 + 4 * h_now;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -196,13 +199,12 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
             asm volatile("v_lshrrev_b32 %0, 2, %1" : "=v"(off4) : "v"(lane_off));
             if (wave < 2)
                 kz_glds4_s(p.ybias + (int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE, off4, bbuf + ((tile + 1) & 1) * 128 + wave * 64);
-            else if (DUAL)
-                // ... and its thresholds, by the other two waves (the -128 floats of their lane offset are folded into the
-                // scalar base).  THREE buffers: the thresholds are read at the END of a tile (kz_tile_col3), so a wave that is
-                // already here may not overwrite what a slower wave still reads for the previous tile; the buffer written
-                // here was last read two tiles ago, with a slice barrier in between.
-                kz_glds4_s(p.theta + ((int64_t)min(tile + 1, p.n_ytiles - 1) - 1) * KZ_TILE, off4,
-                           tbuf + (th_cur == 2 ? 0 : th_cur + 1) * 128 + (wave - 2) * 64);
+            else if (DUAL && wave == 2)
+                // ... and its smallest thresholds (the rows are sorted by threshold: the epilogue only reads the first), by a
+                // third wave (the -128 floats of its lane offset are folded into the scalar base).  THREE buffers: the value is
+                // read at the END of a tile, so a wave that is already here may not overwrite what a slower wave still reads
+                // for the previous tile; the buffer written here was last read two tiles ago, with a slice barrier in between.
+                kz_glds4_s(p.theta + ((int64_t)min(tile + 1, p.n_ytiles - 1) - 1) * KZ_TILE, off4, tbuf + (th_cur == 2 ? 0 : th_cur + 1) * 64);
         }
         constexpr bool carry_in = !ONE_SET && (CARRY || (P0 == 1 && (NSR & 1)));
         constexpr bool carry_out = !ONE_SET && (CARRY || (((P0 + NSR) & 1) != 0));
@@ -263,11 +265,12 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         __builtin_amdgcn_sched_barrier(0);
 #ifdef KZ_STAMP
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        float cthr = INFINITY;
         if constexpr (DUAL) {
-            kz_tile_col3<KP, CAP, IN_LDS, RECOMP>(acc, tbuf + th_cur * 128 + 4 * h, nbq, st, pool, bmin, tile, msync, du);
+            cthr = tbuf[192 + 32 * (tid >> 6) + j] + tbuf[th_cur * 64];   // this query's offset + the tile's smallest theta (rows sorted by theta)
             th_cur = th_cur == 2 ? 0 : th_cur + 1;
         }
-        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du, c_merge, n_pass, n_ins, c_e1, c_e2);
+        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du, cthr, c_merge, n_pass, n_ins, c_e1, c_e2, c_col, n_col);
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
@@ -275,11 +278,12 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         // diagnostic build (tools/ablate.sh, never shipped): no candidate scan at all -- the accumulators are only kept alive
         asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
 #else
+        float cthr = INFINITY;
         if constexpr (DUAL) {
-            kz_tile_col3<KP, CAP, IN_LDS, RECOMP>(acc, tbuf + th_cur * 128 + 4 * h, nbq, st, pool, bmin, tile, msync, du);
+            cthr = tbuf[192 + 32 * (tid >> 6) + j] + tbuf[th_cur * 64];   // this query's offset + the tile's smallest theta (rows sorted by theta)
             th_cur = th_cur == 2 ? 0 : th_cur + 1;
         }
-        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du);
+        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du, cthr);
 #endif
     };
 
@@ -293,7 +297,10 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     if constexpr (IN_LDS) {
         // the sweep is over: the list goes to the output arrays in the layout kz_knn_finalize_kernel reads
         const int64_t listoff = out_list_offset();
-        if (h == 0) {
+        // (lane number re-made here: the `h == 0` mask of the prologue, kept for this one use, cost a VGPR as SGPR spill space)
+        int lane_now;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_now));
+        if (lane_now < 32) {
 #pragma unroll 4
             for (int e = 0; e < KP; ++e) {
                 p.out_key[listoff + e] = st.list.kp()[e * 128];
@@ -313,6 +320,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         atomicAdd(p.dbg + 8, c_bar);
         atomicAdd(p.dbg + 2, c_e1);
         atomicAdd(p.dbg + 9, c_e2);
+        atomicAdd(p.dbg + 10, c_col);
+        atomicAdd(p.dbg + 11, n_col);
     }
 #endif
 }

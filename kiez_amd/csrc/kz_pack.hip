@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void kz_pack_h_kernel(const T* __restrict__ ra
                                                         int metric, int nsr, int64_t n_pad, const float* __restrict__ mu,
                                                         const double* __restrict__ scale, unsigned short* __restrict__ packed,
                                                         float* __restrict__ bias, double* __restrict__ rowq,
-                                                        unsigned long long* __restrict__ dmax) {
+                                                        unsigned long long* __restrict__ dmax, const int* __restrict__ perm) {
     __shared__ double s_m[3][4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256) void kz_pack_h_kernel(const T* __restrict__ ra
             if (lane == 0) bias[row] = -INFINITY;
             continue;
         }
-        const T* x = raw + row * (int64_t)d;
-        const double nrm = metric == KZ_COSINE ? sqn[row] : 1.0;
+        // perm (dual pass, kz_knn_dual.h): image row `row` holds matrix row perm[row]; only the image and the bias are written
+        const int64_t srow = perm ? (int64_t)perm[row] : row;
+        const T* x = raw + srow * (int64_t)d;
+        const double nrm = metric == KZ_COSINE ? sqn[srow] : 1.0;
         double c2 = 0.0, h2 = 0.0, r2 = 0.0;
         for (int k = lane; k < d_pad; k += 64) {
             float v = 0.0f;
@@ -244,9 +246,11 @@ __global__ __launch_bounds__(256) void kz_pack_h_kernel(const T* __restrict__ ra
         r2 = kz_wave_sum(r2);
         const double nh = sqrt(h2), nr = sqrt(r2);
         if (lane == 0) {
-            rowq[row * 3 + 0] = c2;
-            rowq[row * 3 + 1] = nh;
-            rowq[row * 3 + 2] = nr;
+            if (rowq) {
+                rowq[row * 3 + 0] = c2;
+                rowq[row * 3 + 1] = nh;
+                rowq[row * 3 + 2] = nr;
+            }
             bias[row] = (float)(-0.5 * c2 * S * S);
         }
         m_h = fmax(m_h, nh);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256) void kz_pack_h_kernel(const T* __restrict__ ra
         s_m[2][wave] = m_c;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 3 && dmax) {
         const double m = fmax(fmax(s_m[threadIdx.x][0], s_m[threadIdx.x][1]), fmax(s_m[threadIdx.x][2], s_m[threadIdx.x][3]));
         atomicMax(dmax + threadIdx.x, (unsigned long long)__double_as_longlong(m));
     }
@@ -376,11 +380,11 @@ static int kz_himage_build(kz_matrix* m, kz_center* center) {
         if (m->dtype == KZ_F32)
             hipLaunchKernelGGL(kz_pack_h_kernel<float>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const float*)m->raw,
                                m->sqn, m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, im->packed, im->bias,
-                               im->rowq, (unsigned long long*)im->d_max);
+                               im->rowq, (unsigned long long*)im->d_max, nullptr);
         else
             hipLaunchKernelGGL(kz_pack_h_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw,
                                m->sqn, m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, im->packed, im->bias,
-                               im->rowq, (unsigned long long*)im->d_max);
+                               im->rowq, (unsigned long long*)im->d_max, nullptr);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
@@ -388,6 +392,27 @@ static int kz_himage_build(kz_matrix* m, kz_center* center) {
         kz_set_error("kz_knn: fp16 pack kernel failed: %s", hipGetErrorString(e));
         return KZ_ERR_HIP;
     }
+    return KZ_OK;
+}
+
+// The fp16 image of m's rows in the order perm[0 .. n) (dual pass: index rows sorted by their event threshold), with m's
+// own centre and scale, into caller-provided buffers: packed [n_tiles][nsr] x 4 KiB (+ the DMA ring's padding), bias
+// [n_tiles * 128].  Bit-identical operands and biases to m's own image, row for row.
+int kz_himage_pack_permuted(kz_matrix* m, const int* d_perm, unsigned short* packed, float* bias) {
+    kz_ctx* ctx = m->ctx;
+    KZ_REQUIRE(m->himg, "kz_himage_pack_permuted: the matrix has no fp16 image");
+    const kz_center* center = m->himg->center;
+    const int nsr = m->kg / 4;
+    const int64_t n_pad = m->n_tiles * KZ_TILE;
+    if (m->dtype == KZ_F32)
+        hipLaunchKernelGGL(kz_pack_h_kernel<float>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const float*)m->raw, m->sqn,
+                           m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, packed, bias, (double*)nullptr,
+                           (unsigned long long*)nullptr, d_perm);
+    else
+        hipLaunchKernelGGL(kz_pack_h_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw, m->sqn,
+                           m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, packed, bias, (double*)nullptr,
+                           (unsigned long long*)nullptr, d_perm);
+    KZ_HIP(hipGetLastError());
     return KZ_OK;
 }
 

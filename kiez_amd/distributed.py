@@ -92,6 +92,19 @@ class HipEngine:
         self.last_stats = st.as_dict()
         return dist, ind
 
+    def knn_dual(self, am, bm, k: int):
+        """kz_knn_dual: ((dist, ind) of a -> b [a.n, k], (dist, ind) of b -> a [b.n, k]) from one sweep; stats of both in
+        `last_stats` (a -> b) and `last_stats_reverse`."""
+        torch, N = self.torch, self.N
+        d_ab, i_ab = self.empty((am.shape[0], k), torch.float64), self.empty((am.shape[0], k), torch.int64)
+        d_ba, i_ba = self.empty((bm.shape[0], k), torch.float64), self.empty((bm.shape[0], k), torch.int64)
+        s_ab, s_ba = N.KnnStats(), N.KnnStats()
+        N._check(self.lib.kz_knn_dual(self.ctx.handle, am.handle, bm.handle, int(k), self._ptr(d_ab), self._ptr(i_ab),
+                                      self._ptr(d_ba), self._ptr(i_ba), C.byref(s_ab), C.byref(s_ba)), "kz_knn_dual")
+        self.last_stats = s_ab.as_dict()
+        self.last_stats_reverse = s_ba.as_dict()
+        return (d_ab, i_ab), (d_ba, i_ba)
+
     def row_stats(self, dist, mean=False, std=False, last=False):
         torch = self.torch
         n, K = dist.shape
@@ -229,6 +242,33 @@ class Comm:
         self._timed("all_gather", pad, lambda: self.dist.all_gather(parts, pad, group=self.group))
         return torch.cat([parts[r][: counts[r]] for r in range(self.world)], dim=0)
 
+    def all_to_all_rows(self, t, counts):
+        """Row blocks of `t` (block r = counts[r] rows, in rank order) go to rank r; returns what this rank received, stacked
+        in rank order: [world, counts[rank], ...].  The exchange step of the shared sweep: every rank holds, for ALL
+        target rows, their neighbours inside its own source shard; rank r merges the rows of its target slice."""
+        torch = _torch()
+        mine = counts[self.rank]
+        if self.world == 1 and not self.always:
+            return t.reshape((1,) + tuple(t.shape))
+        out = torch.empty((self.world * mine,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        tail = 1
+        for x in t.shape[1:]:
+            tail *= int(x)
+        t = t.contiguous()
+        try:
+            self._timed("all_to_all", t, lambda: self.dist.all_to_all_single(out, t, output_split_sizes=[mine] * self.world,
+                                                                            input_split_sizes=list(counts), group=self.group))
+        except (RuntimeError, NotImplementedError):   # a backend without all-to-all: one broadcast per block
+            off = 0
+            for r in range(self.world):
+                blk = t[off: off + counts[r]]
+                gathered = [torch.empty_like(blk) for _ in range(self.world)] if self.rank == r else None
+                self.dist.gather(blk.contiguous(), gathered, dst=r, group=self.group)
+                if self.rank == r:
+                    out = torch.cat(gathered, dim=0)
+                off += counts[r]
+        return out.reshape((self.world, mine) + tuple(t.shape[1:]))
+
     def all_gather_ints(self, value: int, device):
         return [v[0] for v in self.all_gather_vec([int(value)], device)]
 
@@ -305,6 +345,7 @@ class ShardedKiez:
         self.engine = engine if engine is not None else HipEngine()
         self.comm = comm if comm is not None else Comm()
         self.state: Dict[str, Any] = {}
+        self.shared_sweep = bool(hkw.get("shared_sweep", True))   # False: search twice, as the reference does
 
     # -- fit -----------------------------------------------------------------------------------------
     def fit(self, source_shard, target=None, single_source: bool = False, target_from_rank0: bool = True):
@@ -327,7 +368,17 @@ class ShardedKiez:
         self.n_local = counts[comm.rank]
         n_s = sum(counts)
         self.single = bool(single_source)
-        need_full_source = self.single or self.hub != "none"
+        self._fwd = None
+        # Shared sweep (kz_knn_dual): the reverse neighbours of ALL targets inside this rank's source shard and the forward
+        # neighbours of the shard come out of one sweep of shard x target; the per-shard reverse lists of a target are then
+        # merged on the rank that owns its slice (all-to-all of [n_t, K] distances).  Needs only the distances of the
+        # reverse lists when more than one rank takes part (CSLS, LocalScaling, MP normal: the K smallest distances of a
+        # target are the same multiset however ties between shards are broken); with one rank every kind qualifies.
+        k_cap = getattr(eng, "MAX_SELECT", 128)
+        self.shared = (self.shared_sweep and hasattr(eng, "knn_dual") and not self.single and self.hub != "none"
+                       and (comm.world == 1 or (self.hub in ("csls", "ls") or (self.hub == "mp" and self.method == "normal")))
+                       and self.K <= min(counts) and comm.world * self.K <= k_cap)
+        need_full_source = self.single or (self.hub != "none" and not self.shared)
         src_full = comm.all_gather_rows(src, counts) if need_full_source else None
         if self.single:
             tgt = src_full
@@ -354,11 +405,32 @@ class ShardedKiez:
             self.q_begin = 0
         if self.hub == "none":
             return self
-        # reverse pass, sharded over target rows (explicit query: self is NOT stripped, base.py:37-42)
-        Kr = min(self.K, n_s)
         t_begin, t_count = row_slice(self.n_t, comm.rank, comm.world)
         t_counts = [row_slice(self.n_t, r, comm.world)[1] for r in range(comm.world)]
-        d_t2s, i_t2s = eng.knn(self.T, t_begin, t_count, self.S, Kr, False)
+        if self.shared and self.K <= self.n_t:
+            # one sweep: larger side as the query side (fewer rows get event buffers)
+            if self.n_t >= self.n_local:
+                (d_rev, i_rev), self._fwd = eng.knn_dual(self.T, self.S, self.K)
+            else:
+                self._fwd, (d_rev, i_rev) = eng.knn_dual(self.S, self.T, self.K)
+            if comm.world > 1 or comm.always:
+                parts = comm.all_to_all_rows(d_rev, t_counts)                      # [world, t_count, K]
+                merged = parts.permute(1, 0, 2).reshape(t_count, comm.world * self.K).contiguous()
+                if self.hub in ("dsl",) or (self.hub == "mp" and self.method == "empiric"):
+                    # kinds that need the reverse INDICES only share the sweep with one rank (forced collectives of the
+                    # single-rank RCCL test): the indices travel too and the "merge" is the identity
+                    iparts = comm.all_to_all_rows(i_rev + self.s_begin, t_counts)
+                    merged_i = iparts.permute(1, 0, 2).reshape(t_count, comm.world * self.K).contiguous()
+                else:
+                    merged_i = torch.zeros(merged.shape, dtype=torch.int64, device=merged.device)
+                d_t2s, i_t2s = eng.select_topk(merged, merged_i, self.K)
+            else:
+                d_t2s, i_t2s = d_rev, i_rev
+        else:
+            self.shared = False
+            # reverse pass, sharded over target rows (explicit query: self is NOT stripped, base.py:37-42)
+            Kr = min(self.K, n_s)
+            d_t2s, i_t2s = eng.knn(self.T, t_begin, t_count, self.S, Kr, False)
         st = self.state
         if self.hub == "csls" or (self.hub == "ls" and self.method == "nicdm"):
             m, _, _ = eng.row_stats(d_t2s, mean=True)
@@ -387,7 +459,10 @@ class ShardedKiez:
             kk = min(k, self.n_t)
             return eng.knn(self.S, self.q_begin, self.n_local, self.T, kk, self.single)
         Kf = min(self.K, self.n_t)
-        dist, ind = eng.knn(self.S, self.q_begin, self.n_local, self.T, Kf, self.single)
+        if self._fwd is not None:
+            dist, ind = self._fwd   # came out of fit's sweep
+        else:
+            dist, ind = eng.knn(self.S, self.q_begin, self.n_local, self.T, Kf, self.single)
         if self.hub == "csls":
             out = eng.csls(dist, ind, st["r_t"])
         elif self.hub == "ls":

@@ -44,6 +44,10 @@ class HubnessReduction(ABC):
     # Subclasses shipped here consume device arrays; a user-written subclass (docs/source/using_your_own.rst:11-19)
     # gets numpy arrays exactly as in the reference.
     _device_native = False
+    # fit() takes its reverse search and the forward search of the kneighbors() that follows out of ONE sweep of the
+    # distance matrix where the native library can (kz_knn_dual; results identical to the two searches).  Set to False on
+    # an instance to search twice, as the reference does.
+    _shared_sweep = True
 
     # ---- device helpers ---------------------------------------------------------------------------
     @property
@@ -74,8 +78,14 @@ class HubnessReduction(ABC):
         if target is None:
             target = source
         if self._gpu_nn:
-            neigh_dist_t_to_s, neigh_ind_t_to_s = self.nn_algo.kneighbors_device(
-                k=self.nn_algo.n_candidates, query=target, s_to_t=False)
+            # one sweep of the distance matrix serves this reverse search AND the forward search of kneighbors()
+            # (kz_knn_dual); where that does not apply, the reverse search alone
+            both = self.nn_algo.kneighbors_device_both(k=self.nn_algo.n_candidates) if self._shared_sweep else None
+            if both is not None:
+                neigh_dist_t_to_s, neigh_ind_t_to_s = both
+            else:
+                neigh_dist_t_to_s, neigh_ind_t_to_s = self.nn_algo.kneighbors_device(
+                    k=self.nn_algo.n_candidates, query=target, s_to_t=False)
         else:
             neigh_dist_t_to_s, neigh_ind_t_to_s = self.nn_algo.kneighbors(
                 k=self.nn_algo.n_candidates, query=target, s_to_t=False, return_distance=True)

@@ -194,6 +194,7 @@ class SklearnNN(NNAlgorithm):
                                       "MI355X exact backend supports")
         self._ctx = None
         self._aux = None  # (array, DeviceMatrix) of the most recent query array that is not a fitted side
+        self._forward = None  # (k, dist, ind): source -> target result that came out of a shared sweep (kneighbors_device_both)
         self.last_stats = None
 
     def __repr__(self):
@@ -258,6 +259,7 @@ class SklearnNN(NNAlgorithm):
     def _fit(self, data, is_source: bool):
         """Replaces SklearnNN._fit (sklearn_nearest_neighbors.py:83-94): upload + norms + MFMA tile packing."""
         self._aux = None
+        self._forward = None
         return self._make_matrix(data)
 
     def fit(self, source, target=None, only_fit_target: bool = False):
@@ -292,11 +294,40 @@ class SklearnNN(NNAlgorithm):
 
     def kneighbors_device(self, k=None, query=None, s_to_t=True, q_begin=0, q_count=None):
         """`kneighbors` that leaves (dist float64, ind int64) in HBM; used by the GPU hubness reductions."""
+        default_query = query is None
         k, query, index, is_self_querying = self._select_direction(k, query, s_to_t)
+        if (default_query and s_to_t and self._forward is not None and self._forward[0] == k and q_begin == 0
+                and q_count is None):
+            # the forward result of the shared sweep (kneighbors_device_both): handed out once, then dropped
+            _, dist, ind = self._forward
+            self._forward = None
+            return dist, ind
         qm = self._matrix_for(query)
         dist, ind, stats = N.knn(self.ctx, qm, index, k, exclude_self=is_self_querying, q_begin=q_begin, q_count=q_count)
         self.last_stats = stats
         return dist, ind
+
+    def kneighbors_device_both(self, k=None):
+        """Both directions between the fitted source and target from ONE sweep of the distance matrix (kz_knn_dual): returns
+        the target -> source result (what HubnessReduction.fit needs, base.py:37-42) and keeps the source -> target result
+        for the `kneighbors_device(query=None, k)` call that follows (base.py:95-96).  Identical results to the two separate
+        searches.  None when the shared sweep does not apply (single-source fit, sides clamped to different k)."""
+        check_is_fitted(self, ["source_index", "target_index"], all_or_any=all)
+        if self.source_equals_target:
+            return None
+        k = self.n_candidates if k is None else k
+        n_s, n_t = self.source_.shape[0], self.target_.shape[0]
+        if not np.issubdtype(type(k), np.integer) or k <= 0 or k > min(n_s, n_t):
+            return None   # (the per-direction checks and clamps of kneighbors() apply: leave it to the separate searches)
+        # the larger side sweeps as the query side: fewer rows get event buffers
+        s_is_a = n_s >= n_t
+        a, b = (self.source_index, self.target_index) if s_is_a else (self.target_index, self.source_index)
+        (d_ab, i_ab, st_ab), (d_ba, i_ba, st_ba) = N.knn_dual(self.ctx, a, b, k)
+        self.last_stats = st_ab
+        self.last_stats_reverse = st_ba
+        fwd, rev = ((d_ab, i_ab), (d_ba, i_ba)) if s_is_a else ((d_ba, i_ba), (d_ab, i_ab))
+        self._forward = (k,) + fwd
+        return rev
 
     def _kneighbors(self, k, query, index, return_distance, is_self_querying):
         """Replaces SklearnNN._kneighbors (sklearn_nearest_neighbors.py:96-101)."""

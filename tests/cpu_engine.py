@@ -46,6 +46,14 @@ class OracleEngine:
             d, i = O.knn_exact(q, im.rows, k, im.metric)
         return torch.from_numpy(d), torch.from_numpy(i)
 
+    def knn_dual(self, am, bm, k):
+        """Both directions (the HIP engine takes them out of one sweep; the results are those of two searches)."""
+        class _M:   # knn() only reads .rows / .metric
+            pass
+        ab = self.knn(am, 0, am.rows.shape[0], bm, k, False)
+        ba = self.knn(bm, 0, bm.rows.shape[0], am, k, False)
+        return ab, ba
+
     def row_stats(self, dist, mean=False, std=False, last=False):
         a = dist.numpy()
         m = torch.from_numpy(a.mean(axis=1)) if mean else None

@@ -50,6 +50,8 @@ def _worker(rank, world, port, q):
             sk.fit(source[b:b + c], None if single else (target if rank == 0 else None), single_source=single)
             d, i = sk.kneighbors(4)
             od, oi = O.kiez_pipeline(source, None if single else target, 7, 4, metric, 2, hub, kw)
+            # the kinds that only need reverse DISTANCES share one sweep per rank and merge by all-to-all; the others search twice
+            assert getattr(sk, "shared", False) == (name in ("csls", "ls", "nicdm", "mp_normal")), (name, sk.shared)
             results[name] = (bool(np.array_equal(i.numpy(), oi[b:b + c])),
                              bool(np.allclose(d.numpy(), od[b:b + c], rtol=1e-9, atol=1e-9)), tuple(i.shape))
         dist.barrier()

@@ -1,0 +1,228 @@
+"""Shared sweep (kz_knn_dual): both search directions out of one pass over the distance matrix must be IDENTICAL -- indices
+and distances, bit for bit -- to two ordinary kz_knn searches, on every shape, metric, dtype and list length, through the
+fallback routes (event-buffer overflow, poisoned or overflowing log, certification failures, ineligible settings) and
+through the API layers built on it.  Needs an MI355X: `pytest -m gpu`."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from tests.golden_util import HUB, case_params, knife_edge_rows, knife_edge_topk_ok, ktag, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx():
+    from kiez_amd import _native as N
+    c = N.Context.get()
+    c.set_option("dual_force", 1)   # the test shapes are far below the size at which the shared sweep pays
+    yield c
+    for name, value in (("dual_force", 0), ("dual_stride", 10), ("chunk_rows", 0), ("eps_scale", 1.0), ("precision", 0)):
+        c.set_option(name, value)
+
+
+def _data(kind, n, d, seed, dtype):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.random((n, d)).astype(dtype)
+    if kind == "normal":
+        return rng.standard_normal((n, d)).astype(dtype)
+    if kind == "clustered":   # strong hubness: a few dense clusters + a sparse cloud, rows in cluster order
+        centres = rng.standard_normal((8, d)) * 3
+        sizes = rng.multinomial(n - n // 5, np.ones(8) / 8)
+        parts = [centres[c] + 0.2 * rng.standard_normal((sizes[c], d)) for c in range(8)]
+        parts.append(5 * rng.standard_normal((n - sum(sizes), d)))
+        return np.concatenate(parts).astype(dtype)
+    if kind == "duplicates":  # exact ties: every row occurs several times
+        base = rng.random((max(n // 7, 8), d))
+        return base[rng.integers(0, len(base), n)].astype(dtype)
+    raise ValueError(kind)
+
+
+def _both_ways(ctx, a, b, k, metric):
+    from kiez_amd import _native as N
+    am, bm = N.DeviceMatrix(ctx, a, metric), N.DeviceMatrix(ctx, b, metric)
+    ctx.set_option("dual_force", 0)
+    d_ab, i_ab, _ = N.knn(ctx, am, bm, k)
+    d_ba, i_ba, _ = N.knn(ctx, bm, am, k)
+    ctx.set_option("dual_force", 1)
+    (xd, xi, s_ab), (yd, yi, s_ba) = N.knn_dual(ctx, am, bm, k)
+    return (d_ab.numpy(), i_ab.numpy(), d_ba.numpy(), i_ba.numpy()), (xd.numpy(), xi.numpy(), yd.numpy(), yi.numpy()), s_ab, s_ba
+
+
+def _assert_same(sep, dual):
+    for name, x, y in zip(("dist a->b", "ind a->b", "dist b->a", "ind b->a"), sep, dual):
+        np.testing.assert_array_equal(y, x, err_msg=name)
+
+
+@pytest.mark.parametrize("kind,na,nb,d,k,metric,dtype", [
+    ("uniform", 20000, 6000, 64, 10, "euclidean", np.float32),      # K' = 16, three workgroups per CU
+    ("uniform", 9000, 30011, 72, 5, "sqeuclidean", np.float64),      # odd slice count, a smaller than b, float64
+    ("normal", 12000, 8000, 200, 50, "cosine", np.float32),          # K' = 64, 13 slices, two workgroups per CU
+    ("uniform", 15000, 9000, 48, 26, "euclidean", np.float32),       # K' = 32
+    ("normal", 12000, 5000, 32, 100, "euclidean", np.float32),       # K' = 128
+    ("uniform", 16384, 4096, 200, 10, "euclidean", np.float32),      # 13 slices at three workgroups per CU (single fragment set)
+    ("clustered", 20000, 12000, 40, 10, "euclidean", np.float32),    # hubs: uneven event counts, rows in cluster order
+    ("duplicates", 10000, 7000, 24, 10, "sqeuclidean", np.float32),  # exact ties in both directions
+    ("uniform", 5000, 1029, 300, 3, "cosine", np.float64),           # 19 slices, ragged last tiles
+])
+def test_both_directions_identical_to_two_searches(ctx, kind, na, nb, d, k, metric, dtype):
+    a, b = _data(kind, na, d, 1, dtype), _data(kind, nb, d, 2, dtype)
+    sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, k, metric)
+    _assert_same(sep, dual)
+    assert s_ab["dual"] == 1                      # the forward direction always comes out of the shared sweep ...
+    assert s_ab["max_err_ratio"] < 1.0 and s_ba["max_err_ratio"] < 1.0
+    if s_ba["dual"] == 1:                         # ... the reverse one unless the log overflowed (tiny inputs: many events per tile)
+        assert s_ba["n_events"] >= k * nb
+        assert s_ba["n_logged_groups"] * 4 >= s_ba["n_events"]
+
+
+def test_reverse_direction_uses_the_sweep_on_a_shape_where_it_pays(ctx):
+    """250k query rows: events are rare per tile, nothing overflows, (nearly) every row of b is certified from its events."""
+    a, b = _data("uniform", 250000, 64, 3, np.float32), _data("uniform", 20000, 64, 4, np.float32)
+    sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 10, "euclidean")
+    _assert_same(sep, dual)
+    assert s_ab["dual"] == 1 and s_ba["dual"] == 1
+    assert 100 < s_ba["n_events"] / len(b) < 250          # K' (stride - 1) = 144 expected
+    assert s_ba["n_logged_groups"] < 1.3 * s_ba["n_events"]   # the per-tile threshold (rows sorted by threshold) is nearly exact
+    assert s_ba["n_escalated_rows"] < 0.01 * len(b)
+
+
+@pytest.mark.parametrize("stride", [2, 5, 32])
+def test_sample_strides(ctx, stride):
+    ctx.set_option("dual_stride", stride)
+    a, b = _data("uniform", 40000, 32, 5, np.float32), _data("uniform", 3000, 32, 6, np.float32)
+    sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 10, "euclidean")
+    _assert_same(sep, dual)
+
+
+def test_query_side_swept_in_several_chunks(ctx):
+    """Events of a row of b accumulate over the chunks of a."""
+    ctx.set_option("chunk_rows", 4096)
+    a, b = _data("uniform", 30000, 64, 7, np.float32), _data("uniform", 5000, 64, 8, np.float32)
+    sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 10, "euclidean")
+    _assert_same(sep, dual)
+    assert s_ab["dual"] == 1
+
+
+def test_rows_that_fail_certification_are_searched_again(ctx):
+    """A huge rounding bound: no candidate set is certified in either direction, every row goes down the tiers."""
+    ctx.set_option("eps_scale", 1e12)
+    a, b = _data("uniform", 6000, 32, 9, np.float32), _data("uniform", 2000, 32, 10, np.float32)
+    sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 5, "euclidean")
+    _assert_same(sep, dual)
+    assert s_ba["n_escalated_rows"] + s_ba["n_fallback_rows"] >= len(b) or s_ba["dual"] == 0
+
+
+def test_settings_without_a_shared_sweep_fall_back_to_two_searches(ctx):
+    from kiez_amd import _native as N
+    a, b = _data("uniform", 5000, 32, 11, np.float32), _data("uniform", 3000, 32, 12, np.float32)
+    am, bm = N.DeviceMatrix(ctx, a, "euclidean"), N.DeviceMatrix(ctx, b, "euclidean")
+    ref = N.knn(ctx, am, bm, 7)[:2], N.knn(ctx, bm, am, 7)[:2]
+    for name, value in (("dual_stride", 0), ("precision", 1), ("precision", 2), ("dual_force", 0)):
+        ctx.set_option(name, value)
+        (xd, xi, s_ab), (yd, yi, s_ba) = N.knn_dual(ctx, am, bm, 7)
+        assert s_ab["dual"] == 0 and s_ba["dual"] == 0, name
+        np.testing.assert_array_equal(xi.numpy(), ref[0][1].numpy())
+        np.testing.assert_array_equal(yd.numpy(), ref[1][0].numpy())
+        ctx.set_option("dual_stride", 10)
+        ctx.set_option("precision", 0)
+        ctx.set_option("dual_force", 1)
+    # more than 110 neighbours: exact-only route in both directions
+    (xd, xi, s_ab), (yd, yi, s_ba) = N.knn_dual(ctx, am, bm, 120)
+    rd, ri, _ = N.knn(ctx, bm, am, 120)
+    np.testing.assert_array_equal(yi.numpy(), ri.numpy())
+    with pytest.raises(ValueError):
+        N.knn_dual(ctx, am, am, 5)
+    with pytest.raises(ValueError):
+        N.knn_dual(ctx, am, bm, 3001)
+
+
+@pytest.mark.parametrize("hub,kw", [("CSLS", {}), ("LocalScaling", {"method": "nicdm"}), ("LocalScaling", {"method": "standard"}),
+                                    ("MutualProximity", {"method": "normal"}), ("MutualProximity", {"method": "empiric"}),
+                                    ("DisSimLocal", {})])
+@pytest.mark.parametrize("swap", [False, True])
+def test_kiez_api_same_result_with_and_without_the_shared_sweep(ctx, hub, kw, swap):
+    from kiez_amd import Kiez
+    s, t = _data("uniform", 30000, 48, 13, np.float32), _data("uniform", 20000, 48, 14, np.float32)
+    if swap:
+        s, t = t, s
+    out = []
+    for shared in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            kz = Kiez(n_candidates=10, algorithm="SklearnNN", algorithm_kwargs={"metric": "euclidean"}, hubness=hub,
+                      hubness_kwargs=dict(kw))
+            kz.hubness._shared_sweep = shared
+            out.append(kz.fit(s, t).kneighbors(5))
+            if shared:
+                assert kz.algorithm.last_stats["dual"] == 1
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("case,tag,k", [p for p in case_params() if p[0] in ("c0_two_source", "f32_euclidean", "cosine_k50")])
+def test_golden_pipeline_through_the_shared_sweep(ctx, case, tag, k):
+    """The reference's own outputs (tests/golden/), with the shared sweep forced on these small cases."""
+    from kiez_amd import Kiez
+    g = load_case(case)
+    hname, kw = HUB[tag]
+    if hname in (None, "NoHubnessReduction") or g["_target"] is None:
+        pytest.skip("no reverse search in this case")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = Kiez(n_candidates=g["_K"], algorithm="SklearnNN", algorithm_kwargs=dict(metric=g["_metric"], p=g["_p"]),
+                  hubness=hname, hubness_kwargs=dict(kw))
+        kz.fit(g["source"], g["_target"])
+        d, i = kz.kneighbors(k)
+    ref_d, ref_i = g[f"{tag}__k{ktag(k)}__dist"], g[f"{tag}__k{ktag(k)}__ind"]
+    keep = np.ones(len(i), dtype=bool)
+    if tag == "mp_empiric":
+        keep &= ~knife_edge_rows(g["mp_empiric__ind_s2t"])
+        for r in np.flatnonzero(~keep):
+            assert knife_edge_topk_ok(ref_d[r], ref_i[r], d[r], i[r], r, g["_K"], g["mp_empiric__ind_t2s"]), f"knife-edge row {r}"
+    np.testing.assert_array_equal(i[keep], ref_i[keep])
+    np.testing.assert_allclose(d[keep], ref_d[keep], rtol=1e-5, atol=5e-6 if tag == "dsl" else 1e-6)
+
+
+SHARDED_SCRIPT = r"""
+import os, sys, warnings
+sys.path.insert(0, %r)
+os.environ["KIEZ_AMD_WITH_TORCH"] = "1"
+import torch
+import numpy as np
+from kiez_amd.distributed import Comm, HipEngine, ShardedKiez
+warnings.simplefilter("ignore")
+eng = HipEngine(0)
+eng.ctx.set_option("dual_force", 1)
+rng = np.random.default_rng(15)
+s, t = rng.random((12000, 32), dtype=np.float32), rng.random((30000, 32), dtype=np.float32)
+for hub, kw in (("CSLS", {}), ("LocalScaling", {"method": "nicdm"}), ("MutualProximity", {"method": "normal"}),
+                ("MutualProximity", {"method": "empiric"}), ("DisSimLocal", {})):
+    res = []
+    for shared in (True, False):
+        sk = ShardedKiez(n_candidates=10, algorithm_kwargs={"metric": "euclidean"}, hubness=hub,
+                         hubness_kwargs=dict(kw, shared_sweep=shared), engine=eng, comm=Comm())
+        sk.fit(eng.to_engine(s), eng.to_engine(t))
+        assert sk.shared == shared, (hub, shared, sk.shared)
+        if shared:
+            assert eng.last_stats["dual"] == 1 and eng.last_stats_reverse["dual"] == 1, (eng.last_stats, eng.last_stats_reverse)
+        d, i = sk.kneighbors(5)
+        torch.cuda.synchronize()
+        res.append((d.cpu().numpy(), i.cpu().numpy()))
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0]), hub
+print("SHARDED_DUAL_OK")
+"""
+
+
+def test_sharded_pipeline_single_rank():
+    """ShardedKiez on the HIP engine (what bench.py runs): shared sweep against two searches, every hubness kind.
+    Subprocess: torch has to be imported before libkiez_amd.so is loaded (one HIP runtime per process)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-c", SHARDED_SCRIPT % str(root)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "SHARDED_DUAL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]

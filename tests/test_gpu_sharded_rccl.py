@@ -3,7 +3,7 @@
 The world-size-2 gloo test (tests/test_distributed_cpu.py) covers the sharding / exchange logic with a CPU engine; this one
 covers what it cannot: the product engine (C ABI on torch CUDA tensors, one HIP stream shared by torch, RCCL and our
 kernels) with every collective of the pipeline actually issued (`KIEZ_AMD_FORCE_COLLECTIVES=1` runs broadcast /
-all_gather / all_reduce even at world size 1).  Subprocess: torch must be imported and the process group created before
+all_gather / all_reduce / all_to_all even at world size 1).  Subprocess: torch must be imported and the process group created before
 any other GPU call, and the pytest process has usually loaded libkiez_amd.so already."""
 import subprocess
 import sys
@@ -32,9 +32,10 @@ from oracle import kiez_oracle as O
 from tests.golden_util import knife_edge_rows, knife_edge_topk_ok
 warnings.simplefilter("ignore")
 eng = HipEngine(0)
+eng.ctx.set_option("dual_force", 1)   # the shared sweep (kz_knn_dual) also on these small shapes: its exchange step runs too
 comm = Comm()
 assert comm.always and comm.world == 1
-calls = {"broadcast": 0, "all_gather_into_tensor": 0, "all_reduce": 0}
+calls = {"broadcast": 0, "all_gather_into_tensor": 0, "all_reduce": 0, "all_to_all_single": 0}
 for name in calls:
     orig = getattr(dist, name)
     def wrap(*a, _o=orig, _n=name, **k):
@@ -66,7 +67,8 @@ for name, hub, kw, metric, single in CASES:
             assert knife_edge_topk_ok(od[r], oi[r], d[r], i[r], r, K, ind_t2s), (name, r)
     assert np.array_equal(i[keep], oi[keep]), name
     assert np.allclose(d[keep], od[keep], rtol=1e-5, atol=5e-6), name
-assert calls["broadcast"] >= 7 and calls["all_gather_into_tensor"] >= 9 and calls["all_reduce"] >= 1, calls
+# (CSLS, both LocalScaling kinds and MP normal take their reverse lists out of the shared sweep and merge them by all-to-all)
+assert calls["broadcast"] >= 7 and calls["all_gather_into_tensor"] >= 9 and calls["all_reduce"] >= 1 and calls["all_to_all_single"] >= 4, calls
 print("collectives", calls)
 dist.barrier()
 dist.destroy_process_group()

@@ -25,6 +25,9 @@ def run(name):
         b = rng.random((nb, d), dtype=np.float32)
     ctx = N.Context.get()
     ctx.set_option("dual_force", 1)
+    import os
+    if os.environ.get("DUAL_STRIDE"):
+        ctx.set_option("dual_stride", int(os.environ["DUAL_STRIDE"]))
     am, bm = N.DeviceMatrix(ctx, a, metric), N.DeviceMatrix(ctx, b, metric)
     # warm (images, pools)
     N.knn(ctx, am, bm, k); N.knn(ctx, bm, am, k)
@@ -42,8 +45,8 @@ def run(name):
     print(f"{name}: a->b {'OK' if ok_ab else 'BAD'}  b->a {'OK' if ok_ba else 'BAD (%d rows)' % nbad} | separate {t_sep*1e3:.1f} ms "
           f"(main {s1['main_kernel_ms']:.1f}+{s2['main_kernel_ms']:.1f}) dual {t_dual*1e3:.1f} ms (sweep {sa['main_kernel_ms']:.1f}, fin {sa['finalize_ms']:.1f}; "
           f"reverse: sample+scatter+select {sb['main_kernel_ms']:.1f}, fin {sb['finalize_ms']:.1f}, fb {sb['fallback_ms']:.1f}) "
-          f"dual={sa['dual']}/{sb['dual']} events/row {sb['n_events']/nb:.1f} overflow {sb['n_overflow_rows']} esc {sb['n_escalated_rows']} "
-          f"err {sa['max_err_ratio']:.3f}/{sb['max_err_ratio']:.3f}", flush=True)
+          f"dual={sa['dual']}/{sb['dual']} events/row {sb['n_events']/nb:.1f} logged/row {sb['n_logged_groups']/nb:.1f} overflow {sb['n_overflow_rows']} esc {sb['n_escalated_rows']} "
+          f"err {sa['max_err_ratio']:.3f}/{sb['max_err_ratio']:.3f} blocks {s1['n_blocks']}/{sa['n_blocks']} splits {s1['n_splits']}/{sa['n_splits']}", flush=True)
     return ok_ab and ok_ba
 
 if __name__ == "__main__":

@@ -1,0 +1,9 @@
+timeout 2400 python3 -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+timeout 900 python3 bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err; python3 tools/show.py $O/bench.json | cut -c1-200
+python3 - <<'PY'
+import json,sys,os
+j=json.load(open(os.environ["O"]+"/bench.json"))
+print("value", j["value"], "ms/step", j["ms_per_step"], "roofline", j["roofline"]["frac"], j["roofline"]["avg_launch_ms"], "shared", j.get("shared_sweep"))
+for o in j.get("other_workloads", []): print(o["workload"][:40], round(o["ms_per_step"],2), "%.3g"%o["value"], round(o["roofline_frac"],3), o.get("shared_sweeps"), o.get("check"))
+print("cpu", j.get("cpu_baseline"))
+PY

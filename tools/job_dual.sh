@@ -1,1 +1,1 @@
-KIEZ_AMD_LIB=$PWD/build/abl/libkiez_amd_stamp.so timeout 900 python3 tools/dual_check.py ns > $O/stamp.log 2>&1; grep "fp16 kernel" $O/stamp.log | sort | uniq -c | sort -rn | head -8; tail -2 $O/stamp.log
+timeout 1200 python3 -m pytest tests/test_gpu_dual.py tests/test_gpu_sharded_rccl.py -x -q -m gpu > $O/pytest_dual.log 2>&1; tail -25 $O/pytest_dual.log
