@@ -252,11 +252,14 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // rows of A in the sample (the last tile of A may be partial and may or may not be part of it)
     int64_t s_rows = s_tiles * KZ_TILE;
     if (stride > 0 && (a_tiles - 1) % stride == 0) s_rows -= a_tiles * KZ_TILE - a->n;
-    // The column scan pays while events are rare: a (wave, tile) pair covers 4096 (query, index row) pairs, each an event
-    // with probability K' stride / |A|; beyond ~2 expected events per wave-tile the rescans and appends cost more than the
-    // second sweep they save (measured: 100k x 100k, K' = 16: 12.3 ms dual against 6.9 ms separately).  "dual_force" (test
-    // knob) skips this gate.
-    const bool pays = ctx->dual_force || (int64_t)KP * stride * 2048 <= a->n;
+    // Does sharing the sweep pay?  It saves one sweep (T ~ 2 |A| |B| d / 1e15 s at the rate the kernel reaches) and costs: the
+    // sweep itself ~20-25 % slower, the sample sweep T / stride, ~0.15 ns per event (log, scatter, select; |B| K' stride events)
+    // and ~2 ms of fixed work (sort, permuted image, small kernels).  Measured: 1M x 250k, d 200, K' 16: 134 against 186 ms per
+    // fit + kneighbors; 500k x 500k, K' 64: 207 against 249 ms; 100k x 100k, d 128: 11.0 against 6.8 ms -- the last one is what
+    // the margin below keeps out.  "dual_force" (test knob) skips this gate.
+    const double t_sweep_ms = 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12;
+    const double t_events_ms = (double)b->n * KP * stride * 0.15e-6;
+    const bool pays = ctx->dual_force || 0.5 * t_sweep_ms > t_events_ms + 2.0;
     const bool eligible = pays && ctx->dual_stride >= 2 && ctx->precision == 0 && KP > 0 && n_slices >= 2 && n_slices <= 24 && a->kg == b->kg &&
                           s_rows >= (int64_t)8 * KP && b->n >= 1024 && b_tiles < (1 << 20);
     if (!eligible) return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
@@ -267,8 +270,9 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     const kz_himage* ib = b->himg;
     const int64_t b_pad = b_tiles * KZ_TILE, a_pad = a_tiles * KZ_TILE;
 
-    // expected events per row of B: K' (stride - 1), deviation sqrt(K') stride; the buffer takes mean + ~5 deviations
-    const int ev_cap = (int)(((int64_t)KP * stride + (int64_t)(5.0 * sqrt((double)KP) * stride) + 63) & ~(int64_t)63);
+    // expected events per row of B: K' (stride - 1), deviation sqrt(K') stride; the buffer takes mean + ~7 deviations (a row that
+    // overflows is searched again on its own: ~1.5 ms for a single row against a million index rows)
+    const int ev_cap = (int)(((int64_t)KP * stride + (int64_t)(7.0 * sqrt((double)KP) * stride) + 63) & ~(int64_t)63);
     // logged groups: about one per event (rarely two events share a group) plus the groups that pass the tile's smallest
     // threshold but not their own rows' (few: the rows of a tile are neighbours in threshold order) -- three times the
     // expected number of events, plus slack for small inputs.  An overflowing log is detected and the direction redone.

@@ -385,6 +385,12 @@ __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3
             float cthr_l = cthr;
             for (;;) {
                 bool need_room = false;
+                // (the tile number re-read through an opaque copy: hoisted out of this loop, the 16 + 16 entry codes made from
+                //  it sat in 31 scalar registers for the whole epilogue -- with the dual pass' extra pointers that pushed the
+                //  kernel to re-load its arguments from memory at the top of EVERY tile)
+                int tile_l = tile;
+                asm volatile("" : "+s"(tile_l));
+                const int tile = tile_l;
                 // (opaque to the compiler: the 16 column masks are loop invariant, and hoisted out of this loop they held 32
                 //  scalar registers -- SGPRs spilled into a VGPR the kernel does not have at three workgroups per CU)
                 if constexpr (DUAL) asm volatile("" : "+v"(cthr_l));

@@ -29,7 +29,9 @@ template <int KP, int WPS, int NSR, bool DUAL = false>
 struct KzHCfg {
     static constexpr bool LDS_LIST = KP <= 32;
     static constexpr int RING = (WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8;
-    static constexpr int CAP = WPS == 3 ? (KP == 16 ? 192 : 256) : 256;     // event-pool entries per wave (24 B each)
+    // (dual-pass build at three per CU: 16 entries fewer pay for the 1.5 KiB of thresholds and query offsets -- the workgroup
+    //  must not grow beyond the 52.5 KiB of the ordinary build)
+    static constexpr int CAP = WPS == 3 ? (KP == 16 ? (DUAL ? 176 : 192) : 256) : 256;     // event-pool entries per wave (24 B each)
     static constexpr bool LISTS_FIT = WPS == 2 || KP == 16;           // K' = 32 lists do not fit beside the ring at 3 per CU
     static constexpr bool IN_LDS = LDS_LIST && LISTS_FIT;
     static constexpr int RING_BYTES = RING * 4096;

@@ -4,6 +4,6 @@ python3 - <<'PY'
 import json,sys,os
 j=json.load(open(os.environ["O"]+"/bench.json"))
 print("value", j["value"], "ms/step", j["ms_per_step"], "roofline", j["roofline"]["frac"], j["roofline"]["avg_launch_ms"], "shared", j.get("shared_sweep"))
-for o in j.get("other_workloads", []): print(o["workload"][:40], round(o["ms_per_step"],2), "%.3g"%o["value"], round(o["roofline_frac"],3), o.get("shared_sweeps"), o.get("check"))
+for n,o in j.get("other_workloads", {}).items(): print(n, round(o["ms_per_step"],2), "%.4g"%o["value"], round(o["roofline_frac"],3), o.get("shared_sweeps"), o.get("check"))
 print("cpu", j.get("cpu_baseline"))
 PY
