@@ -73,7 +73,7 @@ int kz_ctx_sync(kz_ctx* ctx);
 /* Options.  "precision": 0 (default) = fp16 first pass on centred operands (16 <= d_pad <= 384), uncertified rows go
  * down the tiers (longer lists -> float32 operands -> exact float64); 2 = split-bf16 first pass; 1 = float32 operands
  * only.  The neighbour order is the float64 one either way.  "dual_stride": kz_knn_dual samples every n-th tile of a
- * for its thresholds (default 10; 0 = always two ordinary searches).  Test/diagnostic knobs: "eps_scale" multiplies the
+ * for its thresholds (default 1 = chosen from the shapes; 0 = always two ordinary searches).  Test/diagnostic knobs: "eps_scale" multiplies the
  * certification bound (huge value => every row takes the exact fallback); "force_splits" fixes the index split count
  * (0 = automatic); "min_splits", "chunk_rows", "h_wps", "lds_pad": scheduling / occupancy knobs. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);

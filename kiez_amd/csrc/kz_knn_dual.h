@@ -11,10 +11,10 @@
 // The test the sweep itself performs is coarser and nearly free: B's rows are SORTED by their threshold, so the 128 rows of
 // a tile have almost the same one, and a group of four keys is logged when its maximum (which the list scan has already
 // computed) reaches the tile's smallest threshold -- one extra compare per tile on the common path.
-// tau(t) is fixed before the sweep: the K'-th best key of t against a SAMPLE of A (every s-th tile of A's fp16 image,
+// tau(t) is fixed before the sweep: the k-th best key of t against a SAMPLE of A (every s-th tile of A's fp16 image,
 // copied into a small image and swept by the ordinary kernel with B as the query side: 1/s of a full sweep).  By
-// construction about K' s rows of A pass tau(t), whatever the data looks like (the count of population members above
-// the K'-th order statistic of a sample is negative binomial: mean K' (s - 1), deviation sqrt(K') s), so the event
+// construction about k s rows of A pass tau(t), whatever the data looks like (the count of population members above
+// the k-th order statistic of a sample is negative binomial: mean k (s - 1), deviation sqrt(k) s), so the event
 // buffers are small and of predictable size.
 //
 // After the sweep: kz_dual_scatter_kernel files the logged groups per index row (per-key test, atomic slot),
@@ -26,13 +26,14 @@
 #pragma once
 
 // ---- thresholds from the sample sweep --------------------------------------------------------------------------------
-// One wave per row t of B.  The row's lists from the sample sweep hold pieces x K' <= 256 entries; tau = the K'-th best of
-// them (by key, ties by entry order).  theta(t) = tau + bias(t) - margin, rounded DOWN to float32: an event is
+// One wave per row t of B.  The row's lists from the sample sweep hold pieces x K' <= 256 entries; tau = the `rank`-th best of
+// them (by key, ties by entry order; rank = k: the sample rows are rows of A, so at least k rows reach tau in the sweep,
+// and about k stride do -- the list length K' is for the certification's margin, not for the threshold).  theta(t) = tau + bias(t) - margin, rounded DOWN to float32: an event is
 // fl(acc - theta) >= -bias(q), so a NON-event has acc - theta < -bias(q) + 2^-24 |acc - theta|, and with
 // margin = 2^-22 S^2 (Ah Bh + Ac2 + Bc2) >= 2^-24 (|acc| + |theta|) that gives  acc - bias(t) + bias(q) < tau  in exact
 // arithmetic on the float32 values: every row outside the events has key' < tau.
 __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restrict__ in_key, const int* __restrict__ in_idx,
-                                                            KzListLayout lay, int KP, int64_t n_b, int64_t n_b_pad,
+                                                            KzListLayout lay, int KP, int rank, int64_t n_b, int64_t n_b_pad,
                                                             const float* __restrict__ bias_b, const double* __restrict__ a_hmax,
                                                             const double* __restrict__ b_hmax, const double* __restrict__ hscale,
                                                             float* __restrict__ theta, float* __restrict__ floor_) {
@@ -46,13 +47,13 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
     const int M = lay.pieces[kz_list_region(t, lay)] * KP;
     const int64_t l0 = kz_list_contig_off(t, lay, KP, 0);
     float x[4];
-    int valid[4], rank[4];
+    int valid[4], rnk[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int e = lane + 64 * u;
         x[u] = e < M ? in_key[l0 + e] : -INFINITY;
         valid[u] = e < M && in_idx[l0 + e] >= 0;
-        rank[u] = 0;
+        rnk[u] = 0;
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -62,13 +63,13 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
             const int ov = __shfl(valid[v], jj, 64);
             const int oe = jj + 64 * v;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rank[u] += (ov && (ox > x[u] || (ox == x[u] && oe < lane + 64 * u))) ? 1 : 0;
+            for (int u = 0; u < 4; ++u) rnk[u] += (ov && (ox > x[u] || (ox == x[u] && oe < lane + 64 * u))) ? 1 : 0;
         }
     }
     float tau = -INFINITY;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-        if (valid[u] && rank[u] == KP - 1) tau = x[u];
+        if (valid[u] && rnk[u] == rank - 1) tau = x[u];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) tau = fmaxf(tau, __shfl_xor(tau, off, 64));
     if (lane == 0) {
@@ -246,21 +247,29 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
 
     const int KP = kz_pick_list_len(k);
     const int n_slices = b->kg / 4;
-    const int stride = ctx->dual_stride;                        // every stride-th tile of A is in the sample
+    // every stride-th tile of A is in the sample.  Automatic (dual_stride = 1): the sample sweep costs T / stride, the events
+    // (log, scatter, select) ~0.07 ns each with |B| k stride of them: stride = sqrt(T / (|B| k 0.07 ns)), T ~ 2 |A| |B| d / 1e15 s
+    // (ns: 22, measured flat between 16 and 24; 500k x 500k, k = 50: 8)
+    int stride = ctx->dual_stride;
+    if (stride == 1) {
+        const double t_ms = 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12;
+        const double s_opt = sqrt(t_ms / ((double)b->n * k * 0.07e-6));
+        stride = s_opt < 4.0 ? 4 : (s_opt > 32.0 ? 32 : (int)(s_opt + 0.5));
+    }
     const int64_t a_tiles = a->n_tiles, b_tiles = b->n_tiles;
     const int64_t s_tiles = stride > 0 ? (a_tiles + stride - 1) / stride : 0;
     // rows of A in the sample (the last tile of A may be partial and may or may not be part of it)
     int64_t s_rows = s_tiles * KZ_TILE;
     if (stride > 0 && (a_tiles - 1) % stride == 0) s_rows -= a_tiles * KZ_TILE - a->n;
     // Does sharing the sweep pay?  It saves one sweep (T ~ 2 |A| |B| d / 1e15 s at the rate the kernel reaches) and costs: the
-    // sweep itself ~20-25 % slower, the sample sweep T / stride, ~0.15 ns per event (log, scatter, select; |B| K' stride events)
+    // sweep itself ~20-25 % slower, the sample sweep T / stride, ~0.15 ns per event (log, scatter, select; |B| k stride events)
     // and ~2 ms of fixed work (sort, permuted image, small kernels).  Measured: 1M x 250k, d 200, K' 16: 134 against 186 ms per
     // fit + kneighbors; 500k x 500k, K' 64: 207 against 249 ms; 100k x 100k, d 128: 11.0 against 6.8 ms -- the last one is what
     // the margin below keeps out.  "dual_force" (test knob) skips this gate.
     const double t_sweep_ms = 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12;
-    const double t_events_ms = (double)b->n * KP * stride * 0.15e-6;
+    const double t_events_ms = (double)b->n * k * stride * 0.15e-6;
     const bool pays = ctx->dual_force || 0.5 * t_sweep_ms > t_events_ms + 2.0;
-    const bool eligible = pays && ctx->dual_stride >= 2 && ctx->precision == 0 && KP > 0 && n_slices >= 2 && n_slices <= 24 && a->kg == b->kg &&
+    const bool eligible = pays && stride >= 2 && ctx->precision == 0 && KP > 0 && n_slices >= 2 && n_slices <= 24 && a->kg == b->kg &&
                           s_rows >= (int64_t)8 * KP && b->n >= 1024 && b_tiles < (1 << 20);
     if (!eligible) return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
 
@@ -270,13 +279,14 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     const kz_himage* ib = b->himg;
     const int64_t b_pad = b_tiles * KZ_TILE, a_pad = a_tiles * KZ_TILE;
 
-    // expected events per row of B: K' (stride - 1), deviation sqrt(K') stride; the buffer takes mean + ~7 deviations (a row that
-    // overflows is searched again on its own: ~1.5 ms for a single row against a million index rows)
-    const int ev_cap = (int)(((int64_t)KP * stride + (int64_t)(7.0 * sqrt((double)KP) * stride) + 63) & ~(int64_t)63);
+    // expected events per row of B: k (stride - 1) + k, deviation sqrt(k) stride; the buffer takes mean + ~7 deviations (a row
+    // that overflows is searched again on its own: ~1.5 ms for a single row against a million index rows)
+    const int ev_cap = (int)(((int64_t)k * stride + (int64_t)(7.0 * sqrt((double)k) * stride) + 63) & ~(int64_t)63);
     // logged groups: about one per event (rarely two events share a group) plus the groups that pass the tile's smallest
-    // threshold but not their own rows' (few: the rows of a tile are neighbours in threshold order) -- three times the
-    // expected number of events, plus slack for small inputs.  An overflowing log is detected and the direction redone.
-    const long long log_cap = (long long)b->n * KP * stride * 3 + (1 << 16);
+    // threshold but not their own rows' (few: the rows of a tile are neighbours in threshold order); the TOTAL over all rows
+    // is sharply concentrated around |B| k stride -- 1.5 times that, plus slack for small inputs (24 B per entry).  An
+    // overflowing log is detected and the direction redone.
+    const long long log_cap = (long long)((double)b->n * k * stride * 1.5) + (1 << 20);
 
     unsigned short *s_packed = nullptr, *p_packed = nullptr;
     float *s_bias = nullptr, *p_bias = nullptr, *theta = nullptr, *theta_s = nullptr, *theta_min = nullptr, *floor_ = nullptr, *qnb = nullptr, *col_key = nullptr;
@@ -386,7 +396,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             return rc;
         }
         hipLaunchKernelGGL(kz_dual_theta_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, ctx->stream, ps.out_key, ps.out_idx,
-                           ps.lay, KP, b->n, b_pad, ib->bias, ia->d_max, ib->d_max, ib->center->d_scale, theta, floor_);
+                           ps.lay, KP, k, b->n, b_pad, ib->bias, ia->d_max, ib->d_max, ib->center->d_scale, theta, floor_);
         KZ_DUAL_HIP(hipGetLastError());
     }
     // ---- B's rows in DESCENDING order of their threshold: permutation, sorted thresholds (+inf behind them), sorted image.

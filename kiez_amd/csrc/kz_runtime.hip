@@ -44,7 +44,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->force_splits = 0;
     c->h_wps = 0;
     c->min_splits = 1;
-    c->dual_stride = 10;
+    c->dual_stride = 1;
     c->lds_pad = 0;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
@@ -106,7 +106,7 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
                    "precision must be 0 (fp16 first pass), 2 (split-bf16 first pass) or 1 (float32 operands only)");
         c->precision = (int)value;
     } else if (strcmp(name, "dual_stride") == 0) {
-        KZ_REQUIRE(value == 0 || (value >= 2 && value <= 64), "dual_stride must be 0 (no dual pass) or in [2, 64]");
+        KZ_REQUIRE(value >= 0 && value <= 64, "dual_stride must be 0 (no dual pass), 1 (automatic) or in [2, 64]");
         c->dual_stride = (int)value;
     } else if (strcmp(name, "dual_force") == 0) {
         c->dual_force = value != 0;
@@ -168,7 +168,7 @@ int kz_memcpy_d2d(kz_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
 // ---- stream-ordered buffer pool ---------------------------------------------------------------------
 // All work of a context runs on ONE stream, so handing a released buffer to the next allocation of a similar size is
 // ordered behind its last use; this avoids hipFree (device-wide sync) + hipMalloc on every fit().
-static const size_t KZ_POOL_MAX_BYTES = (size_t)24 << 30;
+static const size_t KZ_POOL_MAX_BYTES = (size_t)48 << 30;   // of 288 GB
 
 static void kz_live_add(kz_ctx* c, void* ptr, size_t bytes) {
     for (int i = 0; i < KZ_LIVE_MAX; ++i)
@@ -202,7 +202,8 @@ int kz_pool_alloc(kz_ctx* c, size_t bytes, void** out) {
         *out = c->pool[best].ptr;
         kz_live_add(c, c->pool[best].ptr, c->pool[best].bytes);
         c->pool_bytes -= c->pool[best].bytes;
-        c->pool[best] = c->pool[--c->pool_n];
+        for (int i = best + 1; i < c->pool_n; ++i) c->pool[i - 1] = c->pool[i];   // (keeps the entries in release order)
+        --c->pool_n;
         return KZ_OK;
     }
     void* base = nullptr;
@@ -226,7 +227,19 @@ int kz_pool_alloc(kz_ctx* c, size_t bytes, void** out) {
 void kz_pool_free(kz_ctx* c, void* ptr, size_t /*bytes*/) {
     if (!ptr) return;
     const size_t cap = kz_live_take(c, ptr);
-    if (cap > 0 && c->pool_n < 64 && c->pool_bytes + cap <= KZ_POOL_MAX_BYTES) {
+    if (cap > 0 && cap <= KZ_POOL_MAX_BYTES) {
+        // keep the buffer just released (the next call of the same shape asks for it again); when the cache is full the OLDEST
+        // entries go -- a cache that refuses new buffers once stale ones fill it turns every call into hipMalloc + hipFree of
+        // gigabytes (seen: 260 ms per fit after other workloads had run in the same process)
+        bool synced = false;
+        while (c->pool_n > 0 && (c->pool_n >= 64 || c->pool_bytes + cap > KZ_POOL_MAX_BYTES)) {
+            if (!synced) (void)hipStreamSynchronize(c->stream);
+            synced = true;
+            (void)hipFree(c->pool[0].ptr);
+            c->pool_bytes -= c->pool[0].bytes;
+            for (int i = 1; i < c->pool_n; ++i) c->pool[i - 1] = c->pool[i];
+            --c->pool_n;
+        }
         c->pool[c->pool_n].ptr = ptr;
         c->pool[c->pool_n].bytes = cap;
         ++c->pool_n;
