@@ -281,6 +281,8 @@ struct KnnFinParams {
     const float* excl_floor;
     int dual_col;
     const int* idx_map;   // dual pass, forward direction: list entry r stands for index row idx_map[r] (NULL: identity)
+    const int* row_map;   // dual pass, forward direction: the query image is permuted too -- image row r is matrix row row_map[r];
+                          // raw row, norms, residuals, the output position and the fail-list entry all go by the MATRIX row
     double* out_dist;     // [q_count][k]
     int64_t* out_ind;
     int* fail_count;
@@ -475,7 +477,8 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     }
     kz_wave_sync();
 
-    const int64_t qrow = p.q_begin + q;
+    const int64_t qrow = p.row_map ? (int64_t)p.row_map[p.q_begin + q] : p.q_begin + q;
+    const int64_t qout = p.row_map ? qrow : q;   // output row (row_map: out_dist / out_ind / fail_list are indexed by matrix rows)
     const T* qptr = reinterpret_cast<const T*>(p.qraw) + qrow * (int64_t)p.d;
     const double qs = p.qsqn[qrow];
 
@@ -639,12 +642,12 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     if (!certified) {
         if (lane == 0) {
             const int pos = atomicAdd(p.fail_count, 1);
-            p.fail_list[pos] = (int)q;
+            p.fail_list[pos] = (int)qout;
         }
         return;
     }
     kz_emit_sorted<T>(sv, si, Vr, p.k, p.exclude_self, p.self_ids ? p.self_ids[q] : qrow, p.metric,
-                      p.out_dist + q * (int64_t)p.k, p.out_ind + q * (int64_t)p.k, lane);
+                      p.out_dist + qout * (int64_t)p.k, p.out_ind + qout * (int64_t)p.k, lane);
 }
 
 // A workgroup finalizes KZ_FIN_QPB consecutive queries (wave w takes queries w, w+4, ...).  32 per workgroup (sharing the list
@@ -1050,6 +1053,8 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
 // and scatter the results into out_dist / out_ind at the rows' positions.  Ends with a stream synchronisation.
 // Dual pass (kz_knn_dual.h): what the main sweep needs to report the events of the index rows besides its own lists.
 struct KzDualPass {
+    const float* qpack;            // fp16 image of the query rows in a load-balanced order (kz_knn_dual.h "stratified deal") ...
+    const int* row_map;            // ... and [query tiles * 128] the matrix row of each of its rows
     const float* ypack;            // fp16 image of the index rows SORTED by their event threshold (kz_himage_pack_permuted) ...
     const float* ybias;            // ... and its accumulator-init rows
     const int* perm;               // [index rows] matrix row of image row r: list entries are translated by the finalize kernel
@@ -1269,6 +1274,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((cq_count + 255) / 256)), dim3(256), 0, ctx->stream, fail_list, (int)cq_count);
             KZ_HIP(hipGetLastError());
         } else if (tier == KZ_TIER_H && dual) {
+            cp.qpack = dual->qpack;
             cp.ypack = dual->ypack;
             cp.ybias = dual->ybias;
             cp.theta = dual->theta;
@@ -1317,9 +1323,14 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             fp.y_hmax = index->himg->d_max;
             fp.hscale = index->himg->center->d_scale;
         }
-        if (tier == KZ_TIER_H && dual) fp.idx_map = dual->perm;   // the lists hold rows of the sorted image
         fp.out_dist = d_dist + c0 * (int64_t)k;
         fp.out_ind = d_ind + c0 * (int64_t)k;
+        if (tier == KZ_TIER_H && dual) {
+            fp.idx_map = dual->perm;      // the lists hold rows of the sorted index image
+            fp.row_map = dual->row_map;   // the chunk is a range of IMAGE rows: results and failures go by matrix row
+            fp.out_dist = d_dist;
+            fp.out_ind = d_ind;
+        }
         fp.fail_count = fail_count;
         fp.fail_list = fail_list;
         fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
@@ -1377,6 +1388,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fin_ms += ms;
         last_splits = lay.pieces[0];
         last_blocks = W;
+        if (dual && tier == KZ_TIER_H && (int64_t)n_fail * 4 > cq_count) {
+            // the chunk is a range of image rows in the dual pass' own order: it cannot simply be redone with the float32
+            // kernel -- the caller (kz_knn_dual) runs both directions the ordinary way instead
+            dual->broken = 2;
+            return KZ_OK;
+        }
         if (tier != KZ_TIER_F32 && (int64_t)n_fail * 4 > cq_count) {
             // more than a quarter of the chunk's rows could not be certified under this tier's margin: this data needs the
             // float32 operands; redo the chunk (and run the rest of the call) with the float32-MFMA kernel
@@ -1392,8 +1409,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             // exact float64 kernels).  Results are scattered back.
             const bool widen = tier == KZ_TIER_H && KP < 128;
             kz_knn_stats st2;
-            rc = kz_escalate_rows(ctx, query, cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids, widen ? 0 : 1,
-                                  widen ? (KP * 4 < 128 ? KP * 4 : 128) : 0, fp.out_dist, fp.out_ind, &st2, &ms);
+            rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids,
+                                  widen ? 0 : 1, widen ? (KP * 4 < 128 ? KP * 4 : 128) : 0, fp.out_dist, fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;
             n_escalated += n_fail + st2.n_escalated_rows;

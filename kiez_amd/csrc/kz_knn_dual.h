@@ -97,6 +97,29 @@ __global__ void kz_dual_tilemin_kernel(const float* __restrict__ theta_sorted, i
     out[i] = theta_sorted[(tile_end < n ? tile_end : n) - 1];
 }
 
+// Load balance of the query side.  How many events a query row takes part in is heavy-tailed (hubness: rows near the data
+// centre are near neighbours of many index rows; simulated on uniform data: mean 10, deviation 14, maximum 388 per row, and
+// the sums over the 128 rows of a tile still range over a factor 2.3), and the count correlates with |q_c|^2 at -0.75.  A
+// workgroup with an event-rich tile falls behind the others of its XCD; once it is more than an L2's worth of index tiles
+// behind, its index stream misses L2 (measured: hit rate 96 % -> 58 %, 171 GB of fabric reads per launch).  So the rows of A
+// are dealt into tiles like cards: sorted by |q_c|^2, full tile t takes the ranks t, t + T, t + 2T, ... -- every tile gets the
+// same mix.  (The ragged tail keeps the last ranks.)
+__global__ void kz_dual_c2key_kernel(const double* __restrict__ rowq, int64_t n, float* __restrict__ key) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = (float)rowq[i * 3];
+}
+__global__ void kz_dual_deal_kernel(const int* __restrict__ sorted_rows, int64_t n, int64_t n_pad, int* __restrict__ row_map) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pad) return;
+    const int64_t T = n / KZ_TILE, n_full = T * KZ_TILE;
+    int r = -1;
+    if (p < n_full)
+        r = sorted_rows[(p % KZ_TILE) * T + p / KZ_TILE];
+    else if (p < n)
+        r = sorted_rows[p];
+    row_map[p] = r;
+}
+
 // -bias of the query side (pad rows: +inf, never an event)
 __global__ void kz_dual_negbias_kernel(const float* __restrict__ bias, int64_t n, int64_t n_pad, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,7 +133,8 @@ __global__ void kz_dual_negbias_kernel(const float* __restrict__ bias, int64_t n
 __global__ __launch_bounds__(256) void kz_dual_scatter_kernel(const f32x4e* __restrict__ log_keys, const i32x2e* __restrict__ log_meta,
                                                               const unsigned long long* __restrict__ log_cnt, long long log_cap,
                                                               const float* __restrict__ theta, const float* __restrict__ qnb,
-                                                              int* __restrict__ ev_cnt, uint2* __restrict__ ev, int ev_cap) {
+                                                              const int* __restrict__ row_map, int* __restrict__ ev_cnt,
+                                                              uint2* __restrict__ ev, int ev_cap) {
     const unsigned long long filled = *log_cnt;
     // (an overflowed or poisoned log holds entries that were never written: nothing is filed, the host falls back)
     const long long n = filled <= (unsigned long long)log_cap ? (long long)filled : 0;
@@ -127,7 +151,8 @@ __global__ __launch_bounds__(256) void kz_dual_scatter_kernel(const f32x4e* __re
         for (int u = 0; u < 4; ++u) {
             if (kk[u] - tt[u] >= nb) {
                 const int slot = atomicAdd(ev_cnt + row0 + u, 1);
-                if (slot < ev_cap) ev[(int64_t)(row0 + u) * ev_cap + slot] = make_uint2(__float_as_uint(kk[u]), (unsigned)mt.y);
+                // (events are filed under the MATRIX row of the query: mt.y is a row of the dealt query image)
+                if (slot < ev_cap) ev[(int64_t)(row0 + u) * ev_cap + slot] = make_uint2(__float_as_uint(kk[u]), (unsigned)row_map[mt.y]);
             }
         }
     }
@@ -288,9 +313,9 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // overflowing log is detected and the direction redone.
     const long long log_cap = (long long)((double)b->n * k * stride * 1.5) + (1 << 20);
 
-    unsigned short *s_packed = nullptr, *p_packed = nullptr;
-    float *s_bias = nullptr, *p_bias = nullptr, *theta = nullptr, *theta_s = nullptr, *theta_min = nullptr, *floor_ = nullptr, *qnb = nullptr, *col_key = nullptr;
-    int *ev_cnt = nullptr, *col_idx = nullptr, *fail_list = nullptr, *iota = nullptr, *perm = nullptr;
+    unsigned short *s_packed = nullptr, *p_packed = nullptr, *q_packed = nullptr;
+    float *s_bias = nullptr, *p_bias = nullptr, *q_bias = nullptr, *q_key = nullptr, *q_key_s = nullptr, *theta = nullptr, *theta_s = nullptr, *theta_min = nullptr, *floor_ = nullptr, *qnb = nullptr, *col_key = nullptr;
+    int *ev_cnt = nullptr, *col_idx = nullptr, *fail_list = nullptr, *iota = nullptr, *perm = nullptr, *q_iota = nullptr, *q_sorted = nullptr, *row_map = nullptr;
     uint2* ev = nullptr;
     void *log_keys = nullptr, *log_meta = nullptr;
     unsigned long long* d_cnt = nullptr;   // [0] log counter, [1] events filed, [2] rows with an overflowing buffer
@@ -299,6 +324,13 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         kz_pool_free(ctx, s_bias, 0);
         kz_pool_free(ctx, p_packed, 0);
         kz_pool_free(ctx, p_bias, 0);
+        kz_pool_free(ctx, q_packed, 0);
+        kz_pool_free(ctx, q_bias, 0);
+        kz_pool_free(ctx, q_key, 0);
+        kz_pool_free(ctx, q_key_s, 0);
+        kz_pool_free(ctx, q_iota, 0);
+        kz_pool_free(ctx, q_sorted, 0);
+        kz_pool_free(ctx, row_map, 0);
         kz_pool_free(ctx, theta_s, 0);
         kz_pool_free(ctx, theta_min, 0);
         kz_pool_free(ctx, iota, 0);
@@ -319,6 +351,13 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     rc = kz_pool_alloc(ctx, (size_t)s_tiles * tile_bytes + 32 * 4096, (void**)&s_packed);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)s_tiles * KZ_TILE * 4, (void**)&s_bias);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_tiles * tile_bytes + 32 * 4096, (void**)&p_packed);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_tiles * tile_bytes + 32 * 4096, (void**)&q_packed);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&q_bias);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&q_key);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&q_key_s);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&q_iota);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&q_sorted);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&row_map);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&p_bias);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&theta_s);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&theta_min);
@@ -366,7 +405,15 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
                                  hipMemcpyDeviceToDevice, ctx->stream));
     KZ_DUAL_HIP(hipMemsetAsync(ev_cnt, 0, (size_t)b_pad * 4, ctx->stream));
     KZ_DUAL_HIP(hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(kz_dual_negbias_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, ia->bias, a->n, a_pad, qnb);
+    // ---- query side: rows dealt into tiles by |q_c|^2 (load balance), its image and its offsets in that order --------------
+    hipLaunchKernelGGL(kz_dual_c2key_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, ctx->stream, ia->rowq, a->n, q_key);
+    hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_iota, (int)a_pad);
+    KZ_DUAL_HIP(hipGetLastError());
+    KZ_DUAL_RC(kz_sort_pairs_f32_i32(ctx, q_key, q_key_s, q_iota, q_sorted, (int)a->n, 0));
+    hipLaunchKernelGGL(kz_dual_deal_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_sorted, a->n, a_pad, row_map);
+    KZ_DUAL_HIP(hipGetLastError());
+    KZ_DUAL_RC(kz_himage_pack_permuted(a, row_map, q_packed, q_bias));
+    hipLaunchKernelGGL(kz_dual_negbias_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_bias, a->n, a_pad, qnb);
 
     // ---- sample sweep: B x sample(A) with the ordinary kernel, lists of at most 256 entries per row -----------------------
     {
@@ -406,6 +453,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, iota, (int)b_pad);
     hipLaunchKernelGGL(kz_dual_fill_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, theta_s, b_pad, INFINITY);
     KZ_DUAL_HIP(hipGetLastError());
+#ifdef KZ_EXP
+    if (getenv("KZ_DUAL_NOSORT")) {   // diagnostic (with KZ_DUAL_NOEV): the sweep over the image in its natural order
+        KZ_DUAL_HIP(hipMemcpyAsync(perm, iota, (size_t)b->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        KZ_DUAL_HIP(hipMemcpyAsync(theta_s, theta, (size_t)b->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    } else
+#endif
     KZ_DUAL_RC(kz_sort_pairs_f32_i32(ctx, theta, theta_s, iota, perm, (int)b->n, 1));
     hipLaunchKernelGGL(kz_dual_tilemin_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, theta_s, b->n, b_pad, theta_min);
     KZ_DUAL_HIP(hipGetLastError());
@@ -419,6 +472,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // ---- main sweep: A x B, lists of A's rows + event log of B's rows ---------------------------------------------------------
     KzDualPass dp;
     memset(&dp, 0, sizeof(dp));
+    dp.qpack = (const float*)q_packed;
+    dp.row_map = row_map;
     dp.ypack = (const float*)p_packed;
     dp.ybias = p_bias;
     dp.perm = perm;
@@ -441,7 +496,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         // ---- events -> lists -> ordinary finalize with B as the query side --------------------------------------------------
         KZ_DUAL_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         hipLaunchKernelGGL(kz_dual_scatter_kernel, dim3(ctx->n_cus * 8), dim3(256), 0, ctx->stream, (const f32x4e*)log_keys,
-                           (const i32x2e*)log_meta, d_cnt, log_cap, theta_s, qnb, ev_cnt, ev, ev_cap);
+                           (const i32x2e*)log_meta, d_cnt, log_cap, theta_s, qnb, row_map, ev_cnt, ev, ev_cap);
         const size_t sel_lds = (size_t)4 * 2 * ev_cap * 4;
         if (sel_lds > 65536)
             KZ_DUAL_HIP(hipFuncSetAttribute((const void*)kz_dual_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
@@ -524,6 +579,10 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         }
     }
     release();
+    if (dp.broken == 2) {
+        // the forward sweep gave up on a chunk (too many uncertified rows for the fp16 tier): both directions the ordinary way
+        return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
+    }
     if (dp.broken) {
         // the sweep left the fp16 tier on the way, or the log overflowed: this direction the ordinary way
         rc = kz_knn_impl(ctx, b, 0, b->n, a, k, 0, nullptr, -1, 0, d_dist_ba, d_ind_ba, &st_ba, nullptr);

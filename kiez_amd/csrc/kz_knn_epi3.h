@@ -108,11 +108,12 @@ __device__ __forceinline__ void kz_flush_col3(const KzWavePool& pool, const KzDu
         if (col) {
             const unsigned long long pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
             if ((long long)pos < log_cap) {
-                log_keys[pos] = pool.keys[e];
+                // (streaming stores: the log is written once and read by another kernel)
                 i32x2e mo;
                 mo.x = mt.x & 0x7fffffff;
                 mo.y = du.qrow0 + (mt.x & 31);
-                log_meta[pos] = mo;
+                __builtin_nontemporal_store(pool.keys[e], log_keys + pos);
+                __builtin_nontemporal_store(mo, log_meta + pos);
             }
         }
         base += __popcll(mask);

@@ -72,7 +72,8 @@ def test_both_directions_identical_to_two_searches(ctx, kind, na, nb, d, k, metr
     a, b = _data(kind, na, d, 1, dtype), _data(kind, nb, d, 2, dtype)
     sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, k, metric)
     _assert_same(sep, dual)
-    assert s_ab["dual"] == 1                      # the forward direction always comes out of the shared sweep ...
+    if kind != "duplicates":                      # (exact ties: more than a quarter of the rows fail the fp16 certification, the
+        assert s_ab["dual"] == 1                  #  call gives up on sharing; the forward direction otherwise always shares ...
     assert s_ab["max_err_ratio"] < 1.0 and s_ba["max_err_ratio"] < 1.0
     if s_ba["dual"] == 1:                         # ... the reverse one unless the log overflowed (tiny inputs: many events per tile)
         assert s_ba["n_events"] >= k * nb

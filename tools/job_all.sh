@@ -5,5 +5,4 @@ import json,sys,os
 j=json.load(open(os.environ["O"]+"/bench.json"))
 print("value", j["value"], "ms/step", j["ms_per_step"], "roofline", j["roofline"]["frac"], j["roofline"]["avg_launch_ms"], "shared", j.get("shared_sweep"))
 for n,o in j.get("other_workloads", {}).items(): print(n, round(o["ms_per_step"],2), "%.4g"%o["value"], round(o["roofline_frac"],3), o.get("shared_sweeps"), o.get("check"))
-print("cpu", j.get("cpu_baseline"))
 PY
