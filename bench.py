@@ -348,11 +348,21 @@ def main():
     if rank == 0:
         s = main_s
         tier = s["tier"]
+        # HBM-side bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools/pmc_derive.py).  The
+        # counters are per KERNEL DISPATCH; a launch here (one kz_knn / kz_knn_dual call) sweeps its query rows in chunks of
+        # 524288, one dispatch each -- scaled by the ratio of the two durations so that `traffic` refers to the same launch
+        # as `achieved`
         traffic = None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"   # HBM bytes per launch from separate rocprofv3 --pmc passes
+        traffic_dispatches = None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists():
             try:
-                traffic = json.loads(pmc.read_text()).get(args.workload + "_" + TIER_NAME[tier], {}).get("hbm_bytes_per_launch")
+                rec = json.loads(pmc.read_text()).get(args.workload + "_" + TIER_NAME[tier], {})
+                per_dispatch = rec.get("hbm_bytes_per_launch")
+                if per_dispatch is not None and s["n_launch"]:
+                    avg_launch_ms = s["kernel_s"] / s["n_launch"] * 1e3
+                    traffic_dispatches = max(1, round(avg_launch_ms / rec["avg_ms_under_pmc"]))
+                    traffic = per_dispatch * traffic_dispatches
             except Exception:
                 traffic = None
         line = {
@@ -373,10 +383,10 @@ def main():
                        "n_candidates": K, "k": k, "hubness": hub, "hubness_kwargs": hub_kw,
                        "inputs": "float32 rng.rand, resident in HBM; results left in HBM",
                        "parallelism": f"source row-sharded x{world}, target replicated"
-                                      + (" (RCCL broadcast; fit state RCCL all-gather)" if world > 1 else " (single rank: no collective runs)")},
+                                      + (" (RCCL broadcast; per-shard reverse lists RCCL all-to-all; fit state RCCL all-gather)" if world > 1 else " (single rank: no collective runs)")},
             "roofline": {"bound": "mfma", "kernel": TIER_KERNEL[tier],
                          "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s",
-                         "frac": s["achieved"] / s["peak"], "traffic": traffic,
+                         "frac": s["achieved"] / s["peak"], "traffic": traffic, "traffic_kernel_dispatches_per_launch": traffic_dispatches,
                          "launches": s["n_launch"], "avg_launch_ms": s["kernel_s"] / max(s["n_launch"], 1) * 1e3,
                          "algorithmic_flop_per_launch": s["flops"] / max(s["n_launch"], 1),
                          "mfma_products_per_mac": TIER_PRODUCTS[tier],
