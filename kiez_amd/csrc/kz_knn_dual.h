@@ -133,6 +133,7 @@ __global__ void kz_dual_negbias_kernel(const float* __restrict__ bias, int64_t n
 __global__ __launch_bounds__(256) void kz_dual_scatter_kernel(const f32x4e* __restrict__ log_keys, const i32x2e* __restrict__ log_meta,
                                                               const unsigned long long* __restrict__ log_cnt, long long log_cap,
                                                               const float* __restrict__ theta, const float* __restrict__ qnb,
+                                                              const float* __restrict__ bias_b_sorted,
                                                               const int* __restrict__ row_map, int* __restrict__ ev_cnt,
                                                               uint2* __restrict__ ev, int ev_cap) {
     const unsigned long long filled = *log_cnt;
@@ -145,27 +146,29 @@ __global__ __launch_bounds__(256) void kz_dual_scatter_kernel(const f32x4e* __re
         const int row0 = (tg >> 4) * KZ_TILE + ((tg >> 2) & 3) * 32 + (tg & 3) * 8 + 4 * (ql >> 5);
         const float nb = qnb[mt.y];
         const float4 th = *reinterpret_cast<const float4*>(theta + row0);
+        const float4 bt = *reinterpret_cast<const float4*>(bias_b_sorted + row0);
         const float kk[4] = {kv.x, kv.y, kv.z, kv.w};
         const float tt[4] = {th.x, th.y, th.z, th.w};
+        const float bb[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (kk[u] - tt[u] >= nb) {
                 const int slot = atomicAdd(ev_cnt + row0 + u, 1);
-                // (events are filed under the MATRIX row of the query: mt.y is a row of the dealt query image)
-                if (slot < ev_cap) ev[(int64_t)(row0 + u) * ev_cap + slot] = make_uint2(__float_as_uint(kk[u]), (unsigned)row_map[mt.y]);
+                // The event is filed as the reverse-direction key  key'(t, q) = acc - bias(t) + bias(q), evaluated in float64
+                // on the float32 values (exact) and rounded once to float32 (the list format), under the MATRIX row of the
+                // query (mt.y is a row of the dealt query image; -nb is its bias).
+                const float kf = (float)(((double)kk[u] - (double)bb[u]) - (double)nb);
+                if (slot < ev_cap) ev[(int64_t)(row0 + u) * ev_cap + slot] = make_uint2(__float_as_uint(kf), (unsigned)row_map[mt.y]);
             }
         }
     }
 }
 
 // ---- the K' best events of a row -> an ordinary candidate list ---------------------------------------------------------
-// One wave per row t of B.  key'(t, q) = acc - bias(t) + bias(q) is evaluated in float64 on the float32 values (exact) and
-// rounded once to float32 (the list format); selection by (key' descending, q ascending) is a total order, so the list
-// does not depend on the order the atomics filed the events in.  K'-th key by radix select on the sortable bit pattern.
+// One wave per row t of B.  Selection by (key' descending, q ascending) is a total order, so the list does not depend on
+// the order the atomics filed the events in.  K'-th key by radix select on the sortable bit pattern.
 __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restrict__ ev_cnt, const uint2* __restrict__ ev, int ev_cap,
-                                                             int64_t n_b, const int* __restrict__ perm,
-                                                             const float* __restrict__ bias_b_sorted,
-                                                             const float* __restrict__ bias_a, int KP, float* __restrict__ out_key,
+                                                             int64_t n_b, const int* __restrict__ perm, int KP, float* __restrict__ out_key,
                                                              int* __restrict__ out_idx, float* __restrict__ floor_,
                                                              unsigned long long* __restrict__ totals) {
     extern __shared__ __attribute__((aligned(16))) char ssm[];
@@ -184,11 +187,9 @@ __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restri
             atomicAdd(totals + 1, 1ull);
         }
     }
-    const double bt = (double)bias_b_sorted[t];
     for (int e = lane; e < n; e += 64) {
         const uint2 v = ev[t * (int64_t)ev_cap + e];
-        const float kf = (float)(((double)__uint_as_float(v.x) - bt) + (double)bias_a[v.y]);
-        const unsigned b = __float_as_uint(kf);
+        const unsigned b = v.x;   // the reverse-direction key as filed by kz_dual_scatter_kernel
         su[e] = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
         sq[e] = (int)v.y;
     }
@@ -496,12 +497,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         // ---- events -> lists -> ordinary finalize with B as the query side --------------------------------------------------
         KZ_DUAL_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         hipLaunchKernelGGL(kz_dual_scatter_kernel, dim3(ctx->n_cus * 8), dim3(256), 0, ctx->stream, (const f32x4e*)log_keys,
-                           (const i32x2e*)log_meta, d_cnt, log_cap, theta_s, qnb, row_map, ev_cnt, ev, ev_cap);
+                           (const i32x2e*)log_meta, d_cnt, log_cap, theta_s, qnb, p_bias, row_map, ev_cnt, ev, ev_cap);
         const size_t sel_lds = (size_t)4 * 2 * ev_cap * 4;
         if (sel_lds > 65536)
             KZ_DUAL_HIP(hipFuncSetAttribute((const void*)kz_dual_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
         hipLaunchKernelGGL(kz_dual_select_kernel, dim3((unsigned)((b->n + 3) / 4)), dim3(256), sel_lds, ctx->stream, ev_cnt, ev, ev_cap,
-                           b->n, perm, p_bias, ia->bias, KP, col_key, col_idx, floor_, d_cnt + 1);
+                           b->n, perm, KP, col_key, col_idx, floor_, d_cnt + 1);
         KZ_DUAL_HIP(hipGetLastError());
         KZ_DUAL_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
         KzListLayout lay;
