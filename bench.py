@@ -393,6 +393,10 @@ def main():
                          "executed_mfma_frac": s["achieved"] * TIER_PRODUCTS[tier] / s["peak"],
                          "vs_fp32_mfma_peak": s["achieved"] / PEAK_F32_MFMA_TFLOPS,
                          "shared_sweeps": s["shared_sweeps"],
+                         # SURVEY.md section 8(d) prices a hubness-reduced step at TWO passes (4 n_s n_t d flop, what the reference
+                         # executes); that figure over the same kernel time, for comparison only -- `achieved` / `frac` above
+                         # count what this kernel executes
+                         "reference_work_tflops": (s["achieved"] * (1 + s["shared_sweeps"] / max(s["n_launch"], 1))),
                          "note": ("algorithmic flop = 2 n_q n_i d per launch, counted ONCE for a launch that serves both search "
                                   "directions (kz_knn_dual): the reference evaluates that distance matrix twice")},
             "shared_sweep": {"launches": s["shared_sweeps"], "reverse_extra_ms_per_step": s["reverse_extra_ms_per_step"],

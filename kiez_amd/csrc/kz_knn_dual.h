@@ -282,6 +282,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         const double s_opt = sqrt(t_ms / ((double)b->n * k * 0.07e-6));
         stride = s_opt < 4.0 ? 4 : (s_opt > 32.0 ? 32 : (int)(s_opt + 0.5));
     }
+    // (a row's event buffer -- k stride + 7 sqrt(k) stride entries -- is selected from LDS, 8 B per entry and four rows per
+    //  workgroup: at most 4096 entries)
+    if (stride > 1 && KP > 0) {
+        const int s_max = (int)(4096.0 / ((double)k + 7.0 * sqrt((double)k) + 1.0));
+        if (stride > s_max) stride = s_max;
+    }
     const int64_t a_tiles = a->n_tiles, b_tiles = b->n_tiles;
     const int64_t s_tiles = stride > 0 ? (a_tiles + stride - 1) / stride : 0;
     // rows of A in the sample (the last tile of A may be partial and may or may not be part of it)

@@ -227,3 +227,12 @@ def test_sharded_pipeline_single_rank():
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, "-c", SHARDED_SCRIPT % str(root)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "SHARDED_DUAL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
+
+
+def test_large_k_keeps_the_event_buffers_within_lds(ctx):
+    """k = 100 with the largest stride the option admits: the stride is cut back so that a row's events still fit the
+    select kernel's LDS."""
+    ctx.set_option("dual_stride", 64)
+    a, b = _data("normal", 20000, 24, 21, np.float32), _data("normal", 3000, 24, 22, np.float32)
+    sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 100, "euclidean")
+    _assert_same(sep, dual)
