@@ -159,6 +159,14 @@ int kz_dsl_finalize(kz_ctx* ctx, double* d_out, int64_t count, double min_value,
 int kz_select_topk(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K, int k,
                    double* d_odist, int64_t* d_oind);
 
+/* Single-source mode (fit(source) only): d_dist / d_ind = [n, K1] result of ONE kz_knn of the matrix against itself for
+ * K1 = K + 1 neighbours WITHOUT exclude_self, rows row0 .. row0 + n.  Writes both views the reference computes with two
+ * searches: rev = the first K columns (HubnessReduction.fit's reverse pass keeps each row as its own first neighbour,
+ * base.py:37-42) and fwd = the row minus itself, removed as sklearn does (neighbors/_base.py:937-965) = kz_knn(..., K,
+ * exclude_self = 1).  All four outputs are [n, K]. */
+int kz_split_self(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K1, int64_t row0,
+                  double* d_rev_dist, int64_t* d_rev_ind, double* d_fwd_dist, int64_t* d_fwd_ind);
+
 /* ---- "next" row (f-1): kiez.analysis.hubness_score on the neighbour index matrix (kiez/analysis/estimation.py:197-351) */
 /* min / max of an int64 device array (validation + bincount length). */
 int kz_minmax_i64(kz_ctx* ctx, const int64_t* d_in, int64_t count, int64_t* h_min, int64_t* h_max);

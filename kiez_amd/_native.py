@@ -78,6 +78,7 @@ SYMBOLS = [
     ("kz_matrix_shape", C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("kz_knn", C.c_int, [_P, _P, _I64, _I64, _P, C.c_int, C.c_int, _P, _P, C.POINTER(KnnStats)]),
     ("kz_knn_dual", C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(KnnStats), C.POINTER(KnnStats)]),
+    ("kz_split_self", C.c_int, [_P, _P, _P, _I64, C.c_int, _I64, _P, _P, _P, _P]),
     ("kz_knn_plan", C.c_int, [_I64, _I64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                               C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("kz_row_stats", C.c_int, [_P, _P, _I64, C.c_int, _P, _P, _P]),
@@ -317,6 +318,16 @@ def knn_dual(ctx: Context, a: DeviceMatrix, b: DeviceMatrix, k: int):
     _check(ctx.lib.kz_knn_dual(ctx.handle, a.handle, b.handle, int(k), d_ab.ptr, i_ab.ptr, d_ba.ptr, i_ba.ptr,
                                C.byref(s_ab), C.byref(s_ba)), "kz_knn_dual")
     return (d_ab, i_ab, s_ab.as_dict()), (d_ba, i_ba, s_ba.as_dict())
+
+
+def split_self(ctx: Context, dist: DeviceArray, ind: DeviceArray, row0: int = 0):
+    """kz_split_self: [n, K + 1] self-search without stripping -> ((rev_dist, rev_ind), (fwd_dist, fwd_ind)), each [n, K]."""
+    n, k1 = dist.shape
+    outs = [ctx.empty((n, k1 - 1), np.float64), ctx.empty((n, k1 - 1), np.int64), ctx.empty((n, k1 - 1), np.float64),
+            ctx.empty((n, k1 - 1), np.int64)]
+    _check(ctx.lib.kz_split_self(ctx.handle, dist.ptr, ind.ptr, n, int(k1), int(row0), outs[0].ptr, outs[1].ptr, outs[2].ptr,
+                                 outs[3].ptr), "kz_split_self")
+    return (outs[0], outs[1]), (outs[2], outs[3])
 
 
 def row_stats(ctx: Context, dist: DeviceArray, mean=False, std=False, last=False):

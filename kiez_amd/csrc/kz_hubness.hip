@@ -512,6 +512,47 @@ int kz_select_topk(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int6
     return KZ_OK;
 }
 
+// Single-source mode: the reverse search of HubnessReduction.fit (explicit query = the source itself: every row keeps itself
+// as its first neighbour, base.py:37-42) and the forward search of kneighbors (query = None: the row itself is stripped the way
+// sklearn does, neighbors/_base.py:937-965) are both views of ONE search for K + 1 neighbours without stripping: the reverse
+// lists are its first K columns, the forward lists are the row minus the entry whose index is the row (or minus the first
+// entry when the row is not among its own K + 1) -- exactly what kz_knn's exclude_self does on its K + 1 candidates.
+__global__ __launch_bounds__(256) void kz_split_self_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind, int64_t n,
+                                                            int K1, int64_t row0, double* __restrict__ rev_d,
+                                                            int64_t* __restrict__ rev_i, double* __restrict__ fwd_d,
+                                                            int64_t* __restrict__ fwd_i) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int K = K1 - 1;
+    const double* d = dist + r * K1;
+    const int64_t* i = ind + r * K1;
+    int self_rank = 0;
+    for (int c = 0; c < K1; ++c)
+        if (i[c] == row0 + r) {
+            self_rank = c;
+            break;
+        }
+    for (int c = 0; c < K; ++c) {
+        rev_d[r * K + c] = d[c];
+        rev_i[r * K + c] = i[c];
+        const int s = c < self_rank ? c : c + 1;
+        fwd_d[r * K + c] = d[s];
+        fwd_i[r * K + c] = i[s];
+    }
+}
+
+int kz_split_self(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K1, int64_t row0, double* d_rev_dist,
+                  int64_t* d_rev_ind, double* d_fwd_dist, int64_t* d_fwd_ind) {
+    KZ_REQUIRE(ctx && d_dist && d_ind && d_rev_dist && d_rev_ind && d_fwd_dist && d_fwd_ind, "kz_split_self: null argument");
+    KZ_REQUIRE(n >= 0 && K1 >= 2, "kz_split_self: need n >= 0 and at least two columns");
+    KZ_HIP(hipSetDevice(ctx->device));
+    if (n == 0) return KZ_OK;
+    hipLaunchKernelGGL(kz_split_self_kernel, kz_grid1d(n, 256), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K1, row0, d_rev_dist, d_rev_ind,
+                       d_fwd_dist, d_fwd_ind);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
 int kz_cast_f64_f32(kz_ctx* ctx, const double* d_in, float* d_out, int64_t count) {
     KZ_REQUIRE(ctx && d_in && d_out && count >= 0, "kz_cast_f64_f32: bad argument");
     KZ_HIP(hipSetDevice(ctx->device));

@@ -311,11 +311,20 @@ class SklearnNN(NNAlgorithm):
         """Both directions between the fitted source and target from ONE sweep of the distance matrix (kz_knn_dual): returns
         the target -> source result (what HubnessReduction.fit needs, base.py:37-42) and keeps the source -> target result
         for the `kneighbors_device(query=None, k)` call that follows (base.py:95-96).  Identical results to the two separate
-        searches.  None when the shared sweep does not apply (single-source fit, sides clamped to different k)."""
+        searches.  None when sharing does not apply (sides clamped to different k, more neighbours than the fused kernels keep)."""
         check_is_fitted(self, ["source_index", "target_index"], all_or_any=all)
-        if self.source_equals_target:
-            return None
         k = self.n_candidates if k is None else k
+        if self.source_equals_target:
+            # single source: the reverse search (explicit query: every row keeps itself) and the forward search (the row
+            # itself stripped) are two views of ONE search for k + 1 neighbours (kz_split_self)
+            n = self.source_.shape[0]
+            if not np.issubdtype(type(k), np.integer) or k <= 0 or k + 1 > n or k + 1 > N.MAX_FUSED_NEIGHBORS:
+                return None
+            dist, ind, stats = N.knn(self.ctx, self.source_index, self.source_index, k + 1, exclude_self=False)
+            self.last_stats = stats
+            rev, fwd = N.split_self(self.ctx, dist, ind)
+            self._forward = (k,) + fwd
+            return rev
         n_s, n_t = self.source_.shape[0], self.target_.shape[0]
         if not np.issubdtype(type(k), np.integer) or k <= 0 or k > min(n_s, n_t):
             return None   # (the per-direction checks and clamps of kneighbors() apply: leave it to the separate searches)

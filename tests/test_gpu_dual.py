@@ -236,3 +236,24 @@ def test_large_k_keeps_the_event_buffers_within_lds(ctx):
     a, b = _data("normal", 20000, 24, 21, np.float32), _data("normal", 3000, 24, 22, np.float32)
     sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 100, "euclidean")
     _assert_same(sep, dual)
+
+
+@pytest.mark.parametrize("hub,kw", [("CSLS", {}), ("LocalScaling", {"method": "standard"}), ("MutualProximity", {"method": "normal"}),
+                                    ("MutualProximity", {"method": "empiric"}), ("DisSimLocal", {})])
+@pytest.mark.parametrize("kind,metric", [("uniform", "euclidean"), ("duplicates", "sqeuclidean")])
+def test_single_source_one_search_serves_both_views(hub, kw, kind, metric):
+    """fit(source) alone: the reverse pass (rows keep themselves) and the forward pass (rows stripped as sklearn does) are
+    two views of ONE search for K + 1 neighbours (kz_split_self) -- same results as the two searches, also on exact
+    duplicates (where a row is not necessarily its own first neighbour)."""
+    from kiez_amd import Kiez
+    s = _data(kind, 9000, 40, 31, np.float32)
+    out = []
+    for shared in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            kz = Kiez(n_candidates=10, algorithm="SklearnNN", algorithm_kwargs={"metric": metric}, hubness=hub,
+                      hubness_kwargs=dict(kw))
+            kz.hubness._shared_sweep = shared
+            out.append(kz.fit(s).kneighbors(5))
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
