@@ -25,6 +25,7 @@ struct kz_ctx {
     int min_splits;   // tuning knob: minimum index splits per query tile in the large-item region
     int precision;    // 0: fp16 first pass where eligible (default), 2: split-bf16 first pass, 1: float32 operands only
     int dual_stride;  // kz_knn_dual: every dual_stride-th tile of the query side is in the threshold sample (0: no dual pass, 1: automatic)
+    int dual_deal;    // tuning knob: 1 (default) = the dual pass deals the query rows into load-balanced tiles, 0 = natural order
     int dual_force;   // test knob: run the dual pass also where it does not pay (few query rows)
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)

@@ -120,6 +120,11 @@ __global__ void kz_dual_deal_kernel(const int* __restrict__ sorted_rows, int64_t
     row_map[p] = r;
 }
 
+__global__ void kz_dual_natural_kernel(int64_t n, int64_t n_pad, int* __restrict__ row_map) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_pad) row_map[p] = p < n ? (int)p : -1;
+}
+
 // -bias of the query side (pad rows: +inf, never an event)
 __global__ void kz_dual_negbias_kernel(const float* __restrict__ bias, int64_t n, int64_t n_pad, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -416,8 +421,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     hipLaunchKernelGGL(kz_dual_c2key_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, ctx->stream, ia->rowq, a->n, q_key);
     hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_iota, (int)a_pad);
     KZ_DUAL_HIP(hipGetLastError());
-    KZ_DUAL_RC(kz_sort_pairs_f32_i32(ctx, q_key, q_key_s, q_iota, q_sorted, (int)a->n, 0));
-    hipLaunchKernelGGL(kz_dual_deal_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_sorted, a->n, a_pad, row_map);
+    if (ctx->dual_deal) {
+        KZ_DUAL_RC(kz_sort_pairs_f32_i32(ctx, q_key, q_key_s, q_iota, q_sorted, (int)a->n, 0));
+        hipLaunchKernelGGL(kz_dual_deal_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_sorted, a->n, a_pad, row_map);
+    } else {   // tuning knob "dual_deal" = 0: the query rows in their natural order
+        hipLaunchKernelGGL(kz_dual_natural_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, a->n, a_pad, row_map);
+    }
     KZ_DUAL_HIP(hipGetLastError());
     KZ_DUAL_RC(kz_himage_pack_permuted(a, row_map, q_packed, q_bias));
     hipLaunchKernelGGL(kz_dual_negbias_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_bias, a->n, a_pad, qnb);

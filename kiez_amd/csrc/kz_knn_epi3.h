@@ -21,29 +21,44 @@
 typedef __attribute__((address_space(3))) float kz_lds_f32;
 typedef __attribute__((address_space(3))) int kz_lds_i32;
 
-// list storage: LDS ([entry][128 queries of the workgroup]) or the output arrays (K' contiguous entries per list)
-template <bool IN_LDS>
+// list storage (template parameter IN_LDS: 0, 1 or 2):
+//   1  keys and rows in LDS, [entry][128 queries of the workgroup] (K' <= 32)
+//   0  keys and rows in the output arrays, K' contiguous entries per list
+//   2  HYBRID: keys in LDS, rows in the output arrays.  A merge insert READS only keys (find the block minimum's position)
+//      and WRITES one key and one row: with the keys in LDS the only global traffic of an insert is a fire-and-forget
+//      4-byte store, no L2 round trip (K' = 64 at two workgroups per CU: a merge pass cost 26k cycles against 10k with
+//      LDS lists).  32 KiB of keys at K' = 64.
+template <int IN_LDS>
 struct KzListRef;
 template <>
-struct KzListRef<true> {
+struct KzListRef<1> {
     kz_lds_f32* k;
     int i_off;   // rows live i_off floats behind the keys (a constant of the build: one address register, not two)
-    static constexpr int STRIDE = 128;
+    static constexpr int KSTRIDE = 128, ISTRIDE = 128;
     __device__ __forceinline__ kz_lds_f32* kp() const { return k; }
     __device__ __forceinline__ kz_lds_i32* ip() const { return (kz_lds_i32*)(k + i_off); }
 };
 template <>
-struct KzListRef<false> {
+struct KzListRef<0> {
     float* kb;      // wave-uniform bases of the output arrays ...
     int* ib;
     unsigned off;   // ... and this query's first list entry (element offset)
-    static constexpr int STRIDE = 1;
+    static constexpr int KSTRIDE = 1, ISTRIDE = 1;
     __device__ __forceinline__ float* kp() const { return kb + off; }
+    __device__ __forceinline__ int* ip() const { return ib + off; }
+};
+template <>
+struct KzListRef<2> {
+    kz_lds_f32* k;
+    int* ib;
+    unsigned off;
+    static constexpr int KSTRIDE = 128, ISTRIDE = 1;
+    __device__ __forceinline__ kz_lds_f32* kp() const { return k; }
     __device__ __forceinline__ int* ip() const { return ib + off; }
 };
 
 // Per-lane candidate state (one lane = one (query, lane-half) pair) ...
-template <bool IN_LDS>
+template <int IN_LDS>
 struct KzCandState3 {
     KzListRef<IN_LDS> list;   // this query's list (lanes < 32 own it)
     float tau;                // K'-th best key of the list as of the last merge (same value in both lane halves)
@@ -136,9 +151,9 @@ struct KzBlockMin3 {
 // Insert (v, idx) over the current minimum of the list (caller guarantees v > tau); returns the new minimum in tau.
 // Replacing the global minimum touches ONE block: read its K'/NB keys (one round trip), overwrite the first key equal to
 // the block minimum, refresh the block minimum -- instead of re-scanning all K' keys.
-template <int KP, bool IN_LDS>
+template <int KP, int IN_LDS>
 __device__ __forceinline__ void kz_list_insert3(const KzListRef<IN_LDS>& L, KzBlockMin3<KP>& bs, float v, int idx, float& tau) {
-    constexpr int NB = KzBlockMin3<KP>::NB, BS = KzBlockMin3<KP>::BS, S = KzListRef<IN_LDS>::STRIDE;
+    constexpr int NB = KzBlockMin3<KP>::NB, BS = KzBlockMin3<KP>::BS, S = KzListRef<IN_LDS>::KSTRIDE, SI = KzListRef<IN_LDS>::ISTRIDE;
     float m = bs.bm[0];
     int b = 0;
 #pragma unroll
@@ -156,7 +171,7 @@ __device__ __forceinline__ void kz_list_insert3(const KzListRef<IN_LDS>& L, KzBl
 #pragma unroll
     for (int jj = BS - 2; jj >= 0; --jj) pos = (kk[jj] == m) ? jj : pos;   // first key equal to the block minimum
     blk[pos * S] = v;
-    L.ip()[(b * BS + pos) * S] = idx;
+    L.ip()[(b * BS + pos) * SI] = idx;
     float nm = INFINITY;
 #pragma unroll
     for (int jj = 0; jj < BS; ++jj) nm = fminf(nm, (jj == pos) ? v : kk[jj]);
@@ -175,14 +190,14 @@ __device__ __forceinline__ void kz_list_insert3(const KzListRef<IN_LDS>& L, KzBl
 // RECOMP: the block minima are NOT carried from merge to merge but re-read from the list at the start of every merge
 // (K' reads per merge against K'/4 registers per lane for the whole sweep: what the dual-pass build lacks at three
 // workgroups per CU and 13 stationary slices).
-template <int KP, bool IN_LDS, bool DUAL, bool RECOMP>
+template <int KP, int IN_LDS, bool DUAL, bool RECOMP>
 __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWavePool& pool, KzBlockMin3<KP>& bs, const KzDualRef& du) {
     const int lane = threadIdx.x & 63;
     if constexpr (DUAL) kz_flush_col3(pool, du);
     const int other = __shfl_xor(st.head, 32, 64);
     if (lane < 32) {
         if constexpr (RECOMP) {
-            constexpr int NB = KzBlockMin3<KP>::NB, BS = KzBlockMin3<KP>::BS, S = KzListRef<IN_LDS>::STRIDE;
+            constexpr int NB = KzBlockMin3<KP>::NB, BS = KzBlockMin3<KP>::BS, S = KzListRef<IN_LDS>::KSTRIDE;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 float m = INFINITY;
@@ -277,7 +292,7 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
 // CAP / 2 asks every wave of the workgroup to merge at the start of the next tile, so that no wave merges alone while
 // its siblings wait for it at the slice barrier; the flag of tile t is written during epilogue t, read during epilogue
 // t+1, cleared during epilogue t+2, and a workgroup barrier lies between any two epilogues).
-template <int KP, int CAP, bool IN_LDS, bool DUAL, bool RECOMP>
+template <int KP, int CAP, int IN_LDS, bool DUAL, bool RECOMP>
 __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3<IN_LDS>& st, KzWavePool& pool, KzBlockMin3<KP>& bs,
                                                   const int tile, const bool last_tile, kz_lds_i32* sync, const KzDualRef& du,
                                                   const float cthr KZ_EPI3_STAMP_ARGS) {

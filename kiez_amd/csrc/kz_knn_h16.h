@@ -28,12 +28,15 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 template <int KP, int WPS, int NSR, bool DUAL = false>
 struct KzHCfg {
     static constexpr bool LDS_LIST = KP <= 32;
-    static constexpr int RING = (WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8;
-    // (dual-pass build at three per CU: 16 entries fewer pay for the 1.5 KiB of thresholds and query offsets -- the workgroup
-    //  must not grow beyond the 52.5 KiB of the ordinary build)
-    static constexpr int CAP = WPS == 3 ? (KP == 16 ? (DUAL ? 176 : 192) : 256) : 256;     // event-pool entries per wave (24 B each)
     static constexpr bool LISTS_FIT = WPS == 2 || KP == 16;           // K' = 32 lists do not fit beside the ring at 3 per CU
-    static constexpr bool IN_LDS = LDS_LIST && LISTS_FIT;
+    // where the lists live (KzListRef, kz_knn_epi3.h): 1 = LDS, 2 = keys in LDS + rows in the output arrays, 0 = output arrays.
+    // The hybrid needs K' x 512 B: K' = 64 at two per CU (with a 4-slot ring), K' = 32 at three per CU (with a smaller pool).
+    static constexpr int LMODE = (LDS_LIST && LISTS_FIT) ? 1 : (((KP == 64 && WPS == 2) || (KP == 32 && WPS == 3)) ? 2 : 0);
+    static constexpr bool IN_LDS = LMODE == 1;
+    static constexpr int RING = (WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8;
+    // (three per CU: the workgroup must stay within 42 LDS granules of 1280 B -- 52.5 KiB with the lists of K' = 16 or the
+    //  keys of K' = 32; the dual-pass build pays for its 1.5 KiB of thresholds and query offsets with 16 pool entries)
+    static constexpr int CAP = WPS == 3 ? (KP <= 32 ? (DUAL ? 176 : 192) : 256) : (LMODE == 2 && RING == 8 ? (DUAL ? 140 : 156) : 256);     // event-pool entries per wave (24 B each)
     static constexpr int RING_BYTES = RING * 4096;
     static constexpr int BIAS_OFF = RING_BYTES;                        // 2 x 128 floats
     static constexpr int SYNC_OFF = BIAS_OFF + 1024;                   // 4 merge flags (+ padding)
@@ -41,14 +44,14 @@ struct KzHCfg {
     static constexpr int POOLK_OFF = THETA_OFF + (DUAL ? 1536 : 0);    // [4 waves][CAP] x 4 floats
     static constexpr int POOLM_OFF = POOLK_OFF + 4 * CAP * 16;         // [4 waves][CAP] x {code, next}
     static constexpr int LIST_OFF = POOLM_OFF + 4 * CAP * 8;           // keys [KP][128], then rows [KP][128]
-    static constexpr int LDS_BYTES = LIST_OFF + (IN_LDS ? KP * 128 * 8 : 0);
+    static constexpr int LDS_BYTES = LIST_OFF + (LMODE == 1 ? KP * 128 * 8 : (LMODE == 2 ? KP * 128 * 4 : 0));
 };
 
 template <int KP, int NSR, int WPS, bool DUAL = false>
 __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p) {
     using Cfg = KzHCfg<KP, WPS, NSR, DUAL>;
     constexpr int R = Cfg::RING, P = R / 2, CAP = Cfg::CAP;
-    constexpr bool IN_LDS = Cfg::IN_LDS;
+    constexpr int IN_LDS = Cfg::LMODE;   // list storage mode (KzListRef)
     // at three waves per SIMD (168 VGPRs) the first fragments of the next tile are NOT fetched across the epilogue: the 16
     // registers they would occupy there are what keeps the stationary query tile out of scratch memory.  Exception: a tile
     // whose LAST slice carries the barrier (even global slice index: odd NSR, tile starting at parity 0) must have read
@@ -76,9 +79,13 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     // this query's list in the output arrays (ONE list per query and index range, K' contiguous entries)
     auto out_list_offset = [&]() { return kz_list_contig_off((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s); };
     KzCandState3<IN_LDS> st;
-    if constexpr (IN_LDS) {
+    if constexpr (IN_LDS == 1) {
         st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF) + 32 * (tid >> 6) + j;
         st.list.i_off = KP * 128;
+    } else if constexpr (IN_LDS == 2) {
+        st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF) + 32 * (tid >> 6) + j;
+        st.list.ib = p.out_idx;
+        st.list.off = (unsigned)out_list_offset();
     } else {
         // (uniform bases + a 32-bit per-lane element offset: no 64-bit per-lane pointers to keep alive; a launch's lists stay
         //  far below 2^32 elements: <= 524288 rows x 64 ranges x K')
@@ -92,17 +99,17 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     if (h == 0) {  // the list belongs to the query: lane-half 0 owns it (kz_merge_logs3)
 #pragma unroll 4
         for (int e = 0; e < KP; ++e) {
-            st.list.kp()[e * KzListRef<IN_LDS>::STRIDE] = -INFINITY;
-            st.list.ip()[e * KzListRef<IN_LDS>::STRIDE] = -1;
+            st.list.kp()[e * KzListRef<IN_LDS>::KSTRIDE] = -INFINITY;
+            st.list.ip()[e * KzListRef<IN_LDS>::ISTRIDE] = -1;
         }
     }
     if (total <= 0) {
-        if constexpr (IN_LDS) {
+        if constexpr (IN_LDS != 0) {
             const int64_t listoff = out_list_offset();
             if (h == 0)
                 for (int e = 0; e < KP; ++e) {
                     p.out_key[listoff + e] = -INFINITY;
-                    p.out_idx[listoff + e] = -1;
+                    if constexpr (IN_LDS == 1) p.out_idx[listoff + e] = -1;   // (hybrid: the rows were initialised in place above)
                 }
         }
         return;
@@ -296,8 +303,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         run_tile(tile, std::integral_constant<int, (NSR & 1)>{});
         if (++tile >= t_end) break;
     }
-    if constexpr (IN_LDS) {
-        // the sweep is over: the list goes to the output arrays in the layout kz_knn_finalize_kernel reads
+    if constexpr (IN_LDS != 0) {
+        // the sweep is over: what lived in LDS goes to the output arrays in the layout kz_knn_finalize_kernel reads
         const int64_t listoff = out_list_offset();
         // (lane number re-made here: the `h == 0` mask of the prologue, kept for this one use, cost a VGPR as SGPR spill space)
         int lane_now;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
 #pragma unroll 4
             for (int e = 0; e < KP; ++e) {
                 p.out_key[listoff + e] = st.list.kp()[e * 128];
-                p.out_idx[listoff + e] = st.list.ip()[e * 128];
+                if constexpr (IN_LDS == 1) p.out_idx[listoff + e] = st.list.ip()[e * 128];
             }
         }
     }

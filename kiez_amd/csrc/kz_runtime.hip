@@ -45,6 +45,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->h_wps = 0;
     c->min_splits = 1;
     c->dual_stride = 1;
+    c->dual_deal = 1;
     c->lds_pad = 0;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
@@ -108,6 +109,8 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "dual_stride") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 64, "dual_stride must be 0 (no dual pass), 1 (automatic) or in [2, 64]");
         c->dual_stride = (int)value;
+    } else if (strcmp(name, "dual_deal") == 0) {
+        c->dual_deal = value != 0;
     } else if (strcmp(name, "dual_force") == 0) {
         c->dual_force = value != 0;
     } else if (strcmp(name, "lds_pad") == 0) {
