@@ -1207,8 +1207,10 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         *out = slots_cache[t];
         return KZ_OK;
     };
-    // query rows are processed in chunks so that the candidate lists stay below ~1 GiB
-    const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096;
+    // query rows are processed in chunks so that the candidate lists stay below ~1 GiB: 524288 rows for K' >= 64, up to four
+    // times as many for shorter lists (1 M x 250 k, K' = 16: one launch instead of two -- one tail round, one read-back, one
+    // re-search of the uncertified rows)
+    const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (KP <= 16 ? 4 : (KP <= 32 ? 2 : 1));
     double main_ms = 0, fin_ms = 0, fb_ms = 0;
     int64_t n_fail_total = 0, n_escalated = 0;
     double max_err_ratio = 0.0;
