@@ -90,3 +90,26 @@ def test_row_slice_partitions_everything():
             for b, c in parts:
                 assert b == pos
                 pos += c
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_single_process_pipeline_with_and_without_the_shared_sweep(shared):
+    """World size 1, no process group: ShardedKiez on the CPU engine must equal the oracle pipeline whether fit() takes both
+    search directions out of one `knn_dual` call (every hubness kind qualifies with one rank) or searches twice."""
+    import warnings
+    from kiez_amd.distributed import Comm, ShardedKiez
+    from oracle import kiez_oracle as O
+    from tests.cpu_engine import OracleEngine
+    rng = np.random.RandomState(23)
+    source, target = rng.rand(151, 9), rng.rand(190, 9)
+    for name, hub, kw, metric, single in CASES:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sk = ShardedKiez(n_candidates=6, algorithm_kwargs={"metric": metric}, hubness=hub,
+                             hubness_kwargs=dict(kw, shared_sweep=shared), engine=OracleEngine(), comm=Comm())
+            sk.fit(source, None if single else target, single_source=single)
+            d, i = sk.kneighbors(3)
+            od, oi = O.kiez_pipeline(source, None if single else target, 6, 3, metric, 2, hub, kw)
+        assert sk.shared == (shared and hub is not None and not single), (name, sk.shared)
+        np.testing.assert_array_equal(i.numpy(), oi, err_msg=name)
+        np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=1e-9, err_msg=name)
