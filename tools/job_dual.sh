@@ -1,2 +1,1 @@
-export AB=r8 WL="c1 ns"
-bash tools/job_ab.sh
+timeout 600 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
