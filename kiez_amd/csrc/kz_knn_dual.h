@@ -11,7 +11,7 @@
 // The test the sweep itself performs is coarser and nearly free: B's rows are SORTED by their threshold, so the 128 rows of
 // a tile have almost the same one, and a group of four keys is logged when its maximum (which the list scan has already
 // computed) reaches the tile's smallest threshold -- one extra compare per tile on the common path.
-// tau(t) is fixed before the sweep: the k-th best key of t against a SAMPLE of A (every s-th tile of A's fp16 image,
+// tau(t) is fixed before the sweep: the (k+1)-th best key of t against a SAMPLE of A (every s-th tile of A's fp16 image,
 // copied into a small image and swept by the ordinary kernel with B as the query side: 1/s of a full sweep).  By
 // construction about k s rows of A pass tau(t), whatever the data looks like (the count of population members above
 // the k-th order statistic of a sample is negative binomial: mean k (s - 1), deviation sqrt(k) s), so the event
@@ -27,8 +27,8 @@
 
 // ---- thresholds from the sample sweep --------------------------------------------------------------------------------
 // One wave per row t of B.  The row's lists from the sample sweep hold pieces x K' <= 256 entries; tau = the `rank`-th best of
-// them (by key, ties by entry order; rank = k: the sample rows are rows of A, so at least k rows reach tau in the sweep,
-// and about k stride do -- the list length K' is for the certification's margin, not for the threshold).  theta(t) = tau + bias(t) - margin, rounded DOWN to float32: an event is
+// them (by key, ties by entry order; rank = k + 1: the sample rows are rows of A, so k rows above tau are there by
+// construction, and about rank x stride in all -- the list length K' is for the certification's margin, not for the threshold).  theta(t) = tau + bias(t) - margin, rounded DOWN to float32: an event is
 // fl(acc - theta) >= -bias(q), so a NON-event has acc - theta < -bias(q) + 2^-24 |acc - theta|, and with
 // margin = 2^-22 S^2 (Ah Bh + Ac2 + Bc2) >= 2^-24 (|acc| + |theta|) that gives  acc - bias(t) + bias(q) < tau  in exact
 // arithmetic on the float32 values: every row outside the events has key' < tau.
@@ -277,6 +277,10 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     KZ_HIP(hipSetDevice(ctx->device));
 
     const int KP = kz_pick_list_len(k);
+    // the threshold of a row is its (k + 1)-th best sample key: the sample rows are rows of a, so k rows STRICTLY above the
+    // threshold are there by construction (at rank k a row whose k best all happen to be sample rows -- probability stride^-k:
+    // 4-25 % of the rows at k = 1 -- could not be certified and was searched again)
+    const int rank = k + 1 < KP ? k + 1 : KP;
     const int n_slices = b->kg / 4;
     // every stride-th tile of A is in the sample.  Automatic (dual_stride = 1): the sample sweep costs T / stride, the events
     // (log, scatter, select) ~0.07 ns each with |B| k stride of them: stride = sqrt(T / (|B| k 0.07 ns)), T ~ 2 |A| |B| d / 1e15 s
@@ -284,13 +288,13 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     int stride = ctx->dual_stride;
     if (stride == 1) {
         const double t_ms = 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12;
-        const double s_opt = sqrt(t_ms / ((double)b->n * k * 0.07e-6));
+        const double s_opt = sqrt(t_ms / ((double)b->n * rank * 0.07e-6));
         stride = s_opt < 4.0 ? 4 : (s_opt > 32.0 ? 32 : (int)(s_opt + 0.5));
     }
     // (a row's event buffer -- k stride + 7 sqrt(k) stride entries -- is selected from LDS, 8 B per entry and four rows per
     //  workgroup: at most 4096 entries)
     if (stride > 1 && KP > 0) {
-        const int s_max = (int)(4096.0 / ((double)k + 7.0 * sqrt((double)k) + 1.0));
+        const int s_max = (int)(4096.0 / ((double)rank + 7.0 * sqrt((double)rank) + 1.0));
         if (stride > s_max) stride = s_max;
     }
     const int64_t a_tiles = a->n_tiles, b_tiles = b->n_tiles;
@@ -304,7 +308,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // fit + kneighbors; 500k x 500k, K' 64: 207 against 249 ms; 100k x 100k, d 128: 11.0 against 6.8 ms -- the last one is what
     // the margin below keeps out.  "dual_force" (test knob) skips this gate.
     const double t_sweep_ms = 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12;
-    const double t_events_ms = (double)b->n * k * stride * 0.15e-6;
+    const double t_events_ms = (double)b->n * rank * stride * 0.15e-6;
     const bool pays = ctx->dual_force || 0.5 * t_sweep_ms > t_events_ms + 2.0;
     const bool eligible = pays && stride >= 2 && ctx->precision == 0 && KP > 0 && n_slices >= 2 && n_slices <= 24 && a->kg == b->kg &&
                           s_rows >= (int64_t)8 * KP && b->n >= 1024 && b_tiles < (1 << 20);
@@ -318,12 +322,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
 
     // expected events per row of B: k (stride - 1) + k, deviation sqrt(k) stride; the buffer takes mean + ~7 deviations (a row
     // that overflows is searched again on its own: ~1.5 ms for a single row against a million index rows)
-    const int ev_cap = (int)(((int64_t)k * stride + (int64_t)(7.0 * sqrt((double)k) * stride) + 63) & ~(int64_t)63);
+    const int ev_cap = (int)(((int64_t)rank * stride + (int64_t)(7.0 * sqrt((double)rank) * stride) + 63) & ~(int64_t)63);
     // logged groups: about one per event (rarely two events share a group) plus the groups that pass the tile's smallest
     // threshold but not their own rows' (few: the rows of a tile are neighbours in threshold order); the TOTAL over all rows
     // is sharply concentrated around |B| k stride -- 1.5 times that, plus slack for small inputs (24 B per entry).  An
     // overflowing log is detected and the direction redone.
-    const long long log_cap = (long long)((double)b->n * k * stride * 1.5) + (1 << 20);
+    const long long log_cap = (long long)((double)b->n * rank * stride * 1.5) + (1 << 20);
 
     unsigned short *s_packed = nullptr, *p_packed = nullptr, *q_packed = nullptr;
     float *s_bias = nullptr, *p_bias = nullptr, *q_bias = nullptr, *q_key = nullptr, *q_key_s = nullptr, *theta = nullptr, *theta_s = nullptr, *theta_min = nullptr, *floor_ = nullptr, *qnb = nullptr, *col_key = nullptr;
@@ -459,7 +463,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             return rc;
         }
         hipLaunchKernelGGL(kz_dual_theta_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, ctx->stream, ps.out_key, ps.out_idx,
-                           ps.lay, KP, k, b->n, b_pad, ib->bias, ia->d_max, ib->d_max, ib->center->d_scale, theta, floor_);
+                           ps.lay, KP, rank, b->n, b_pad, ib->bias, ia->d_max, ib->d_max, ib->center->d_scale, theta, floor_);
         KZ_DUAL_HIP(hipGetLastError());
     }
     // ---- B's rows in DESCENDING order of their threshold: permutation, sorted thresholds (+inf behind them), sorted image.
