@@ -257,3 +257,14 @@ def test_single_source_one_search_serves_both_views(hub, kw, kind, metric):
             out.append(kz.fit(s).kneighbors(5))
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("na,nb,d,k,metric,dtype", [(30000, 5000, 64, 1, "euclidean", np.float32), (30000, 5000, 64, 2, "cosine", np.float64),
+                                                    (5000, 30000, 33, 1, "sqeuclidean", np.float32)])
+def test_one_or_two_neighbours(ctx, na, nb, d, k, metric, dtype):
+    """k = 1: the threshold sits at the SECOND best sample key, so the best row is strictly above it also when it is a sample
+    row -- (nearly) every row is certified from its handful of events."""
+    a, b = _data("uniform", na, d, 41, dtype), _data("uniform", nb, d, 42, dtype)
+    sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, k, metric)
+    _assert_same(sep, dual)
+    assert s_ba["dual"] == 1 and s_ba["n_escalated_rows"] < 0.02 * nb
