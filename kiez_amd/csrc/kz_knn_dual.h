@@ -186,17 +186,29 @@ __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restri
     const int filed = ev_cnt[t];
     const int n = filed < ev_cap ? filed : ev_cap;
     if (lane == 0) {
-        atomicAdd(totals + 0, (unsigned long long)filed);
+        // (statistics only: spread over 32 counter pairs -- one pair for all 250 k waves serialised the whole kernel on a
+        //  single L2 atomic: 3.1 ms of which 2 were this line)
+        unsigned long long* tot = totals + 2 * (blockIdx.x & 31);
+        atomicAdd(tot + 0, (unsigned long long)filed);
         if (filed > ev_cap) {
             floor_[orig] = INFINITY;   // incomplete events: the certification must fail, the row is searched again
-            atomicAdd(totals + 1, 1ull);
+            atomicAdd(tot + 1, 1ull);
         }
     }
+    unsigned all_or = 0u, all_and = 0xffffffffu;
     for (int e = lane; e < n; e += 64) {
         const uint2 v = ev[t * (int64_t)ev_cap + e];
         const unsigned b = v.x;   // the reverse-direction key as filed by kz_dual_scatter_kernel
-        su[e] = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+        const unsigned u = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+        su[e] = u;
         sq[e] = (int)v.y;
+        all_or |= u;
+        all_and &= u;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        all_or |= __shfl_xor(all_or, off, 64);
+        all_and &= __shfl_xor(all_and, off, 64);
     }
     kz_wave_sync();
     float* ok = out_key + orig * (int64_t)KP;
@@ -210,8 +222,12 @@ __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restri
         return;
     }
     // thr = the largest value with at least K' entries >= it
-    unsigned thr = 0;
-    for (int bit = 31; bit >= 0; --bit) {
+    // (the keys of a row share their leading bits -- same sign, same exponent range: the radix select starts below the common
+    //  prefix instead of at bit 31)
+    const unsigned differ = all_or ^ all_and;
+    const int top = differ ? 31 - __clz(differ) : -1;
+    unsigned thr = top >= 31 ? 0u : (all_and & ~((2u << top) - 1u));   // top = -1: every key equal, thr = that key
+    for (int bit = top; bit >= 0; --bit) {
         const unsigned cand = thr | (1u << bit);
         int c = 0;
         for (int e0 = 0; e0 < n; e0 += 64) c += (int)__popcll(__ballot(e0 + lane < n && su[e0 + lane] >= cand));
@@ -242,6 +258,19 @@ __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restri
             oi[base] = best;
         }
         last = best;
+    }
+}
+
+__global__ void kz_dual_sum_kernel(const unsigned long long* __restrict__ spread, unsigned long long* __restrict__ out) {
+    unsigned long long a = threadIdx.x < 32 ? spread[2 * threadIdx.x] : 0ull, b = threadIdx.x < 32 ? spread[2 * threadIdx.x + 1] : 0ull;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        out[0] = a;
+        out[1] = b;
     }
 }
 
@@ -334,7 +363,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     int *ev_cnt = nullptr, *col_idx = nullptr, *fail_list = nullptr, *iota = nullptr, *perm = nullptr, *q_iota = nullptr, *q_sorted = nullptr, *row_map = nullptr;
     uint2* ev = nullptr;
     void *log_keys = nullptr, *log_meta = nullptr;
-    unsigned long long* d_cnt = nullptr;   // [0] log counter, [1] events filed, [2] rows with an overflowing buffer
+    unsigned long long* d_cnt = nullptr;   // [0] log counter, [1] events filed, [2] rows with an overflowing buffer, [16 ..] 32 spread pairs of [1], [2]
     auto release = [&]() {
         kz_pool_free(ctx, s_packed, 0);
         kz_pool_free(ctx, s_bias, 0);
@@ -389,7 +418,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * ev_cap * 8, (void**)&ev);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 16, &log_keys);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 8, &log_meta);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, 64, (void**)&d_cnt);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, 1024, (void**)&d_cnt);
     if (rc != KZ_OK) {
         release();
         // (not enough memory for the event buffers: the two ordinary searches need far less)
@@ -420,7 +449,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     KZ_DUAL_HIP(hipMemcpy2DAsync(s_bias, KZ_TILE * 4, ia->bias, (size_t)KZ_TILE * 4 * stride, KZ_TILE * 4, (size_t)s_tiles,
                                  hipMemcpyDeviceToDevice, ctx->stream));
     KZ_DUAL_HIP(hipMemsetAsync(ev_cnt, 0, (size_t)b_pad * 4, ctx->stream));
-    KZ_DUAL_HIP(hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
+    KZ_DUAL_HIP(hipMemsetAsync(d_cnt, 0, 1024, ctx->stream));
     // ---- query side: rows dealt into tiles by |q_c|^2 (load balance), its image and its offsets in that order --------------
     hipLaunchKernelGGL(kz_dual_c2key_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, ctx->stream, ia->rowq, a->n, q_key);
     hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_iota, (int)a_pad);
@@ -521,7 +550,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         if (sel_lds > 65536)
             KZ_DUAL_HIP(hipFuncSetAttribute((const void*)kz_dual_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
         hipLaunchKernelGGL(kz_dual_select_kernel, dim3((unsigned)((b->n + 3) / 4)), dim3(256), sel_lds, ctx->stream, ev_cnt, ev, ev_cap,
-                           b->n, perm, KP, col_key, col_idx, floor_, d_cnt + 1);
+                           b->n, perm, KP, col_key, col_idx, floor_, d_cnt + 16);
+        hipLaunchKernelGGL(kz_dual_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, d_cnt + 16, d_cnt + 1);
         KZ_DUAL_HIP(hipGetLastError());
         KZ_DUAL_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
         KzListLayout lay;
