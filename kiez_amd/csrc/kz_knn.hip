@@ -613,9 +613,11 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off, 64));
         bound_violated = worst > 1.0;   // (wave-uniform after the butterfly) never expected: see the certification below
         if (lane == 0 && worst > 0.0) {
-            // 100k waves hit ONE address: read first, only the (rare) new maxima pay for the atomic
+            // a million waves hit ONE address: read first -- an ordinary load (served by this XCD's L2; a stale value only costs
+            // a redundant atomicMax), not an agent-scope atomic load that goes to the memory side every time -- and only the
+            // (rare) new maxima pay for the atomic
             const unsigned long long bits = (unsigned long long)__double_as_longlong(worst);
-            if (bits > __hip_atomic_load(p.err_ratio_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.err_ratio_bits, bits);
+            if (bits > *(const volatile unsigned long long*)p.err_ratio_bits) atomicMax(p.err_ratio_bits, bits);
         }
     }
 
