@@ -541,6 +541,66 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     // overlap); the per-candidate arithmetic is exactly kz_wave_dot / kz_wave_dot_normalized (kz_common.h)
     const T* yraw = reinterpret_cast<const T*>(p.yraw);
     const bool vec = kz_row_vec_ok(qptr, p.d) && kz_row_vec_ok(yraw, p.d);
+    if (sizeof(T) == 4 && vec && p.d <= 256 && Vr > 0) {   // (Vr == 0: a reverse-direction row without a single event)
+        // float32 rows of up to 256 elements (one 16-byte load per lane and row): the loads of the NEXT group of KZ_FIN_ROWS
+        // candidates are issued before the current group's fma chains and butterfly sums -- same arithmetic in the same order
+        // as the generic loop below (and as kz_wave_dot), only the memory latency of group g+1 hides under the sums of group g
+        const int k0 = 4 * lane;
+        const bool act = k0 < p.d;
+        double qk[4] = {0.0, 0.0, 0.0, 0.0};
+        if (act) {
+            kz_row4(qptr, k0, p.d, true, qk);
+            if (p.metric == KZ_COSINE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qk[e] = qk[e] / qs;
+            }
+        }
+        float4 cur[KZ_FIN_ROWS], nxt[KZ_FIN_ROWS];
+        double ys_c[KZ_FIN_ROWS], ys_n[KZ_FIN_ROWS];
+        auto issue = [&](int c0, float4 (&buf)[KZ_FIN_ROWS], double (&ysb)[KZ_FIN_ROWS]) {
+#pragma unroll
+            for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+                const int yi = ci[min(c0 + u, Vr - 1)];
+                ysb[u] = p.ysqn[yi];
+                buf[u] = act ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(yraw) + (int64_t)yi * p.d + k0)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        issue(0, cur, ys_c);
+        for (int c0 = 0; c0 < Vr; c0 += KZ_FIN_ROWS) {
+            const bool more = c0 + KZ_FIN_ROWS < Vr;   // wave-uniform
+            if (more) issue(c0 + KZ_FIN_ROWS, nxt, ys_n);
+#pragma unroll
+            for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+                const double yk[4] = {(double)cur[u].x, (double)cur[u].y, (double)cur[u].z, (double)cur[u].w};
+                double a = 0.0;
+                if (act) {
+                    if (p.metric == KZ_COSINE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e] / ys_c[u], a);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e], a);
+                    }
+                }
+                const double dot = kz_wave_sum(a);
+                double v;
+                if (p.metric == KZ_COSINE) {
+                    v = fmin(fmax(1.0 - dot, 0.0), 2.0);
+                } else {
+                    v = fmax((qs + ys_c[u]) - 2.0 * dot, 0.0);
+                }
+                if (lane == 0 && c0 + u < Vr) cv[c0 + u] = v;
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+                    cur[u] = nxt[u];
+                    ys_c[u] = ys_n[u];
+                }
+            }
+        }
+    } else
     for (int c0 = 0; c0 < Vr; c0 += KZ_FIN_ROWS) {
         const T* yp[KZ_FIN_ROWS];
         double ys[KZ_FIN_ROWS], acc[KZ_FIN_ROWS];

@@ -12,12 +12,13 @@ CASES = {
     "k26": (40000, 20000, 48, 26, "euclidean"),
     "ns": (1000000, 250000, 200, 10, "euclidean"),
     "c3": (500000, 500000, 200, 50, "cosine"),
+    "c3e": (500000, 500000, 200, 50, "euclidean"),
 }
 
 def run(name):
     na, nb, d, k, metric = CASES[name]
     rng = np.random.default_rng(len(name) + na)
-    if name in ("cos", "c3"):
+    if name in ("cos", "c3", "c3e"):
         a = rng.standard_normal((na, d), dtype=np.float32)
         b = rng.standard_normal((nb, d), dtype=np.float32)
     else:
