@@ -541,7 +541,11 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     // overlap); the per-candidate arithmetic is exactly kz_wave_dot / kz_wave_dot_normalized (kz_common.h)
     const T* yraw = reinterpret_cast<const T*>(p.yraw);
     const bool vec = kz_row_vec_ok(qptr, p.d) && kz_row_vec_ok(yraw, p.d);
-    if (sizeof(T) == 4 && vec && p.d <= 256 && Vr > 0) {   // (Vr == 0: a reverse-direction row without a single event)
+#ifdef KZ_NO_FIN_PIPE
+    if (false) {
+#else
+    if (sizeof(T) == 4 && vec && p.d <= 256 && Vr > 0) {
+#endif   // (Vr == 0: a reverse-direction row without a single event)
         // float32 rows of up to 256 elements (one 16-byte load per lane and row): the loads of the NEXT group of KZ_FIN_ROWS
         // candidates are issued before the current group's fma chains and butterfly sums -- same arithmetic in the same order
         // as the generic loop below (and as kz_wave_dot), only the memory latency of group g+1 hides under the sums of group g
@@ -1225,7 +1229,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         }
         KP = 128;   // (list geometry of the scratch block only; no list kernel runs)
     }
-    if (KP < kp_min) KP = kp_min;
+    if (KP < kp_min) KP = kp_min < 128 ? kp_min : 128;   // (list lengths are 16 / 32 / 64 / 128)
     if (stats) memset(stats, 0, sizeof(*stats));
     if (q_count == 0) return KZ_OK;
     KZ_HIP(hipSetDevice(ctx->device));

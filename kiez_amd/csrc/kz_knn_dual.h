@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restri
     //  prefix instead of at bit 31)
     const unsigned differ = all_or ^ all_and;
     const int top = differ ? 31 - __clz(differ) : -1;
-    unsigned thr = top >= 31 ? 0u : (all_and & ~((2u << top) - 1u));   // top = -1: every key equal, thr = that key
+    unsigned thr = top >= 31 ? 0u : (top < 0 ? all_and : (all_and & ~((2u << top) - 1u)));   // top = -1: every key equal, thr = that key
     for (int bit = top; bit >= 0; --bit) {
         const unsigned cand = thr | (1u << bit);
         int c = 0;
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restri
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
         if (lane == 0) {
-            ok[base] = key_of(thr);
-            oi[base] = best;
+            ok[base] = best != 0x7fffffff ? key_of(thr) : -INFINITY;
+            oi[base] = best != 0x7fffffff ? best : -1;   // (cannot happen: at least K' entries are >= thr; an empty slot, not a wild row, if it ever does)
         }
         last = best;
     }
@@ -619,7 +619,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             dp.broken = 1;   // the log itself overflowed: events are missing for unknown rows
         } else if (n_fail > 0) {
             // rows of B with an overflowing buffer or an uncertified list: the ordinary search, longer lists when they are few
-            const int kp_min = ((int64_t)n_fail * 8 > b->n || KP >= 128) ? 0 : KP * 4;
+            const int kp_min = ((int64_t)n_fail * 8 > b->n || KP >= 128) ? 0 : (KP * 4 < 128 ? KP * 4 : 128);
             kz_knn_stats st2;
             KZ_DUAL_RC(kz_escalate_rows(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, -1, kp_min, d_dist_ba, d_ind_ba, &st2, &ms));
             st_ba.fallback_ms = ms;

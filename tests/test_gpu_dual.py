@@ -268,3 +268,12 @@ def test_one_or_two_neighbours(ctx, na, nb, d, k, metric, dtype):
     sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, k, metric)
     _assert_same(sep, dual)
     assert s_ba["dual"] == 1 and s_ba["n_escalated_rows"] < 0.02 * nb
+
+
+def test_reverse_rows_of_a_k64_search_that_fail_are_researched_with_a_valid_list_length(ctx):
+    """Regression (found by tools/fuzz_dual.py): K' = 64 with a few percent of uncertified reverse rows (exact duplicates)
+    asked the re-search for lists of 4 x 64 = 256 entries; list lengths end at 128."""
+    a, b = _data("duplicates", 21114, 200, 51, np.float32), _data("duplicates", 32829, 200, 52, np.float32)
+    sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 54, "sqeuclidean")
+    _assert_same(sep, dual)
+    assert s_ba["n_escalated_rows"] > 0

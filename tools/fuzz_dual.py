@@ -1,0 +1,60 @@
+"""GPU box: randomised shapes for kz_knn_dual (shared sweep forced) against two kz_knn calls, bit for bit.
+   python3 tools/fuzz_dual.py [n_cases] [seed]"""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from kiez_amd import _native as N
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # run just this case (the random stream is advanced through the others)
+ctx = N.Context.get()
+bad = 0
+for case in range(n_cases):
+    na = int(rng.integers(1100, 60000))
+    nb = int(rng.integers(1100, 40000))
+    d = int(rng.choice([17, 24, 32, 40, 48, 64, 72, 100, 128, 129, 200, 208, 256, 300, 384]))
+    k = int(rng.choice([1, 2, 3, 5, 10, 12, 13, 20, 26, 27, 50, 54, 60, 100, 110]))
+    k = min(k, na, nb)
+    metric = str(rng.choice(["euclidean", "sqeuclidean", "cosine"]))
+    dtype = np.float32 if rng.random() < 0.7 else np.float64
+    kind = str(rng.choice(["uniform", "normal", "clustered", "dups", "scaled"]))
+    def gen(n):
+        if kind == "uniform":
+            return rng.random((n, d))
+        if kind == "normal":
+            return rng.standard_normal((n, d))
+        if kind == "scaled":
+            return rng.standard_normal((n, d)) * 1e3 + 5e3
+        if kind == "clustered":
+            c = rng.standard_normal((6, d)) * 4
+            return c[rng.integers(0, 6, n)] + 0.3 * rng.standard_normal((n, d)) * rng.random((n, 1)) * 3
+        base = rng.random((max(n // 5, 4), d))
+        return base[rng.integers(0, len(base), n)]
+    a, b = gen(na).astype(dtype), gen(nb).astype(dtype)
+    opt = (int(rng.choice([1, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 0, 4096, 16384])), int(rng.integers(0, 2)))
+    if only >= 0 and case != only:
+        continue
+    print(f"case {case}: na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} stride/chunk/deal {opt}", flush=True)
+    ctx.set_option("dual_stride", opt[0])
+    ctx.set_option("chunk_rows", opt[1])
+    ctx.set_option("dual_deal", opt[2])
+    am, bm = N.DeviceMatrix(ctx, a, metric), N.DeviceMatrix(ctx, b, metric)
+    ctx.set_option("dual_force", 0)
+    r1 = N.knn(ctx, am, bm, k); ctx.sync()
+    if only >= 0: print("  a->b done", r1[2]["n_escalated_rows"], r1[2]["n_fallback_rows"], flush=True)
+    r2 = N.knn(ctx, bm, am, k); ctx.sync()
+    if only >= 0: print("  b->a done", r2[2]["n_escalated_rows"], r2[2]["n_fallback_rows"], flush=True)
+    ctx.set_option("dual_force", 1)
+    (xd, xi, sa), (yd, yi, sb) = N.knn_dual(ctx, am, bm, k)
+    ok = (np.array_equal(r1[1].numpy(), xi.numpy()) and np.array_equal(r1[0].numpy(), xd.numpy())
+          and np.array_equal(r2[1].numpy(), yi.numpy()) and np.array_equal(r2[0].numpy(), yd.numpy()))
+    ratio = max(sa["max_err_ratio"], sb["max_err_ratio"])
+    if not ok or ratio >= 1.0:
+        bad += 1
+    print(("ok " if ok else "BAD"), f"na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} dual {sa['dual']}/{sb['dual']} "
+          f"ev/row {sb['n_events'] / nb:.1f} esc {sb['n_escalated_rows']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
+for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1)):
+    ctx.set_option(name, v)
+print("cases", n_cases, "bad", bad)
+sys.exit(1 if bad else 0)
