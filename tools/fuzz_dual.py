@@ -8,11 +8,12 @@ from kiez_amd import _native as N
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # run just this case (the random stream is advanced through the others)
+scale = int(sys.argv[4]) if len(sys.argv) > 4 else 1     # multiplies the row counts (10: up to 600 k x 400 k)
 ctx = N.Context.get()
 bad = 0
 for case in range(n_cases):
-    na = int(rng.integers(1100, 60000))
-    nb = int(rng.integers(1100, 40000))
+    na = int(rng.integers(1100, 60000)) * scale
+    nb = int(rng.integers(1100, 40000)) * scale
     d = int(rng.choice([17, 24, 32, 40, 48, 64, 72, 100, 128, 129, 200, 208, 256, 300, 384]))
     k = int(rng.choice([1, 2, 3, 5, 10, 12, 13, 20, 26, 27, 50, 54, 60, 100, 110]))
     k = min(k, na, nb)
