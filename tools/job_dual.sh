@@ -1,1 +1,2 @@
-timeout 1700 python3 tools/fuzz_dual.py 16 21 -1 10 > $O/fuzz_big.log 2>&1; grep -c "^ok" $O/fuzz_big.log; grep "^ok\|BAD" $O/fuzz_big.log | cut -c1-170 | head -20; grep "^cases\|fault\|Error" $O/fuzz_big.log | head -3
+export AB=prio2 WL="c1 ns"
+bash tools/job_ab.sh
