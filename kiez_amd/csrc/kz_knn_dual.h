@@ -28,10 +28,16 @@
 // ---- thresholds from the sample sweep --------------------------------------------------------------------------------
 // One wave per row t of B.  The row's lists from the sample sweep hold pieces x K' <= 256 entries; tau = the `rank`-th best of
 // them (by key, ties by entry order; rank = k + 1: the sample rows are rows of A, so k rows above tau are there by
-// construction, and about rank x stride in all -- the list length K' is for the certification's margin, not for the threshold).  theta(t) = tau + bias(t) - margin, rounded DOWN to float32: an event is
-// fl(acc - theta) >= -bias(q), so a NON-event has acc - theta < -bias(q) + 2^-24 |acc - theta|, and with
-// margin = 2^-22 S^2 (Ah Bh + Ac2 + Bc2) >= 2^-24 (|acc| + |theta|) that gives  acc - bias(t) + bias(q) < tau  in exact
-// arithmetic on the float32 values: every row outside the events has key' < tau.
+// construction, and about rank x stride in all -- the list length K' is for the certification's margin, not for the threshold).
+// theta(t) = tau + bias(t) - margin, rounded DOWN to float32.  The certification of the reverse direction needs: a (q, t) pair
+// that is NOT filed as an event has  acc - bias(t) + bias(q) < tau  in exact arithmetic on the float32 values.  A pair can miss
+// the events in two ways, with Mx = S^2 (Ah Bh + Ac2 + Bc2) >= |acc|, |theta|, |bias(q)|:
+//   * the per-key test of kz_dual_scatter_kernel fails: fl(acc - theta) < -bias(q), hence acc - theta < -bias(q) + 2^-24 |acc - theta|
+//     <= -bias(q) + 2^-23 Mx;
+//   * its group fails the kernel's per-tile test  max(group) >= fl(-bias(q) + theta_min)  (theta_min <= theta(t): the tile's
+//     smallest threshold): acc < (-bias(q) + theta_min)(1 + 2^-24), hence acc - theta(t) < -bias(q) + 2^-23 Mx as well.
+// Either way  acc + bias(q) < theta + 2^-23 Mx <= tau + bias(t)  once margin >= 2^-23 Mx; the kernel uses 2^-21 Mx (four times
+// that; in key units a few 1e-7 of the squared scale -- no visible effect on the event counts).
 __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restrict__ in_key, const int* __restrict__ in_idx,
                                                             KzListLayout lay, int KP, int rank, int64_t n_b, int64_t n_b_pad,
                                                             const float* __restrict__ bias_b, const double* __restrict__ a_hmax,
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
     for (int off = 32; off >= 1; off >>= 1) tau = fmaxf(tau, __shfl_xor(tau, off, 64));
     if (lane == 0) {
         const double S2 = hscale[0] * hscale[0];
-        const double margin = 2.384185791015625e-07 * S2 * (a_hmax[0] * b_hmax[0] + a_hmax[2] + b_hmax[2]);
+        const double margin = 4.76837158203125e-07 * S2 * (a_hmax[0] * b_hmax[0] + a_hmax[2] + b_hmax[2]);   // 2^-21 Mx
         const double th = (double)tau + (double)bias_b[t] - margin;
         float tf = (float)th;
         if ((double)tf > th) tf = nextafterf(tf, -INFINITY);

@@ -1,3 +1,3 @@
-timeout 1700 python3 tools/fuzz_dual.py 300 101 > $O/fuzz_a.log 2>&1; grep -c "^ok" $O/fuzz_a.log; grep "BAD\|^cases\|fault" $O/fuzz_a.log | head -5
-timeout 900 python3 tools/fuzz_api.py 150 202 > $O/fuzz_b.log 2>&1; grep -c "^ok" $O/fuzz_b.log; grep -B1 "BAD" $O/fuzz_b.log | head -6; grep "^cases\|fault" $O/fuzz_b.log | head -3
-timeout 900 python3 tools/fuzz_tiers.py 150 > $O/fuzz_c.log 2>&1; tail -1 $O/fuzz_c.log
+timeout 900 python3 -m pytest tests/test_gpu_dual.py -x -q -m gpu 2>&1 | tail -2
+timeout 1500 python3 tools/fuzz_dual.py 100 303 > $O/fuzz_a.log 2>&1; grep -c "^ok" $O/fuzz_a.log; grep "BAD\|^cases\|fault" $O/fuzz_a.log | head -3
+timeout 300 python3 tools/dual_check.py ns 2>&1 | tail -2 | head -1 | cut -c1-220
