@@ -1,0 +1,146 @@
+"""The shapes the headline number is quoted on, under `pytest -m gpu`, with the oracle, THROUGH THE SHARED SWEEP:
+
+  * ns   = BASELINE.json's target shape, one GPU's share: 250k source rows x 1M targets, d = 200, k = 10, CSLS;
+  * c4s  = configuration 4's per-GPU share: the same at d = 300 (19 slices, two workgroups per CU).
+
+At these sizes the statistics of the shared sweep (events per row, log capacity, L2 behaviour, one launch per 250k query
+rows) differ from every small test shape.  Checked per shape:
+  (a) `Kiez(hubness="CSLS").fit(source, target)` takes both directions out of ONE sweep (`last_stats["dual"] == 1` on both
+      sides); a 512-row sample of BOTH raw kNN results is array_equal to the oracle's exact float64 search
+      (kiez/hubness_reduction/base.py:33-50 reverse pass, :89-105 forward pass);
+  (b) `r_train` (csls.py:90) is bit-equal to the oracle's on sampled targets; the final `(dist, ind)` equals the oracle's
+      CSLS transform (csls.py:85-96) + `_sort` (base.py:72-87) on sampled rows;
+  (c) ALL rows of the result and of the fit state agree with a second fit that searches twice (`_shared_sweep = False`);
+  (d) `ShardedKiez(HipEngine)` over a real RCCL group with every collective forced (key exchange + merge of the per-shard
+      reverse lists included) gives the same rows (c4s shape, subprocess).
+"""
+import subprocess
+import sys
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+SHAPES = {"ns": (250_000, 1_000_000, 200), "c4s": (250_000, 1_000_000, 300)}
+K = 10
+
+
+def _data(n_s, n_t, d):
+    rng = np.random.RandomState(0)   # the reference's docstring data style (kiez/kiez.py:50-52), float32; bench.py's generator
+    return rng.rand(n_s, d).astype(np.float32), rng.rand(n_t, d).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["ns", "c4s"])
+def test_headline_shape_through_the_shared_sweep_against_the_oracle(name):
+    from kiez_amd import Kiez
+    from oracle import kiez_oracle as O
+    n_s, n_t, d = SHAPES[name]
+    s, t = _data(n_s, n_t, d)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = Kiez(n_candidates=K, algorithm="SklearnNN", algorithm_kwargs={"metric": "euclidean"}, hubness="CSLS")
+        kz.fit(s, t)
+        nn = kz.algorithm
+        # (a) one sweep served both directions
+        assert nn.last_stats["dual"] == 1 and nn.last_stats_reverse["dual"] == 1, (nn.last_stats, nn.last_stats_reverse)
+        assert nn.last_stats["max_err_ratio"] < 1.0 and nn.last_stats_reverse["max_err_ratio"] < 1.0
+        assert nn.last_stats["n_fallback_rows"] == 0 and nn.last_stats_reverse["n_fallback_rows"] == 0
+        k_fwd, fd_dev, fi_dev = nn._forward                    # the forward result the sweep left for kneighbors()
+        assert k_fwd == K
+        fd, fi = fd_dev.numpy(), fi_dev.numpy()
+        rd, ri = kz.hubness.r_dist_train_.numpy(), kz.hubness.r_ind_train_.numpy()
+        r_train = kz.hubness._r_train_dev.numpy()
+        dist, ind = kz.kneighbors(K)
+    assert fd.shape == (n_s, K) and rd.shape == (n_t, K) and dist.shape == (n_s, K) and ind.dtype == np.int64
+    assert (np.diff(fd, axis=1) >= 0).all() and (np.diff(rd, axis=1) >= 0).all() and (np.diff(dist, axis=1) >= 0).all()
+    assert fi.min() >= 0 and fi.max() < n_t and ri.min() >= 0 and ri.max() < n_s
+
+    rows = np.random.RandomState(1).choice(n_s, 512, replace=False)
+    od, oi = O.knn_exact(s[rows], t, K, "euclidean")
+    np.testing.assert_array_equal(fi[rows], oi)
+    np.testing.assert_array_equal(fd[rows], od)                # float32 inputs: bit-identical distances (sqrt rule)
+    trows = np.random.RandomState(2).choice(n_t, 512, replace=False)
+    ord_, ori = O.knn_exact(t[trows], s, K, "euclidean")
+    np.testing.assert_array_equal(ri[trows], ori)
+    np.testing.assert_array_equal(rd[trows], ord_)
+    # (b) fit state and final result
+    np.testing.assert_array_equal(r_train[trows], ord_.mean(axis=1))
+    tr = 2 * od - od.mean(axis=1).reshape(-1, 1) - r_train[oi]
+    sd, si = O.sort_topk(tr, oi, K)
+    np.testing.assert_array_equal(ind[rows], si)
+    np.testing.assert_array_equal(dist[rows], sd)
+
+    # (c) every row against a fit that searches twice
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz2 = Kiez(n_candidates=K, algorithm="SklearnNN", algorithm_kwargs={"metric": "euclidean"}, hubness="CSLS")
+        kz2.hubness._shared_sweep = False
+        kz2.fit(s, t)
+        assert kz2.algorithm.last_stats["dual"] == 0
+        rd2, ri2 = kz2.hubness.r_dist_train_.numpy(), kz2.hubness.r_ind_train_.numpy()
+        dist2, ind2 = kz2.kneighbors(K)
+    np.testing.assert_array_equal(ri, ri2)
+    np.testing.assert_array_equal(rd, rd2)
+    np.testing.assert_array_equal(ind, ind2)
+    np.testing.assert_array_equal(dist, dist2)
+
+
+SCRIPT = r"""
+import os, sys, warnings
+sys.path.insert(0, %r)
+os.environ["KIEZ_AMD_WITH_TORCH"] = "1"
+os.environ["KIEZ_AMD_FORCE_COLLECTIVES"] = "1"
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = "29631"
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # RCCL, before any other GPU call
+import numpy as np
+from kiez_amd.distributed import Comm, HipEngine, ShardedKiez
+from oracle import kiez_oracle as O
+warnings.simplefilter("ignore")
+n_s, n_t, d, K = 250_000, 1_000_000, 300, 10
+rng = np.random.RandomState(0)
+s = rng.rand(n_s, d).astype(np.float32)
+t = rng.rand(n_t, d).astype(np.float32)
+eng = HipEngine(0)
+comm = Comm(time_collectives=True)
+assert comm.always and comm.world == 1
+sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": "euclidean"}, hubness="CSLS", engine=eng, comm=comm)
+sk.fit(s, t)
+assert sk.shared and eng.last_stats["dual"] == 1 and eng.last_stats_reverse["dual"] == 1, (eng.last_stats, eng.last_stats_reverse)
+dd, ii = sk.kneighbors(K)
+dd, ii = dd.cpu().numpy(), ii.cpu().numpy()
+r_t = sk.state["r_t"].cpu().numpy()
+ms = comm.timers_ms(1)
+assert ms.get("broadcast", 0) > 0 and ms.get("all_to_all", 0) > 0 and ms.get("all_gather", 0) > 0, ms
+rows = np.random.RandomState(1).choice(n_s, 256, replace=False)
+od, oi = O.knn_exact(s[rows], t, K, "euclidean")
+trows = np.random.RandomState(2).choice(n_t, 256, replace=False)
+ord_, ori = O.knn_exact(t[trows], s, K, "euclidean")
+assert np.array_equal(r_t[trows], ord_.mean(axis=1)), "r_train differs from the oracle"
+tr = 2 * od - od.mean(axis=1).reshape(-1, 1) - r_t[oi]
+sd, si = O.sort_topk(tr, oi, K)
+assert np.array_equal(ii[rows], si), "indices differ from the oracle"
+assert np.array_equal(dd[rows], sd), "distances differ from the oracle"
+# every row against the single-process drop-in API
+from kiez_amd import Kiez
+kz = Kiez(n_candidates=K, algorithm="SklearnNN", algorithm_kwargs={"metric": "euclidean"}, hubness="CSLS").fit(s, t)
+d1, i1 = kz.kneighbors(K)
+assert np.array_equal(i1, ii) and np.array_equal(d1, dd), "ShardedKiez differs from Kiez"
+print("collective_ms", ms)
+dist.barrier()
+dist.destroy_process_group()
+print("NORTHSTAR_SHARDED_OK")
+"""
+
+
+def test_c4_share_sharded_over_rccl_with_every_collective_forced():
+    r = subprocess.run([sys.executable, "-c", SCRIPT % str(ROOT)], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "NORTHSTAR_SHARDED_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
