@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 3
+#define KZ_ABI_VERSION 4
+/* candidates per query the rescaling / sort kernels take (kz_knn itself returns up to 4096 neighbours) */
+#define KZ_MAX_CANDIDATES 4096
+/* entries per row kz_merge_topk merges (segments x segment length) */
+#define KZ_MERGE_MAX_ENTRIES 8192
 
 /* status codes */
 enum { KZ_OK = 0, KZ_ERR_INVALID = 1, KZ_ERR_HIP = 2, KZ_ERR_UNSUPPORTED = 3, KZ_ERR_NOMEM = 4, KZ_ERR_NONFINITE = 5 };
@@ -158,6 +162,22 @@ int kz_dsl_finalize(kz_ctx* ctx, double* d_out, int64_t count, double min_value,
  * (SURVEY.md §8 a-6).  d_odist/d_oind: [n, k]. */
 int kz_select_topk(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64_t n, int K, int k,
                    double* d_odist, int64_t* d_oind);
+
+/* ---- multi-GPU exchange step (source row-sharded, SURVEY.md section 8e "alternative": per-shard partial top-K + merge) ----- */
+/* The reverse search of HubnessReduction.fit (every target row against ALL source rows, base.py:37-42) over a row-sharded
+ * source is the merge of the per-shard searches.  kz_knn orders neighbours by the exact float64 value (squared euclidean /
+ * cosine distance), ties by smaller row, but RETURNS rounded distances (float32 + euclidean: (double)sqrtf((float)d2)), so
+ * per-shard lists are merged by the exact values:
+ * kz_pair_values: d_val[r, c] = the value kz_knn ranks index row d_ind[r, c] by for query row q_begin + r -- bit-identical to
+ * what the search computed (one canonical dot product); entries with d_ind outside [0, index.n) get +inf. */
+int kz_pair_values(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index,
+                   const int64_t* d_ind, int k, double* d_val);
+/* kz_merge_topk: every row of d_key / d_ind / d_dist [n, segs * seg_len] holds `segs` segments (columns [s seg_len,
+ * (s + 1) seg_len)), each sorted ascending by (key, ind) -- one per shard, ind = GLOBAL row ids.  Writes the k smallest
+ * entries by (key, ind) in that order: d_odist[n, k] = their d_dist (or their key when d_dist is NULL), d_oind[n, k] = their ind
+ * (0 when d_ind is NULL: kinds that only need the merged distances).  segs * seg_len <= KZ_MERGE_MAX_ENTRIES. */
+int kz_merge_topk(kz_ctx* ctx, const double* d_key, const int64_t* d_ind, const double* d_dist, int64_t n, int segs, int seg_len,
+                  int k, double* d_odist, int64_t* d_oind);
 
 /* Single-source mode (fit(source) only): d_dist / d_ind = [n, K1] result of ONE kz_knn of the matrix against itself for
  * K1 = K + 1 neighbours WITHOUT exclude_self, rows row0 .. row0 + n.  Writes both views the reference computes with two

@@ -29,7 +29,9 @@ METRIC_IDS = {"euclidean": KZ_EUCLIDEAN, "sqeuclidean": KZ_SQEUCLIDEAN, "cosine"
 MAX_FUSED_NEIGHBORS = 110   # neighbours per query the fused kernels keep (list length 128 minus the certification margin);
                             # beyond it kz_knn runs on the exact float64 kernels only (correct, slow), up to MAX_NEIGHBORS
 MAX_NEIGHBORS = 4096
-MAX_HUBNESS_CANDIDATES = 128  # n_candidates the device hubness kernels (transform, final sort) handle
+MAX_HUBNESS_CANDIDATES = 4096  # n_candidates the device hubness kernels (transform, final sort) handle (KZ_MAX_CANDIDATES)
+MERGE_MAX_ENTRIES = 8192       # entries per row kz_merge_topk merges (KZ_MERGE_MAX_ENTRIES)
+ABI_VERSION = 4
 
 _ERR_TYPES = {1: ValueError, 2: RuntimeError, 3: NotImplementedError, 4: MemoryError, 5: ValueError}
 
@@ -78,6 +80,8 @@ SYMBOLS = [
     ("kz_matrix_shape", C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("kz_knn", C.c_int, [_P, _P, _I64, _I64, _P, C.c_int, C.c_int, _P, _P, C.POINTER(KnnStats)]),
     ("kz_knn_dual", C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(KnnStats), C.POINTER(KnnStats)]),
+    ("kz_pair_values", C.c_int, [_P, _P, _I64, _I64, _P, _P, C.c_int, _P]),
+    ("kz_merge_topk", C.c_int, [_P, _P, _P, _P, _I64, C.c_int, C.c_int, C.c_int, _P, _P]),
     ("kz_split_self", C.c_int, [_P, _P, _P, _I64, C.c_int, _I64, _P, _P, _P, _P]),
     ("kz_knn_plan", C.c_int, [_I64, _I64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                               C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -125,8 +129,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.kz_abi_version() != 3:
-            raise RuntimeError(f"{path}: ABI version {lib.kz_abi_version()} != 3")
+        if lib.kz_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI version {lib.kz_abi_version()} != {ABI_VERSION}")
         _lib = lib
     return _lib
 

@@ -185,3 +185,19 @@ __device__ __forceinline__ double kz_wave_dot_normalized(const T* __restrict__ a
     }
     return kz_wave_sum(acc);
 }
+
+// The exact float64 value the search ranks an index row by (squared euclidean distance / cosine distance): the re-rank of
+// kz_knn_finalize_kernel, the exact fallback and kz_pair_values all evaluate THIS expression on the canonical dot product.
+template <typename T>
+__device__ __forceinline__ double kz_exact_value(const T* q, const T* y, double qs, double ys, int d, int metric, int lane) {
+    if (metric == KZ_COSINE) {
+        const double sim = kz_wave_dot_normalized(q, qs, y, ys, d, lane);
+        double v = 1.0 - sim;  // sklearn cosine_distances: S *= -1; S += 1; clip(0, 2)
+        v = fmin(fmax(v, 0.0), 2.0);
+        return v;
+    }
+    const double dot = kz_wave_dot(q, y, d, lane);
+    const double d2 = (qs + ys) - 2.0 * dot;  // |x|^2 - 2 x.y + |y|^2 (_argkmin.pyx.tp:494-499)
+    return fmax(d2, 0.0);                     // _argkmin.pyx.tp:502
+}
+

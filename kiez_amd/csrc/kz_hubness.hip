@@ -244,6 +244,73 @@ __global__ __launch_bounds__(256) void kz_mp_empiric_kernel(const double* __rest
     }
 }
 
+// The same for K > 128 candidates per query (no per-lane register copies; ids, their ranks and T in dynamic LDS, 20 bytes per
+// candidate and wave).  The reference has no limit on n_candidates (kiez/hubness_reduction/base.py:20-27).
+__global__ __launch_bounds__(256) void kz_mp_empiric_wide_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind,
+                                                                 int64_t n, int K, const double* __restrict__ dist_t2s,
+                                                                 const int64_t* __restrict__ ind_t2s, int64_t n_t, int Kt,
+                                                                 double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char mpw_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * wpb + wave;
+    if (i >= n) return;  // whole wave; only wave-level synchronisation below
+    long long* sorted = reinterpret_cast<long long*>(mpw_smem) + (size_t)wave * K;
+    double* T = reinterpret_cast<double*>(mpw_smem + (size_t)wpb * K * 8) + (size_t)wave * K;
+    int* rk = reinterpret_cast<int*>(mpw_smem + (size_t)wpb * K * 16) + (size_t)wave * K;
+    const double* d_i = dist + i * (int64_t)K;
+    const int64_t* c_i = ind + i * (int64_t)K;
+    for (int m = lane; m < K; m += 64) {
+        const long long cm = c_i[m];
+        int r = 0;
+        for (int o = 0; o < K; ++o) {
+            const long long co = c_i[o];
+            r += (co < cm || (co == cm && o < m)) ? 1 : 0;
+        }
+        rk[m] = r;
+        sorted[r] = cm;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = 0; j < K; ++j) {
+        const double dj = d_i[j];
+        const int64_t cj = c_i[j];
+        const double* rd = dist_t2s + cj * (int64_t)Kt;
+        const int64_t* ri = ind_t2s + cj * (int64_t)Kt;
+        const double fill = rd[Kt - 1] + 1e-6;
+        for (int m = lane; m < K; m += 64) T[m] = fill;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int pp = lane; pp < Kt; pp += 64) {
+            const long long id = ri[pp];
+            int lo = 0, hi = K - 1, pos = -1;
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1;
+                const long long v = sorted[mid];
+                if (v == id) {
+                    pos = mid;
+                    break;
+                }
+                if (v < id) lo = mid + 1; else hi = mid - 1;
+            }
+            if (pos >= 0) T[pos] = rd[pp];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int cnt = 0;
+        for (int m = lane; m < K; m += 64)
+            if (d_i[m] > dj && T[rk[m]] > dj) ++cnt;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (lane == 0) out[i * (int64_t)K + j] = 1.0 - (double)cnt / (double)K;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // DisSimLocal fit (dis_sim.py:96-102): t2c[j] = | target[t_begin+j] - mean_m source[ind_t2s[j,m]] |^2 ; wave per row
 template <typename T>
 __global__ __launch_bounds__(256) void kz_dsl_fit_kernel(const int64_t* __restrict__ ind_t2s, int64_t n_rows, int Kt,
@@ -394,6 +461,65 @@ __global__ __launch_bounds__(64) void kz_select_topk_kernel(const double* __rest
     }
 }
 
+// The same selection sort for rows of more than 128 candidates: one WAVE per row, the row in LDS (12 bytes per candidate).
+// Step i: every lane scans its strided share of positions [i, K) for its first minimum (NaN last), a butterfly picks the
+// smallest value at the lowest position -- the first minimum of the whole range -- and lane 0 swaps it into position i.
+__global__ __launch_bounds__(256) void kz_select_topk_wide_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind,
+                                                                  int64_t n, int K, int k, double* __restrict__ odist,
+                                                                  int64_t* __restrict__ oind) {
+    extern __shared__ __attribute__((aligned(16))) char selw_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * wpb + wave;
+    if (r >= n) return;  // whole wave; only wave-level synchronisation below
+    double* v = reinterpret_cast<double*>(selw_smem) + (size_t)wave * K;
+    int* ps = reinterpret_cast<int*>(selw_smem + (size_t)wpb * K * 8) + (size_t)wave * K;
+    for (int j = lane; j < K; j += 64) {
+        v[j] = dist[r * (int64_t)K + j];
+        ps[j] = j;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = 0; i < k; ++i) {
+        double m = NAN;
+        int mp = 0x7fffffff;
+        for (int j = i + lane; j < K; j += 64) {
+            const double x = v[j];
+            const bool less = mp == 0x7fffffff || (x < m) || ((m != m) && (x == x));
+            m = less ? x : m;
+            mp = less ? j : mp;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double om = __shfl_xor(m, off, 64);
+            const int omp = __shfl_xor(mp, off, 64);
+            // the other lane's candidate wins if it is smaller (NaN last), or equal / both NaN and at a lower position
+            const bool other_less = (om < m) || ((m != m) && (om == om));
+            const bool same = (om == m) || ((m != m) && (om != om));
+            const bool take = omp != 0x7fffffff && (mp == 0x7fffffff || other_less || (same && omp < mp));
+            m = take ? om : m;
+            mp = take ? omp : mp;
+        }
+        if (lane == 0 && mp != i) {
+            const double vi = v[i];
+            v[mp] = vi;
+            v[i] = m;
+            const int a = ps[i], b = ps[mp];
+            ps[i] = b;
+            ps[mp] = a;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    for (int i = lane; i < k; i += 64) {
+        odist[r * (int64_t)k + i] = v[i];
+        oind[r * (int64_t)k + i] = ind[r * (int64_t)K + ps[i]];
+    }
+}
+
 __global__ void kz_cast_f64_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t count) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < count) out[e] = (float)in[e];
@@ -404,7 +530,7 @@ static inline dim3 kz_grid1d(int64_t n, int per_block) { return dim3((unsigned)(
 
 #define KZ_CHECK_NK(fn)                                                                       \
     KZ_REQUIRE(ctx != nullptr, fn ": null context");                                           \
-    KZ_REQUIRE(n >= 0 && K >= 1 && K <= 128, fn ": bad shape n=%lld K=%d (K must be in [1,128])", (long long)n, K); \
+    KZ_REQUIRE(n >= 0 && K >= 1 && K <= KZ_MAX_CANDIDATES, fn ": bad shape n=%lld K=%d (K must be in [1,%d])", (long long)n, K, KZ_MAX_CANDIDATES); \
     KZ_HIP(hipSetDevice(ctx->device));                                                         \
     if (n == 0) return KZ_OK;
 
@@ -450,8 +576,17 @@ int kz_mp_empiric(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64
     KZ_CHECK_NK("kz_mp_empiric");
     KZ_REQUIRE(d_dist && d_ind && d_dist_t2s && d_ind_t2s && d_out, "kz_mp_empiric: null argument");
     KZ_REQUIRE(Kt >= 1 && n_t >= 1, "kz_mp_empiric: bad reverse list shape");
-    hipLaunchKernelGGL(kz_mp_empiric_kernel, kz_grid1d(n, 4), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K, d_dist_t2s,
-                       d_ind_t2s, n_t, Kt, d_out);
+    if (K <= KZ_MP_MAXK) {
+        hipLaunchKernelGGL(kz_mp_empiric_kernel, kz_grid1d(n, 4), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K, d_dist_t2s,
+                           d_ind_t2s, n_t, Kt, d_out);
+    } else {
+        const int wpb = K <= 1024 ? 4 : 1;
+        const int lds = wpb * K * 20;
+        if (lds > 65536)
+            KZ_HIP(hipFuncSetAttribute((const void*)kz_mp_empiric_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kz_mp_empiric_wide_kernel, kz_grid1d(n, wpb), dim3(64 * wpb), lds, ctx->stream, d_dist, d_ind, n, K,
+                           d_dist_t2s, d_ind_t2s, n_t, Kt, d_out);
+    }
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }
@@ -504,10 +639,17 @@ int kz_select_topk(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int6
     KZ_CHECK_NK("kz_select_topk");
     KZ_REQUIRE(d_dist && d_ind && d_odist && d_oind, "kz_select_topk: null argument");
     KZ_REQUIRE(k >= 1 && k <= K, "kz_select_topk: k=%d must be in [1, K=%d]", k, K);
-    const int lds = kz_sel_lds_bytes(K);
-    if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kz_select_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kz_select_topk_kernel, kz_grid1d(n, KZ_SEL_ROWS), dim3(64), lds, ctx->stream, d_dist, d_ind, n, K, k, d_odist,
-                       d_oind);
+    if (K <= 128) {
+        const int lds = kz_sel_lds_bytes(K);
+        if (lds > 65536) KZ_HIP(hipFuncSetAttribute((const void*)kz_select_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kz_select_topk_kernel, kz_grid1d(n, KZ_SEL_ROWS), dim3(64), lds, ctx->stream, d_dist, d_ind, n, K, k, d_odist,
+                           d_oind);
+    } else {
+        const int wpb = K <= 1024 ? 4 : 1;
+        const int lds = wpb * K * 12;
+        hipLaunchKernelGGL(kz_select_topk_wide_kernel, kz_grid1d(n, wpb), dim3(64 * wpb), lds, ctx->stream, d_dist, d_ind, n, K, k,
+                           d_odist, d_oind);
+    }
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }

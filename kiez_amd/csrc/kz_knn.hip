@@ -290,19 +290,7 @@ struct KnnFinParams {
     unsigned long long* err_ratio_bits;  // max over certified candidates of |key~ - key| / eps (bits of a non-negative double)
 };
 
-template <typename T>
-__device__ __forceinline__ double kz_exact_value(const T* q, const T* y, double qs, double ys, int d, int metric, int lane) {
-    if (metric == KZ_COSINE) {
-        const double sim = kz_wave_dot_normalized(q, qs, y, ys, d, lane);
-        double v = 1.0 - sim;  // sklearn cosine_distances: S *= -1; S += 1; clip(0, 2)
-        v = fmin(fmax(v, 0.0), 2.0);
-        return v;
-    }
-    const double dot = kz_wave_dot(q, y, d, lane);
-    const double d2 = (qs + ys) - 2.0 * dot;  // |x|^2 - 2 x.y + |y|^2 (_argkmin.pyx.tp:494-499)
-    return fmax(d2, 0.0);                     // _argkmin.pyx.tp:502
-}
-
+// (kz_exact_value: kz_common.h -- shared with kz_pair_values, which must reproduce the re-rank's values bit for bit)
 template <typename T>
 __device__ __forceinline__ double kz_output_distance(double v, int metric) {
     if (metric == KZ_EUCLIDEAN) {

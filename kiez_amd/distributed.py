@@ -3,12 +3,18 @@
 Partitioning (DESIGN.md "Multi-GPU"):
   * every rank owns a ROW SHARD of the source; the target is replicated (RCCL broadcast from rank 0);
   * hubness=None: nothing else moves — each rank searches its shard against the replicated target;
-  * hubness != None: `fit` needs the reverse kNN of every target row against ALL source rows, so the source
-    shards are all-gathered once (both matrices are small next to 288 GB of HBM), each rank runs the reverse
-    pass for ITS slice of target rows, and only the per-target-row fit state is all-gathered:
+  * hubness != None: `fit` needs the reverse kNN of every target row against ALL source rows.  SHARED SWEEP (default): every
+    rank sweeps its shard against the target once (kz_knn_dual): the forward lists of its rows and, for all target rows,
+    their K nearest rows INSIDE the shard; an all-to-all hands every rank the per-shard lists of its slice of target rows and
+    kz_merge_topk merges them -- by the distances for the kinds that only need reverse distances (CSLS, LocalScaling, MP
+    normal), by exact ordering values + global ids (kz_pair_values) for the kinds that need the reverse indices in the
+    single-GPU order (MP empiric, DSL).  Then only the per-target-row fit state is all-gathered:
       CSLS / NICDM: mean reverse distance, LS: K-th reverse distance, MP normal: mean + std (8-16 B per row),
-      DSL: distance to the local centroid (8 B per row), MP empiric: the full reverse lists;
+      DSL: distance to the local centroid (8 B per row; its centroid gather needs the source shards all-gathered once),
+      MP empiric: the merged reverse lists;
     DSL additionally all-reduces ONE scalar (MIN) before its global shift (kiez/hubness_reduction/dis_sim.py:171-173).
+    Without the shared sweep (`hubness_kwargs={"shared_sweep": False}`, single-source mode, shards smaller than K): the source
+    shards are all-gathered and each rank runs the reverse search for ITS slice of target rows against the full source.
   * `kneighbors` returns the rows of the local shard (global target ids).
 
 The arithmetic is delegated to an *engine*.  `HipEngine` (the product) drives the C ABI on torch CUDA tensors;
@@ -167,6 +173,26 @@ class HipEngine:
                                               self._ptr(od), self._ptr(oi)), "kz_select_topk")
         return od, oi
 
+    def pair_values(self, qm, q_begin: int, q_count: int, im, ind):
+        """kz_pair_values: the exact float64 value the search ranks index row ind[r, c] by for query row q_begin + r."""
+        out = self.empty(tuple(ind.shape), self.torch.float64)
+        self.N._check(self.lib.kz_pair_values(self.ctx.handle, qm.handle, q_begin, q_count, im.handle, self._ptr(ind),
+                                              ind.shape[1], self._ptr(out)), "kz_pair_values")
+        return out
+
+    MAX_MERGE = 8192   # KZ_MERGE_MAX_ENTRIES
+
+    def merge_topk(self, key, ind, dist, segs: int, seg_len: int, k: int):
+        """kz_merge_topk: per row the k smallest of `segs` sorted segments by (key, ind); returns (dist or key, ind)."""
+        torch = self.torch
+        n = key.shape[0]
+        od = self.empty((n, k), torch.float64)
+        oi = self.empty((n, k), torch.int64)
+        self.N._check(self.lib.kz_merge_topk(self.ctx.handle, self._ptr(key), self._ptr(ind) if ind is not None else None,
+                                             self._ptr(dist) if dist is not None else None, n, segs, seg_len, k,
+                                             self._ptr(od), self._ptr(oi)), "kz_merge_topk")
+        return od, oi
+
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -189,13 +215,22 @@ class Comm:
         self.timed = bool(time_collectives)
         self._events = []   # (kind, start event, end event) -- resolved lazily, no sync inside the step
         self._wall = {}
+        self._bytes = {}    # kind -> [calls, payload bytes this rank handed to the collective]
 
     # -- timing ---------------------------------------------------------------------------------------
     def reset_timers(self):
         self._events = []
         self._wall = {}
+        self._bytes = {}
+
+    def traffic(self, steps: int = 1):
+        """Per step and kind: number of collectives and payload bytes (this rank's send buffer; all_gather: its own block)."""
+        return {k: {"calls": c / max(steps, 1), "bytes": b / max(steps, 1)} for k, (c, b) in self._bytes.items()}
 
     def _timed(self, kind, t, fn):
+        rec = self._bytes.setdefault(kind, [0, 0])
+        rec[0] += 1
+        rec[1] += t.numel() * t.element_size()
         if not self.timed:
             return fn()
         if t.is_cuda:
@@ -251,22 +286,11 @@ class Comm:
         if self.world == 1 and not self.always:
             return t.reshape((1,) + tuple(t.shape))
         out = torch.empty((self.world * mine,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        tail = 1
-        for x in t.shape[1:]:
-            tail *= int(x)
         t = t.contiguous()
-        try:
-            self._timed("all_to_all", t, lambda: self.dist.all_to_all_single(out, t, output_split_sizes=[mine] * self.world,
-                                                                            input_split_sizes=list(counts), group=self.group))
-        except (RuntimeError, NotImplementedError):   # a backend without all-to-all: one broadcast per block
-            off = 0
-            for r in range(self.world):
-                blk = t[off: off + counts[r]]
-                gathered = [torch.empty_like(blk) for _ in range(self.world)] if self.rank == r else None
-                self.dist.gather(blk.contiguous(), gathered, dst=r, group=self.group)
-                if self.rank == r:
-                    out = torch.cat(gathered, dim=0)
-                off += counts[r]
+        # one path on every rank and every backend (RCCL and gloo both implement all_to_all_single); an error of the
+        # collective propagates -- a rank-local fallback to other collectives would leave the ranks in different calls
+        self._timed("all_to_all", t, lambda: self.dist.all_to_all_single(out, t, output_split_sizes=[mine] * self.world,
+                                                                        input_split_sizes=list(counts), group=self.group))
         return out.reshape((self.world, mine) + tuple(t.shape[1:]))
 
     def all_gather_ints(self, value: int, device):
@@ -357,7 +381,8 @@ class ShardedKiez:
         torch = _torch()
         tgt0 = None
         meta = [src.shape[0], 0, 0, 0]
-        bcast_target = (not single_source) and target_from_rank0 and (comm.world > 1 or comm.always)
+        multi = comm.world > 1 or comm.always
+        bcast_target = (not single_source) and target_from_rank0 and multi
         if bcast_target and comm.rank == 0:
             tgt0 = eng.to_engine(target)
             meta[1:] = [tgt0.shape[0], tgt0.shape[1], 0 if tgt0.dtype == torch.float32 else 1]
@@ -369,32 +394,39 @@ class ShardedKiez:
         n_s = sum(counts)
         self.single = bool(single_source)
         self._fwd = None
+        # the target's row count is known BEFORE anything is decided (every rank decides the same way)
+        tgt = None
+        if self.single:
+            n_t = n_s
+        elif bcast_target:
+            n_t = gathered[0][1]
+        else:
+            tgt = eng.to_engine(target)
+            n_t = tgt.shape[0]
         # Shared sweep (kz_knn_dual): the reverse neighbours of ALL targets inside this rank's source shard and the forward
         # neighbours of the shard come out of one sweep of shard x target; the per-shard reverse lists of a target are then
-        # merged on the rank that owns its slice (all-to-all of [n_t, K] distances).  Needs only the distances of the
-        # reverse lists when more than one rank takes part (CSLS, LocalScaling, MP normal: the K smallest distances of a
-        # target are the same multiset however ties between shards are broken); with one rank every kind qualifies.
-        k_cap = getattr(eng, "MAX_SELECT", 128)
+        # merged on the rank that owns its slice (all-to-all + kz_merge_topk).  Every hubness kind qualifies: the kinds
+        # that only need the reverse DISTANCES (CSLS, LocalScaling, MP normal) exchange the distances, the kinds that need
+        # the reverse INDICES in the single-GPU order (MP empiric, DSL) exchange exact ordering values + global ids too.
+        # Every shard must hold K rows (its own search returns K) and the target side K rows (the forward search).
         self.shared = (self.shared_sweep and hasattr(eng, "knn_dual") and not self.single and self.hub != "none"
-                       and (comm.world == 1 or (self.hub in ("csls", "ls") or (self.hub == "mp" and self.method == "normal")))
-                       and self.K <= min(counts) and comm.world * self.K <= k_cap)
+                       and self.K <= min(counts) and self.K <= n_t
+                       and (not multi or comm.world * self.K <= getattr(eng, "MAX_MERGE", 8192)))
         need_full_source = self.single or (self.hub != "none" and not self.shared)
         src_full = comm.all_gather_rows(src, counts) if need_full_source else None
         if self.single:
             tgt = src_full
         else:
             if bcast_target:
-                n_t, d, code = gathered[0][1], gathered[0][2], gathered[0][3]
+                d, code = gathered[0][2], gathered[0][3]
                 tgt = tgt0 if comm.rank == 0 else eng.empty((n_t, d), torch.float32 if code == 0 else torch.float64)
                 comm.broadcast(tgt, 0)  # RCCL broadcast of the replicated target over xGMI
-            else:
-                tgt = eng.to_engine(target)
             if tgt.shape[1] != src.shape[1]:
                 raise ValueError("Expected source and target to have the same number of features,"
                                  f" but got source.shape: {tuple(src.shape)} and target.shape: {tuple(tgt.shape)}")
             if tgt.dtype != src.dtype:
                 raise ValueError("source and target must have the same dtype")
-        self._keep = (src, src_full, tgt)  # the engine matrices borrow nothing, but keep inputs alive for clarity
+        self._keep = (src, src_full, tgt)  # the engine matrices borrow these tensors
         self.n_s, self.n_t = n_s, tgt.shape[0]
         self.T = eng.matrix(tgt, self.metric)
         if need_full_source:
@@ -407,27 +439,39 @@ class ShardedKiez:
             return self
         t_begin, t_count = row_slice(self.n_t, comm.rank, comm.world)
         t_counts = [row_slice(self.n_t, r, comm.world)[1] for r in range(comm.world)]
-        if self.shared and self.K <= self.n_t:
+        needs_ind = self.hub == "dsl" or (self.hub == "mp" and self.method == "empiric")
+        S_fit = self.S      # the matrix DSL's centroids gather source rows from (global ids)
+        if self.shared:
             # one sweep: larger side as the query side (fewer rows get event buffers)
             if self.n_t >= self.n_local:
                 (d_rev, i_rev), self._fwd = eng.knn_dual(self.T, self.S, self.K)
             else:
                 self._fwd, (d_rev, i_rev) = eng.knn_dual(self.S, self.T, self.K)
-            if comm.world > 1 or comm.always:
-                parts = comm.all_to_all_rows(d_rev, t_counts)                      # [world, t_count, K]
-                merged = parts.permute(1, 0, 2).reshape(t_count, comm.world * self.K).contiguous()
-                if self.hub in ("dsl",) or (self.hub == "mp" and self.method == "empiric"):
-                    # kinds that need the reverse INDICES only share the sweep with one rank (forced collectives of the
-                    # single-rank RCCL test): the indices travel too and the "merge" is the identity
-                    iparts = comm.all_to_all_rows(i_rev + self.s_begin, t_counts)
-                    merged_i = iparts.permute(1, 0, 2).reshape(t_count, comm.world * self.K).contiguous()
+            if multi:
+                W, K = comm.world, self.K
+                if needs_ind:
+                    # exact ordering values (the rounded output distances hide ties) + distances + global ids: ONE all-to-all
+                    keys = eng.pair_values(self.T, 0, self.n_t, self.S, i_rev)
+                    gids = (i_rev + self.s_begin).contiguous()
+                    pack = torch.stack([keys, d_rev, gids.view(torch.float64)], dim=1)          # [n_t, 3, K]
+                    parts = comm.all_to_all_rows(pack, t_counts)                                # [W, t_count, 3, K]
+
+                    def seg(c):
+                        return parts[:, :, c].permute(1, 0, 2).reshape(t_count, W * K).contiguous()
+                    d_t2s, i_t2s = eng.merge_topk(seg(0), seg(2).view(torch.int64), seg(1), W, K, K)
                 else:
-                    merged_i = torch.zeros(merged.shape, dtype=torch.int64, device=merged.device)
-                d_t2s, i_t2s = eng.select_topk(merged, merged_i, self.K)
+                    parts = comm.all_to_all_rows(d_rev, t_counts)                               # [W, t_count, K]
+                    merged = parts.permute(1, 0, 2).reshape(t_count, W * K).contiguous()
+                    d_t2s, i_t2s = eng.merge_topk(merged, None, None, W, K, K)                  # (ids unused by these kinds)
+                if self.hub == "dsl":
+                    # the centroids average SOURCE ROWS of all shards (dis_sim.py:96-101): the shards are gathered after all,
+                    # but only for this gather kernel -- the second sweep stays saved
+                    src_full = comm.all_gather_rows(src, counts)
+                    self._keep = self._keep + (src_full,)
+                    S_fit = eng.matrix(src_full, self.metric)
             else:
                 d_t2s, i_t2s = d_rev, i_rev
         else:
-            self.shared = False
             # reverse pass, sharded over target rows (explicit query: self is NOT stripped, base.py:37-42)
             Kr = min(self.K, n_s)
             d_t2s, i_t2s = eng.knn(self.T, t_begin, t_count, self.S, Kr, False)
@@ -446,7 +490,8 @@ class ShardedKiez:
             st["dist_t2s"] = comm.all_gather_rows(d_t2s, t_counts)
             st["ind_t2s"] = comm.all_gather_rows(i_t2s, t_counts)
         elif self.hub == "dsl":
-            t2c = eng.dsl_fit(i_t2s, self.S, self.T, t_begin)
+            # (single rank without forced collectives: d_t2s covers all targets and t_begin = 0, t_count = n_t)
+            t2c = eng.dsl_fit(i_t2s, S_fit, self.T, t_begin)
             st["t2c"] = comm.all_gather_rows(t2c, t_counts)
         return self
 

@@ -35,7 +35,7 @@ class HubnessReduction(ABC):
         if nn_algo.n_candidates == 1:
             raise ValueError("Cannot perform hubness reduction with a single candidate per query!")
         # known at construction, so say it at construction (not after a long fit): the device transforms and the final
-        # sort handle up to 128 candidates per query (INTEGRATION.md "Deviations"); NoHubnessReduction has no such limit
+        # sort take up to KZ_MAX_CANDIDATES = 4096 candidates per query (the NN backend itself stops at 4095 neighbours)
         if (self._device_native and type(self).__name__ != "NoHubnessReduction" and isinstance(nn_algo.n_candidates, (int, np.integer))
                 and nn_algo.n_candidates > N.MAX_HUBNESS_CANDIDATES):
             raise NotImplementedError(f"n_candidates={nn_algo.n_candidates}: the MI355X hubness reductions support up to "

@@ -111,5 +111,34 @@ class OracleEngine:
         d, i = O.sort_topk(dist.numpy(), ind.numpy(), k)
         return torch.from_numpy(np.ascontiguousarray(d)), torch.from_numpy(np.ascontiguousarray(i))
 
+    def pair_values(self, qm, q_begin, q_count, im, ind):
+        """Exact float64 ordering value of (query row, index row) pairs, the expression of O.knn_exact."""
+        i = ind.numpy()
+        q = qm.rows[q_begin:q_begin + q_count].astype(np.float64)
+        y = im.rows.astype(np.float64)
+        if O.canonical_metric(im.metric) == "cosine":
+            qn, yn = np.sqrt((q * q).sum(1)), np.sqrt((y * y).sum(1))
+            qn[qn == 0] = 1.0
+            yn[yn == 0] = 1.0
+            v = np.clip(1.0 - np.einsum("nd,nkd->nk", q / qn[:, None], (y / yn[:, None])[i]), 0.0, 2.0)
+        else:
+            v = np.maximum((q * q).sum(1)[:, None] - 2.0 * np.einsum("nd,nkd->nk", q, y[i]) + (y * y).sum(1)[i], 0.0)
+        return torch.from_numpy(v)
+
+    MAX_MERGE = 8192
+
+    def merge_topk(self, key, ind, dist, segs, seg_len, k):
+        """k smallest per row by (key, ind), ties by column (= segment, position): what kz_merge_topk does."""
+        kk = key.numpy()
+        ii = ind.numpy() if ind is not None else np.zeros(kk.shape, dtype=np.int64)
+        dd = dist.numpy() if dist is not None else kk
+        assert kk.shape[1] == segs * seg_len
+        for s_ in range(segs):   # the contract: every segment sorted by (key, ind)
+            a = slice(s_ * seg_len, (s_ + 1) * seg_len)
+            assert ((kk[:, a][:, 1:] > kk[:, a][:, :-1]) | ((kk[:, a][:, 1:] == kk[:, a][:, :-1]) & (ii[:, a][:, 1:] >= ii[:, a][:, :-1]))).all()
+        order = np.lexsort((ii, kk), axis=1)[:, :k]
+        return (torch.from_numpy(np.ascontiguousarray(np.take_along_axis(dd, order, axis=1))),
+                torch.from_numpy(np.ascontiguousarray(np.take_along_axis(ii, order, axis=1))))
+
     def sync(self):
         pass

@@ -1,5 +1,7 @@
-"""World-size-2 gloo tests of the multi-GPU sharding logic (kiez_amd.distributed.ShardedKiez) with the CPU engine.
-The sharded run must equal the single-process oracle pipeline on the concatenated source."""
+"""gloo tests (world size 2, 3 and 8) of the multi-GPU sharding logic (kiez_amd.distributed.ShardedKiez) with the CPU engine.
+The sharded run must equal the single-process oracle pipeline on the concatenated source -- for every hubness kind, with
+uneven shards, target row counts that do not divide, K = 50, exact ties across shards, and every route that leaves the
+shared sweep (single source, shards smaller than K, fewer targets than K, the merge capacity)."""
 import os
 import socket
 import sys
@@ -20,6 +22,7 @@ CASES = [
     ("none_single", None, {}, "euclidean", True),
     ("dsl_single", "DisSimLocal", {}, "euclidean", True),
 ]
+SEVEN = [c for c in CASES if not c[4]]
 
 
 def _free_port():
@@ -28,32 +31,79 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _scenario(name):
+    """(source, target, K, k, cases, engine attributes, expected `shared` per case name or None = by rule)."""
+    rng = np.random.RandomState(17)
+    if name == "base":          # uneven shards (203 rows), 157 targets: neither divides by 2, 3 or 8
+        return rng.rand(203, 12), rng.rand(157, 12), 7, 4, CASES, {}, None
+    if name == "k50":           # the C3 candidate count: world x K = 100 ... 400 entries per merged row
+        return rng.rand(431, 10), rng.rand(333, 10), 50, 50, SEVEN, {}, None
+    if name == "ties":          # integer data: all arithmetic exact, MANY exact distance ties across the shards
+        return (rng.randint(0, 3, (180, 4)).astype(np.float64), rng.randint(0, 3, (150, 4)).astype(np.float64), 9, 9,
+                [c for c in SEVEN if c[0] in ("none", "csls", "ls", "mp_empiric", "dsl")], {}, None)
+    if name == "few_targets":   # n_t < K <= every shard (ADVICE round 2: the shared sweep must not be chosen)
+        return rng.rand(60, 8), rng.rand(5, 8), 7, 4, [c for c in SEVEN if c[0] in ("csls", "mp_empiric", "dsl", "none")], {}, False
+    if name == "small_shards":  # K > rows of a shard: every rank must take the gathered-source route
+        return rng.rand(41, 6), rng.rand(64, 6), 7, 3, [c for c in SEVEN if c[0] in ("csls", "mp_empiric", "dsl")], {}, False
+    if name == "merge_cap_in":  # world x K == capacity of the merge: shared
+        return rng.rand(120, 6), rng.rand(90, 6), 7, 4, [c for c in SEVEN if c[0] in ("csls", "mp_empiric")], {"MAX_MERGE": 14}, True
+    if name == "merge_cap_out":  # one more: two searches
+        return rng.rand(120, 6), rng.rand(90, 6), 8, 4, [c for c in SEVEN if c[0] in ("csls", "mp_empiric")], {"MAX_MERGE": 14}, False
+    raise KeyError(name)
+
+
+def _worker(rank, world, port, scenario, q):
     try:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import warnings
+
         import torch.distributed as dist
         from kiez_amd.distributed import Comm, ShardedKiez, row_slice
         from oracle import kiez_oracle as O
         from tests.cpu_engine import OracleEngine
+        from tests.golden_util import knife_edge_rows, knife_edge_topk_ok
 
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        rng = np.random.RandomState(17)
-        source = rng.rand(203, 12)
-        target = rng.rand(157, 12)
+        source, target, K, k, cases, attrs, expect_shared = _scenario(scenario)
         b, c = row_slice(len(source), rank, world)
         results = {}
-        for name, hub, kw, metric, single in CASES:
-            sk = ShardedKiez(n_candidates=7, algorithm_kwargs={"metric": metric}, hubness=hub, hubness_kwargs=kw,
-                             engine=OracleEngine(), comm=Comm())
+        warnings.simplefilter("ignore")
+        for name, hub, kw, metric, single in cases:
+            eng = OracleEngine()
+            for a, v in attrs.items():
+                setattr(eng, a, v)
+            comm = Comm()
+            sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": metric}, hubness=hub, hubness_kwargs=kw, engine=eng, comm=comm)
             sk.fit(source[b:b + c], None if single else (target if rank == 0 else None), single_source=single)
-            d, i = sk.kneighbors(4)
-            od, oi = O.kiez_pipeline(source, None if single else target, 7, 4, metric, 2, hub, kw)
-            # the kinds that only need reverse DISTANCES share one sweep per rank and merge by all-to-all; the others search twice
-            assert getattr(sk, "shared", False) == (name in ("csls", "ls", "nicdm", "mp_normal")), (name, sk.shared)
-            results[name] = (bool(np.array_equal(i.numpy(), oi[b:b + c])),
-                             bool(np.allclose(d.numpy(), od[b:b + c], rtol=1e-9, atol=1e-9)), tuple(i.shape))
+            d, i = sk.kneighbors(k)
+            od, oi = O.kiez_pipeline(source, None if single else target, K, k, metric, 2, hub, kw)
+            want = (hub is not None and not single) if expect_shared is None else (expect_shared and hub is not None)
+            assert bool(getattr(sk, "shared", False)) == want, (name, sk.shared, want)
+            tr = comm.traffic()
+            if want and world > 1:
+                assert tr["all_to_all"]["calls"] == 1, (name, tr)     # ONE exchange, whatever the kind needs
+            elif world > 1:
+                assert "all_to_all" not in tr, (name, tr)
+            # (atol: in single-source mode a row's distance to itself is sqrt(|x|^2 - 2 x.x + |x|^2) -- 0 or ~1e-8 depending on
+            #  how BLAS blocks the CPU engine's gemm for THIS shard's shape; the HIP engine's canonical dot product gives 0)
+            got_i, got_d, ref_i, ref_d = i.numpy(), d.numpy(), oi[b:b + c], od[b:b + c]
+            keep = np.ones(len(got_i), dtype=bool)
+            if name == "mp_empiric":
+                # the fit state itself: the merged reverse lists must BE the single-process lists (order included)
+                rd, ri = O.knn_exact(target, source, K, metric)
+                assert np.array_equal(sk.state["ind_t2s"].numpy(), ri), "merged reverse indices differ from the single-process search"
+                assert np.allclose(sk.state["dist_t2s"].numpy(), rd, rtol=1e-12, atol=1e-12)
+                # rows whose candidates include the query's own id are decided by last-bit rounding in the reference
+                # (tests/golden_util.py: knife_edge_*): compared tie-tolerantly, nothing dropped
+                fi = O.knn_exact(source, target, min(K, len(target)), metric)[1]
+                keep = ~knife_edge_rows(fi)[b:b + c]
+                for r in np.flatnonzero(~keep):
+                    assert knife_edge_topk_ok(ref_d[r], ref_i[r], got_d[r], got_i[r], b + r, K, ri), (name, b + r)
+            results[name] = (bool(np.array_equal(got_i[keep], ref_i[keep])),
+                             bool(np.allclose(got_d[keep], ref_d[keep], rtol=1e-9, atol=1e-7 if single else 1e-9)), tuple(i.shape),
+                             int(oi.shape[1]))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, results, None))
@@ -61,23 +111,43 @@ def _worker(rank, world, port, q):
         q.put((rank, None, traceback.format_exc()))
 
 
-def test_sharded_pipeline_world2_gloo():
+def _run(world, scenario):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scenario, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=300) for _ in procs]
+    out = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, results, err in out:
         assert err is None, f"rank {rank} failed:\n{err}"
-        for name, (idx_ok, dist_ok, shape) in results.items():
-            assert idx_ok, f"rank {rank} case {name}: indices differ from the single-process oracle"
-            assert dist_ok, f"rank {rank} case {name}: distances differ"
-            assert shape[1] == 4
+        for name, (idx_ok, dist_ok, shape, k_ref) in results.items():
+            assert idx_ok, f"world {world} rank {rank} {scenario}/{name}: indices differ from the single-process oracle"
+            assert dist_ok, f"world {world} rank {rank} {scenario}/{name}: distances differ"
+            assert shape[1] == k_ref
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_pipeline_gloo_every_kind(world):
+    _run(world, "base")
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_pipeline_gloo_k50_all_seven_kinds_share_the_sweep(world):
+    _run(world, "k50")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pipeline_gloo_exact_ties_across_shards(world):
+    _run(world, "ties")
+
+
+@pytest.mark.parametrize("scenario,world", [("few_targets", 2), ("small_shards", 8), ("merge_cap_in", 2), ("merge_cap_out", 2)])
+def test_sharded_pipeline_gloo_routes_that_leave_the_shared_sweep(scenario, world):
+    _run(world, scenario)
 
 
 def test_row_slice_partitions_everything():
@@ -95,7 +165,7 @@ def test_row_slice_partitions_everything():
 @pytest.mark.parametrize("shared", [True, False])
 def test_single_process_pipeline_with_and_without_the_shared_sweep(shared):
     """World size 1, no process group: ShardedKiez on the CPU engine must equal the oracle pipeline whether fit() takes both
-    search directions out of one `knn_dual` call (every hubness kind qualifies with one rank) or searches twice."""
+    search directions out of one `knn_dual` call (every hubness kind qualifies) or searches twice."""
     import warnings
     from kiez_amd.distributed import Comm, ShardedKiez
     from oracle import kiez_oracle as O
