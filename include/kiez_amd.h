@@ -74,6 +74,10 @@ int kz_device_count(int* n);
 int kz_ctx_create(int device, void* stream, kz_ctx** out);
 int kz_ctx_destroy(kz_ctx* ctx);
 int kz_ctx_sync(kz_ctx* ctx);
+/* Hands the context's cached device buffers back to the driver (buffers released by kz_free / kz_matrix_destroy / the
+ * searches are kept for reuse -- up to 48 GiB -- so that a repeated fit() does not pay hipMalloc + hipFree; a process that
+ * shares the GPU with another allocator, e.g. torch's, calls this after a large search).  Waits for the stream. */
+int kz_ctx_trim(kz_ctx* ctx);
 /* Options.  "precision": 0 (default) = fp16 first pass on centred operands (16 <= d_pad <= 384), uncertified rows go
  * down the tiers (longer lists -> float32 operands -> exact float64); 2 = split-bf16 first pass; 1 = float32 operands
  * only.  The neighbour order is the float64 one either way.  "dual_stride": kz_knn_dual samples every n-th tile of a

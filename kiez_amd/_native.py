@@ -69,6 +69,7 @@ SYMBOLS = [
     ("kz_ctx_create", C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     ("kz_ctx_destroy", C.c_int, [_P]),
     ("kz_ctx_sync", C.c_int, [_P]),
+    ("kz_ctx_trim", C.c_int, [_P]),
     ("kz_ctx_set_option", C.c_int, [_P, C.c_char_p, C.c_double]),
     ("kz_malloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     ("kz_free", C.c_int, [_P, _P]),
@@ -179,6 +180,10 @@ class Context:
 
     def sync(self):
         _check(self.lib.kz_ctx_sync(self.handle), "kz_ctx_sync")
+
+    def trim(self):
+        """Release the context's cached device buffers (kz_ctx_trim)."""
+        _check(self.lib.kz_ctx_trim(self.handle), "kz_ctx_trim")
 
     # ---- device arrays -------------------------------------------------------------------------------
     def empty(self, shape, dtype) -> "DeviceArray":

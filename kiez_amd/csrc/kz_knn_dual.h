@@ -281,6 +281,7 @@ __global__ void kz_dual_sum_kernel(const unsigned long long* __restrict__ spread
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------
+static const double KZ_DUAL_MAX_BYTES = 32.0 * (double)(1ull << 30);   // transient footprint the shared sweep may claim (of 288 GB)
 static void kz_dual_fill_stats(kz_knn_stats* st, const kz_knn_stats& v) {
     if (st) *st = v;
 }
@@ -348,6 +349,20 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     const bool eligible = pays && stride >= 2 && ctx->precision == 0 && KP > 0 && n_slices >= 2 && n_slices <= 24 && a->kg == b->kg &&
                           s_rows >= (int64_t)8 * KP && b->n >= 1024 && b_tiles < (1 << 20);
     if (!eligible) return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
+    {
+        // Footprint gate: the event buffers (8 B x capacity per row of B), the log (24 B per expected group) and three permuted
+        // fp16 images live for the duration of the call and stay in the context's buffer cache afterwards (kz_ctx_trim drops
+        // it).  1M x 1M at k = 100 would ask for ~30 GB: beyond a budget -- or what the device has free -- search twice.
+        const double rk = (double)(k + 1 < KP ? k + 1 : KP);
+        const double ev_b = (double)b->n_tiles * KZ_TILE * (rk * stride + 7.0 * sqrt(rk) * stride + 64.0) * 8.0;
+        const double log_b = ((double)b->n * rk * stride * 1.5 + (double)(1 << 20)) * 24.0;
+        const double img_b = ((double)s_tiles + (double)a_tiles + (double)b_tiles) * (double)n_slices * 4096.0;
+        size_t free_b = 0, total_b = 0;
+        KZ_HIP(hipMemGetInfo(&free_b, &total_b));
+        const double avail = (double)free_b + (double)ctx->pool_bytes - 2.0 * (double)(1ull << 30);
+        if (ev_b + log_b + img_b > KZ_DUAL_MAX_BYTES || ev_b + log_b + img_b > avail)
+            return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
+    }
 
     int rc = kz_himage_ensure(a, b);
     if (rc != KZ_OK) return rc;

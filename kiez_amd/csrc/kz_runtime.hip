@@ -82,6 +82,21 @@ int kz_ctx_destroy(kz_ctx* c) {
     return KZ_OK;
 }
 
+int kz_ctx_trim(kz_ctx* c) {
+    KZ_REQUIRE(c != nullptr, "kz_ctx_trim: null context");
+    KZ_HIP(hipSetDevice(c->device));
+    KZ_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->pool_n; ++i) (void)hipFree(c->pool[i].ptr);
+    c->pool_n = 0;
+    c->pool_bytes = 0;
+    if (c->scratch) {
+        (void)hipFree(c->scratch);
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+    }
+    return KZ_OK;
+}
+
 int kz_ctx_sync(kz_ctx* c) {
     KZ_REQUIRE(c != nullptr, "kz_ctx_sync: null context");
     KZ_HIP(hipStreamSynchronize(c->stream));

@@ -196,6 +196,7 @@ class SklearnNN(NNAlgorithm):
         self._aux = None  # (array, DeviceMatrix) of the most recent query array that is not a fitted side
         self._forward = None  # (k, dist, ind): source -> target result that came out of a shared sweep (kneighbors_device_both)
         self.last_stats = None
+        self.last_stats_reverse = None   # statistics of the target -> source direction of the last shared sweep (else None)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}(n_candidates={self.n_candidates},algorithm={self.algorithm},"
@@ -260,6 +261,7 @@ class SklearnNN(NNAlgorithm):
         """Replaces SklearnNN._fit (sklearn_nearest_neighbors.py:83-94): upload + norms + MFMA tile packing."""
         self._aux = None
         self._forward = None
+        self.last_stats_reverse = None
         return self._make_matrix(data)
 
     def fit(self, source, target=None, only_fit_target: bool = False):
@@ -296,12 +298,14 @@ class SklearnNN(NNAlgorithm):
         """`kneighbors` that leaves (dist float64, ind int64) in HBM; used by the GPU hubness reductions."""
         default_query = query is None
         k, query, index, is_self_querying = self._select_direction(k, query, s_to_t)
-        if (default_query and s_to_t and self._forward is not None and self._forward[0] == k and q_begin == 0
-                and q_count is None):
-            # the forward result of the shared sweep (kneighbors_device_both): handed out once, then dropped
-            _, dist, ind = self._forward
+        if default_query and s_to_t and self._forward is not None:
+            # the forward result of the shared sweep (kneighbors_device_both): handed out once, then dropped -- also when this
+            # call asks for something else (another k, a row range): the cached [n_s, k] arrays must not stay pinned in HBM
+            fk, dist, ind = self._forward
             self._forward = None
-            return dist, ind
+            if fk == k and q_begin == 0 and q_count is None:
+                return dist, ind
+            del dist, ind
         qm = self._matrix_for(query)
         dist, ind, stats = N.knn(self.ctx, qm, index, k, exclude_self=is_self_querying, q_begin=q_begin, q_count=q_count)
         self.last_stats = stats
@@ -322,6 +326,7 @@ class SklearnNN(NNAlgorithm):
                 return None
             dist, ind, stats = N.knn(self.ctx, self.source_index, self.source_index, k + 1, exclude_self=False)
             self.last_stats = stats
+            self.last_stats_reverse = None   # (one search serves both views: there is no second set of statistics)
             rev, fwd = N.split_self(self.ctx, dist, ind)
             self._forward = (k,) + fwd
             return rev
