@@ -2,6 +2,7 @@
 """Benchmark of the hot path: source queries/s over fit + kneighbors (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c1|c2|c3|c3s|c4s|c1g] [--no-others]
+    python bench.py --openea EMB_DIR KG_DIR [--steps K] [--warmup W]      (real entity-alignment embeddings)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -189,7 +190,7 @@ def sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, ro
     return out
 
 
-def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, min_seconds=0.0):
+def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True):
     """Generate the data, run warm-up + timed steps, return (summary dict, host arrays) on every rank."""
     from kiez_amd.distributed import ShardedKiez
     n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[name]
@@ -270,7 +271,7 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
     peak = PEAK_F32_MFMA_TFLOPS if tier == 0 else PEAK_BF16_MFMA_TFLOPS
     summary = {
         "name": name, "desc": desc, "n_s": n_s, "n_t": n_t, "d": d, "metric": metric, "K": K, "k": k, "hub": hub, "hub_kw": hub_kw,
-        "elapsed": elapsed, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": n_s * world * steps / elapsed,
+        "elapsed": elapsed, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "value": n_s * world * steps / elapsed,
         "tier": tier, "peak": peak, "achieved": achieved, "n_launch": n_launch, "kernel_s": kernel_s, "flops": flops,
         "fallback_rows": int(sum(st["n_fallback_rows"] for _, _, st in knn_log)),
         "escalated_rows": int(sum(st.get("n_escalated_rows", 0) for _, _, st in knn_log)),
@@ -278,6 +279,7 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
         "finalize_avg_ms": sum(st["finalize_ms"] for _, _, st in knn_log) / max(n_launch, 1),
         "fallback_total_ms": sum(st["fallback_ms"] for _, _, st in knn_log),
         "collective_ms_per_step": comm.timers_ms(steps),
+        "collective_traffic_per_step": comm.traffic(steps),   # per kind: calls and payload bytes this rank handed over
         # shared sweeps (kz_knn_dual): how many of the launches served both directions, and what the reverse direction cost
         # on top of the sweep (sample sweep + scatter + select, its finalize, rows searched again)
         "shared_sweeps": len(rev_log),
@@ -291,16 +293,109 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
     return summary, (source_h, target_h), res
 
 
+def pmc_traffic(workload, s):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
+    tools/pmc_derive.py).  The counters are per KERNEL DISPATCH; a launch here (one kz_knn / kz_knn_dual call) sweeps its query
+    rows in chunks of 524288, one dispatch each -- scaled by the ratio of the two durations so that `traffic` refers to the
+    same launch as `achieved`.  (None, None) where no PMC pass was taken."""
+    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    if not pmc.exists() or not s["n_launch"]:
+        return None, None
+    try:
+        rec = json.loads(pmc.read_text()).get(workload + "_" + TIER_NAME[s["tier"]], {})
+        per_dispatch = rec.get("hbm_bytes_per_launch")
+        if per_dispatch is None:
+            return None, None
+        avg_launch_ms = s["kernel_s"] / s["n_launch"] * 1e3
+        dispatches = max(1, round(avg_launch_ms / rec["avg_ms_under_pmc"]))
+        return per_dispatch * dispatches, dispatches
+    except Exception:
+        return None, None
+
+
+def roofline_of(workload, s):
+    """The `roofline` object of one workload's dominant kernel (contract in the task statement)."""
+    tier = s["tier"]
+    traffic, dispatches = pmc_traffic(workload, s)
+    return {"bound": "mfma", "kernel": TIER_KERNEL[tier], "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s",
+            "frac": s["achieved"] / s["peak"], "traffic": traffic, "traffic_kernel_dispatches_per_launch": dispatches,
+            "launches": s["n_launch"], "avg_launch_ms": s["kernel_s"] / max(s["n_launch"], 1) * 1e3,
+            "algorithmic_flop_per_launch": s["flops"] / max(s["n_launch"], 1), "mfma_products_per_mac": TIER_PRODUCTS[tier],
+            "shared_sweeps": s["shared_sweeps"]}
+
+
 def short(summary):
     """Compact per-workload record for `other_workloads`."""
     s = summary
-    return {"workload": s["desc"], "ms_per_step": s["ms_per_step"], "value": s["value"], "unit": "queries/s",
+    return {"workload": s["desc"], "roofline": roofline_of(s["name"], s), "warmup": s["warmup"], "ms_per_step": s["ms_per_step"], "value": s["value"], "unit": "queries/s",
             "main_kernel_avg_ms": s["kernel_s"] / max(s["n_launch"], 1) * 1e3, "dtype": TIER_NAME[s["tier"]],
             "roofline_frac": s["achieved"] / s["peak"], "achieved_tflops": s["achieved"],
             "finalize_avg_ms": s["finalize_avg_ms"], "certification_fallback_rows": s["fallback_rows"],
             "escalated_rows": s["escalated_rows"], "fallback_total_ms": s["fallback_total_ms"],
             "max_err_over_eps": s["max_err_ratio"], "steps": s["steps"], "shared_sweeps": s["shared_sweeps"],
             "reverse_extra_ms_per_step": s["reverse_extra_ms_per_step"], "check": s["check"]}
+
+
+def run_openea(args):
+    """Real entity-alignment embeddings: OpenEA directory -> kiez_amd.io.from_openea -> Kiez.fit/kneighbors
+    on the GPU -> kiez_amd.evaluate.hits on the device.  A step = fit + kneighbors with both matrices resident in HBM (torch
+    tensors, zero-copy) and the result left in HBM; hits@k is evaluated once, outside the timed region."""
+    import warnings
+    from kiez_amd import Kiez
+    from kiez_amd.evaluate import hits
+    from kiez_amd.io import from_openea
+    emb_dir, kg_dir = args.openea
+    t0 = time.perf_counter()
+    emb1, emb2, _, _, links = from_openea(emb_dir, kg_dir)
+    t_load = time.perf_counter() - t0
+    K = k = args.openea_k
+    hub = None if args.openea_hubness.lower() in ("none", "no") else args.openea_hubness
+    dev = torch.device("cuda", 0)
+    s_dev, t_dev = torch.from_numpy(np.ascontiguousarray(emb1)).to(dev), torch.from_numpy(np.ascontiguousarray(emb2)).to(dev)
+    torch.cuda.synchronize()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kz = Kiez(n_candidates=K, algorithm="SklearnNN", algorithm_kwargs={"metric": args.openea_metric}, hubness=hub)
+
+        def step():
+            kz.fit(s_dev, t_dev)
+            return kz.kneighbors_device(k)
+        res = None
+        for _ in range(args.warmup):
+            res = step()
+        kz.algorithm.ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        kz.algorithm.ctx.sync()
+        elapsed = time.perf_counter() - t0
+        dist_dev, ind_dev = res
+        t0 = time.perf_counter()
+        h = hits(ind_dev, links, k=[1, 5, 10])
+        t_hits = time.perf_counter() - t0
+    n_s, d = emb1.shape
+    line = {"metric": "source queries/sec (fit+kneighbors) + recall@k vs reference, 1/2/4/8 GPU", "value": n_s * args.steps / elapsed,
+            "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": TIER_NAME.get((kz.algorithm.last_stats or {}).get("first_pass", 2), "f16"),
+            "data": f"OpenEA layout: {emb_dir} + {kg_dir}",
+            "config": {"workload": "OpenEA dataset", "n_source": int(n_s), "n_target": int(emb2.shape[0]), "d": int(d), "metric": args.openea_metric,
+                       "n_candidates": K, "k": k, "hubness": hub, "gold_links": len(links), "inputs": f"{emb1.dtype}, resident in HBM"},
+            "hits": {str(kk): v for kk, v in h.items()}, "load_seconds": t_load, "hits_ms": t_hits * 1e3}
+    if not args.no_check:
+        # the neighbour matrix against the oracle pipeline on a row sample + hits@k by the reference's formula on the full result
+        from oracle import kiez_oracle as O
+        ind = ind_dev.numpy()
+        rows = np.arange(0, n_s, max(1, n_s // 256))[:256]
+        chk = {"rows": int(len(rows)), "hits_reference_formula":
+               {kk: sum(1 for i in range(n_s) if i in links and links[i] in ind[i][:kk]) / len(links) for kk in (1, 5, 10)}}
+        if n_s * emb2.shape[0] <= 4e8:   # the oracle pipeline needs the full reverse pass: small datasets only
+            metric_c = O.canonical_metric(args.openea_metric)
+            s64 = emb1.astype(np.float64) if metric_c == "cosine" else emb1
+            t64 = emb2.astype(np.float64) if metric_c == "cosine" else emb2
+            od, oi = O.kiez_pipeline(s64, t64, K, k, metric_c, 2, hub, {})
+            chk["index_rows_identical"] = int((ind[rows] == oi[rows]).all(axis=1).sum())
+        line["check"] = chk
+    return line
 
 
 def main():
@@ -317,6 +412,13 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the oracle sample check")
     ap.add_argument("--no-others", action="store_true", help="do not run the other BASELINE configurations after the main workload")
     ap.add_argument("--opt", action="append", default=[], help="context option name=value (tuning experiments)")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each secondary workload (other_workloads)")
+    ap.add_argument("--other-warmup", type=int, default=2)
+    ap.add_argument("--openea", nargs=2, metavar=("EMB_DIR", "KG_DIR"), default=None,
+                    help="benchmark an OpenEA-layout dataset (kiez/io/data_loading.py:75-99) instead of a synthetic workload")
+    ap.add_argument("--openea-hubness", default="CSLS")
+    ap.add_argument("--openea-metric", default="euclidean")
+    ap.add_argument("--openea-k", type=int, default=10)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -333,6 +435,14 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.openea is not None:
+        if world != 1:
+            raise SystemExit("--openea runs on one GPU")
+        line = run_openea(args)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        return
+
     from kiez_amd.distributed import Comm, HipEngine
     eng = HipEngine(local_rank)
     comm = Comm(time_collectives=True)
@@ -348,23 +458,7 @@ def main():
     if rank == 0:
         s = main_s
         tier = s["tier"]
-        # HBM-side bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools/pmc_derive.py).  The
-        # counters are per KERNEL DISPATCH; a launch here (one kz_knn / kz_knn_dual call) sweeps its query rows in chunks of
-        # 524288, one dispatch each -- scaled by the ratio of the two durations so that `traffic` refers to the same launch
-        # as `achieved`
-        traffic = None
-        traffic_dispatches = None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists():
-            try:
-                rec = json.loads(pmc.read_text()).get(args.workload + "_" + TIER_NAME[tier], {})
-                per_dispatch = rec.get("hbm_bytes_per_launch")
-                if per_dispatch is not None and s["n_launch"]:
-                    avg_launch_ms = s["kernel_s"] / s["n_launch"] * 1e3
-                    traffic_dispatches = max(1, round(avg_launch_ms / rec["avg_ms_under_pmc"]))
-                    traffic = per_dispatch * traffic_dispatches
-            except Exception:
-                traffic = None
+        traffic, traffic_dispatches = pmc_traffic(args.workload, s)
         line = {
             "metric": "source queries/sec (fit+kneighbors) + recall@k vs reference, 1/2/4/8 GPU",  # BASELINE.json's metric
             "recall_at_k": (s["check"] or {}).get("recall_at_k"),   # against the oracle on a row sample (None if not checked)
@@ -383,7 +477,9 @@ def main():
                        "n_candidates": K, "k": k, "hubness": hub, "hubness_kwargs": hub_kw,
                        "inputs": "float32 rng.rand, resident in HBM; results left in HBM",
                        "parallelism": f"source row-sharded x{world}, target replicated"
-                                      + (" (RCCL broadcast; per-shard reverse lists RCCL all-to-all; fit state RCCL all-gather)" if world > 1 else " (single rank: no collective runs)")},
+                                      + (" (per step: 1 RCCL broadcast of the target, 1 all-to-all of the per-shard reverse lists, 1 all-gather"
+                                         " of the per-target fit state; measured times and bytes: collective_ms_per_step, collective_traffic_per_step)"
+                                         if world > 1 else " (single rank: no collective runs)")},
             "roofline": {"bound": "mfma", "kernel": TIER_KERNEL[tier],
                          "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s",
                          "frac": s["achieved"] / s["peak"], "traffic": traffic, "traffic_kernel_dispatches_per_launch": traffic_dispatches,
@@ -407,6 +503,7 @@ def main():
                                           "note": "max |approximate key - exact key| / eps over all re-ranked candidates; the certification needs < 1"},
             "other_kernels_ms": {"finalize_avg": s["finalize_avg_ms"], "fallback_total": s["fallback_total_ms"]},
             "collective_ms_per_step": s["collective_ms_per_step"],
+            "collective_traffic_per_step": s["collective_traffic_per_step"],
         }
         if s["check"] is not None:
             line["check"] = s["check"]
@@ -434,7 +531,11 @@ def main():
             if name == args.workload:
                 continue
             try:
-                osum, _, _ = run_workload(name, eng, comm, dist, rank, world, 3, 1, check=not args.no_check)
+                # (each workload starts from an empty buffer cache: what the previous one left behind is of the wrong sizes and
+                #  only turns this one's first releases into hipFree calls)
+                eng.ctx.trim()
+                osum, _, _ = run_workload(name, eng, comm, dist, rank, world, args.other_steps, args.other_warmup,
+                                          check=not args.no_check)
                 others[name] = short(osum)
             except Exception as e:  # pragma: no cover  (a secondary workload must never cost the main line)
                 others[name] = {"error": f"{type(e).__name__}: {e}"}

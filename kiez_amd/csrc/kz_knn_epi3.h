@@ -51,10 +51,17 @@ template <>
 struct KzListRef<2> {
     kz_lds_f32* k;
     int* ib;
-    unsigned off;
+    // this query's first list entry = off_u + (lane & 31) * stride: both parts wave-uniform (scalar registers), the lane
+    // part re-made where a row is stored (merges are rare; a per-lane offset held for the whole sweep is a VGPR the
+    // three-workgroups-per-CU builds do not have)
+    unsigned off_u, stride;
     static constexpr int KSTRIDE = 128, ISTRIDE = 1;
     __device__ __forceinline__ kz_lds_f32* kp() const { return k; }
-    __device__ __forceinline__ int* ip() const { return ib + off; }
+    __device__ __forceinline__ int* ip() const {
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return ib + off_u + (l & 31u) * stride;
+    }
 };
 
 // Per-lane candidate state (one lane = one (query, lane-half) pair) ...

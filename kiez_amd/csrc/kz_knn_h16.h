@@ -25,15 +25,26 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 // (Every tile must contain a slice barrier -- the bias double buffer and the merge flags rely on it -- so the barrier
 // period RING / 2 never exceeds the slice count; NSR >= 2 is required by the host.)
 // DUAL: the dual-pass build (kz_knn_epi3.h "Dual pass"): + 1.5 KiB (thresholds of three tiles, the queries' offsets).
+#ifndef KZ_H_DEEP_RING
+#define KZ_H_DEEP_RING 0   // A/B switch (tools/ab_build.sh deep -DKZ_H_DEEP_RING=1).  Measured same-box on 250k x 1M x 200: ordinary kernel 90.8 against 90.7 ms, shared sweep 97.5 against 94.8 ms -- the wait in front of the barrier is not a latency a deeper ring hides
+#endif
 template <int KP, int WPS, int NSR, bool DUAL = false>
 struct KzHCfg {
+    // DEEP: three workgroups per CU with a single fragment set (more than 8 slices, K' = 16: the north-star shape).  The wave
+    // reads a slice right before its MFMAs, so a ring of 2 periods leaves the DMA engine ONE period (2 slices ~ 700 cycles)
+    // between issue and use -- less than an L2 round trip under load (stamp build, 250k x 1M x 200: 1914 of 8775 cycles per
+    // wave-tile waiting at s_waitcnt vmcnt(0), another 769 at the barrier behind it).  Six slots = three periods: the slices
+    // issued at one barrier are needed two barriers later (s_waitcnt vmcnt(2)); the 8 KiB come from the list rows, which move
+    // to the output arrays (hybrid lists: the keys stay in LDS).
+    static constexpr bool DEEP = KZ_H_DEEP_RING && WPS == 3 && KP == 16 && NSR > 8;
     static constexpr bool LDS_LIST = KP <= 32;
-    static constexpr bool LISTS_FIT = WPS == 2 || KP == 16;           // K' = 32 lists do not fit beside the ring at 3 per CU
+    static constexpr bool LISTS_FIT = (WPS == 2 || KP == 16) && !DEEP;   // K' = 32 lists do not fit beside the ring at 3 per CU
     // where the lists live (KzListRef, kz_knn_epi3.h): 1 = LDS, 2 = keys in LDS + rows in the output arrays, 0 = output arrays.
     // The hybrid needs K' x 512 B: K' = 64 at two per CU (with a 4-slot ring), K' = 32 at three per CU (with a smaller pool).
-    static constexpr int LMODE = (LDS_LIST && LISTS_FIT) ? 1 : (((KP == 64 && WPS == 2) || (KP == 32 && WPS == 3)) ? 2 : 0);
+    static constexpr int LMODE = (LDS_LIST && LISTS_FIT) ? 1 : (((KP == 64 && WPS == 2) || (KP == 32 && WPS == 3) || DEEP) ? 2 : 0);
     static constexpr bool IN_LDS = LMODE == 1;
-    static constexpr int RING = (WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8;
+    static constexpr int RING = DEEP ? 6 : ((WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8);
+    static constexpr int PERIOD = DEEP ? 2 : RING / 2;                 // slices per barrier; RING / PERIOD periods in the ring
     // (three per CU: the workgroup must stay within 42 LDS granules of 1280 B -- 52.5 KiB with the lists of K' = 16 or the
     //  keys of K' = 32; the dual-pass build pays for its 1.5 KiB of thresholds and query offsets with 16 pool entries)
     static constexpr int CAP = WPS == 3 ? (KP <= 32 ? (DUAL ? 176 : 192) : 256) : (LMODE == 2 && RING == 8 ? (DUAL ? 140 : 156) : 256);     // event-pool entries per wave (24 B each)
@@ -50,7 +61,9 @@ struct KzHCfg {
 template <int KP, int NSR, int WPS, bool DUAL = false>
 __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p) {
     using Cfg = KzHCfg<KP, WPS, NSR, DUAL>;
-    constexpr int R = Cfg::RING, P = R / 2, CAP = Cfg::CAP;
+    constexpr int R = Cfg::RING, P = Cfg::PERIOD, CAP = Cfg::CAP;
+    constexpr int DEPTH = R / P;          // periods in the ring: 2 (a slot is refilled one period before it is read) or 3
+    constexpr bool POW2 = (R & (R - 1)) == 0;
     constexpr int IN_LDS = Cfg::LMODE;   // list storage mode (KzListRef)
     // at three waves per SIMD (168 VGPRs) the first fragments of the next tile are NOT fetched across the epilogue: the 16
     // registers they would occupy there are what keeps the stationary query tile out of scratch memory.  Exception: a tile
@@ -62,6 +75,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     constexpr bool ONE_SET = WPS == 3 && NSR > 8;
     constexpr bool RECOMP = DUAL && ONE_SET;   // kz_merge_pool3: block minima re-read per merge instead of carried
     constexpr int LAG = ONE_SET ? 1 : 2;   // slices between a barrier and the oldest slot it may hand to the DMA engine
+    static_assert(DEPTH == 2 || (DEPTH == 3 && P == 2), "the counted wait below is written for two slices per barrier");
+    static_assert(POW2 || ONE_SET, "a ring that is not a power of two tracks the read slot of the CURRENT slice only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);                       // R slots x 1024 floats
     float* bbuf = reinterpret_cast<float*>(smem + Cfg::BIAS_OFF);       // 2 x 128 bias floats
@@ -85,7 +100,13 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     } else if constexpr (IN_LDS == 2) {
         st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF) + 32 * (tid >> 6) + j;
         st.list.ib = p.out_idx;
-        st.list.off = (unsigned)out_list_offset();
+        {
+            // (uniform: the offsets of this wave's query 0 and of its query 1 -- lists of consecutive queries are equally spaced)
+            const int64_t row0 = (int64_t)qt * KZ_TILE + 32 * wave;
+            const int64_t o0 = kz_list_contig_off(row0, p.lay, KP, s);
+            st.list.off_u = (unsigned)o0;
+            st.list.stride = (unsigned)(kz_list_contig_off(row0 + 1, p.lay, KP, s) - o0);
+        }
     } else {
         // (uniform bases + a 32-bit per-lane element offset: no 64-bit per-lane pointers to keep alive; a launch's lists stay
         //  far below 2^32 elements: <= 524288 rows x 64 ranges x K')
@@ -134,7 +155,10 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         float* dst = ybuf + dma_slot * 1024 + wave * 256;  // wave-uniform LDS base (floats)
         kz_glds16_s(dma_src, (unsigned)lane_off, dst);
         dma_src += 4096;
-        dma_slot = (dma_slot + 1) & (R - 1);
+        if constexpr (POW2)
+            dma_slot = (dma_slot + 1) & (R - 1);
+        else
+            dma_slot = dma_slot + 1 == R ? 0 : dma_slot + 1;
     };
 #pragma unroll
     for (int i = 0; i < R; ++i) dma_next();
@@ -158,8 +182,9 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     const float* fbase = ybuf + (h * KZ_TILE + j) * 4;  // this lane's fragment inside a slot: plane h, row j (+ 32 mt)
     // two static fragment sets selected by the parity of the global slice counter (no register copies)
     kz_f16x8 f0[4], f1[4];
+    int rslot = 0;   // (ring that is not a power of two) slot of the current slice g: g mod R, kept incrementally (uniform)
     auto fetch_frags = [&](kz_f16x8 (&f)[4], const int gi) {
-        const float* fb = fbase + (gi & (R - 1)) * 1024;
+        const float* fb = fbase + (POW2 ? (gi & (R - 1)) : rslot) * 1024;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) f[mt] = *reinterpret_cast<const kz_f16x8*>(fb + 128 * mt);
     };
@@ -167,6 +192,26 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     int g = 0;
     int th_cur = 0;   // dual pass: threshold buffer of the current tile (uniform)
     f32x16 acc[4];
+#if defined(KZ_EXP) && KZ_EXP == 4
+    // diagnostic build (timing only, results WRONG): the bare MFMA + LDS-fragment loop with v_mfma_f32_16x16x32_f16 --
+    // 32 queries x 128 rows per wave = 2 x 8 accumulators of 16x16, one step = 32 k (two slices), ceil(NSR / 2) steps
+    constexpr int NS2 = (NSR + 1) / 2;
+    f32x4v c16[2][8];
+    kz_f16x8 qf2[NS2][2];
+    {
+        const int c = lane >> 4;
+#pragma unroll
+        for (int u2 = 0; u2 < NS2; ++u2)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg)
+                qf2[u2][qg] = *reinterpret_cast<const kz_f16x8*>(p.qpack + ((int64_t)(p.qt0 + qt) * NSR + min(2 * u2 + (c >> 1), NSR - 1)) * 1024 +
+                                                                  ((c & 1) * KZ_TILE + 32 * (tid >> 6) + 16 * qg + (lane & 15)) * 4);
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) c16[qg][rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+#endif
 #ifdef KZ_STAMP
     unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0, c_col = 0, n_col = 0;
 #endif
@@ -215,6 +260,32 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
                 // for the previous tile; the buffer written here was last read two tiles ago, with a slice barrier in between.
                 kz_glds4_s(p.theta + ((int64_t)min(tile + 1, p.n_ytiles - 1) - 1) * KZ_TILE, off4, tbuf + (th_cur == 2 ? 0 : th_cur + 1) * 64);
         }
+#if defined(KZ_EXP) && KZ_EXP == 4
+        {
+            const int c = lane >> 4;
+#pragma unroll
+            for (int u2 = 0; u2 < NS2; ++u2) {
+                const float* fb = ybuf + ((2 * u2 + (c >> 1)) & (R - 1)) * 1024 + ((c & 1) * KZ_TILE + (lane & 15)) * 4;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    kz_f16x8 fr[4];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) fr[rt] = *reinterpret_cast<const kz_f16x8*>(fb + 64 * (4 * hf + rt));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                        for (int qg = 0; qg < 2; ++qg)
+                            c16[qg][4 * hf + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[rt], qf2[u2][qg], c16[qg][4 * hf + rt], 0, 0, 0);
+                }
+            }
+            g += NSR;
+            asm volatile("" ::"v"(c16[0][0]), "v"(c16[0][1]), "v"(c16[0][2]), "v"(c16[0][3]), "v"(c16[0][4]), "v"(c16[0][5]), "v"(c16[0][6]), "v"(c16[0][7]));
+            asm volatile("" ::"v"(c16[1][0]), "v"(c16[1][1]), "v"(c16[1][2]), "v"(c16[1][3]), "v"(c16[1][4]), "v"(c16[1][5]), "v"(c16[1][6]), "v"(c16[1][7]));
+            return;
+        }
+#endif
         constexpr bool carry_in = !ONE_SET && (CARRY || (P0 == 1 && (NSR & 1)));
         constexpr bool carry_out = !ONE_SET && (CARRY || (((P0 + NSR) & 1) != 0));
         if (!carry_in && !ONE_SET) {
@@ -256,7 +327,10 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
                 {
                     __builtin_amdgcn_sched_barrier(0);
                     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if constexpr (DEPTH == 3)
+                        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     const unsigned long long w1 = __builtin_amdgcn_s_memtime();
                     asm volatile("s_barrier" ::: "memory");
                     c_dma += w1 - w0;
@@ -264,12 +338,19 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #else
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // (DEPTH 3: the slices of the NEXT period were issued two barriers ago; the P issued at the previous barrier are
+                //  this wave's youngest LDS-DMAs and may stay in flight.  Anything issued later -- the bias / threshold copy of
+                //  this tile, list stores of a merge -- only makes the counted wait stricter: completion is in issue order)
+                if constexpr (DEPTH == 3)
+                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 #pragma unroll
-                for (int i = 0; i < P; ++i) dma_next();   // slices g+P+LAG .. g+2P+LAG-1, in order
+                for (int i = 0; i < P; ++i) dma_next();   // slices g+(DEPTH-1)P+LAG .. g+DEPTH P+LAG-1, in order
             }
             ++g;
+            if constexpr (!POW2) rslot = rslot + 1 == R ? 0 : rslot + 1;
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef KZ_STAMP

@@ -13,6 +13,20 @@ from . import _native as N
 _NO_GOLD = np.iinfo(np.int64).min
 
 
+def _gold_vector(gold: Dict[Any, Any], n_rows: int) -> np.ndarray:
+    """gold target per source row (or _NO_GOLD): one vectorised scatter instead of a Python loop over all rows."""
+    out = np.full(n_rows, _NO_GOLD, dtype=np.int64)
+    # (array input: the reference tests `i in gold and gold[i] in nn_ind[i][:k]` with integer row numbers i, so only
+    #  integer keys with integer targets can ever hit; everything still counts in the denominator len(gold))
+    pairs = [(k_, v) for k_, v in gold.items() if isinstance(k_, (int, np.integer)) and isinstance(v, (int, np.integer))]
+    if pairs:
+        keys = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
+        vals = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))
+        ok = (keys >= 0) & (keys < n_rows)
+        out[keys[ok]] = vals[ok]
+    return out
+
+
 def hits(nn_ind: Union[np.ndarray, list, Dict[Any, List], "N.DeviceArray"], gold: Dict[Any, Any], k=None,
          ctx: Optional[N.Context] = None) -> Dict[int, float]:
     """Relative hits@k for every k in `k` (default [1, 5, 10]); same semantics as the reference."""
@@ -36,12 +50,12 @@ def hits(nn_ind: Union[np.ndarray, list, Dict[Any, List], "N.DeviceArray"], gold
     elif isinstance(nn_ind, N.DeviceArray):
         ind_host = None
         n_rows = nn_ind.shape[0]
-        gold_arr = np.array([int(gold[i]) if i in gold else _NO_GOLD for i in range(n_rows)], dtype=np.int64)
+        gold_arr = _gold_vector(gold, n_rows)
     else:
         ind_host = np.ascontiguousarray(np.asarray(nn_ind), dtype=np.int64)
         if ind_host.ndim != 2:
             raise ValueError("nn_ind must be a 2D neighbour index matrix")
-        gold_arr = np.array([int(gold[i]) if i in gold else _NO_GOLD for i in range(ind_host.shape[0])], dtype=np.int64)
+        gold_arr = _gold_vector(gold, ind_host.shape[0])
     if isinstance(nn_ind, N.DeviceArray):
         ctx = nn_ind.ctx
         ind_dev = nn_ind
