@@ -844,22 +844,22 @@ static int kz_launch_cand(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
     } while (0)
 
 // fp16 and split-bf16 kernels: instantiated per list length in kz_knn_h_kp*.hip / kz_knn_bf_kp*.hip (parallel compilation)
-int kz_h_occupancy_kp16(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
-int kz_h_occupancy_kp32(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
-int kz_h_occupancy_kp64(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
-int kz_h_occupancy_kp128(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
-int kz_h_launch_kp16(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
-int kz_h_launch_kp32(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
-int kz_h_launch_kp64(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
-int kz_h_launch_kp128(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
-int kz_hd_occupancy_kp16(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
-int kz_hd_occupancy_kp32(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
-int kz_hd_occupancy_kp64(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
-int kz_hd_occupancy_kp128(int n_slices, int* blocks_per_cu, int wps, int lds_pad);
-int kz_hd_launch_kp16(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
-int kz_hd_launch_kp32(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
-int kz_hd_launch_kp64(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
-int kz_hd_launch_kp128(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps);
+int kz_h_occupancy_kp16(int n_slices, int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad);
+int kz_h_occupancy_kp32(int n_slices, int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad);
+int kz_h_occupancy_kp64(int n_slices, int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad);
+int kz_h_occupancy_kp128(int n_slices, int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad);
+int kz_h_launch_kp16(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
+int kz_h_launch_kp32(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
+int kz_h_launch_kp64(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
+int kz_h_launch_kp128(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
+int kz_hd_occupancy_kp16(int n_slices, int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad);
+int kz_hd_occupancy_kp32(int n_slices, int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad);
+int kz_hd_occupancy_kp64(int n_slices, int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad);
+int kz_hd_occupancy_kp128(int n_slices, int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad);
+int kz_hd_launch_kp16(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
+int kz_hd_launch_kp32(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
+int kz_hd_launch_kp64(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
+int kz_hd_launch_kp128(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
 int kz_bf_occupancy_kp16(int n_slices_bf, int* blocks_per_cu, int lds_pad);
 int kz_bf_occupancy_kp32(int n_slices_bf, int* blocks_per_cu, int lds_pad);
 int kz_bf_occupancy_kp64(int n_slices_bf, int* blocks_per_cu, int lds_pad);
@@ -1010,8 +1010,12 @@ struct KzPass {
 
 // Plans the rounds (kz_plan_rounds), carves the context's scratch block and uploads the work table.  tier decides the
 // list layout (fp16: K' contiguous entries per list; float32 kernels: two lane-half lists per query and range).
+// tpw = query tiles per workgroup (wide fp16 builds: 2 or 3, kz_knn_h16.h "WIDE"): the plan is made for UNITS of tpw consecutive
+// query tiles -- one work item = one unit x one index range, w4.x = its first tile -- and converted back to tiles for the list
+// layout (a region ends on a unit boundary, the last one at the last tile).
 static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, int max_pieces, int KP, int tier, int64_t fail_rows,
-                           KzPass* out) {
+                           KzPass* out, int tpw = 1) {
+    const int n_units = (n_qtiles + tpw - 1) / tpw;
     auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
     auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
     KzListLayout lay;
@@ -1021,17 +1025,19 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
     size_t list_elems = 0;
     {
         int n_reg = 0;
-        kz_plan_rounds(n_qtiles, n_ytiles, slots, max_pieces, ctx->force_splits, ctx->min_splits, &n_reg, reg_nq, reg_s);
-        int q0 = 0;
+        kz_plan_rounds(n_units, n_ytiles, slots, max_pieces, ctx->force_splits, ctx->min_splits, &n_reg, reg_nq, reg_s);
+        int q0 = 0;   // (units)
         for (int r = 0; r < n_reg; ++r) {
             reg_q0[r] = q0;
             reg_w0[r] = W;
-            lay.qt_end[r] = q0 + reg_nq[r];
+            const int t0 = q0 * tpw;
+            const int t1 = (q0 + reg_nq[r]) * tpw < n_qtiles ? (q0 + reg_nq[r]) * tpw : n_qtiles;
+            lay.qt_end[r] = t1;
             lay.pieces[r] = split_cnt(reg_s[r]);
             lay.base[r] = (long long)list_elems;
             // entries per (query, index range): K' in the contiguous layout, 2 K' in the interleaved one (two lane-half
             // columns per list block, also where only one is used)
-            list_elems += (size_t)reg_nq[r] * KZ_TILE * (size_t)(lay.pieces[r] * (tier == KZ_TIER_H ? 1 : 2) * KP);
+            list_elems += (size_t)(t1 - t0) * KZ_TILE * (size_t)(lay.pieces[r] * (tier == KZ_TIER_H ? 1 : 2) * KP);
             W += reg_nq[r] * lay.pieces[r];
             q0 += reg_nq[r];
         }
@@ -1088,7 +1094,7 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
                     const int sidx = within / gsz, qt = q0 + gq0 + within % gsz;
                     ++next;
                     int4 w4;
-                    w4.x = qt;
+                    w4.x = qt * tpw;   // first query tile of the unit
                     w4.y = sidx * len;
                     w4.z = (sidx + 1) * len < n_ytiles ? (sidx + 1) * len : n_ytiles;
                     w4.w = sidx;
@@ -1243,14 +1249,15 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (rc != KZ_OK) return rc;
     }
     int slots_cache[3] = {0, 0, 0};
+    int tpw_h = 1;   // query tiles per workgroup of the fp16 kernel this call runs (wide builds: 2 or 3)
     auto slots_for = [&](int t, int* out) -> int {
         if (slots_cache[t] == 0) {
             int blocks_per_cu = 1;
             int rc0;
             if (t == KZ_TIER_H && dual)
-                KZ_DISPATCH_KP(rc0, kz_hd_occupancy, (n_slices, &blocks_per_cu, ctx->h_wps, ctx->lds_pad));
+                KZ_DISPATCH_KP(rc0, kz_hd_occupancy, (n_slices, &blocks_per_cu, &tpw_h, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
             else if (t == KZ_TIER_H)
-                KZ_DISPATCH_KP(rc0, kz_h_occupancy, (n_slices, &blocks_per_cu, ctx->h_wps, ctx->lds_pad));
+                KZ_DISPATCH_KP(rc0, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw_h, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
             else if (t == KZ_TIER_BF)
                 KZ_DISPATCH_KP(rc0, kz_bf_occupancy, (n_slices, &blocks_per_cu, ctx->lds_pad));
             else
@@ -1291,7 +1298,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         const int n_qtiles = qt1 - qt0 + 1;
         // ---- schedule: which workgroup sweeps which (query tile, index-tile range): kz_prepare_pass above --------------
         KzPass ps;
-        int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1), KP, tier, cq_count, &ps);
+        int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1), KP, tier, cq_count, &ps,
+                                 tier == KZ_TIER_H ? tpw_h : 1);
         if (rc != KZ_OK) return rc;
         const KzListLayout& lay = ps.lay;
         const int W = ps.W;
@@ -1315,6 +1323,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         cp.work = d_work;
         cp.qt0 = qt0;
         cp.n_ytiles = n_ytiles;
+        cp.n_qtiles = n_qtiles;
         cp.lay = lay;
         cp.kg = index->kg;
         cp.out_key = out_key;
@@ -1339,9 +1348,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             cp.log_meta = dual->log_meta;
             cp.log_cnt = dual->log_cnt;
             cp.log_cap = dual->log_cap;
-            KZ_DISPATCH_KP(rc, kz_hd_launch, (n_slices, ctx, cp, W, ctx->h_wps));
+            KZ_DISPATCH_KP(rc, kz_hd_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
         } else if (tier == KZ_TIER_H)
-            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps));
+            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
         else if (tier == KZ_TIER_BF)
             KZ_DISPATCH_KP(rc, kz_bf_launch, (n_slices, ctx, cp, W));
         else

@@ -104,6 +104,7 @@ struct KnnCandParams {
     const int4* work;     // one descriptor per workgroup: {query tile (local), first index tile, end index tile, list slot}
     int qt0;              // first query tile of this launch (global tile index into qpack)
     int n_ytiles;         // index tiles
+    int n_qtiles;         // query tiles of this launch (wide workgroups: the last one may reach past them)
     KzListLayout lay;     // candidate-list layout of this launch (kz_list_base)
     int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
     float* out_key;       // per region: [query rows][pieces][2 lane halves][KP]

@@ -487,14 +487,14 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
 
     // ---- sample sweep: B x sample(A) with the ordinary kernel, lists of at most 256 entries per row -----------------------
     {
-        int blocks_per_cu = 1;
-        KZ_DISPATCH_KP(rc, kz_h_occupancy, (n_slices, &blocks_per_cu, ctx->h_wps, ctx->lds_pad));
+        int blocks_per_cu = 1, tpw = 1;
+        KZ_DISPATCH_KP(rc, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
         if (rc != KZ_OK) {
             release();
             return rc;
         }
         KzPass ps;
-        KZ_DUAL_RC(kz_prepare_pass(ctx, (int)b_tiles, (int)s_tiles, blocks_per_cu * ctx->n_cus, 256 / KP, KP, KZ_TIER_H, 0, &ps));
+        KZ_DUAL_RC(kz_prepare_pass(ctx, (int)b_tiles, (int)s_tiles, blocks_per_cu * ctx->n_cus, 256 / KP, KP, KZ_TIER_H, 0, &ps, tpw));
         KnnCandParams cp;
         memset(&cp, 0, sizeof(cp));
         cp.qpack = (const float*)ib->packed;
@@ -503,11 +503,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         cp.work = ps.d_work;
         cp.qt0 = 0;
         cp.n_ytiles = (int)s_tiles;
+        cp.n_qtiles = (int)b_tiles;
         cp.lay = ps.lay;
         cp.kg = b->kg;
         cp.out_key = ps.out_key;
         cp.out_idx = ps.out_idx;
-        KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W, ctx->h_wps));
+        KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W, ctx->h_wps, ctx->h_wide));
         if (rc != KZ_OK) {
             release();
             return rc;

@@ -28,8 +28,23 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 #ifndef KZ_H_DEEP_RING
 #define KZ_H_DEEP_RING 0   // A/B switch (tools/ab_build.sh deep -DKZ_H_DEEP_RING=1).  Measured same-box on 250k x 1M x 200: ordinary kernel 90.8 against 90.7 ms, shared sweep 97.5 against 94.8 ms -- the wait in front of the barrier is not a latency a deeper ring hides
 #endif
-template <int KP, int WPS, int NSR, bool DUAL = false>
+#ifndef KZ_WIDE_PERIOD
+#define KZ_WIDE_PERIOD 2
+#endif
+#ifndef KZ_WIDE_LAG
+#define KZ_WIDE_LAG 0   // staggered groups (see LAGP): measured with 2 slices per barrier, 250k x 1M x 200: 106 ms against 87 ms narrow
+#endif
+// WIDE: ONE workgroup of 4 x WPS waves per CU instead of WPS workgroups of 4 waves: its WPS query tiles share one ring, so
+// every index slice is copied into the CU's LDS once instead of WPS times.  Measured on the scan-less kernel (tools/ablate.sh
+// 1 5 6 7; 250k x 1M x 200, same box): bare loop 71.2 ms, + slice barriers 71.2 -> 72.9, + the LDS-DMA traffic 83.4 -- and
+// with a third of the DMA volume 75.3: the copies, not the barriers, are what the ring costs, in proportion to their volume.
+// What the wide build gives back: all waves of the CU now run in lockstep -- they reach every barrier and every tile epilogue
+// together, so nothing covers them (narrow: the three workgroups of a CU are in different phases).  Net, same-box: ordinary
+// kernel 250k x 1M x 200 -3 % ... +0.5 %, x 300 -1 % ... -4 %, shared sweep +1 % ... +10 %; 100k x 100k x 128 +3 %; K' = 64 +8 %.
+// Off by default (context option "h_wide" = 1 turns it on for K' = 16 with more than 8 slices); parity-tested both ways.
+template <int KP, int WPS, int NSR, bool DUAL = false, bool WIDE = false>
 struct KzHCfg {
+    static constexpr int TPW = WIDE ? WPS : 1;                         // query tiles (of 128 rows) per workgroup
     // DEEP: three workgroups per CU with a single fragment set (more than 8 slices, K' = 16: the north-star shape).  The wave
     // reads a slice right before its MFMAs, so a ring of 2 periods leaves the DMA engine ONE period (2 slices ~ 700 cycles)
     // between issue and use -- less than an L2 round trip under load (stamp build, 250k x 1M x 200: 1914 of 8775 cycles per
@@ -43,26 +58,38 @@ struct KzHCfg {
     // The hybrid needs K' x 512 B: K' = 64 at two per CU (with a 4-slot ring), K' = 32 at three per CU (with a smaller pool).
     static constexpr int LMODE = (LDS_LIST && LISTS_FIT) ? 1 : (((KP == 64 && WPS == 2) || (KP == 32 && WPS == 3) || DEEP) ? 2 : 0);
     static constexpr bool IN_LDS = LMODE == 1;
-    static constexpr int RING = DEEP ? 6 : ((WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8);
-    static constexpr int PERIOD = DEEP ? 2 : RING / 2;                 // slices per barrier; RING / PERIOD periods in the ring
+    // (WIDE: the ring is shared, so the LDS of the other rings is free -- eight slots, which is what lets the groups of a wide
+    //  workgroup run staggered, see LAGP)
+    // WIDE: eight slots, one barrier per four slices -- a barrier of a wide workgroup stops every wave of the CU (same-box,
+    // 250k x 1M x 200, ordinary kernel: 4 slots / 2 slices per barrier 91.8 ms, 8 / 4: 85.0 ms, 12 / 6: 90.0 ms, narrow 88-89.6)
+    static constexpr int RING = DEEP ? 6 : (WIDE ? 8 : ((WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8));
+    // WIDE: the groups of four waves are STAGGERED -- group b runs LAGP periods behind group b - 1 -- so that their tile
+    // epilogues fall at different times (a wide workgroup is all the CU has: waves that reach the epilogue together leave the
+    // matrix pipe empty).  A slot is refilled only when the LAST group has read it: (TPW - 1) LAGP + 2 periods must fit the ring.
+    static constexpr int PERIOD = DEEP ? 2 : ((WIDE && KZ_WIDE_LAG > 0) ? KZ_WIDE_PERIOD : RING / 2);   // slices per barrier
+    static constexpr int LAGP = WIDE ? KZ_WIDE_LAG : 0;                // periods between consecutive groups of a wide workgroup
+    static_assert(!WIDE || ((TPW - 1) * LAGP + 2) * PERIOD <= RING, "staggered groups overrun the ring");
     // (three per CU: the workgroup must stay within 42 LDS granules of 1280 B -- 52.5 KiB with the lists of K' = 16 or the
     //  keys of K' = 32; the dual-pass build pays for its 1.5 KiB of thresholds and query offsets with 16 pool entries)
     static constexpr int CAP = WPS == 3 ? (KP <= 32 ? (DUAL ? 176 : 192) : 256) : (LMODE == 2 && RING == 8 ? (DUAL ? 140 : 156) : 256);     // event-pool entries per wave (24 B each)
     static constexpr int RING_BYTES = RING * 4096;
     static constexpr int BIAS_OFF = RING_BYTES;                        // 2 x 128 floats
     static constexpr int SYNC_OFF = BIAS_OFF + 1024;                   // 4 merge flags (+ padding)
-    static constexpr int THETA_OFF = SYNC_OFF + 256;                   // dual pass: 3 x 64 threshold floats + 128 query offsets
-    static constexpr int POOLK_OFF = THETA_OFF + (DUAL ? 1536 : 0);    // [4 waves][CAP] x 4 floats
-    static constexpr int POOLM_OFF = POOLK_OFF + 4 * CAP * 16;         // [4 waves][CAP] x {code, next}
-    static constexpr int LIST_OFF = POOLM_OFF + 4 * CAP * 8;           // keys [KP][128], then rows [KP][128]
-    static constexpr int LDS_BYTES = LIST_OFF + (LMODE == 1 ? KP * 128 * 8 : (LMODE == 2 ? KP * 128 * 4 : 0));
+    static constexpr int THETA_OFF = SYNC_OFF + 256;                   // dual pass: 3 x 64 threshold floats + 128 query offsets per tile
+    static constexpr int POOLK_OFF = THETA_OFF + (DUAL ? 768 + 768 * TPW : 0);    // [4 TPW waves][CAP] x 4 floats
+    static constexpr int POOLM_OFF = POOLK_OFF + 4 * TPW * CAP * 16;   // [4 TPW waves][CAP] x {code, next}
+    static constexpr int LIST_OFF = POOLM_OFF + 4 * TPW * CAP * 8;     // per tile: keys [KP][128], then rows [KP][128]
+    static constexpr int LIST_BLOCK = LMODE == 1 ? KP * 128 * 8 : (LMODE == 2 ? KP * 128 * 4 : 0);
+    static constexpr int LDS_BYTES = LIST_OFF + TPW * LIST_BLOCK;
+    static_assert(LDS_BYTES <= 160 * 1024, "workgroup exceeds the CU's LDS");
 };
 
-template <int KP, int NSR, int WPS, bool DUAL = false>
-__global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p) {
-    using Cfg = KzHCfg<KP, WPS, NSR, DUAL>;
+template <int KP, int NSR, int WPS, bool DUAL = false, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn_cand_h_kernel(KnnCandParams p) {
+    using Cfg = KzHCfg<KP, WPS, NSR, DUAL, WIDE>;
+    constexpr int TPW = Cfg::TPW;
     constexpr int R = Cfg::RING, P = Cfg::PERIOD, CAP = Cfg::CAP;
-    constexpr int DEPTH = R / P;          // periods in the ring: 2 (a slot is refilled one period before it is read) or 3
+    constexpr int DEPTH = Cfg::DEEP ? 3 : 2;   // 2: a slice is issued one period before it is read (whatever the ring holds besides); 3: two
     constexpr bool POW2 = (R & (R - 1)) == 0;
     constexpr int IN_LDS = Cfg::LMODE;   // list storage mode (KzListRef)
     // at three waves per SIMD (168 VGPRs) the first fragments of the next tile are NOT fetched across the epilogue: the 16
@@ -75,7 +102,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     constexpr bool ONE_SET = WPS == 3 && NSR > 8;
     constexpr bool RECOMP = DUAL && ONE_SET;   // kz_merge_pool3: block minima re-read per merge instead of carried
     constexpr int LAG = ONE_SET ? 1 : 2;   // slices between a barrier and the oldest slot it may hand to the DMA engine
-    static_assert(DEPTH == 2 || (DEPTH == 3 && P == 2), "the counted wait below is written for two slices per barrier");
+    static_assert(!Cfg::DEEP || P == 2, "the counted wait below is written for two slices per barrier");
     static_assert(POW2 || ONE_SET, "a ring that is not a power of two tracks the read slot of the CURRENT slice only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);                       // R slots x 1024 floats
@@ -88,21 +115,29 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     const int j = lane & 31;
     const int h = lane >> 5;
     const int4 wd = p.work[blockIdx.x];
-    const int qt = wd.x, t_begin = wd.y, t_end = wd.z, s = wd.w;
+    const int t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
+    // WIDE: waves 4 b .. 4 b + 3 take query tile wd.x + b; a workgroup at the end of the launch may reach past its last
+    // tile: those waves sweep along (barriers, and nothing else, need them) on the last valid tile's rows with every
+    // threshold at +inf -- no event, no list traffic, no output
+    const int wq = WIDE ? (wave & 3) : wave;            // wave within its query tile (uniform)
+    const int wq_v = WIDE ? ((tid >> 6) & 3) : (tid >> 6);
+    const int tb = WIDE ? (wave >> 2) : 0;              // tile within the workgroup (uniform)
+    const bool valid = !WIDE || wd.x + tb < p.n_qtiles;
+    const int qt = WIDE ? (valid ? wd.x + tb : p.n_qtiles - 1) : wd.x;
 
     // this query's list in the output arrays (ONE list per query and index range, K' contiguous entries)
-    auto out_list_offset = [&]() { return kz_list_contig_off((int64_t)qt * KZ_TILE + 32 * (tid >> 6) + j, p.lay, KP, s); };
+    auto out_list_offset = [&]() { return kz_list_contig_off((int64_t)qt * KZ_TILE + 32 * wq_v + j, p.lay, KP, s); };
     KzCandState3<IN_LDS> st;
     if constexpr (IN_LDS == 1) {
-        st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF) + 32 * (tid >> 6) + j;
+        st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF + tb * Cfg::LIST_BLOCK) + 32 * wq_v + j;
         st.list.i_off = KP * 128;
     } else if constexpr (IN_LDS == 2) {
-        st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF) + 32 * (tid >> 6) + j;
+        st.list.k = (kz_lds_f32*)(smem + Cfg::LIST_OFF + tb * Cfg::LIST_BLOCK) + 32 * wq_v + j;
         st.list.ib = p.out_idx;
         {
             // (uniform: the offsets of this wave's query 0 and of its query 1 -- lists of consecutive queries are equally spaced)
-            const int64_t row0 = (int64_t)qt * KZ_TILE + 32 * wave;
+            const int64_t row0 = (int64_t)qt * KZ_TILE + 32 * wq;
             const int64_t o0 = kz_list_contig_off(row0, p.lay, KP, s);
             st.list.off_u = (unsigned)o0;
             st.list.stride = (unsigned)(kz_list_contig_off(row0 + 1, p.lay, KP, s) - o0);
@@ -117,7 +152,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     KzWavePool pool;
     pool.keys = (__attribute__((address_space(3))) f32x4e*)(smem + Cfg::POOLK_OFF) + wave * CAP;
     pool.meta = (__attribute__((address_space(3))) i32x2e*)(smem + Cfg::POOLM_OFF) + wave * CAP;
-    if (h == 0) {  // the list belongs to the query: lane-half 0 owns it (kz_merge_logs3)
+    if (h == 0 && valid) {  // the list belongs to the query: lane-half 0 owns it (kz_merge_logs3)
 #pragma unroll 4
         for (int e = 0; e < KP; ++e) {
             st.list.kp()[e * KzListRef<IN_LDS>::KSTRIDE] = -INFINITY;
@@ -127,7 +162,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     if (total <= 0) {
         if constexpr (IN_LDS != 0) {
             const int64_t listoff = out_list_offset();
-            if (h == 0)
+            if (h == 0 && valid)
                 for (int e = 0; e < KP; ++e) {
                     p.out_key[listoff + e] = -INFINITY;
                     if constexpr (IN_LDS == 1) p.out_idx[listoff + e] = -1;   // (hybrid: the rows were initialised in place above)
@@ -135,7 +170,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         }
         return;
     }
-    st.tau = -INFINITY;
+    st.tau = valid ? -INFINITY : INFINITY;
     KzBlockMin3<KP> bmin;
     bmin.init();
     st.head = -1;
@@ -149,31 +184,35 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
     // order, and the ring runs up to R + P slices past the end of the sweep -- into the next tiles of the image or into
     // the padding kz_himage_build allocates behind it (those slots are never read).
     const char* dma_src = reinterpret_cast<const char*>(p.ypack) + ((int64_t)t_begin * NSR) * 4096;   // uniform
-    const int lane_off = tid * 16;
     int dma_slot = 0;   // uniform: slot of the next slice to issue
+    int dma_turn = 0;   // WIDE: the group of four waves that copies the next slice (the groups take turns)
+    const int lane_off = (WIDE ? (tid & 255) : tid) * 16;
     auto dma_next = [&]() {
-        float* dst = ybuf + dma_slot * 1024 + wave * 256;  // wave-uniform LDS base (floats)
-        kz_glds16_s(dma_src, (unsigned)lane_off, dst);
+        float* dst = ybuf + dma_slot * 1024 + wq * 256;  // wave-uniform LDS base (floats)
+        if (!WIDE || tb == dma_turn) kz_glds16_s(dma_src, (unsigned)lane_off, dst);
+        if constexpr (WIDE) dma_turn = dma_turn + 1 == TPW ? 0 : dma_turn + 1;
         dma_src += 4096;
         if constexpr (POW2)
             dma_slot = (dma_slot + 1) & (R - 1);
         else
             dma_slot = dma_slot + 1 == R ? 0 : dma_slot + 1;
     };
+    // (DEPTH periods ahead of the first group's reads -- the whole ring unless it also holds the slices the staggered groups
+    //  of a wide workgroup have yet to read)
 #pragma unroll
-    for (int i = 0; i < R; ++i) dma_next();
+    for (int i = 0; i < DEPTH * P; ++i) dma_next();
     bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
     KzDualRef du;
     if constexpr (DUAL) {
         if (tid < 64) tbuf[tid] = p.theta[(int64_t)t_begin * KZ_TILE + tid];
-        du.qrow0 = (p.qt0 + qt) * KZ_TILE + 32 * wave;
+        du.qrow0 = (p.qt0 + qt) * KZ_TILE + 32 * wq;
         // this query's own offset: read back from LDS in every epilogue (a register held for the whole sweep was spilled at
         // three workgroups per CU, and reloaded behind a wait for the DMA ring)
-        if (h == 0) tbuf[192 + 32 * (tid >> 6) + j] = p.qnbias[du.qrow0 + j];
+        if (h == 0) tbuf[192 + 32 * (tid >> 6) + j] = valid ? p.qnbias[du.qrow0 + j] : INFINITY;
     }
     if (tid < 4) msync[tid] = 0;
     // stationary query fragments: lane (j, h) holds k = 16 u + 8 h + 0..7 of query row 32 wave + j
-    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * NSR) * 1024 + (h * KZ_TILE + 32 * (tid >> 6) + j) * 4;
+    const float* qbase = p.qpack + ((int64_t)(p.qt0 + qt) * NSR) * 1024 + (h * KZ_TILE + 32 * wq_v + j) * 4;
     kz_f16x8 qf[NSR];
 #pragma unroll
     for (int u = 0; u < NSR; ++u) qf[u] = *reinterpret_cast<const kz_f16x8*>(qbase + u * 1024);
@@ -321,7 +360,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
 #else
             // (ONE_SET: nothing is prefetched, a wave at the barrier has read the slices <= g only: the barrier sits one
             //  slice later in the period -- (g + 1) % P == 0 -- and hands out the slots of slices g-P+1 .. g.)
-            if ((ONE_SET ? odd : !odd) && (P == 2 || ((g + LAG) & (P - 1)) == 0)) {
+            // (a ring that is not a power of two -- ONE_SET only -- counts with rslot = g mod R, R = 2 P: (g + 1) % P == 0)
+            if (POW2 ? ((ONE_SET ? odd : !odd) && (P == 2 || ((g + LAG) & (P - 1)) == 0)) : (rslot == P - 1 || rslot == R - 1)) {
 #endif
 #ifdef KZ_STAMP
                 {
@@ -341,13 +381,22 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
                 // (DEPTH 3: the slices of the NEXT period were issued two barriers ago; the P issued at the previous barrier are
                 //  this wave's youngest LDS-DMAs and may stay in flight.  Anything issued later -- the bias / threshold copy of
                 //  this tile, list stores of a merge -- only makes the counted wait stricter: completion is in issue order)
+#if defined(KZ_EXP) && KZ_EXP == 6
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // diagnostic build: DMA ring without the slice barrier (races; timing only)
+#else
                 if constexpr (DEPTH == 3)
                     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
+#endif
+#if defined(KZ_EXP) && KZ_EXP == 7   // (7: diagnostic build that refills the ring in one period out of three -- a third of the DMA volume; stale data, timing only)
+                if ((g >> 1) % 3 == 0)
+#endif
+#if !(defined(KZ_EXP) && KZ_EXP == 5)   // (5: diagnostic build with the slice barrier but no DMA behind the prologue -- stale data; timing only)
 #pragma unroll
                 for (int i = 0; i < P; ++i) dma_next();   // slices g+(DEPTH-1)P+LAG .. g+DEPTH P+LAG-1, in order
+#endif
             }
             ++g;
             if constexpr (!POW2) rslot = rslot + 1 == R ? 0 : rslot + 1;
@@ -364,7 +413,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
-#elif defined(KZ_EXP) && (KZ_EXP == 1 || KZ_EXP == 2)
+#elif defined(KZ_EXP) && (KZ_EXP == 1 || KZ_EXP == 2 || KZ_EXP == 5 || KZ_EXP == 6 || KZ_EXP == 7)
         // diagnostic build (tools/ablate.sh, never shipped): no candidate scan at all -- the accumulators are only kept alive
         asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
 #else
@@ -377,6 +426,15 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
 #endif
     };
 
+    // an empty period: the barrier of a period in which this group reads nothing (every wave of the workgroup executes the
+    // same sequence of barriers and DMA issues; a staggered group starts late and the leading groups wait at the end)
+    auto empty_period = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < P; ++i) dma_next();
+    };
+    if constexpr (WIDE && Cfg::LAGP > 0)
+        for (int i = 0; i < tb * Cfg::LAGP; ++i) empty_period();
     int tile = t_begin;
     for (;;) {
         run_tile(tile, std::integral_constant<int, 0>{});
@@ -384,13 +442,15 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_h_kernel(KnnCandParams p
         run_tile(tile, std::integral_constant<int, (NSR & 1)>{});
         if (++tile >= t_end) break;
     }
+    if constexpr (WIDE && Cfg::LAGP > 0)
+        for (int i = 0; i < (TPW - 1 - tb) * Cfg::LAGP; ++i) empty_period();
     if constexpr (IN_LDS != 0) {
         // the sweep is over: what lived in LDS goes to the output arrays in the layout kz_knn_finalize_kernel reads
         const int64_t listoff = out_list_offset();
         // (lane number re-made here: the `h == 0` mask of the prologue, kept for this one use, cost a VGPR as SGPR spill space)
         int lane_now;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_now));
-        if (lane_now < 32) {
+        if (lane_now < 32 && valid) {
 #pragma unroll 4
             for (int e = 0; e < KP; ++e) {
                 p.out_key[listoff + e] = st.list.kp()[e * 128];

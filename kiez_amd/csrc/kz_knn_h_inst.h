@@ -25,35 +25,60 @@
 constexpr int KZ_H_WPS3_MAX = 8;        // d <= 128: every list length
 constexpr int KZ_H_WPS3_MAX_KP16 = 13;  // d <= 208: K' = 16 only
 
+// wide != 0: the wide build (kz_knn_h16.h "WIDE": one workgroup of 4 x WPS waves per CU, WPS query tiles on one ring);
+// *tpw = query tiles per workgroup of the kernel returned.
+// The wide builds pay where the sweep is long and the epilogue light (K' = 16, more than 8 slices; measured same-box, ms narrow
+// -> wide: 250k x 1M x 200: 88.0 -> 85.0, x 300: 124.5 -> 119.3; 100k x 100k x 128: 2.86 -> 2.95; 500k x 500k x 200, K' = 64:
+// 103 -> 111: every wave of the CU reaches the tile epilogue at the same time); elsewhere the narrow builds run.
 template <int KP, int NSR>
-static const void* kz_h_kernel(int wps, int* lds) {
+static const void* kz_h_kernel(int wps, int wide_opt, int* lds, int* tpw) {
     constexpr bool three = NSR <= KZ_H_WPS3_MAX || (KP == 16 && NSR <= KZ_H_WPS3_MAX_KP16);
+    constexpr bool WIDE_OK = KP == 16 && NSR > 8;
+    const int wide = WIDE_OK ? wide_opt : 0;
     if (three && wps != 2) {
+        constexpr int N3 = three ? NSR : 2;
+        if constexpr (WIDE_OK) {
+            if (wide) {
+                *lds = KzHCfg<KP, 3, N3, KZ_H_DUALV, true>::LDS_BYTES;
+                *tpw = 3;
+                return (const void*)kz_knn_cand_h_kernel<KP, N3, 3, KZ_H_DUALV, true>;
+            }
+        }
         *lds = KzHCfg<KP, 3, NSR, KZ_H_DUALV>::LDS_BYTES;
-        return (const void*)kz_knn_cand_h_kernel<KP, (three ? NSR : 2), 3, KZ_H_DUALV>;
+        *tpw = 1;
+        return (const void*)kz_knn_cand_h_kernel<KP, N3, 3, KZ_H_DUALV>;
+    }
+    if constexpr (WIDE_OK) {
+        if (wide) {
+            *lds = KzHCfg<KP, 2, NSR, KZ_H_DUALV, true>::LDS_BYTES;
+            *tpw = 2;
+            return (const void*)kz_knn_cand_h_kernel<KP, NSR, 2, KZ_H_DUALV, true>;
+        }
     }
     *lds = KzHCfg<KP, 2, NSR, KZ_H_DUALV>::LDS_BYTES;
+    *tpw = 1;
     return (const void*)kz_knn_cand_h_kernel<KP, NSR, 2, KZ_H_DUALV>;
 }
 
+// *blocks_per_cu = workgroups of the kernel resident per CU, *tpw = query tiles each of them takes
 template <int KP, int NSR>
-static int kz_h_occupancy(int* blocks_per_cu, int wps, int lds_pad) {
+static int kz_h_occupancy(int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad) {
     int lds = 0;
-    const void* kern = kz_h_kernel<KP, NSR>(wps, &lds);
+    const void* kern = kz_h_kernel<KP, NSR>(wps, wide, &lds, tpw);
     KZ_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds + lds_pad));
     int nb = 0;
-    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds + lds_pad));
+    KZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256 * *tpw, lds + lds_pad));
     *blocks_per_cu = nb < 1 ? 1 : nb;
     return KZ_OK;
 }
 
 template <int KP, int NSR>
-static int kz_launch_h(kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps) {
-    int lds = 0;
-    const void* kern = kz_h_kernel<KP, NSR>(wps, &lds);
+static int kz_launch_h(kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide) {
+    int lds = 0, tpw = 1;
+    const void* kern = kz_h_kernel<KP, NSR>(wps, wide, &lds, &tpw);
     KnnCandParams pc = p;
     void* args[] = {&pc};
-    KZ_HIP(hipLaunchKernel(kern, dim3(n_blocks), dim3(256), args, (size_t)(lds + ctx->lds_pad), ctx->stream));
+    KZ_HIP(hipLaunchKernel(kern, dim3(n_blocks), dim3(256 * tpw), args, (size_t)(lds + ctx->lds_pad), ctx->stream));
     return KZ_OK;
 }
 
@@ -86,14 +111,14 @@ static int kz_launch_h(kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wp
         }                                                 \
     } while (0)
 
-int KZ_H_NAME(occupancy)(int n_slices, int* blocks_per_cu, int wps, int lds_pad) {
+int KZ_H_NAME(occupancy)(int n_slices, int* blocks_per_cu, int* tpw, int wps, int wide, int lds_pad) {
     int rc;
-    KZ_DISPATCH_H_NSR(rc, kz_h_occupancy, (blocks_per_cu, wps, lds_pad), KZ_H_KP);
+    KZ_DISPATCH_H_NSR(rc, kz_h_occupancy, (blocks_per_cu, tpw, wps, wide, lds_pad), KZ_H_KP);
     return rc;
 }
 
-int KZ_H_NAME(launch)(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps) {
+int KZ_H_NAME(launch)(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide) {
     int rc;
-    KZ_DISPATCH_H_NSR(rc, kz_launch_h, (ctx, p, n_blocks, wps), KZ_H_KP);
+    KZ_DISPATCH_H_NSR(rc, kz_launch_h, (ctx, p, n_blocks, wps, wide), KZ_H_KP);
     return rc;
 }

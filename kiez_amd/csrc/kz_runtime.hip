@@ -43,6 +43,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->eps_scale = 1.0;
     c->force_splits = 0;
     c->h_wps = 0;
+    c->h_wide = 0;
     c->min_splits = 1;
     c->dual_stride = 1;
     c->dual_deal = 1;
@@ -111,6 +112,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "force_splits") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
         c->force_splits = (int)value;
+    } else if (strcmp(name, "h_wide") == 0) {
+        KZ_REQUIRE(value == 0 || value == 1, "h_wide must be 0 or 1");
+        c->h_wide = (int)value;
     } else if (strcmp(name, "h_wps") == 0) {
         KZ_REQUIRE(value == 0 || value == 2 || value == 3, "h_wps must be 0 (automatic), 2 or 3");
         c->h_wps = (int)value;

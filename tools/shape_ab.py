@@ -6,8 +6,9 @@ import numpy as np
 from kiez_amd import _native as N
 n_q, n_i, d, k = (int(x) for x in sys.argv[1:5])
 ctx = N.Context.get()
-if len(sys.argv) > 5:
-    ctx.set_option("h_wps", float(sys.argv[5]))
+for o in sys.argv[5:]:      # context options name=value (a bare number: h_wps)
+    name, _, val = o.partition("=")
+    ctx.set_option(name if val else "h_wps", float(val or name))
 rng = np.random.RandomState(0)
 q = rng.rand(n_q, d).astype(np.float32)
 y = rng.rand(n_i, d).astype(np.float32)
