@@ -17,7 +17,8 @@ struct kz_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
-    hipEvent_t ev[8];
+    hipEvent_t ev[12];   // [0..7] work on `stream`, [8..11] the reverse direction of kz_knn_dual on `stream2`
+    hipStream_t stream2; // second stream: kz_knn_dual runs the reverse direction's event chain beside the forward direction's finalize
     double eps_scale;
     int force_splits;
     int h_wps;        // tuning knob: 2 = run the fp16 kernel's two-workgroups-per-CU build also where three would fit
@@ -27,6 +28,7 @@ struct kz_ctx {
     int precision;    // 0: fp16 first pass where eligible (default), 2: split-bf16 first pass, 1: float32 operands only
     int dual_stride;  // kz_knn_dual: every dual_stride-th tile of the query side is in the threshold sample (0: no dual pass, 1: automatic)
     int dual_deal;    // tuning knob: 1 (default) = the dual pass deals the query rows into load-balanced tiles, 0 = natural order
+    int dual_overlap; // 1 (default): kz_knn_dual runs the reverse direction's chain on the second stream beside the forward finalize; 0: behind it
     int dual_force;   // test knob: run the dual pass also where it does not pay (few query rows)
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)

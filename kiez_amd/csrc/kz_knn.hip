@@ -1126,6 +1126,12 @@ struct KzDualPass {
     long long log_cap;
     int broken;                    // set by kz_knn_impl when a chunk did not run the dual build (tier change): events incomplete
     double main_ms;
+    // called by kz_knn_impl right behind the launch of the LAST chunk's sweep (the event log is complete once that kernel has
+    // run): kz_knn_dual enqueues the reverse direction's chain on the context's second stream there, so that it runs beside the
+    // forward direction's finalize kernel, read-back and re-search instead of behind them
+    int (*post_sweep)(void* user);
+    void* post_user;
+    int post_called;
 };
 static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q_count, kz_matrix* index, int k,
                        int exclude_self, const int64_t* d_self_ids, int precision_override, int kp_min, double* d_dist,
@@ -1358,6 +1364,11 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (rc != KZ_OK) return rc;
         if (dual && tier != KZ_TIER_H) dual->broken = 1;   // this chunk's pairs were not scanned for events
         KZ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        if (dual && dual->post_sweep && !dual->broken && c0 + cq_count >= q_count) {
+            dual->post_called = 1;
+            rc = dual->post_sweep(dual->post_user);
+            if (rc != KZ_OK) return rc;
+        }
 
         KnnFinParams fp;
         memset(&fp, 0, sizeof(fp));

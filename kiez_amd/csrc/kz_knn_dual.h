@@ -554,8 +554,108 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     dp.log_meta = log_meta;
     dp.log_cnt = d_cnt;
     dp.log_cap = log_cap;
+    // ---- the reverse direction's chain: events -> lists -> ordinary finalize with B as the query side.  Enqueued on the
+    // context's SECOND stream from inside kz_knn_impl, right behind the sweep (KzDualPass::post_sweep): it shares no buffer
+    // with what the first stream does meanwhile (finalize of A's lists, fail-counter read-back, re-search of uncertified rows)
+    int* fail_count_b = ctx->d_counters + 12;   // {fail counter, -, error-ratio bits x 2}: a set of its own beside the forward direction's
+    struct RevCtx {
+        kz_ctx* ctx; kz_matrix *a, *b; const kz_himage *ia, *ib;
+        void *log_keys, *log_meta; unsigned long long* d_cnt; long long log_cap;
+        float *theta_s, *qnb, *p_bias, *col_key, *floor_; int *row_map, *ev_cnt, *perm, *col_idx, *fail_list, *fail_count_b;
+        uint2* ev; int ev_cap, KP, k; int64_t b_tiles; double* d_dist_ba; int64_t* d_ind_ba;
+    } rv = {ctx, a, b, ia, ib, log_keys, log_meta, d_cnt, log_cap, theta_s, qnb, p_bias, col_key, floor_, row_map, ev_cnt, perm,
+            col_idx, fail_list, fail_count_b, ev, ev_cap, KP, k, b_tiles, d_dist_ba, d_ind_ba};
+    auto enqueue_reverse = [](void* user) -> int {
+        RevCtx& r = *(RevCtx*)user;
+        kz_ctx* ctx = r.ctx;
+        hipStream_t first = ctx->stream;
+        // (the sweep was recorded as ev[1] of the first stream by kz_knn_impl just now)
+        KZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev[1], 0));
+        ctx->stream = ctx->stream2;   // every launch helper below enqueues on ctx->stream
+        auto body = [&]() -> int {
+            KZ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
+            hipLaunchKernelGGL(kz_dual_scatter_kernel, dim3(ctx->n_cus * 8), dim3(256), 0, ctx->stream, (const f32x4e*)r.log_keys,
+                               (const i32x2e*)r.log_meta, r.d_cnt, r.log_cap, r.theta_s, r.qnb, r.p_bias, r.row_map, r.ev_cnt, r.ev, r.ev_cap);
+            const size_t sel_lds = (size_t)4 * 2 * r.ev_cap * 4;
+            if (sel_lds > 65536)
+                KZ_HIP(hipFuncSetAttribute((const void*)kz_dual_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+            hipLaunchKernelGGL(kz_dual_select_kernel, dim3((unsigned)((r.b->n + 3) / 4)), dim3(256), sel_lds, ctx->stream, r.ev_cnt, r.ev, r.ev_cap,
+                               r.b->n, r.perm, r.KP, r.col_key, r.col_idx, r.floor_, r.d_cnt + 16);
+            hipLaunchKernelGGL(kz_dual_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, r.d_cnt + 16, r.d_cnt + 1);
+            KZ_HIP(hipGetLastError());
+            KZ_HIP(hipEventRecord(ctx->ev[9], ctx->stream));
+            KzListLayout lay;
+            memset(&lay, 0, sizeof(lay));
+            lay.n_regions = 1;
+            lay.qt_end[0] = (int)r.b_tiles;
+            lay.pieces[0] = 1;
+            lay.halves = 1;
+            lay.contig = 1;
+            KZ_HIP(hipMemsetAsync(r.fail_count_b, 0, 4 * sizeof(int), ctx->stream));
+            KnnFinParams fp;
+            memset(&fp, 0, sizeof(fp));
+            fp.in_key = r.col_key;
+            fp.in_idx = r.col_idx;
+            fp.lay = lay;
+            fp.KP = r.KP;
+            fp.list_row0 = 0;
+            fp.q_begin = 0;
+            fp.q_count = r.b->n;
+            fp.qraw = r.b->raw;
+            fp.yraw = r.a->raw;
+            fp.qsqn = r.b->sqn;
+            fp.ysqn = r.a->sqn;
+            fp.n_i = r.a->n;
+            fp.d = (int)r.a->d;
+            fp.metric = r.a->metric;
+            fp.k = r.k;
+            fp.ystats = r.a->d_stats;
+            fp.tier_h = 1;
+            fp.eps_mult = ctx->eps_scale;
+            fp.gamma_acc = 2.0 * (double)(r.a->kg * 4 + 16) * 5.9604644775390625e-08;
+            fp.q_rowq = r.ib->rowq;
+            fp.y_hmax = r.ia->d_max;
+            fp.hscale = r.ia->center->d_scale;
+            fp.excl_floor = r.floor_;
+            fp.dual_col = 1;
+            fp.out_dist = r.d_dist_ba;
+            fp.out_ind = r.d_ind_ba;
+            fp.fail_count = r.fail_count_b;
+            fp.fail_list = r.fail_list;
+            fp.err_ratio_bits = (unsigned long long*)(r.fail_count_b + 2);
+            const int rc2 = kz_launch_finalize(ctx, fp, lay, r.KP, r.b->n, r.a->dtype);
+            if (rc2 != KZ_OK) return rc2;
+            KZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
+            KZ_HIP(hipMemcpyAsync(ctx->h_counters + 12, r.fail_count_b, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            KZ_HIP(hipMemcpyAsync(ctx->h_counters + 16, r.d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+            return KZ_OK;
+        };
+        const int rc2 = body();
+        ctx->stream = first;
+        return rc2;
+    };
+    if (ctx->dual_overlap) {
+        dp.post_sweep = +enqueue_reverse;
+        dp.post_user = &rv;
+    }
     kz_knn_stats st_ab;
-    KZ_DUAL_RC(kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, -1, 0, d_dist_ab, d_ind_ab, &st_ab, &dp));
+    rc = kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, -1, 0, d_dist_ab, d_ind_ab, &st_ab, &dp);
+    if (rc == KZ_OK && !ctx->dual_overlap && !dp.broken) {   // ("dual_overlap" = 0: the same chain, behind the forward direction)
+        dp.post_called = 1;
+        rc = enqueue_reverse(&rv);
+    }
+    // whatever happened on the first stream: the second one is done with the buffers before anything is released
+    {
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream2);
+        if (rc == KZ_OK && e2 != hipSuccess) {
+            kz_set_error("kz_knn_dual: second stream failed: %s", hipGetErrorString(e2));
+            rc = KZ_ERR_HIP;
+        }
+    }
+    if (rc != KZ_OK) {
+        release();
+        return rc;
+    }
     // (kz_knn_impl ends with a stream synchronisation: ev[5] and ev[6] around the sample sweep have completed)
     KZ_DUAL_HIP(hipEventElapsedTime(&sample_ms, ctx->ev[5], ctx->ev[6]));
     st_ab.dual = 1;
@@ -563,72 +663,16 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
 
     kz_knn_stats st_ba;
     memset(&st_ba, 0, sizeof(st_ba));
+    if (!dp.broken && !dp.post_called) dp.broken = 1;   // (the sweep never got as far as its last chunk in the fp16 tier)
     if (!dp.broken) {
-        // ---- events -> lists -> ordinary finalize with B as the query side --------------------------------------------------
-        KZ_DUAL_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-        hipLaunchKernelGGL(kz_dual_scatter_kernel, dim3(ctx->n_cus * 8), dim3(256), 0, ctx->stream, (const f32x4e*)log_keys,
-                           (const i32x2e*)log_meta, d_cnt, log_cap, theta_s, qnb, p_bias, row_map, ev_cnt, ev, ev_cap);
-        const size_t sel_lds = (size_t)4 * 2 * ev_cap * 4;
-        if (sel_lds > 65536)
-            KZ_DUAL_HIP(hipFuncSetAttribute((const void*)kz_dual_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
-        hipLaunchKernelGGL(kz_dual_select_kernel, dim3((unsigned)((b->n + 3) / 4)), dim3(256), sel_lds, ctx->stream, ev_cnt, ev, ev_cap,
-                           b->n, perm, KP, col_key, col_idx, floor_, d_cnt + 16);
-        hipLaunchKernelGGL(kz_dual_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, d_cnt + 16, d_cnt + 1);
-        KZ_DUAL_HIP(hipGetLastError());
-        KZ_DUAL_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-        KzListLayout lay;
-        memset(&lay, 0, sizeof(lay));
-        lay.n_regions = 1;
-        lay.qt_end[0] = (int)b_tiles;
-        lay.pieces[0] = 1;
-        lay.halves = 1;
-        lay.contig = 1;
-        int* fail_count = ctx->d_counters + 8;
-        KZ_DUAL_HIP(hipMemsetAsync(fail_count, 0, 4 * sizeof(int), ctx->stream));
-        KnnFinParams fp;
-        memset(&fp, 0, sizeof(fp));
-        fp.in_key = col_key;
-        fp.in_idx = col_idx;
-        fp.lay = lay;
-        fp.KP = KP;
-        fp.list_row0 = 0;
-        fp.q_begin = 0;
-        fp.q_count = b->n;
-        fp.qraw = b->raw;
-        fp.yraw = a->raw;
-        fp.qsqn = b->sqn;
-        fp.ysqn = a->sqn;
-        fp.n_i = a->n;
-        fp.d = (int)a->d;
-        fp.metric = a->metric;
-        fp.k = k;
-        fp.ystats = a->d_stats;
-        fp.tier_h = 1;
-        fp.eps_mult = ctx->eps_scale;
-        fp.gamma_acc = 2.0 * (double)(a->kg * 4 + 16) * 5.9604644775390625e-08;
-        fp.q_rowq = ib->rowq;
-        fp.y_hmax = ia->d_max;
-        fp.hscale = ia->center->d_scale;
-        fp.excl_floor = floor_;
-        fp.dual_col = 1;
-        fp.out_dist = d_dist_ba;
-        fp.out_ind = d_ind_ba;
-        fp.fail_count = fail_count;
-        fp.fail_list = fail_list;
-        fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
-        KZ_DUAL_RC(kz_launch_finalize(ctx, fp, lay, KP, b->n, a->dtype));
-        KZ_DUAL_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-        KZ_DUAL_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        KZ_DUAL_HIP(hipMemcpyAsync(ctx->h_counters + 16, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
-        KZ_DUAL_HIP(hipStreamSynchronize(ctx->stream));
-        const int n_fail = ctx->h_counters[8];
+        const int n_fail = ctx->h_counters[12];
         unsigned long long hc[4];
         memcpy(hc, ctx->h_counters + 16, 32);
-        memcpy(&st_ba.max_err_ratio, ctx->h_counters + 10, 8);
+        memcpy(&st_ba.max_err_ratio, ctx->h_counters + 14, 8);
         float ms = 0;
-        KZ_DUAL_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        KZ_DUAL_HIP(hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]));
         st_ba.main_kernel_ms = sample_ms + ms;   // sample sweep + scatter + select: what this direction cost besides the shared sweep
-        KZ_DUAL_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+        KZ_DUAL_HIP(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
         st_ba.finalize_ms = ms;
         st_ba.list_len = KP;
         st_ba.n_splits = 1;

@@ -47,6 +47,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->min_splits = 1;
     c->dual_stride = 1;
     c->dual_deal = 1;
+    c->dual_overlap = 1;
     c->lds_pad = 0;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
@@ -59,7 +60,8 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
         KZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    for (int i = 0; i < 8; ++i) KZ_HIP(hipEventCreate(&c->ev[i]));
+    KZ_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 12; ++i) KZ_HIP(hipEventCreate(&c->ev[i]));
     KZ_HIP(hipMalloc((void**)&c->d_counters, 64 * sizeof(int)));
     KZ_HIP(hipHostMalloc((void**)&c->h_counters, 64 * sizeof(int), hipHostMallocDefault));
     KZ_HIP(hipMemsetAsync(c->d_counters, 0, 64 * sizeof(int), c->stream));
@@ -77,7 +79,8 @@ int kz_ctx_destroy(kz_ctx* c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
-    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 12; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2), (void)hipStreamDestroy(c->stream2);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return KZ_OK;
@@ -112,6 +115,8 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "force_splits") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
         c->force_splits = (int)value;
+    } else if (strcmp(name, "dual_overlap") == 0) {
+        c->dual_overlap = value != 0 ? 1 : 0;
     } else if (strcmp(name, "h_wide") == 0) {
         KZ_REQUIRE(value == 0 || value == 1, "h_wide must be 0 or 1");
         c->h_wide = (int)value;
