@@ -878,47 +878,7 @@ int kz_bf_launch_kp128(int n_slices_bf, kz_ctx* ctx, const KnnCandParams& p, int
         }                                            \
     } while (0)
 
-// Host schedule of one launch: greedy rounds.  slots = workgroups resident on the chip; dispatch is in block-id order, so
-// the items of one round start together and sweep the index in lockstep (each index tile is fetched into L2 once per
-// round).  With R query tiles left, a round cuts the index into s = ceil(slots / R) ranges and takes slots / s query
-// tiles: every round fills the chip with equal-length items, the items shrink from round to round and only the last few
-// query tiles get the shortest allowed ranges (>= 8 index tiles, <= max_pieces ranges).  force_splits (test knob) = one
-// round with exactly that many ranges; min_splits raises the first round's range count (L2 grouping knob).
-// Outputs: per round the number of query tiles and the requested range count (the actual number of ranges is
-// ceil(n_ytiles / ceil(n_ytiles / s))).
-static void kz_plan_rounds(int n_qtiles, int n_ytiles, int slots, int max_pieces, int force_splits, int min_splits,
-                           int* n_rounds, int* round_qtiles, int* round_splits) {
-    const int by_len = n_ytiles / 8 > 1 ? n_ytiles / 8 : 1;
-    auto clamp_s = [&](int v) {
-        if (v > max_pieces) v = max_pieces;
-        if (v > by_len) v = by_len;
-        if (v < 1) v = 1;
-        return v;
-    };
-    auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
-    auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
-    int R = n_qtiles, n = 0;
-    while (R > 0) {
-        int sp, A;
-        if (force_splits > 0) {
-            sp = force_splits < n_ytiles ? force_splits : n_ytiles;
-            if (sp > max_pieces) sp = max_pieces;
-            A = R;
-        } else {
-            sp = clamp_s((slots + R - 1) / R);
-            if (n == 0 && sp < min_splits) sp = clamp_s(min_splits);
-            A = slots / split_cnt(sp);
-            if (A < 1) A = 1;
-            if (A > R || n == KZ_MAX_REGIONS - 1) A = R;
-        }
-        round_qtiles[n] = A;
-        round_splits[n] = sp;
-        ++n;
-        R -= A;
-    }
-    *n_rounds = n;
-}
-
+// (kz_plan_rounds, kz_plan_pass, kz_plan_fill_work: kz_plan.h)
 extern "C" int kz_knn_plan(int64_t n_query_rows, int64_t n_index_rows, int k_eff, int slots, int force_splits, int min_splits,
                            int* n_rounds, int* round_qtiles, int* round_pieces, int* round_piece_tiles) {
     KZ_REQUIRE(n_rounds && round_qtiles && round_pieces && round_piece_tiles, "kz_knn_plan: null argument");
@@ -1015,36 +975,12 @@ struct KzPass {
 // layout (a region ends on a unit boundary, the last one at the last tile).
 static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, int max_pieces, int KP, int tier, int64_t fail_rows,
                            KzPass* out, int tpw = 1) {
-    const int n_units = (n_qtiles + tpw - 1) / tpw;
-    auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
-    auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
-    KzListLayout lay;
-    memset(&lay, 0, sizeof(lay));
-    int reg_q0[KZ_MAX_REGIONS], reg_nq[KZ_MAX_REGIONS], reg_s[KZ_MAX_REGIONS], reg_w0[KZ_MAX_REGIONS];
-    int W = 0;
-    size_t list_elems = 0;
-    {
-        int n_reg = 0;
-        kz_plan_rounds(n_units, n_ytiles, slots, max_pieces, ctx->force_splits, ctx->min_splits, &n_reg, reg_nq, reg_s);
-        int q0 = 0;   // (units)
-        for (int r = 0; r < n_reg; ++r) {
-            reg_q0[r] = q0;
-            reg_w0[r] = W;
-            const int t0 = q0 * tpw;
-            const int t1 = (q0 + reg_nq[r]) * tpw < n_qtiles ? (q0 + reg_nq[r]) * tpw : n_qtiles;
-            lay.qt_end[r] = t1;
-            lay.pieces[r] = split_cnt(reg_s[r]);
-            lay.base[r] = (long long)list_elems;
-            // entries per (query, index range): K' in the contiguous layout, 2 K' in the interleaved one (two lane-half
-            // columns per list block, also where only one is used)
-            list_elems += (size_t)(t1 - t0) * KZ_TILE * (size_t)(lay.pieces[r] * (tier == KZ_TIER_H ? 1 : 2) * KP);
-            W += reg_nq[r] * lay.pieces[r];
-            q0 += reg_nq[r];
-        }
-        lay.n_regions = n_reg;
-        lay.halves = tier == KZ_TIER_F32 ? 2 : 1;
-        lay.contig = tier == KZ_TIER_H ? 1 : 0;
-    }
+    KzPlan pl;
+    kz_plan_pass(n_qtiles, n_ytiles, slots, max_pieces, (tier == KZ_TIER_H ? 1 : 2) * KP, tier == KZ_TIER_F32 ? 2 : 1,
+                 tier == KZ_TIER_H ? 1 : 0, tpw, ctx->force_splits, ctx->min_splits, &pl);
+    const KzListLayout& lay = pl.lay;
+    const int W = pl.W;
+    const size_t list_elems = pl.list_elems;
     const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
     const size_t fail_bytes = ((size_t)fail_rows * 4 + 255) & ~(size_t)255;
     const size_t work_bytes = ((size_t)W * sizeof(int4) + 255) & ~(size_t)255;
@@ -1074,35 +1010,8 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
         // fail-counter read).
         ctx->h_stage_flip ^= 1;
         int4* hw = (int4*)((char*)ctx->h_stage + (ctx->h_stage_flip ? ctx->h_stage_bytes / 2 : 0));
-        // Logical order inside a region: groups of KZ_QGROUP query tiles, inside a group split-major.  The workgroups
-        // resident on one XCD then cover few query tiles (their fragments stay in the 4 MiB L2) times a few index
-        // ranges (each index tile is fetched once and hit by the whole group); items are spread over block ids so that
-        // blocks with equal (id % 8) -- one XCD -- take consecutive items.
-        auto fill_region = [&](int off, int cnt, int q0, int nq, int sp) {
-            if (cnt == 0) return;
-            const int len = split_len(sp);
-            const int nsp = split_cnt(sp);
-            const int G = KZ_QGROUP < nq ? KZ_QGROUP : nq;
-            int next = 0;
-            for (int label = 0; label < 8; ++label) {
-                for (int i = 0; i < cnt; ++i) {
-                    if (((off + i) & 7) != label) continue;
-                    const int grp = next / (G * nsp);
-                    const int gq0 = grp * G;
-                    const int gsz = (nq - gq0) < G ? (nq - gq0) : G;  // last group may be smaller
-                    const int within = next - grp * G * nsp;
-                    const int sidx = within / gsz, qt = q0 + gq0 + within % gsz;
-                    ++next;
-                    int4 w4;
-                    w4.x = qt * tpw;   // first query tile of the unit
-                    w4.y = sidx * len;
-                    w4.z = (sidx + 1) * len < n_ytiles ? (sidx + 1) * len : n_ytiles;
-                    w4.w = sidx;
-                    hw[off + i] = w4;
-                }
-            }
-        };
-        for (int r = 0; r < lay.n_regions; ++r) fill_region(reg_w0[r], reg_nq[r] * lay.pieces[r], reg_q0[r], reg_nq[r], reg_s[r]);
+        static_assert(sizeof(KzWorkItem) == sizeof(int4), "work items are uploaded as int4");
+        kz_plan_fill_work(pl, n_ytiles, tpw, (KzWorkItem*)hw);
         KZ_HIP(hipMemcpyAsync(out->d_work, hw, (size_t)W * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     }
     return KZ_OK;

@@ -2,6 +2,7 @@
 // kz_knn_bf16.h: split-bf16, kz_knn_h16.h: fp16): parameter block, candidate list / log state, tile epilogues.
 #pragma once
 #include "kz_common.h"
+#include "kz_plan.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -58,17 +59,7 @@ __device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-tempora
 // Query operand: per-lane fragments straight from L2 (no reuse across waves, so no LDS round trip).
 // Candidate-list storage.  The host schedule (kz_knn) cuts the query tiles of a launch into a few REGIONS; every
 // query of region r owns pieces[r] lists of 2*KP entries (one per index-range piece and lane half).
-constexpr int KZ_MAX_REGIONS = 8;
-struct KzListLayout {
-    int n_regions;
-    int qt_end[KZ_MAX_REGIONS];      // region r = query tiles [qt_end[r-1], qt_end[r])  (local tile numbers)
-    int pieces[KZ_MAX_REGIONS];      // index-range pieces per query tile
-    int halves;                      // lists per (query, piece): 2 = one per lane half (float32 kernels), 1 = one shared
-                                     // by both lane halves (split-bf16 kernels; column h = 1 of a list block is unused)
-    int contig;                      // 1: every list is K' CONTIGUOUS entries (fp16 kernel, kz_list_contig_off); 0: the
-                                     // wave-interleaved layout below
-    long long base[KZ_MAX_REGIONS];  // element offset of the region's first list
-};
+// (KzListLayout, KZ_MAX_REGIONS, KZ_QGROUP: kz_plan.h -- the host-only planning code, also compiled on the CPU with sanitizers)
 __host__ __device__ __forceinline__ int kz_list_region(int64_t list_row, const KzListLayout& L) {
     const int qt = (int)(list_row / KZ_TILE);
     int r = 0;
@@ -120,7 +111,6 @@ struct KnnCandParams {
 };
 
 constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows
-constexpr int KZ_QGROUP = 24;                   // query tiles sharing an XCD at a time (x splits ~= resident workgroups)
 constexpr int KZ_LOG_CAP = 16;                  // per-lane candidate log entries (keys + rows: 32 KiB per workgroup)
 constexpr int KZ_CAND_LDS = KZ_CAND_LDS_BASE + KZ_LOG_CAP * 256 * 8;
 
