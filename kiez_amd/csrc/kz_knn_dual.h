@@ -319,12 +319,14 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     const int rank = k + 1 < KP ? k + 1 : KP;
     const int n_slices = b->kg / 4;
     // every stride-th tile of A is in the sample.  Automatic (dual_stride = 1): the sample sweep costs T / stride, the events
-    // (log, scatter, select) ~0.07 ns each with |B| k stride of them: stride = sqrt(T / (|B| k 0.07 ns)), T ~ 2 |A| |B| d / 1e15 s
-    // (ns: 22, measured flat between 16 and 24; 500k x 500k, k = 50: 8)
+    // (log, scatter, select, slower sweep) ~0.10 ns each with |B| k stride of them: stride = sqrt(T / (|B| k 0.07 ns)), T ~ 2 |A| |B| d / 1e15 s
+    // (ns: 20, measured flat between 16 and 28; 500k x 500k, k = 50: 6)
     int stride = ctx->dual_stride;
     if (stride == 1) {
         const double t_ms = 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12;
-        const double s_opt = sqrt(t_ms / ((double)b->n * rank * 0.07e-6));
+        // (0.10 ns per event: round 3, same box, 500k x 500k, k = 50: stride 4 / 5 / 6 / 7 / 8 -> 186.0 / 184.8 / 183.8 / 183.8 /
+        //  186.8 ms per step -- every event also slows the sweep itself, 117.6 -> 126.4 ms; 250k x 1M, k = 10: flat from 16 to 28)
+        const double s_opt = sqrt(t_ms / ((double)b->n * rank * 0.10e-6));
         stride = s_opt < 4.0 ? 4 : (s_opt > 32.0 ? 32 : (int)(s_opt + 0.5));
     }
     // (a row's event buffer -- k stride + 7 sqrt(k) stride entries -- is selected from LDS, 8 B per entry and four rows per

@@ -185,7 +185,7 @@ def test_golden_pipeline_through_the_shared_sweep(ctx, case, tag, k):
         for r in np.flatnonzero(~keep):
             assert knife_edge_topk_ok(ref_d[r], ref_i[r], d[r], i[r], r, g["_K"], g["mp_empiric__ind_t2s"]), f"knife-edge row {r}"
     np.testing.assert_array_equal(i[keep], ref_i[keep])
-    np.testing.assert_allclose(d[keep], ref_d[keep], rtol=1e-5, atol=5e-6 if tag == "dsl" else 1e-6)
+    np.testing.assert_allclose(d[keep], ref_d[keep], rtol=1e-5, atol=1e-6)
 
 
 SHARDED_SCRIPT = r"""

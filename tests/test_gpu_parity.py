@@ -51,9 +51,8 @@ def test_golden_pipeline(case, tag, k):
         for r in np.flatnonzero(~keep):
             assert knife_edge_topk_ok(ref_d[r], ref_i[r], d[r], i[r], r, g["_K"], g["mp_empiric__ind_t2s"]), f"knife-edge row {r}"
     np.testing.assert_array_equal(i[keep], ref_i[keep])
-    rtol, atol = RTOL, ATOL
-    if tag == "dsl":
-        atol = 5e-6
+    rtol, atol = RTOL, ATOL   # (DisSimLocal included: float64 on the device against the reference's float32-mixed arithmetic
+                              #  stays within the north-star 1e-5 relative; ATOL is the single-source self-distance floor)
     np.testing.assert_allclose(d[keep], ref_d[keep], rtol=rtol, atol=atol)
 
 
@@ -86,7 +85,7 @@ def test_golden_intermediates(case):
                     assert knife_edge_transform_ok(g[f"{tag}__transformed"][r], tr[r], g[f"{tag}__ind_s2t"][r], r, g["_K"],
                                                    g[f"{tag}__ind_t2s"]), r
             np.testing.assert_allclose(tr[keep], g[f"{tag}__transformed"][keep], rtol=RTOL,
-                                       atol=5e-6 if tag == "dsl" else ATOL)
+                                       atol=ATOL)
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 5, 10])
@@ -147,7 +146,7 @@ def test_oracle_parity(n_s, n_t, d, dtype, metric, K, tag):
                 assert knife_edge_topk_ok(od[r], oi[r], dist[r], ind[r], r, K, ind_t2s), f"knife-edge row {r}"
     bad = (ind != oi).any(axis=1) & keep
     assert not bad.any(), f"{bad.sum()} rows differ"
-    np.testing.assert_allclose(dist[keep], od[keep], rtol=RTOL, atol=5e-6 if tag == "dsl" else ATOL)
+    np.testing.assert_allclose(dist[keep], od[keep], rtol=RTOL, atol=ATOL)
 
 
 def test_single_source_self_is_stripped_forward_but_kept_reverse():

@@ -66,7 +66,7 @@ for name, hub, kw, metric, single in CASES:
         for r in np.flatnonzero(~keep):
             assert knife_edge_topk_ok(od[r], oi[r], d[r], i[r], r, K, ind_t2s), (name, r)
     assert np.array_equal(i[keep], oi[keep]), name
-    assert np.allclose(d[keep], od[keep], rtol=1e-5, atol=5e-6), name
+    assert np.allclose(d[keep], od[keep], rtol=1e-5, atol=1e-6), name
 # (every hubness kind takes its reverse lists out of the shared sweep and merges them after ONE all-to-all: six two-source cases)
 assert calls["broadcast"] >= 7 and calls["all_gather_into_tensor"] >= 9 and calls["all_reduce"] >= 1 and calls["all_to_all_single"] == 6, calls
 print("collectives", calls)
