@@ -1,4 +1,4 @@
-"""profiles/r02_<w>_pmc.jsonl (tools/pmc_profile.sh) -> profiles/pmc_traffic.json: per workload the dominant kernel (largest
+"""profiles/r<NN>_<w>_pmc.jsonl (tools/pmc_profile.sh; the latest round present per workload) -> profiles/pmc_traffic.json: per workload the dominant kernel (largest
 total time) with its HBM-side bytes per launch -- FETCH_SIZE x 2 (gfx950: FETCH_SIZE tallies 128-byte requests at 64 B,
 MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> B -- clock, matrix-pipe busy and instruction mix.  bench.py reads
 `<workload>_<dtype>.hbm_bytes_per_launch` for `roofline.traffic`.      python3 tools/pmc_derive.py [profiles_dir]"""
@@ -10,9 +10,11 @@ from pathlib import Path
 P = Path(sys.argv[1] if len(sys.argv) > 1 else Path(__file__).resolve().parent.parent / "profiles")
 out = {"_note": "HBM-side bytes per launch of the dominant kernel (average over the dispatches of the profiled run): FETCH_SIZE x 2 "
                 "(gfx950 correction) + WRITE_SIZE, KiB -> B; separate rocprofv3 --pmc passes (tools/pmc_profile.sh), summaries in "
-                "r02_<workload>_pmc.jsonl; derived by tools/pmc_derive.py"}
-for f in sorted(P.glob("r02_*_pmc.jsonl")):
-    w = f.name[len("r02_"):-len("_pmc.jsonl")]
+                "r<NN>_<workload>_pmc.jsonl (latest round per workload; `source` names the file); derived by tools/pmc_derive.py"}
+latest = {}
+for f in sorted(P.glob("r[0-9][0-9]_*_pmc.jsonl")):
+    latest[f.name[4:-len("_pmc.jsonl")]] = f      # sorted: a later round replaces an earlier one
+for w, f in sorted(latest.items()):
     per = collections.defaultdict(dict)     # kernel -> counter -> avg ;  plus avg_ns / dispatches
     for line in f.read_text().splitlines():
         r = json.loads(line)
@@ -31,7 +33,7 @@ for f in sorted(P.glob("r02_*_pmc.jsonl")):
     hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
     tier = "f16" if "cand_h_" in k else ("bf16x2" if "cand_bf" in k else "f32")
     out[f"{w}_{tier}"] = {
-        "kernel": k.replace("void ", ""), "dispatches_averaged": c["_disp"], "avg_ms_under_pmc": c["_avg_ns"] / 1e6,
+        "source": f.name, "kernel": k.replace("void ", ""), "dispatches_averaged": c["_disp"], "avg_ms_under_pmc": c["_avg_ns"] / 1e6,
         "hbm_bytes_per_launch": (c.get("FETCH_SIZE", 0.0) * 2 + c.get("WRITE_SIZE", 0.0)) * 1024,
         "fetch_size_kib": c.get("FETCH_SIZE"), "write_size_kib": c.get("WRITE_SIZE"),
         "clock_ghz": g / c["_avg_ns"] if g else None,

@@ -11,7 +11,7 @@ ARGS="--workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-other
 : > "$OUT/summary.jsonl"
 run() { # name counters...
   local name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1
   local f=$(find "$OUT/$name" -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$name" >> "$OUT/summary.jsonl" <<'PY'
 import csv, sys, collections, json
