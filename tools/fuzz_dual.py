@@ -33,10 +33,11 @@ for case in range(n_cases):
         base = rng.random((max(n // 5, 4), d))
         return base[rng.integers(0, len(base), n)]
     a, b = gen(na).astype(dtype), gen(nb).astype(dtype)
-    opt = (int(rng.choice([1, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 0, 4096, 16384])), int(rng.integers(0, 2)))
+    opt = (int(rng.choice([1, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 0, 4096, 16384])), int(rng.integers(0, 2)),
+           int(rng.integers(0, 2)), int(rng.integers(0, 2)))   # ..., wide workgroups for the shared sweep, reverse chain on the second stream
     if only >= 0 and case != only:
         continue
-    print(f"case {case}: na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} stride/chunk/deal {opt}", flush=True)
+    print(f"case {case}: na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} stride/chunk/deal/wide/overlap {opt}", flush=True)
     ctx.set_option("dual_stride", opt[0])
     ctx.set_option("chunk_rows", opt[1])
     ctx.set_option("dual_deal", opt[2])
@@ -47,7 +48,10 @@ for case in range(n_cases):
     r2 = N.knn(ctx, bm, am, k); ctx.sync()
     if only >= 0: print("  b->a done", r2[2]["n_escalated_rows"], r2[2]["n_fallback_rows"], flush=True)
     ctx.set_option("dual_force", 1)
+    ctx.set_option("h_wide", opt[3])          # (the two reference searches above ran the narrow builds)
+    ctx.set_option("dual_overlap", opt[4])
     (xd, xi, sa), (yd, yi, sb) = N.knn_dual(ctx, am, bm, k)
+    ctx.set_option("h_wide", 0)
     ok = (np.array_equal(r1[1].numpy(), xi.numpy()) and np.array_equal(r1[0].numpy(), xd.numpy())
           and np.array_equal(r2[1].numpy(), yi.numpy()) and np.array_equal(r2[0].numpy(), yd.numpy()))
     ratio = max(sa["max_err_ratio"], sb["max_err_ratio"])
@@ -55,7 +59,7 @@ for case in range(n_cases):
         bad += 1
     print(("ok " if ok else "BAD"), f"na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} dual {sa['dual']}/{sb['dual']} "
           f"ev/row {sb['n_events'] / nb:.1f} esc {sb['n_escalated_rows']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
-for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1)):
+for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1), ("h_wide", 0), ("dual_overlap", 1)):
     ctx.set_option(name, v)
 print("cases", n_cases, "bad", bad)
 sys.exit(1 if bad else 0)
