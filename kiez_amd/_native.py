@@ -26,8 +26,9 @@ _lock = threading.Lock()
 KZ_F32, KZ_F64 = 0, 1
 KZ_EUCLIDEAN, KZ_SQEUCLIDEAN, KZ_COSINE = 0, 1, 2
 METRIC_IDS = {"euclidean": KZ_EUCLIDEAN, "sqeuclidean": KZ_SQEUCLIDEAN, "cosine": KZ_COSINE}
-MAX_FUSED_NEIGHBORS = 110   # neighbours per query the fused kernels keep (list length 128 minus the certification margin);
-                            # beyond it kz_knn runs on the exact float64 kernels only (correct, slow), up to MAX_NEIGHBORS
+MAX_FUSED_NEIGHBORS = 110   # neighbours per query ONE fused list keeps (list length 128 minus the certification margin): the limit of
+                            # the shared sweep and of the single-source split; kz_knn itself takes 111 .. ~540 on its long-k route
+                            # (lists over many index ranges) and anything up to MAX_NEIGHBORS on the exact float64 kernels
 MAX_NEIGHBORS = 4096
 MAX_HUBNESS_CANDIDATES = 4096  # n_candidates the device hubness kernels (transform, final sort) handle (KZ_MAX_CANDIDATES)
 MERGE_MAX_ENTRIES = 8192       # entries per row kz_merge_topk merges (KZ_MERGE_MAX_ENTRIES)

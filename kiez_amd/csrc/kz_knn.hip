@@ -253,7 +253,9 @@ struct KnnFinParams {
     KzListLayout lay;     // list layout (kz_list_base)
     int max_m;            // largest entry count of a query in this launch (sizes the dynamic LDS)
     int64_t q_first, q_last;  // local query range [q_first, q_last) handled by this launch
-    int KP;
+    int KP;               // entries per list (per query and index range)
+    int KSEL;             // candidates the finalize kernel selects from a query's lists and re-ranks (0: = KP).  Larger than KP on the
+                          // long-k route (more than 110 neighbours: lists of 128 over many index ranges, kz_knn_impl)
     int64_t list_row0;    // list row of local query 0  (= q_begin - qt0*128)
     int64_t q_begin;      // global query row of local query 0
     int64_t q_count;
@@ -380,13 +382,14 @@ __device__ __forceinline__ int kz_rank_select(const float* ekey, const int* eidx
 // One query, one wave (only wave-level synchronisation inside).
 template <typename T>
 __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const int64_t q, const int lane, char* wbase) {
+    const int KS = p.KSEL > 0 ? p.KSEL : p.KP;   // candidates selected and re-ranked
     double* cv = reinterpret_cast<double*>(wbase);
-    double* sv = cv + p.KP;
-    float* ekey = reinterpret_cast<float*>(sv + p.KP);
+    double* sv = cv + KS;
+    float* ekey = reinterpret_cast<float*>(sv + KS);
     int* eidx = reinterpret_cast<int*>(ekey + p.max_m);
     float* ck = reinterpret_cast<float*>(eidx + p.max_m);
-    int* ci = reinterpret_cast<int*>(ck + p.KP);
-    int* si = ci + p.KP;
+    int* ci = reinterpret_cast<int*>(ck + KS);
+    int* si = ci + KS;
     const int KP = p.KP;
     const int k_eff = p.k + (p.exclude_self ? 1 : 0);
 
@@ -418,19 +421,40 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     }
     kz_wave_sync();
 
-    // top-KP of the M entries by (key desc, idx asc)
+    // Long-k route (KS > KP): the union of the per-range lists holds the KS best approximate keys only if no range
+    // contributes more than its list can hold.  A FULL list may have evicted rows: everything outside it has a key <= its
+    // smallest entry -- the largest such value over the full lists joins the certification bound below.
+    float piece_bound = -INFINITY;
+    if (KS > KP) {
+        for (int l0 = 0; l0 < M; l0 += KP) {   // (uniform; KP is a multiple of 16, lists are at most 128 entries)
+            float mn = INFINITY;
+            int cnt = 0;
+            for (int e = lane; e < KP; e += 64) {
+                const bool ok = eidx[l0 + e] >= 0;
+                cnt += ok ? 1 : 0;
+                mn = ok ? fminf(mn, ekey[l0 + e]) : mn;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                cnt += __shfl_xor(cnt, off, 64);
+                mn = fminf(mn, __shfl_xor(mn, off, 64));
+            }
+            if (cnt == KP) piece_bound = fmaxf(piece_bound, mn);
+        }
+    }
+    // top-KS of the M entries by (key desc, idx asc)
     int V = 0;
     if (M <= 256) {
         // E entries per lane: the rank of an entry among the valid entries is a count over uniform-lane broadcasts
-        // (v_readlane), no cross-lane reduction chains; entries with rank < KP land in ck/ci already ordered
+        // (v_readlane), no cross-lane reduction chains; entries with rank < KS land in ck/ci already ordered
         if (M <= 64)
-            V = kz_rank_select<1>(ekey, eidx, M, KP, ck, ci, lane);
+            V = kz_rank_select<1>(ekey, eidx, M, KS, ck, ci, lane);
         else if (M <= 128)
-            V = kz_rank_select<2>(ekey, eidx, M, KP, ck, ci, lane);
+            V = kz_rank_select<2>(ekey, eidx, M, KS, ck, ci, lane);
         else
-            V = kz_rank_select<4>(ekey, eidx, M, KP, ck, ci, lane);
+            V = kz_rank_select<4>(ekey, eidx, M, KS, ck, ci, lane);
     } else {
-        for (int r = 0; r < KP; ++r) {
+        for (int r = 0; r < KS; ++r) {
             float bk = -INFINITY;
             int bi = 0x7fffffff, be = -1;
             for (int e = lane; e < M; e += 64) {
@@ -684,10 +708,17 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         double bound = (double)p.excl_floor[qrow];
         if (V == KP) bound = fmax(bound, (double)ck[KP - 1]);
         certified = V >= k_eff && bound * key_scale + eps_q < exact_key(sv[k_eff - 1]);
-    } else if (V < KP)
-        certified = (V >= min((int64_t)k_eff, p.n_i));
-    else
-        certified = (double)ck[KP - 1] * key_scale + eps_q < exact_key(sv[k_eff - 1]);
+    } else {
+        // rows outside the selected set: behind the KS-th selected key (when the selection is full), or evicted from a full
+        // list (long-k route: piece_bound; with KS = KP a full list implies a full selection whose KS-th key is at least as
+        // large, so the first term alone is the round-1 rule).  Neither: no list ever evicted anything, the set is complete.
+        float bound = piece_bound;
+        if (V == KS) bound = fmaxf(bound, ck[KS - 1]);
+        if (bound == -INFINITY)
+            certified = (V >= min((int64_t)k_eff, p.n_i));
+        else
+            certified = V >= k_eff && (double)bound * key_scale + eps_q < exact_key(sv[k_eff - 1]);
+    }
     // ... and the candidates that were not re-ranked are out by the same argument (implied by how Vr was chosen; re-checked)
     if (Vr < V && !((double)ck[Vr] * key_scale + eps_q < exact_key(sv[k_eff - 1]))) certified = false;
     // An approximate key further than eps from its exact value contradicts the bound everything above rests on (a kernel
@@ -715,7 +746,7 @@ __global__ __launch_bounds__(256, KZ_FIN_WAVES) void kz_knn_finalize_kernel(KnnF
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    char* wbase = fsm + (size_t)wave * kz_fin_wave_bytes(p.max_m, p.KP);
+    char* wbase = fsm + (size_t)wave * kz_fin_wave_bytes(p.max_m, p.KSEL > 0 ? p.KSEL : p.KP);
     for (int rep = 0; rep < KZ_FIN_QPB / 4; ++rep) {
         const int64_t q = p.q_first + (int64_t)blockIdx.x * KZ_FIN_QPB + rep * 4 + wave;
         if (q >= p.q_last) break;  // whole wave leaves; only wave-level sync inside
@@ -944,7 +975,7 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
         if (fp.q_last <= fp.q_first) continue;
         fp.max_m = lay.pieces[rg] * lay.halves * KP;
         const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
-        const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, KP);
+        const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, fp.KSEL > 0 ? fp.KSEL : KP);
         if (fin_lds > 65536) {
             const void* fk = dtype == KZ_F32 ? (const void*)kz_knn_finalize_kernel<float> : (const void*)kz_knn_finalize_kernel<double>;
             KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
@@ -974,10 +1005,10 @@ struct KzPass {
 // query tiles -- one work item = one unit x one index range, w4.x = its first tile -- and converted back to tiles for the list
 // layout (a region ends on a unit boundary, the last one at the last tile).
 static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, int max_pieces, int KP, int tier, int64_t fail_rows,
-                           KzPass* out, int tpw = 1) {
+                           KzPass* out, int tpw = 1, int force_pieces = 0) {
     KzPlan pl;
     kz_plan_pass(n_qtiles, n_ytiles, slots, max_pieces, (tier == KZ_TIER_H ? 1 : 2) * KP, tier == KZ_TIER_F32 ? 2 : 1,
-                 tier == KZ_TIER_H ? 1 : 0, tpw, ctx->force_splits, ctx->min_splits, &pl);
+                 tier == KZ_TIER_H ? 1 : 0, tpw, force_pieces > 0 ? force_pieces : ctx->force_splits, ctx->min_splits, &pl);
     const KzListLayout& lay = pl.lay;
     const int W = pl.W;
     const size_t list_elems = pl.list_elems;
@@ -1126,10 +1157,28 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                exclude_self ? "<" : "<=", k, (long long)index->n);
     if (exclude_self && !d_self_ids)
         KZ_REQUIRE(query->n == index->n, "kz_knn: exclude_self needs query and index of equal length");
-    // More than 110 neighbours per query: no fused kernel keeps lists that long; the call runs entirely on the exact float64
-    // kernels (k selection rounds over the full distance row per query: correct for any k <= n, and slow -- the reference's
-    // scikit-learn path has no such limit either, sklearn_nearest_neighbors.py:51-65; INTEGRATION.md "Deviations").
+    // More than 110 neighbours per query: no fused kernel keeps a list that long -- but the kernels keep ONE list per query and
+    // index RANGE, and the finalize kernel merges them.  LONG-k ROUTE (111 .. ~540 neighbours): lists of 128 over S >= k / 24
+    // index ranges (a range then holds ~24 of a query's k nearest rows on average; a range that holds more than its list does is
+    // seen by the certification -- kz_finalize_query: piece_bound -- and the row goes down the tiers), from which the finalize
+    // kernel selects and re-ranks KSEL = k + max(16, k / 8) candidates.  Beyond that (or an index too short to cut into S
+    // ranges of >= 4 tiles) the call runs entirely on the exact float64 kernels (k selection rounds over the full distance row
+    // per query: correct for any k <= n, and slow -- the reference's scikit-learn path has no such limit either,
+    // sklearn_nearest_neighbors.py:51-65; INTEGRATION.md "Deviations").
     int KP = kz_pick_list_len(k_eff);
+    int KSEL = 0, long_pieces = 0;
+    if (KP == 0 && !dual) {
+        const int S = k_eff / 24 + 1 > 4 ? k_eff / 24 + 1 : 4;
+        const int sel = k_eff + (k_eff / 8 > 16 ? k_eff / 8 : 16);
+        // (finalize: 4 waves x (S 128 entries x 8 B + KSEL x 28 B) of LDS per workgroup)
+        // (float32-operand tier: two lane-half lists per range, hence at most 8 ranges = 16 lists, see kz_prepare_pass below)
+        if (S <= KZ_FIN_MAXM / 128 && 4 * kz_fin_wave_bytes(S * 128, sel) <= 160 * 1024 &&
+            4 * kz_fin_wave_bytes((S < 8 ? S : 8) * 256, sel) <= 160 * 1024 && (int64_t)index->n_tiles >= (int64_t)4 * S) {
+            KP = 128;
+            KSEL = sel;
+            long_pieces = S;
+        }
+    }
     const bool exact_only = KP == 0;
     if (exact_only) {
         if (k_eff > KZ_EXACT_MAX_K) {
@@ -1213,8 +1262,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         const int n_qtiles = qt1 - qt0 + 1;
         // ---- schedule: which workgroup sweeps which (query tile, index-tile range): kz_prepare_pass above --------------
         KzPass ps;
+        // (long-k route: exactly long_pieces index ranges per query tile, one round)
         int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1), KP, tier, cq_count, &ps,
-                                 tier == KZ_TIER_H ? tpw_h : 1);
+                                 tier == KZ_TIER_H ? tpw_h : 1, (tier == KZ_TIER_F32 && long_pieces > 8) ? 8 : long_pieces);
         if (rc != KZ_OK) return rc;
         const KzListLayout& lay = ps.lay;
         const int W = ps.W;
@@ -1285,6 +1335,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fp.in_idx = out_idx;
         fp.lay = lay;
         fp.KP = KP;
+        fp.KSEL = KSEL;
         fp.list_row0 = cq_begin - (int64_t)qt0 * KZ_TILE;
         fp.q_begin = cq_begin;
         fp.q_count = cq_count;
