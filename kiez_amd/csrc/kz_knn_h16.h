@@ -85,7 +85,11 @@ struct KzHCfg {
 };
 
 template <int KP, int NSR, int WPS, bool DUAL = false, bool WIDE = false>
+#if defined(KZ_EXP) && KZ_EXP == 8
+__global__ __launch_bounds__(256, 1) void kz_knn_cand_h_kernel(KnnCandParams p) {   // (diagnostic: one wave per SIMD, 512 registers)
+#else
 __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn_cand_h_kernel(KnnCandParams p) {
+#endif
     using Cfg = KzHCfg<KP, WPS, NSR, DUAL, WIDE>;
     constexpr int TPW = Cfg::TPW;
     constexpr int R = Cfg::RING, P = Cfg::PERIOD, CAP = Cfg::CAP;
@@ -231,6 +235,24 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     int g = 0;
     int th_cur = 0;   // dual pass: threshold buffer of the current tile (uniform)
     f32x16 acc[4];
+#if defined(KZ_EXP) && KZ_EXP == 8
+    // diagnostic build (timing only, results WRONG): the bare loop of a ONE-WAVE-PER-SIMD kernel -- 64 queries per wave (the
+    // index fragment of a slice feeds two MFMAs: half the LDS reads per MFMA), 8 accumulators.  Every wave does TWICE the work
+    // of the shipped kernel on the same grid: compare half its time with exp2.
+    f32x16 acc8[2][4];
+    kz_f16x8 qf8[NSR];
+    {
+#pragma unroll
+        for (int u = 0; u < NSR; ++u)
+            qf8[u] = *reinterpret_cast<const kz_f16x8*>(p.qpack + ((int64_t)(p.qt0 + qt) * NSR + u) * 1024 + (h * KZ_TILE + 32 * ((tid >> 6) ^ 1) + j) * 4);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc8[a][mt][e] = 0.f;
+    }
+#endif
 #if defined(KZ_EXP) && KZ_EXP == 4
     // diagnostic build (timing only, results WRONG): the bare MFMA + LDS-fragment loop with v_mfma_f32_16x16x32_f16 --
     // 32 queries x 128 rows per wave = 2 x 8 accumulators of 16x16, one step = 32 k (two slices), ceil(NSR / 2) steps
@@ -299,6 +321,33 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
                 // for the previous tile; the buffer written here was last read two tiles ago, with a slice barrier in between.
                 kz_glds4_s(p.theta + ((int64_t)min(tile + 1, p.n_ytiles - 1) - 1) * KZ_TILE, off4, tbuf + (th_cur == 2 ? 0 : th_cur + 1) * 64);
         }
+#if defined(KZ_EXP) && KZ_EXP == 8
+        {
+            kz_f16x8 fa[4], fb4[4];
+            fetch_frags(fa, g);
+#pragma unroll
+            for (int u = 0; u < NSR; ++u) {
+                kz_f16x8 (&cur)[4] = (u & 1) ? fb4 : fa;
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < NSR) {
+                    if (u & 1)
+                        fetch_frags(fa, g + u + 1);
+                    else
+                        fetch_frags(fb4, g + u + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    acc8[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[mt], qf[u], acc8[0][mt], 0, 0, 0);
+                    acc8[1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[mt], qf8[u], acc8[1][mt], 0, 0, 0);
+                }
+            }
+            g += NSR;
+            asm volatile("" ::"v"(acc8[0][0]), "v"(acc8[0][1]), "v"(acc8[0][2]), "v"(acc8[0][3]));
+            asm volatile("" ::"v"(acc8[1][0]), "v"(acc8[1][1]), "v"(acc8[1][2]), "v"(acc8[1][3]));
+            return;
+        }
+#endif
 #if defined(KZ_EXP) && KZ_EXP == 4
         {
             const int c = lane >> 4;
