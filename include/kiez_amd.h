@@ -83,7 +83,9 @@ int kz_ctx_trim(kz_ctx* ctx);
  * only.  The neighbour order is the float64 one either way.  "dual_stride": kz_knn_dual samples every n-th tile of a
  * for its thresholds (default 1 = chosen from the shapes; 0 = always two ordinary searches).  Test/diagnostic knobs: "eps_scale" multiplies the
  * certification bound (huge value => every row takes the exact fallback); "force_splits" fixes the index split count
- * (0 = automatic); "min_splits", "chunk_rows", "h_wps", "h_wide", "lds_pad": scheduling / occupancy knobs. */
+ * (0 = automatic); "min_splits", "chunk_rows", "h_wps", "h_wide", "lds_pad": scheduling / occupancy knobs;
+ * "dual_max_gb": transient footprint kz_knn_dual may claim (GiB; 0 = 32: beyond it, or beyond what the device has free, it
+ * searches twice); "dual_overlap": 1 (default) = its reverse direction's chain runs on a second stream. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 
 int kz_malloc(kz_ctx* ctx, size_t bytes, void** d_ptr);

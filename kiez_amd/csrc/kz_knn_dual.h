@@ -362,7 +362,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         size_t free_b = 0, total_b = 0;
         KZ_HIP(hipMemGetInfo(&free_b, &total_b));
         const double avail = (double)free_b + (double)ctx->pool_bytes - 2.0 * (double)(1ull << 30);
-        if (ev_b + log_b + img_b > KZ_DUAL_MAX_BYTES || ev_b + log_b + img_b > avail)
+        const double budget = ctx->dual_max_gb > 0 ? ctx->dual_max_gb * (double)(1ull << 30) : KZ_DUAL_MAX_BYTES;
+        if (ev_b + log_b + img_b > budget || ev_b + log_b + img_b > avail)
             return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
     }
 

@@ -115,6 +115,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "force_splits") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
         c->force_splits = (int)value;
+    } else if (strcmp(name, "dual_max_gb") == 0) {
+        KZ_REQUIRE(value >= 0, "dual_max_gb must be >= 0");
+        c->dual_max_gb = value;
     } else if (strcmp(name, "dual_overlap") == 0) {
         c->dual_overlap = value != 0 ? 1 : 0;
     } else if (strcmp(name, "h_wide") == 0) {

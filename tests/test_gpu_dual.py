@@ -19,7 +19,8 @@ def ctx():
     c = N.Context.get()
     c.set_option("dual_force", 1)   # the test shapes are far below the size at which the shared sweep pays
     yield c
-    for name, value in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("eps_scale", 1.0), ("precision", 0)):
+    for name, value in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("eps_scale", 1.0), ("precision", 0), ("dual_max_gb", 0),
+                        ("dual_overlap", 1)):
         c.set_option(name, value)
 
 
@@ -277,3 +278,38 @@ def test_reverse_rows_of_a_k64_search_that_fail_are_researched_with_a_valid_list
     sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 54, "sqeuclidean")
     _assert_same(sep, dual)
     assert s_ba["n_escalated_rows"] > 0
+
+
+def test_footprint_gate_and_cache_trim(ctx):
+    """The shared sweep prices its transient buffers first (event buffers, log, permuted images): over budget it searches
+    twice -- same results.  kz_ctx_trim hands the cached buffers back to the driver; the next call simply allocates again."""
+    from kiez_amd import _native as N
+    a, b = _data("uniform", 30000, 64, 1, np.float32), _data("uniform", 9000, 64, 2, np.float32)
+    am, bm = N.DeviceMatrix(ctx, a, "euclidean"), N.DeviceMatrix(ctx, b, "euclidean")
+    (d1, i1, s1), (e1, j1, t1) = N.knn_dual(ctx, am, bm, 10)
+    assert s1["dual"] == 1 and t1["dual"] == 1
+    ctx.set_option("dual_max_gb", 0.001)
+    (d2, i2, s2), (e2, j2, t2) = N.knn_dual(ctx, am, bm, 10)
+    assert s2["dual"] == 0 and t2["dual"] == 0, (s2, t2)          # over budget: two ordinary searches
+    ctx.set_option("dual_max_gb", 0)
+    ctx.trim()
+    (d3, i3, s3), (e3, j3, t3) = N.knn_dual(ctx, am, bm, 10)
+    assert s3["dual"] == 1
+    for x, y, z in ((i1, i2, i3), (d1, d2, d3), (j1, j2, j3), (e1, e2, e3)):
+        np.testing.assert_array_equal(x.numpy(), y.numpy())
+        np.testing.assert_array_equal(x.numpy(), z.numpy())
+
+
+def test_second_stream_on_and_off_give_the_same_result(ctx):
+    from kiez_amd import _native as N
+    a, b = _data("clustered", 25000, 48, 3, np.float32), _data("clustered", 12000, 48, 4, np.float32)
+    am, bm = N.DeviceMatrix(ctx, a, "cosine"), N.DeviceMatrix(ctx, b, "cosine")
+    res = []
+    for ovl in (1, 0, 1):
+        ctx.set_option("dual_overlap", ovl)
+        (d, i, s), (e, j, t) = N.knn_dual(ctx, am, bm, 26)
+        assert s["dual"] == 1 and t["dual"] == 1
+        res.append((d.numpy(), i.numpy(), e.numpy(), j.numpy()))
+    for r in res[1:]:
+        for x, y in zip(res[0], r):
+            np.testing.assert_array_equal(x, y)
