@@ -331,7 +331,19 @@ __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* si
     }
 }
 
-constexpr int KZ_FIN_ROWS = 4;     // candidate rows re-ranked together by one wave (same-box A/B: 4 rows at 5 waves per SIMD beat 8 rows at 4)
+// Gather parallelism of the finalize kernel: candidate rows per group (KZ_FIN_ROWS), groups in flight per wave (KZ_FIN_DEPTH:
+// 2 = one group ahead, 3 = two) and the occupancy the kernel is compiled for (KZ_FIN_WAVES).  Round 3, same box, average
+// launch on ns / C3 (tools/job_fin.sh): rows 4 depth 2 at 4 waves per SIMD (round 2's build, 112 VGPRs) 4.06 / 8.47 ms; rows 2
+// depth 3 at 5 waves (4 spilled) 3.57 / 7.60; rows 1 depth 2 at 7 waves (70 VGPRs, no spill) 3.03 / 7.37; rows 1 depth 3 at 7
+// (6 spilled) 3.14 / 7.25; rows 4 depth 3 at 3 waves 4.96 / 9.59.  Waves in flight beat rows in flight per wave: the phases
+// around the gather loop (list load, rank select, rank sort) of one query hide under the gathers of the other waves' queries.
+#ifndef KZ_FIN_ROWS_N
+#define KZ_FIN_ROWS_N 1
+#endif
+#ifndef KZ_FIN_DEPTH
+#define KZ_FIN_DEPTH 2
+#endif
+constexpr int KZ_FIN_ROWS = KZ_FIN_ROWS_N;
 constexpr int KZ_FIN_MAXM = 4096;  // list entries per query: 4 waves x (4096*8 + 128*28) B = 142 KiB of LDS at most
 constexpr int KZ_MAX_PIECES = 64;  // index ranges per query tile (each range keeps its own K'-entry list per query)
 static int kz_max_pieces(int KP, int halves) {
@@ -571,8 +583,6 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                 for (int e = 0; e < 4; ++e) qk[e] = qk[e] / qs;
             }
         }
-        float4 cur[KZ_FIN_ROWS], nxt[KZ_FIN_ROWS];
-        double ys_c[KZ_FIN_ROWS], ys_n[KZ_FIN_ROWS];
         auto issue = [&](int c0, float4 (&buf)[KZ_FIN_ROWS], double (&ysb)[KZ_FIN_ROWS]) {
 #pragma unroll
             for (int u = 0; u < KZ_FIN_ROWS; ++u) {
@@ -582,18 +592,15 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        issue(0, cur, ys_c);
-        for (int c0 = 0; c0 < Vr; c0 += KZ_FIN_ROWS) {
-            const bool more = c0 + KZ_FIN_ROWS < Vr;   // wave-uniform
-            if (more) issue(c0 + KZ_FIN_ROWS, nxt, ys_n);
+        auto reduce = [&](int c0, const float4 (&buf)[KZ_FIN_ROWS], const double (&ysb)[KZ_FIN_ROWS]) {
 #pragma unroll
             for (int u = 0; u < KZ_FIN_ROWS; ++u) {
-                const double yk[4] = {(double)cur[u].x, (double)cur[u].y, (double)cur[u].z, (double)cur[u].w};
+                const double yk[4] = {(double)buf[u].x, (double)buf[u].y, (double)buf[u].z, (double)buf[u].w};
                 double a = 0.0;
                 if (act) {
                     if (p.metric == KZ_COSINE) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e] / ys_c[u], a);
+                        for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e] / ysb[u], a);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e], a);
@@ -604,10 +611,38 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                 if (p.metric == KZ_COSINE) {
                     v = fmin(fmax(1.0 - dot, 0.0), 2.0);
                 } else {
-                    v = fmax((qs + ys_c[u]) - 2.0 * dot, 0.0);
+                    v = fmax((qs + ysb[u]) - 2.0 * dot, 0.0);
                 }
                 if (lane == 0 && c0 + u < Vr) cv[c0 + u] = v;
             }
+        };
+#if KZ_FIN_DEPTH == 3
+        // three groups in flight (a rotating set of three register buffers, the loop unrolled by three: no copies): the gathers
+        // of groups g + 1 and g + 2 are under way while group g is reduced
+        constexpr int R = KZ_FIN_ROWS;
+        float4 b0[R], b1[R], b2[R];
+        double y0[R], y1[R], y2[R];
+        issue(0, b0, y0);
+        if (R < Vr) issue(R, b1, y1);
+        for (int c0 = 0;;) {   // (all conditions wave-uniform)
+            if (c0 + 2 * R < Vr) issue(c0 + 2 * R, b2, y2);
+            reduce(c0, b0, y0);
+            if ((c0 += R) >= Vr) break;
+            if (c0 + 2 * R < Vr) issue(c0 + 2 * R, b0, y0);
+            reduce(c0, b1, y1);
+            if ((c0 += R) >= Vr) break;
+            if (c0 + 2 * R < Vr) issue(c0 + 2 * R, b1, y1);
+            reduce(c0, b2, y2);
+            if ((c0 += R) >= Vr) break;
+        }
+#else
+        float4 cur[KZ_FIN_ROWS], nxt[KZ_FIN_ROWS];
+        double ys_c[KZ_FIN_ROWS], ys_n[KZ_FIN_ROWS];
+        issue(0, cur, ys_c);
+        for (int c0 = 0; c0 < Vr; c0 += KZ_FIN_ROWS) {
+            const bool more = c0 + KZ_FIN_ROWS < Vr;   // wave-uniform
+            if (more) issue(c0 + KZ_FIN_ROWS, nxt, ys_n);
+            reduce(c0, cur, ys_c);
             if (more) {
 #pragma unroll
                 for (int u = 0; u < KZ_FIN_ROWS; ++u) {
@@ -616,6 +651,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                 }
             }
         }
+#endif
     } else
     for (int c0 = 0; c0 < Vr; c0 += KZ_FIN_ROWS) {
         const T* yp[KZ_FIN_ROWS];
@@ -739,7 +775,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 // cache lines of one wave-interleaved block) measured 2x SLOWER than 4: finalize is latency-bound and wants many workgroups.
 constexpr int KZ_FIN_QPB = 4;
 #ifndef KZ_FIN_WAVES
-#define KZ_FIN_WAVES 4  // minimum waves per SIMD the finalize kernel is compiled for: the 16-byte row loads need ~86 VGPRs (5 waves); at 8 waves / 64 VGPRs they spill
+#define KZ_FIN_WAVES 7  // minimum waves per SIMD the finalize kernel is compiled for (see KZ_FIN_ROWS_N above; at 8 waves / 64 VGPRs it spills)
 #endif
 template <typename T>
 __global__ __launch_bounds__(256, KZ_FIN_WAVES) void kz_knn_finalize_kernel(KnnFinParams p) {
