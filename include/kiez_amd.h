@@ -84,7 +84,8 @@ int kz_ctx_trim(kz_ctx* ctx);
  * for its thresholds (default 1 = chosen from the shapes; 0 = always two ordinary searches).  Test/diagnostic knobs: "eps_scale" multiplies the
  * certification bound (huge value => every row takes the exact fallback); "force_splits" fixes the index split count
  * (0 = automatic); "min_splits", "chunk_rows", "h_wps", "h_wide", "lds_pad": scheduling / occupancy knobs;
- * "dual_max_gb": transient footprint kz_knn_dual may claim (GiB; 0 = 32: beyond it, or beyond what the device has free, it
+ * "long_k": 1 (default) = 111 .. ~540 neighbours per query run on the fused kernels (lists over many index ranges), 0 = on the
+ * exact float64 kernels like everything beyond; "dual_max_gb": transient footprint kz_knn_dual may claim (GiB; 0 = 32: beyond it, or beyond what the device has free, it
  * searches twice); "dual_overlap": 1 (default) = its reverse direction's chain runs on a second stream. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 

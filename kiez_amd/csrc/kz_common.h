@@ -22,6 +22,7 @@ struct kz_ctx {
     double eps_scale;
     int force_splits;
     int h_wps;        // tuning knob: 2 = run the fp16 kernel's two-workgroups-per-CU build also where three would fit
+    int long_k;       // 1 (default): 111 .. ~540 neighbours per query on the fused kernels (kz_knn_impl "long-k route"); 0: exact kernels
     int h_wide;       // 1: the fp16 kernel's WIDE builds (one workgroup per CU, its query tiles share one ring; kz_knn_h16.h); 0 (default): narrow
     int chunk_rows;   // test knob: query rows per chunk (0 = default 524288)
     int min_splits;   // tuning knob: minimum index splits per query tile in the large-item region

@@ -1203,7 +1203,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // sklearn_nearest_neighbors.py:51-65; INTEGRATION.md "Deviations").
     int KP = kz_pick_list_len(k_eff);
     int KSEL = 0, long_pieces = 0;
-    if (KP == 0 && !dual) {
+    if (KP == 0 && !dual && ctx->long_k) {
         const int S = k_eff / 24 + 1 > 4 ? k_eff / 24 + 1 : 4;
         const int sel = k_eff + (k_eff / 8 > 16 ? k_eff / 8 : 16);
         // (finalize: 4 waves x (S 128 entries x 8 B + KSEL x 28 B) of LDS per workgroup)

@@ -44,6 +44,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->force_splits = 0;
     c->h_wps = 0;
     c->h_wide = 0;
+    c->long_k = 1;
     c->min_splits = 1;
     c->dual_stride = 1;
     c->dual_deal = 1;
@@ -120,6 +121,8 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
         c->dual_max_gb = value;
     } else if (strcmp(name, "dual_overlap") == 0) {
         c->dual_overlap = value != 0 ? 1 : 0;
+    } else if (strcmp(name, "long_k") == 0) {
+        c->long_k = value != 0 ? 1 : 0;
     } else if (strcmp(name, "h_wide") == 0) {
         KZ_REQUIRE(value == 0 || value == 1, "h_wide must be 0 or 1");
         c->h_wide = (int)value;
