@@ -1,0 +1,7 @@
+KIEZ_AMD_LIB=$PWD/build/abl/libkiez_amd_latedeep.so timeout 900 python3 -m pytest tests/test_gpu_dual.py tests/test_gpu_northstar.py -x -q 2>&1 | tail -2
+export O=gpurun_out/late; mkdir -p $O
+WL="ns" AB="late latedeep" bash tools/job_ab.sh
+for lib in default late latedeep; do
+  if [ $lib = default ]; then unset KIEZ_AMD_LIB; else export KIEZ_AMD_LIB=$PWD/build/abl/libkiez_amd_$lib.so; fi
+  timeout 100 python3 tools/shape_ab.py 250000 1000000 200 10
+done
