@@ -36,6 +36,9 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 #ifndef KZ_H_DMA_LATE
 #define KZ_H_DMA_LATE 1
 #endif
+#ifndef KZ_H_RING8_3
+#define KZ_H_RING8_3 0
+#endif
 #ifndef KZ_WIDE_PERIOD
 #define KZ_WIDE_PERIOD 2
 #endif
@@ -60,17 +63,21 @@ struct KzHCfg {
     // issued at one barrier are needed two barriers later (s_waitcnt vmcnt(2)); the 8 KiB come from the list rows, which move
     // to the output arrays (hybrid lists: the keys stay in LDS).
     static constexpr bool DEEP = KZ_H_DEEP_RING && WPS == 3 && KP == 16 && NSR > 8;
+    // A/B switch (-DKZ_H_RING8_3=1): eight slots / four slices per barrier also at three workgroups per CU (K' = 16, more than 8
+    // slices), paid for with the list rows (hybrid lists) and a pool of 120 (104) entries per wave -- so that the late issue of
+    // the copies (KZ_H_DMA_LATE) keeps a lead of three slices there too.
+    static constexpr bool RING8_3 = KZ_H_RING8_3 && !WIDE && WPS == 3 && KP == 16 && NSR > 8;
     static constexpr bool LDS_LIST = KP <= 32;
-    static constexpr bool LISTS_FIT = (WPS == 2 || KP == 16) && !DEEP;   // K' = 32 lists do not fit beside the ring at 3 per CU
+    static constexpr bool LISTS_FIT = (WPS == 2 || KP == 16) && !DEEP && !RING8_3;   // K' = 32 lists do not fit beside the ring at 3 per CU
     // where the lists live (KzListRef, kz_knn_epi3.h): 1 = LDS, 2 = keys in LDS + rows in the output arrays, 0 = output arrays.
     // The hybrid needs K' x 512 B: K' = 64 at two per CU (with a 4-slot ring), K' = 32 at three per CU (with a smaller pool).
-    static constexpr int LMODE = (LDS_LIST && LISTS_FIT) ? 1 : (((KP == 64 && WPS == 2) || (KP == 32 && WPS == 3) || DEEP) ? 2 : 0);
+    static constexpr int LMODE = (LDS_LIST && LISTS_FIT) ? 1 : (((KP == 64 && WPS == 2) || (KP == 32 && WPS == 3) || DEEP || RING8_3) ? 2 : 0);
     static constexpr bool IN_LDS = LMODE == 1;
     // (WIDE: the ring is shared, so the LDS of the other rings is free -- eight slots, which is what lets the groups of a wide
     //  workgroup run staggered, see LAGP)
     // WIDE: eight slots, one barrier per four slices -- a barrier of a wide workgroup stops every wave of the CU (same-box,
     // 250k x 1M x 200, ordinary kernel: 4 slots / 2 slices per barrier 91.8 ms, 8 / 4: 85.0 ms, 12 / 6: 90.0 ms, narrow 88-89.6)
-    static constexpr int RING = DEEP ? 6 : (WIDE ? 8 : ((WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8));
+    static constexpr int RING = DEEP ? 6 : ((WIDE || RING8_3) ? 8 : ((WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8));
     // WIDE: the groups of four waves are STAGGERED -- group b runs LAGP periods behind group b - 1 -- so that their tile
     // epilogues fall at different times (a wide workgroup is all the CU has: waves that reach the epilogue together leave the
     // matrix pipe empty).  A slot is refilled only when the LAST group has read it: (TPW - 1) LAGP + 2 periods must fit the ring.
@@ -79,7 +86,7 @@ struct KzHCfg {
     static_assert(!WIDE || ((TPW - 1) * LAGP + 2) * PERIOD <= RING, "staggered groups overrun the ring");
     // (three per CU: the workgroup must stay within 42 LDS granules of 1280 B -- 52.5 KiB with the lists of K' = 16 or the
     //  keys of K' = 32; the dual-pass build pays for its 1.5 KiB of thresholds and query offsets with 16 pool entries)
-    static constexpr int CAP = WPS == 3 ? (KP <= 32 ? (DUAL ? 176 : 192) : 256) : (LMODE == 2 && RING == 8 ? (DUAL ? 140 : 156) : 256);     // event-pool entries per wave (24 B each)
+    static constexpr int CAP = RING8_3 ? (DUAL ? 104 : 120) : WPS == 3 ? (KP <= 32 ? (DUAL ? 176 : 192) : 256) : (LMODE == 2 && RING == 8 ? (DUAL ? 140 : 156) : 256);     // event-pool entries per wave (24 B each)
     static constexpr int RING_BYTES = RING * 4096;
     static constexpr int BIAS_OFF = RING_BYTES;                        // 2 x 128 floats
     static constexpr int SYNC_OFF = BIAS_OFF + 1024;                   // 4 merge flags (+ padding)
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     constexpr int R = Cfg::RING, P = Cfg::PERIOD, CAP = Cfg::CAP;
     constexpr int DEPTH = Cfg::DEEP ? 3 : 2;   // 2: a slice is issued one period before it is read (whatever the ring holds besides); 3: two
     constexpr bool POW2 = (R & (R - 1)) == 0;
-    constexpr bool LATE = KZ_H_DMA_LATE == 2 || (KZ_H_DMA_LATE == 1 && WPS == 2 && !WIDE);
+    constexpr bool LATE = KZ_H_DMA_LATE == 2 || (KZ_H_DMA_LATE == 1 && (WPS == 2 || Cfg::RING8_3) && !WIDE);
     constexpr int IN_LDS = Cfg::LMODE;   // list storage mode (KzListRef)
     // at three waves per SIMD (168 VGPRs) the first fragments of the next tile are NOT fetched across the epilogue: the 16
     // registers they would occupy there are what keeps the stationary query tile out of scratch memory.  Exception: a tile
