@@ -25,9 +25,6 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 // (Every tile must contain a slice barrier -- the bias double buffer and the merge flags rely on it -- so the barrier
 // period RING / 2 never exceeds the slice count; NSR >= 2 is required by the host.)
 // DUAL: the dual-pass build (kz_knn_epi3.h "Dual pass"): + 1.5 KiB (thresholds of three tiles, the queries' offsets).
-#ifndef KZ_H_DEEP_RING
-#define KZ_H_DEEP_RING 0   // A/B switch (tools/ab_build.sh deep -DKZ_H_DEEP_RING=1).  Measured same-box on 250k x 1M x 200: ordinary kernel 90.8 against 90.7 ms, shared sweep 97.5 against 94.8 ms -- the wait in front of the barrier is not a latency a deeper ring hides
-#endif
 // LDS-DMA copies that a barrier releases are issued one slice LATER, behind that slice's MFMAs, where this wave has no LDS read in
 // flight (the guide prices an LDS-DMA issued among LDS reads at 100-185 cycles of the issuing wave, 25-60 in a gap without them).
 // 1 (default) = at two workgroups per CU (8-slot ring, four slices per barrier: the copies still lead their use by three slices);
@@ -35,15 +32,6 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 // workgroups per CU (4-slot ring: the lead shrinks to one slice) ns 91.0 -> 92.1, ordinary kernel 87.9 -> 91.1; C1 2.75 -> 2.75.
 #ifndef KZ_H_DMA_LATE
 #define KZ_H_DMA_LATE 1
-#endif
-#ifndef KZ_H_RING8_3
-#define KZ_H_RING8_3 0
-#endif
-#ifndef KZ_WIDE_PERIOD
-#define KZ_WIDE_PERIOD 2
-#endif
-#ifndef KZ_WIDE_LAG
-#define KZ_WIDE_LAG 0   // staggered groups (see LAGP): measured with 2 slices per barrier, 250k x 1M x 200: 106 ms against 87 ms narrow
 #endif
 // WIDE: ONE workgroup of 4 x WPS waves per CU instead of WPS workgroups of 4 waves: its WPS query tiles share one ring, so
 // every index slice is copied into the CU's LDS once instead of WPS times.  Measured on the scan-less kernel (tools/ablate.sh
@@ -56,37 +44,20 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 template <int KP, int WPS, int NSR, bool DUAL = false, bool WIDE = false>
 struct KzHCfg {
     static constexpr int TPW = WIDE ? WPS : 1;                         // query tiles (of 128 rows) per workgroup
-    // DEEP: three workgroups per CU with a single fragment set (more than 8 slices, K' = 16: the north-star shape).  The wave
-    // reads a slice right before its MFMAs, so a ring of 2 periods leaves the DMA engine ONE period (2 slices ~ 700 cycles)
-    // between issue and use -- less than an L2 round trip under load (stamp build, 250k x 1M x 200: 1914 of 8775 cycles per
-    // wave-tile waiting at s_waitcnt vmcnt(0), another 769 at the barrier behind it).  Six slots = three periods: the slices
-    // issued at one barrier are needed two barriers later (s_waitcnt vmcnt(2)); the 8 KiB come from the list rows, which move
-    // to the output arrays (hybrid lists: the keys stay in LDS).
-    static constexpr bool DEEP = KZ_H_DEEP_RING && WPS == 3 && KP == 16 && NSR > 8;
-    // A/B switch (-DKZ_H_RING8_3=1): eight slots / four slices per barrier also at three workgroups per CU (K' = 16, more than 8
-    // slices), paid for with the list rows (hybrid lists) and a pool of 120 (104) entries per wave -- so that the late issue of
-    // the copies (KZ_H_DMA_LATE) keeps a lead of three slices there too.
-    static constexpr bool RING8_3 = KZ_H_RING8_3 && !WIDE && WPS == 3 && KP == 16 && NSR > 8;
     static constexpr bool LDS_LIST = KP <= 32;
-    static constexpr bool LISTS_FIT = (WPS == 2 || KP == 16) && !DEEP && !RING8_3;   // K' = 32 lists do not fit beside the ring at 3 per CU
+    static constexpr bool LISTS_FIT = WPS == 2 || KP == 16;   // K' = 32 lists do not fit beside the ring at 3 per CU
     // where the lists live (KzListRef, kz_knn_epi3.h): 1 = LDS, 2 = keys in LDS + rows in the output arrays, 0 = output arrays.
     // The hybrid needs K' x 512 B: K' = 64 at two per CU (with a 4-slot ring), K' = 32 at three per CU (with a smaller pool).
-    static constexpr int LMODE = (LDS_LIST && LISTS_FIT) ? 1 : (((KP == 64 && WPS == 2) || (KP == 32 && WPS == 3) || DEEP || RING8_3) ? 2 : 0);
+    static constexpr int LMODE = (LDS_LIST && LISTS_FIT) ? 1 : (((KP == 64 && WPS == 2) || (KP == 32 && WPS == 3)) ? 2 : 0);
     static constexpr bool IN_LDS = LMODE == 1;
-    // (WIDE: the ring is shared, so the LDS of the other rings is free -- eight slots, which is what lets the groups of a wide
-    //  workgroup run staggered, see LAGP)
     // WIDE: eight slots, one barrier per four slices -- a barrier of a wide workgroup stops every wave of the CU (same-box,
-    // 250k x 1M x 200, ordinary kernel: 4 slots / 2 slices per barrier 91.8 ms, 8 / 4: 85.0 ms, 12 / 6: 90.0 ms, narrow 88-89.6)
-    static constexpr int RING = DEEP ? 6 : ((WIDE || RING8_3) ? 8 : ((WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8));
-    // WIDE: the groups of four waves are STAGGERED -- group b runs LAGP periods behind group b - 1 -- so that their tile
-    // epilogues fall at different times (a wide workgroup is all the CU has: waves that reach the epilogue together leave the
-    // matrix pipe empty).  A slot is refilled only when the LAST group has read it: (TPW - 1) LAGP + 2 periods must fit the ring.
-    static constexpr int PERIOD = DEEP ? 2 : ((WIDE && KZ_WIDE_LAG > 0) ? KZ_WIDE_PERIOD : RING / 2);   // slices per barrier
-    static constexpr int LAGP = WIDE ? KZ_WIDE_LAG : 0;                // periods between consecutive groups of a wide workgroup
-    static_assert(!WIDE || ((TPW - 1) * LAGP + 2) * PERIOD <= RING, "staggered groups overrun the ring");
+    // 250k x 1M x 200, ordinary kernel: 4 slots / 2 slices per barrier 91.8 ms, 8 / 4: 85.0 ms, 12 / 6: 90.0 ms, narrow 88-89.6;
+    // the wave groups staggered by a period with a barrier per 2 slices: 106 ms -- profiles/r03_ablation.md)
+    static constexpr int RING = WIDE ? 8 : ((WPS == 3 || KP == 32 || NSR < 4) ? 4 : 8);
+    static constexpr int PERIOD = RING / 2;                            // slices per barrier: a slot is refilled one period before it is read
     // (three per CU: the workgroup must stay within 42 LDS granules of 1280 B -- 52.5 KiB with the lists of K' = 16 or the
     //  keys of K' = 32; the dual-pass build pays for its 1.5 KiB of thresholds and query offsets with 16 pool entries)
-    static constexpr int CAP = RING8_3 ? (DUAL ? 104 : 120) : WPS == 3 ? (KP <= 32 ? (DUAL ? 176 : 192) : 256) : (LMODE == 2 && RING == 8 ? (DUAL ? 140 : 156) : 256);     // event-pool entries per wave (24 B each)
+    static constexpr int CAP = WPS == 3 ? (KP <= 32 ? (DUAL ? 176 : 192) : 256) : (LMODE == 2 && RING == 8 ? (DUAL ? 140 : 156) : 256);     // event-pool entries per wave (24 B each)
     static constexpr int RING_BYTES = RING * 4096;
     static constexpr int BIAS_OFF = RING_BYTES;                        // 2 x 128 floats
     static constexpr int SYNC_OFF = BIAS_OFF + 1024;                   // 4 merge flags (+ padding)
@@ -108,9 +79,8 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     using Cfg = KzHCfg<KP, WPS, NSR, DUAL, WIDE>;
     constexpr int TPW = Cfg::TPW;
     constexpr int R = Cfg::RING, P = Cfg::PERIOD, CAP = Cfg::CAP;
-    constexpr int DEPTH = Cfg::DEEP ? 3 : 2;   // 2: a slice is issued one period before it is read (whatever the ring holds besides); 3: two
-    constexpr bool POW2 = (R & (R - 1)) == 0;
-    constexpr bool LATE = KZ_H_DMA_LATE == 2 || (KZ_H_DMA_LATE == 1 && (WPS == 2 || Cfg::RING8_3) && !WIDE);
+    static_assert((R & (R - 1)) == 0 && R == 2 * P, "slot arithmetic below: a power-of-two ring of two periods");
+    constexpr bool LATE = KZ_H_DMA_LATE == 2 || (KZ_H_DMA_LATE == 1 && WPS == 2 && !WIDE);
     constexpr int IN_LDS = Cfg::LMODE;   // list storage mode (KzListRef)
     // at three waves per SIMD (168 VGPRs) the first fragments of the next tile are NOT fetched across the epilogue: the 16
     // registers they would occupy there are what keeps the stationary query tile out of scratch memory.  Exception: a tile
@@ -122,8 +92,6 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     constexpr bool ONE_SET = WPS == 3 && NSR > 8;
     constexpr bool RECOMP = DUAL && ONE_SET;   // kz_merge_pool3: block minima re-read per merge instead of carried
     constexpr int LAG = ONE_SET ? 1 : 2;   // slices between a barrier and the oldest slot it may hand to the DMA engine
-    static_assert(!Cfg::DEEP || P == 2, "the counted wait below is written for two slices per barrier");
-    static_assert(POW2 || ONE_SET, "a ring that is not a power of two tracks the read slot of the CURRENT slice only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ybuf = reinterpret_cast<float*>(smem);                       // R slots x 1024 floats
     float* bbuf = reinterpret_cast<float*>(smem + Cfg::BIAS_OFF);       // 2 x 128 bias floats
@@ -212,15 +180,10 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
         if (!WIDE || tb == dma_turn) kz_glds16_s(dma_src, (unsigned)lane_off, dst);
         if constexpr (WIDE) dma_turn = dma_turn + 1 == TPW ? 0 : dma_turn + 1;
         dma_src += 4096;
-        if constexpr (POW2)
-            dma_slot = (dma_slot + 1) & (R - 1);
-        else
-            dma_slot = dma_slot + 1 == R ? 0 : dma_slot + 1;
+        dma_slot = (dma_slot + 1) & (R - 1);
     };
-    // (DEPTH periods ahead of the first group's reads -- the whole ring unless it also holds the slices the staggered groups
-    //  of a wide workgroup have yet to read)
 #pragma unroll
-    for (int i = 0; i < DEPTH * P; ++i) dma_next();
+    for (int i = 0; i < R; ++i) dma_next();
     bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
     KzDualRef du;
     if constexpr (DUAL) {
@@ -242,9 +205,8 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     // two static fragment sets selected by the parity of the global slice counter (no register copies)
     kz_f16x8 f0[4], f1[4];
     int dma_due = 0;   // KZ_H_DMA_LATE: a barrier has released slots whose copies are still to be issued (uniform)
-    int rslot = 0;   // (ring that is not a power of two) slot of the current slice g: g mod R, kept incrementally (uniform)
     auto fetch_frags = [&](kz_f16x8 (&f)[4], const int gi) {
-        const float* fb = fbase + (POW2 ? (gi & (R - 1)) : rslot) * 1024;
+        const float* fb = fbase + (gi & (R - 1)) * 1024;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) f[mt] = *reinterpret_cast<const kz_f16x8*>(fb + 128 * mt);
     };
@@ -434,17 +396,13 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
 #else
             // (ONE_SET: nothing is prefetched, a wave at the barrier has read the slices <= g only: the barrier sits one
             //  slice later in the period -- (g + 1) % P == 0 -- and hands out the slots of slices g-P+1 .. g.)
-            // (a ring that is not a power of two -- ONE_SET only -- counts with rslot = g mod R, R a multiple of P: (g + 1) % P == 0)
-            if (POW2 ? ((ONE_SET ? odd : !odd) && (P == 2 || ((g + LAG) & (P - 1)) == 0)) : ((rslot + 1) % P == 0)) {
+            if ((ONE_SET ? odd : !odd) && (P == 2 || ((g + LAG) & (P - 1)) == 0)) {
 #endif
 #ifdef KZ_STAMP
                 {
                     __builtin_amdgcn_sched_barrier(0);
                     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                    if constexpr (DEPTH == 3)
-                        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-                    else
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     const unsigned long long w1 = __builtin_amdgcn_s_memtime();
                     asm volatile("s_barrier" ::: "memory");
                     c_dma += w1 - w0;
@@ -452,16 +410,10 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #else
-                // (DEPTH 3: the slices of the NEXT period were issued two barriers ago; the P issued at the previous barrier are
-                //  this wave's youngest LDS-DMAs and may stay in flight.  Anything issued later -- the bias / threshold copy of
-                //  this tile, list stores of a merge -- only makes the counted wait stricter: completion is in issue order)
 #if defined(KZ_EXP) && KZ_EXP == 6
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // diagnostic build: DMA ring without the slice barrier (races; timing only)
 #else
-                if constexpr (DEPTH == 3)
-                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 #endif
                 if constexpr (LATE) {
@@ -473,13 +425,12 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
                     {
 #if !(defined(KZ_EXP) && KZ_EXP == 5)   // (5: diagnostic build with the slice barrier but no DMA behind the prologue -- stale data; timing only)
 #pragma unroll
-                        for (int i = 0; i < P; ++i) dma_next();   // slices g+(DEPTH-1)P+LAG .. g+DEPTH P+LAG-1, in order
+                        for (int i = 0; i < P; ++i) dma_next();   // slices g+P+LAG .. g+2P+LAG-1, in order
 #endif
                     }
                 }
             }
             ++g;
-            if constexpr (!POW2) rslot = rslot + 1 == R ? 0 : rslot + 1;
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef KZ_STAMP
@@ -506,15 +457,6 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
 #endif
     };
 
-    // an empty period: the barrier of a period in which this group reads nothing (every wave of the workgroup executes the
-    // same sequence of barriers and DMA issues; a staggered group starts late and the leading groups wait at the end)
-    auto empty_period = [&]() {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < P; ++i) dma_next();
-    };
-    if constexpr (WIDE && Cfg::LAGP > 0)
-        for (int i = 0; i < tb * Cfg::LAGP; ++i) empty_period();
     int tile = t_begin;
     for (;;) {
         run_tile(tile, std::integral_constant<int, 0>{});
@@ -522,8 +464,6 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
         run_tile(tile, std::integral_constant<int, (NSR & 1)>{});
         if (++tile >= t_end) break;
     }
-    if constexpr (WIDE && Cfg::LAGP > 0)
-        for (int i = 0; i < (TPW - 1 - tb) * Cfg::LAGP; ++i) empty_period();
     if constexpr (IN_LDS != 0) {
         // the sweep is over: what lived in LDS goes to the output arrays in the layout kz_knn_finalize_kernel reads
         const int64_t listoff = out_list_offset();
