@@ -53,6 +53,15 @@ def _both_ways(ctx, a, b, k, metric):
     return (d_ab.numpy(), i_ab.numpy(), d_ba.numpy(), i_ba.numpy()), (xd.numpy(), xi.numpy(), yd.numpy(), yi.numpy()), s_ab, s_ba
 
 
+def _oracle_sample(a, b, k, metric, dual):
+    """... and not only against the library's own two searches: a row sample of BOTH directions against the oracle."""
+    from oracle import kiez_oracle as O
+    a64, b64 = (a.astype(np.float64), b.astype(np.float64)) if metric == "cosine" else (a, b)
+    ra, rb = np.arange(0, len(a), max(1, len(a) // 200))[:200], np.arange(0, len(b), max(1, len(b) // 200))[:200]
+    np.testing.assert_array_equal(dual[1][ra], O.knn_exact(a64[ra], b64, k, metric)[1])
+    np.testing.assert_array_equal(dual[3][rb], O.knn_exact(b64[rb], a64, k, metric)[1])
+
+
 def _assert_same(sep, dual):
     for name, x, y in zip(("dist a->b", "ind a->b", "dist b->a", "ind b->a"), sep, dual):
         np.testing.assert_array_equal(y, x, err_msg=name)
@@ -73,6 +82,8 @@ def test_both_directions_identical_to_two_searches(ctx, kind, na, nb, d, k, metr
     a, b = _data(kind, na, d, 1, dtype), _data(kind, nb, d, 2, dtype)
     sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, k, metric)
     _assert_same(sep, dual)
+    if kind != "duplicates":
+        _oracle_sample(a, b, k, metric, dual)
     if kind != "duplicates":                      # (exact ties: more than a quarter of the rows fail the fp16 certification, the
         assert s_ab["dual"] == 1                  #  call gives up on sharing; the forward direction otherwise always shares ...
     assert s_ab["max_err_ratio"] < 1.0 and s_ba["max_err_ratio"] < 1.0
