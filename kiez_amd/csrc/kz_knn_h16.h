@@ -73,6 +73,8 @@ struct KzHCfg {
 template <int KP, int NSR, int WPS, bool DUAL = false, bool WIDE = false>
 #if defined(KZ_EXP) && KZ_EXP == 8
 __global__ __launch_bounds__(256, 1) void kz_knn_cand_h_kernel(KnnCandParams p) {   // (diagnostic: one wave per SIMD, 512 registers)
+#elif defined(KZ_EXP) && KZ_EXP == 9
+__global__ __launch_bounds__(256, 2) void kz_knn_cand_h_kernel(KnnCandParams p) {   // (diagnostic: 64 queries per wave at two waves per SIMD)
 #else
 __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn_cand_h_kernel(KnnCandParams p) {
 #endif
@@ -214,8 +216,8 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     int g = 0;
     int th_cur = 0;   // dual pass: threshold buffer of the current tile (uniform)
     f32x16 acc[4];
-#if defined(KZ_EXP) && KZ_EXP == 8
-    // diagnostic build (timing only, results WRONG): the bare loop of a ONE-WAVE-PER-SIMD kernel -- 64 queries per wave (the
+#if defined(KZ_EXP) && (KZ_EXP == 8 || KZ_EXP == 9)
+    // diagnostic build (timing only, results WRONG): the bare loop of a ONE-WAVE-PER-SIMD kernel (9: two waves per SIMD) -- 64 queries per wave (the
     // index fragment of a slice feeds two MFMAs: half the LDS reads per MFMA), 8 accumulators.  Every wave does TWICE the work
     // of the shipped kernel on the same grid: compare half its time with exp2.
     f32x16 acc8[2][4];
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
                 // for the previous tile; the buffer written here was last read two tiles ago, with a slice barrier in between.
                 kz_glds4_s(p.theta + ((int64_t)min(tile + 1, p.n_ytiles - 1) - 1) * KZ_TILE, off4, tbuf + (th_cur == 2 ? 0 : th_cur + 1) * 64);
         }
-#if defined(KZ_EXP) && KZ_EXP == 8
+#if defined(KZ_EXP) && (KZ_EXP == 8 || KZ_EXP == 9)
         {
             kz_f16x8 fa[4], fb4[4];
             fetch_frags(fa, g);
