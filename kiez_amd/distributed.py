@@ -450,15 +450,21 @@ class ShardedKiez:
             if multi:
                 W, K = comm.world, self.K
                 if needs_ind:
-                    # exact ordering values (the rounded output distances hide ties) + distances + global ids: ONE all-to-all
-                    keys = eng.pair_values(self.T, 0, self.n_t, self.S, i_rev)
+                    # distances + global ids, and -- where the OUTPUT distance is a rounded function of the value the search
+                    # ranked by (euclidean: sqrt, for float32 inputs through float32) -- the exact ordering values too: merging
+                    # by rounded distances would break ties differently from one GPU.  ONE all-to-all either way.
                     gids = (i_rev + self.s_begin).contiguous()
-                    pack = torch.stack([keys, d_rev, gids.view(torch.float64)], dim=1)          # [n_t, 3, K]
-                    parts = comm.all_to_all_rows(pack, t_counts)                                # [W, t_count, 3, K]
+                    lossless = self.metric in ("sqeuclidean", "cosine")     # the returned distance IS the ordering value
+                    planes = [d_rev, gids.view(torch.float64)] if lossless else \
+                        [eng.pair_values(self.T, 0, self.n_t, self.S, i_rev), d_rev, gids.view(torch.float64)]
+                    parts = comm.all_to_all_rows(torch.stack(planes, dim=1), t_counts)          # [W, t_count, 2 or 3, K]
 
                     def seg(c):
                         return parts[:, :, c].permute(1, 0, 2).reshape(t_count, W * K).contiguous()
-                    d_t2s, i_t2s = eng.merge_topk(seg(0), seg(2).view(torch.int64), seg(1), W, K, K)
+                    if lossless:
+                        d_t2s, i_t2s = eng.merge_topk(seg(0), seg(1).view(torch.int64), None, W, K, K)
+                    else:
+                        d_t2s, i_t2s = eng.merge_topk(seg(0), seg(2).view(torch.int64), seg(1), W, K, K)
                 else:
                     parts = comm.all_to_all_rows(d_rev, t_counts)                               # [W, t_count, K]
                     merged = parts.permute(1, 0, 2).reshape(t_count, W * K).contiguous()
