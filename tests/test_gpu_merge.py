@@ -1,7 +1,6 @@
 """The multi-GPU exchange kernels (kz_pair_values, kz_merge_topk) and the kernels for more than 128 candidates per query
 (wide kz_select_topk / kz_mp_empiric; the reference has no cap on n_candidates, kiez/hubness_reduction/base.py:20-27).
 Needs an MI355X: `pytest -m gpu`."""
-import ctypes as C
 import warnings
 
 import numpy as np
