@@ -56,10 +56,12 @@ class _StagedComm(Comm):
 eng = HipEngine(0)
 eng.ctx.set_option("dual_force", 1)      # the shared sweep also on these small shards
 rng = np.random.RandomState(29)
-source = rng.rand(9000, 40).astype(np.float32)
+source = rng.rand(9001, 40).astype(np.float32)
 target = rng.rand(7001, 40).astype(np.float32)
-b = 0 if rank == 0 else 5200             # uneven shards: 5200 + 3800 rows
-c = 5200 if rank == 0 else 3800
+if world == 2:
+    b, c = (0, 5200) if rank == 0 else (5200, 3801)      # uneven shards
+else:
+    b, c = row_slice(len(source), rank, world)
 CASES = [("none", None, {}, "euclidean"), ("csls", "CSLS", {}, "euclidean"), ("ls", "LocalScaling", {"method": "standard"}, "euclidean"),
          ("nicdm", "LocalScaling", {"method": "nicdm"}, "cosine"), ("mp_normal", "MutualProximity", {"method": "normal"}, "sqeuclidean"),
          ("mp_empiric", "MutualProximity", {"method": "empiric"}, "euclidean"), ("mp_empiric_cos", "MutualProximity", {"method": "empiric"}, "cosine"),
@@ -69,7 +71,6 @@ for name, hub, kw, metric in CASES:
     s_in = source.astype(np.float64) if metric == "cosine" else source
     t_in = target.astype(np.float64) if metric == "cosine" else target
     comm = _StagedComm()
-    # (row_slice is not used for the shards here: ShardedKiez takes whatever shard sizes the ranks bring)
     sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": metric}, hubness=hub, hubness_kwargs=kw, engine=eng, comm=comm)
     sk.fit(s_in[b:b + c], t_in if rank == 0 else None)
     d, i = sk.kneighbors(k)
@@ -102,11 +103,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_ranks_of_the_hip_engine_on_one_gpu():
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_of_the_hip_engine_on_one_gpu(world):
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
         procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT % str(ROOT)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
