@@ -31,6 +31,13 @@ __device__ __forceinline__ double kz_operand(const T* x, int k, int d, int metri
     return metric == KZ_COSINE ? (double)x[k] / nrm : (double)x[k];
 }
 
+#ifndef KZ_NORM_ROWS
+#define KZ_NORM_ROWS 2   // (1M x 200 float32: 1 row 247 us, 2 rows 238, 4 rows 285, 8 rows 376)
+#endif
+#ifndef KZ_ROWGROUP_MAX_BLOCKS
+#define KZ_ROWGROUP_MAX_BLOCKS 4096
+#endif
+
 // ---- create: norms, bias, maxima, finiteness ------------------------------------------------------------------
 // stats[0] = max row norm, stats[1] = max |operand element| (bits of non-negative doubles order as integers)
 template <typename T>
@@ -41,37 +48,84 @@ __global__ __launch_bounds__(256) void kz_norms_kernel(const T* __restrict__ raw
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double wmax = 0.0, amax = 0.0;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_pad; row += (int64_t)gridDim.x * 4) {
-        if (row >= n) {
-            if (lane == 0) bias[row] = -INFINITY;
-            continue;
+    const bool vec = kz_row_vec_ok(raw, d);
+    // KZ_NORM_ROWS consecutive rows per wave and iteration, their loads issued together (one row at a time left one memory
+    // round trip in flight per wave: 1M x 200 float32 took 490 us, 1.6 TB/s).  Per row the arithmetic IS kz_wave_dot(x, x):
+    // the same lane owns the same elements, the same fma chain, the same butterfly -- sqn keeps its bits.
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * KZ_NORM_ROWS; row0 < n_pad; row0 += (int64_t)gridDim.x * 4 * KZ_NORM_ROWS) {
+        double acc[KZ_NORM_ROWS], am[KZ_NORM_ROWS];
+#pragma unroll
+        for (int r = 0; r < KZ_NORM_ROWS; ++r) acc[r] = am[r] = 0.0;
+        for (int k0 = 4 * lane; k0 < d; k0 += 256) {
+            double x[KZ_NORM_ROWS][4];
+#pragma unroll
+            for (int r = 0; r < KZ_NORM_ROWS; ++r) {
+                if (row0 + r < n) {
+                    kz_row4(raw + (row0 + r) * (int64_t)d, k0, d, vec, x[r]);
+                } else {
+                    x[r][0] = x[r][1] = x[r][2] = x[r][3] = 0.0;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < KZ_NORM_ROWS; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[r] = fma(x[r][u], x[r][u], acc[r]);
+                    const double a = fabs(x[r][u]);
+                    if (a <= 1e300) am[r] = fmax(am[r], a);
+                }
         }
-        const T* x = raw + row * (int64_t)d;
-        const double sq = kz_wave_dot(x, x, d, lane);
-        if (!(sq <= 1e30)) {  // NaN, inf, or too large for the float32 operand image
-            if (lane == 0) atomicOr(bad_flag, 1);
+        // (n_pad is a multiple of 128: a group never straddles it.)  Float64 sqrt and division are long instruction sequences the
+        // whole wave executes: the euclidean family takes ONE sqrt per workgroup (of the largest squared norm -- sqrt is
+        // monotone), cosine one sqrt and one division per GROUP (lane r works for row r of the group).
+        double sq[KZ_NORM_ROWS];
+#pragma unroll
+        for (int r = 0; r < KZ_NORM_ROWS; ++r) {
+            sq[r] = row0 + r < n ? kz_wave_sum(acc[r]) : 0.0;
+            if (!(sq[r] <= 1e30)) {  // NaN, inf, or too large for the float32 operand image
+                if (lane == 0) atomicOr(bad_flag, 1);
+            }
         }
-        double nrm = 1.0;
+        const int sel = lane & (KZ_NORM_ROWS - 1);
+        double mine = sq[0];
+#pragma unroll
+        for (int r = 1; r < KZ_NORM_ROWS; ++r) mine = sel == r ? sq[r] : mine;
+        const int64_t my_row = row0 + sel;
         if (metric == KZ_COSINE) {
-            nrm = sqrt(sq);
+            double a_mine = 0.0;
+#pragma unroll
+            for (int r = 0; r < KZ_NORM_ROWS; ++r) {
+                double a = am[r];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) a = fmax(a, __shfl_xor(a, off, 64));
+                a_mine = sel == r ? a : a_mine;
+            }
+            double nrm = sqrt(mine);
             if (nrm == 0.0) nrm = 1.0;  // sklearn normalize(): zero rows stay zero
-            if (lane == 0) {
-                sqn[row] = nrm;
-                bias[row] = 0.0f;
+            // max |operand element| of the row: |x| / nrm is monotone in |x|, so the largest |x| divided once is the largest quotient
+            const double v = a_mine / nrm;
+            if (my_row < n) {
+                if (v <= 1e300) amax = fmax(amax, v);
+                wmax = 1.0;
+                if (lane < KZ_NORM_ROWS) {
+                    sqn[my_row] = nrm;
+                    bias[my_row] = 0.0f;
+                }
             }
-            wmax = fmax(wmax, 1.0);
         } else {
-            if (lane == 0) {
-                sqn[row] = sq;
-                bias[row] = (float)(-0.5 * sq);
+#pragma unroll
+            for (int r = 0; r < KZ_NORM_ROWS; ++r) {
+                wmax = fmax(wmax, sq[r]);      // (squared; the root is taken once, below)
+                amax = fmax(amax, am[r]);
             }
-            wmax = fmax(wmax, sqrt(sq));
+            if (lane < KZ_NORM_ROWS && my_row < n) {
+                sqn[my_row] = mine;
+                bias[my_row] = (float)(-0.5 * mine);
+            }
         }
-        for (int k = lane; k < d; k += 64) {
-            const double v = fabs(kz_operand(x, k, d, metric, nrm));
-            if (v <= 1e300) amax = fmax(amax, v);
-        }
+        if (lane < KZ_NORM_ROWS && my_row >= n) bias[my_row] = -INFINITY;   // rows past the end
     }
+    if (metric != KZ_COSINE) wmax = sqrt(wmax);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
     if (lane == 0) {
@@ -200,7 +254,7 @@ __global__ __launch_bounds__(256) void kz_center_finish_kernel(const double* __r
     }
 }
 
-// One wave per row.  v = float32(x - mu) is the centred operand (the "exact" vector of the certification: its distance
+// Four rows per wave (lane layout below).  v = float32(x - mu) is the centred operand (the "exact" vector of the certification: its distance
 // to another centred row differs from the true distance only by float32 centring round-off, accounted for in the bound),
 // x_h = fp16(S v) / S the operand the matrix pipe multiplies.  Values below the fp16 normal range are stored as zero
 // (no dependence on the denormal mode of the matrix pipe), values beyond it are clamped; both end up in the residual.
@@ -213,54 +267,87 @@ __global__ __launch_bounds__(256) void kz_pack_h_kernel(const T* __restrict__ ra
     __shared__ double s_m[3][4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int r4 = lane & 3, kb = lane >> 2;
     const int d_pad = nsr * 16;
     const double S = scale[0];
+    const double invS = 1.0 / S;   // S is a power of two: x * invS == x / S, bit for bit, without the float64 division sequence
     const float Sf = (float)S;
+    const bool vec = kz_row_vec_ok(raw, d);
     double m_h = 0.0, m_r = 0.0, m_c = 0.0;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_pad; row += (int64_t)gridDim.x * 4) {
+    // Four consecutive rows per wave: lane 4 kb + r4 owns elements 128 c + 8 kb .. + 7 of row 4 g + r4 -- ONE 16-byte fragment of
+    // the image per chunk c, read with two 16-byte loads and written with one 16-byte store; the four lanes of a kb write
+    // four consecutive rows = 64 contiguous bytes.  (One row per wave with 2-byte stores: 1M x 200 took 790 us, 1.6 TB/s.)
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g * 4 < n_pad; g += (int64_t)gridDim.x * 4) {
+        const int64_t row = g * 4 + r4;
         const int64_t tile = row >> 7;
         const int r = (int)(row & 127);
         _Float16* dst = reinterpret_cast<_Float16*>(packed) + (tile * nsr) * (int64_t)(2 * KZ_TILE * 8) + r * 8;
-        auto off = [](int k) { return (int64_t)(k >> 4) * (2 * KZ_TILE * 8) + ((k >> 3) & 1) * (KZ_TILE * 8) + (k & 7); };
-        if (row >= n) {
-            for (int k = lane; k < d_pad; k += 64) dst[off(k)] = (_Float16)0.0f;
-            if (lane == 0) bias[row] = -INFINITY;
-            continue;
-        }
+        const bool live = row < n;   // rows past the end: zero image, bias -inf
         // perm (dual pass, kz_knn_dual.h): image row `row` holds matrix row perm[row]; only the image and the bias are written
-        const int64_t srow = perm ? (int64_t)perm[row] : row;
+        const int64_t srow = !live ? 0 : (perm ? (int64_t)perm[row] : row);
         const T* x = raw + srow * (int64_t)d;
-        const double nrm = metric == KZ_COSINE ? sqn[srow] : 1.0;
+        const double nrm = (live && metric == KZ_COSINE) ? sqn[srow] : 1.0;
         double c2 = 0.0, h2 = 0.0, r2 = 0.0;
-        for (int k = lane; k < d_pad; k += 64) {
-            float v = 0.0f;
-            if (k < d) v = (float)(kz_operand(x, k, d, metric, nrm) - (double)mu[k]);
-            float vs = v * Sf;                                       // exact: S is a power of two
-            if (fabsf(vs) < 6.103515625e-05f) vs = 0.0f;             // below the fp16 normal range
-            vs = fminf(fmaxf(vs, -65504.0f), 65504.0f);
-            const _Float16 hv = (_Float16)vs;                        // round to nearest even
-            dst[off(k)] = hv;
-            const double xh = (double)(float)hv / S;
-            const double res = (double)v - xh;
-            c2 = fma((double)v, (double)v, c2);
-            h2 = fma(xh, xh, h2);
-            r2 = fma(res, res, r2);
-        }
-        c2 = kz_wave_sum(c2);
-        h2 = kz_wave_sum(h2);
-        r2 = kz_wave_sum(r2);
-        const double nh = sqrt(h2), nr = sqrt(r2);
-        if (lane == 0) {
-            if (rowq) {
-                rowq[row * 3 + 0] = c2;
-                rowq[row * 3 + 1] = nh;
-                rowq[row * 3 + 2] = nr;
+        for (int k0 = 8 * kb; k0 < d_pad; k0 += 128) {
+            double xv[2][4];
+            if (live) {
+                kz_row4(x, k0, d, vec, xv[0]);       // (zero fill past d)
+                kz_row4(x, k0 + 4, d, vec, xv[1]);
+            } else {
+                xv[0][0] = xv[0][1] = xv[0][2] = xv[0][3] = xv[1][0] = xv[1][1] = xv[1][2] = xv[1][3] = 0.0;
             }
-            bias[row] = (float)(-0.5 * c2 * S * S);
+            const float4 mu0 = *reinterpret_cast<const float4*>(mu + k0), mu1 = *reinterpret_cast<const float4*>(mu + k0 + 4);
+            const float mk[8] = {mu0.x, mu0.y, mu0.z, mu0.w, mu1.x, mu1.y, mu1.z, mu1.w};
+            union { _Float16 h[8]; uint4 q; } frag;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float v = 0.0f;
+                if (live && k0 + u < d) {
+                    const double op = metric == KZ_COSINE ? xv[u >> 2][u & 3] / nrm : xv[u >> 2][u & 3];   // (kz_operand)
+                    v = (float)(op - (double)mk[u]);
+                }
+                float vs = v * Sf;                                       // exact: S is a power of two
+                if (fabsf(vs) < 6.103515625e-05f) vs = 0.0f;             // below the fp16 normal range
+                vs = fminf(fmaxf(vs, -65504.0f), 65504.0f);
+                const _Float16 hv = (_Float16)vs;                        // round to nearest even
+                frag.h[u] = hv;
+                const double xh = (double)(float)hv * invS;
+                const double res = (double)v - xh;
+                c2 = fma((double)v, (double)v, c2);
+                h2 = fma(xh, xh, h2);
+                r2 = fma(res, res, r2);
+            }
+            *reinterpret_cast<uint4*>(dst + (int64_t)(k0 >> 4) * (2 * KZ_TILE * 8) + ((k0 >> 3) & 1) * (KZ_TILE * 8)) = frag.q;
         }
-        m_h = fmax(m_h, nh);
+        // the row's sums: over the sixteen lanes of its r4 (lane bits 2..5); every lane of the row ends with the same value
+#pragma unroll
+        for (int off = 32; off >= 4; off >>= 1) {
+            c2 += __shfl_xor(c2, off, 64);
+            h2 += __shfl_xor(h2, off, 64);
+            r2 += __shfl_xor(r2, off, 64);
+        }
+        const double nh = sqrt(h2), nr = sqrt(r2);
+        if (kb == 0) {
+            if (live) {
+                if (rowq) {
+                    rowq[row * 3 + 0] = c2;
+                    rowq[row * 3 + 1] = nh;
+                    rowq[row * 3 + 2] = nr;
+                }
+                bias[row] = (float)(-0.5 * c2 * S * S);
+            } else {
+                bias[row] = -INFINITY;
+            }
+        }
+        m_h = fmax(m_h, nh);   // (rows past the end contribute zeros)
         m_r = fmax(m_r, nr);
         m_c = fmax(m_c, c2);
+    }
+#pragma unroll
+    for (int off = 1; off <= 2; off <<= 1) {   // the four rows of the wave
+        m_h = fmax(m_h, __shfl_xor(m_h, off, 64));
+        m_r = fmax(m_r, __shfl_xor(m_r, off, 64));
+        m_c = fmax(m_c, __shfl_xor(m_c, off, 64));
     }
     if (lane == 0) {
         s_m[0][wave] = m_h;
@@ -278,6 +365,11 @@ __global__ __launch_bounds__(256) void kz_pack_h_kernel(const T* __restrict__ ra
 static int kz_pack_blocks(int64_t n_pad) {
     const int64_t b = (n_pad + 3) / 4;
     return (int)(b < 4096 ? b : 4096);   // (32768: no faster -- 100k x 128: norms 46 -> 68 us, pack 62 -> 64 us)
+}
+// kz_norms_kernel / kz_pack_h_kernel: a wave takes KZ_NORM_ROWS / four rows per iteration
+static int kz_rowgroup_blocks(int64_t n_pad, int rows_per_wave) {
+    const int64_t b = (n_pad / rows_per_wave + 3) / 4;
+    return (int)(b < KZ_ROWGROUP_MAX_BLOCKS ? (b < 1 ? 1 : b) : KZ_ROWGROUP_MAX_BLOCKS);
 }
 
 // ---- lazy images ----------------------------------------------------------------------------------------------
@@ -384,11 +476,11 @@ static int kz_himage_build(kz_matrix* m, kz_center* center) {
     hipError_t e = hipMemsetAsync(im->d_max, 0, 32, ctx->stream);
     if (e == hipSuccess) {
         if (m->dtype == KZ_F32)
-            hipLaunchKernelGGL(kz_pack_h_kernel<float>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const float*)m->raw,
+            hipLaunchKernelGGL(kz_pack_h_kernel<float>, dim3(kz_rowgroup_blocks(n_pad, 4)), dim3(256), 0, ctx->stream, (const float*)m->raw,
                                m->sqn, m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, im->packed, im->bias,
                                im->rowq, (unsigned long long*)im->d_max, nullptr);
         else
-            hipLaunchKernelGGL(kz_pack_h_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw,
+            hipLaunchKernelGGL(kz_pack_h_kernel<double>, dim3(kz_rowgroup_blocks(n_pad, 4)), dim3(256), 0, ctx->stream, (const double*)m->raw,
                                m->sqn, m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, im->packed, im->bias,
                                im->rowq, (unsigned long long*)im->d_max, nullptr);
         e = hipGetLastError();
@@ -411,11 +503,11 @@ int kz_himage_pack_permuted(kz_matrix* m, const int* d_perm, unsigned short* pac
     const int nsr = m->kg / 4;
     const int64_t n_pad = m->n_tiles * KZ_TILE;
     if (m->dtype == KZ_F32)
-        hipLaunchKernelGGL(kz_pack_h_kernel<float>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const float*)m->raw, m->sqn,
+        hipLaunchKernelGGL(kz_pack_h_kernel<float>, dim3(kz_rowgroup_blocks(n_pad, 4)), dim3(256), 0, ctx->stream, (const float*)m->raw, m->sqn,
                            m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, packed, bias, (double*)nullptr,
                            (unsigned long long*)nullptr, d_perm);
     else
-        hipLaunchKernelGGL(kz_pack_h_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw, m->sqn,
+        hipLaunchKernelGGL(kz_pack_h_kernel<double>, dim3(kz_rowgroup_blocks(n_pad, 4)), dim3(256), 0, ctx->stream, (const double*)m->raw, m->sqn,
                            m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, packed, bias, (double*)nullptr,
                            (unsigned long long*)nullptr, d_perm);
     KZ_HIP(hipGetLastError());
@@ -518,10 +610,10 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     auto* st = (unsigned long long*)m->d_stats;
     int* bad = (int*)(m->d_stats + 4);
     if (dtype == KZ_F32)
-        hipLaunchKernelGGL(kz_norms_kernel<float>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const float*)m->raw, n,
+        hipLaunchKernelGGL(kz_norms_kernel<float>, dim3(kz_rowgroup_blocks(n_pad, KZ_NORM_ROWS)), dim3(256), 0, ctx->stream, (const float*)m->raw, n,
                            (int)d, metric, n_pad, m->bias, m->sqn, st, bad);
     else
-        hipLaunchKernelGGL(kz_norms_kernel<double>, dim3(kz_pack_blocks(n_pad)), dim3(256), 0, ctx->stream, (const double*)m->raw, n,
+        hipLaunchKernelGGL(kz_norms_kernel<double>, dim3(kz_rowgroup_blocks(n_pad, KZ_NORM_ROWS)), dim3(256), 0, ctx->stream, (const double*)m->raw, n,
                            (int)d, metric, n_pad, m->bias, m->sqn, st, bad);
     e = hipGetLastError();
     if (e != hipSuccess) {
