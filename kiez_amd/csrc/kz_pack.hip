@@ -326,7 +326,9 @@ __global__ __launch_bounds__(256) void kz_pack_h_kernel(const T* __restrict__ ra
             h2 += __shfl_xor(h2, off, 64);
             r2 += __shfl_xor(r2, off, 64);
         }
-        const double nh = sqrt(h2), nr = sqrt(r2);
+        // one float64 sqrt sequence for both norms of the four rows: the lanes of even kb take |x_h|, those of odd kb the residual
+        const double root = sqrt((kb & 1) ? r2 : h2);
+        const double nh = __shfl(root, r4, 64), nr = __shfl(root, 4 + r4, 64);
         if (kb == 0) {
             if (live) {
                 if (rowq) {
@@ -339,10 +341,12 @@ __global__ __launch_bounds__(256) void kz_pack_h_kernel(const T* __restrict__ ra
                 bias[row] = -INFINITY;
             }
         }
-        m_h = fmax(m_h, nh);   // (rows past the end contribute zeros)
-        m_r = fmax(m_r, nr);
+        m_h = fmax(m_h, h2);   // (squared: the roots are taken once, below; rows past the end contribute zeros)
+        m_r = fmax(m_r, r2);
         m_c = fmax(m_c, c2);
     }
+    m_h = sqrt(m_h);
+    m_r = sqrt(m_r);
 #pragma unroll
     for (int off = 1; off <= 2; off <<= 1) {   // the four rows of the wave
         m_h = fmax(m_h, __shfl_xor(m_h, off, 64));

@@ -49,6 +49,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_stride = 1;
     c->dual_deal = 1;
     c->dual_overlap = 1;
+    c->dual_sample_short = 1;
     c->lds_pad = 0;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
@@ -119,6 +120,8 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "dual_max_gb") == 0) {
         KZ_REQUIRE(value >= 0, "dual_max_gb must be >= 0");
         c->dual_max_gb = value;
+    } else if (strcmp(name, "dual_sample_short") == 0) {
+        c->dual_sample_short = value != 0 ? 1 : 0;
     } else if (strcmp(name, "dual_overlap") == 0) {
         c->dual_overlap = value != 0 ? 1 : 0;
     } else if (strcmp(name, "long_k") == 0) {

@@ -324,3 +324,28 @@ def test_second_stream_on_and_off_give_the_same_result(ctx):
     for r in res[1:]:
         for x, y in zip(res[0], r):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("k", [26, 50, 100])
+def test_short_sample_lists_on_cluster_ordered_rows(ctx, k):
+    """The sample sweep keeps lists of 16 (32) over several parts of the sample whatever k is; the parts interleave the sample's
+    tiles, so data stored cluster by cluster (all near rows of a query in ONE stretch of the index) must give the same
+    thresholds -- hence about the same number of events -- as lists of K', and the same neighbours."""
+    from kiez_amd import _native as N
+    a, b = _data("clustered", 25000, 48, 3, np.float32), _data("clustered", 12000, 48, 4, np.float32)
+    am, bm = N.DeviceMatrix(ctx, a, "cosine"), N.DeviceMatrix(ctx, b, "cosine")
+    ctx.set_option("dual_force", 1)
+    out = {}
+    try:
+        for short in (0, 1):
+            ctx.set_option("dual_sample_short", short)
+            (d, i, s), (e, j, t) = N.knn_dual(ctx, am, bm, k)
+            assert s["dual"] == 1 and t["dual"] == 1, (short, s, t)
+            out[short] = (d.numpy(), i.numpy(), e.numpy(), j.numpy(), t["n_events"], t["n_fallback_rows"] + t["n_escalated_rows"])
+    finally:
+        ctx.set_option("dual_sample_short", 1)
+        ctx.set_option("dual_force", 0)
+    for x, y in zip(out[0][:4], out[1][:4]):
+        np.testing.assert_array_equal(x, y)
+    assert out[1][4] <= 1.25 * out[0][4] + 1000, (out[0][4], out[1][4])      # events: thresholds as tight as with lists of K'
+    assert out[1][5] <= out[0][5] + 20, (out[0][5], out[1][5])                # rows searched again
