@@ -87,7 +87,8 @@ int kz_ctx_trim(kz_ctx* ctx);
  * "long_k": 1 (default) = 111 .. ~540 neighbours per query run on the fused kernels (lists over many index ranges), 0 = on the
  * exact float64 kernels like everything beyond; "dual_max_gb": transient footprint kz_knn_dual may claim (GiB; 0 = 32: beyond it, or beyond what the device has free, it
  * searches twice); "dual_overlap": 1 (default) = its reverse direction's chain runs on a second stream;
- * "dual_sample_short": 1 (default) = its sample sweep keeps lists of 16 (32) entries over several index ranges whatever k is. */
+ * "dual_sample_short": 1 (default) = its sample sweep keeps lists of 16 (32) entries over several index ranges whatever k is;
+ * "dual_short_main": 1 (default) = so does its main sweep for 13 .. 54 neighbours (k / "dual_short_div" lists of 16 per query). */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 
 int kz_malloc(kz_ctx* ctx, size_t bytes, void** d_ptr);

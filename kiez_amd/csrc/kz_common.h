@@ -29,6 +29,10 @@ struct kz_ctx {
     int precision;    // 0: fp16 first pass where eligible (default), 2: split-bf16 first pass, 1: float32 operands only
     int dual_stride;  // kz_knn_dual: every dual_stride-th tile of the query side is in the threshold sample (0: no dual pass, 1: automatic)
     int dual_deal;    // tuning knob: 1 (default) = the dual pass deals the query rows into load-balanced tiles, 0 = natural order
+    int dual_short_main;   // 1 (default): the main sweep of kz_knn_dual keeps k / dual_short_div lists of 16 per query instead of one of 32 / 64; 0: one list of K'
+    int dual_short_div;    // (default 5)
+    int dual_short_kp;     // list length of that route: 16 (default) or 32
+    int dual_short_min_tiles;   // ... taken when an index range has at least this many tiles (default 64; test knob)
     int dual_sample_short; // 1 (default): the sample sweep of kz_knn_dual uses lists of 16 (32) over several index ranges whatever K' is; 0: lists of K'
     int dual_overlap; // 1 (default): kz_knn_dual runs the reverse direction's chain on the second stream beside the forward finalize; 0: behind it
     double dual_max_gb; // kz_knn_dual: transient footprint budget in GiB (0 = the built-in 32)

@@ -1101,6 +1101,8 @@ struct KzDualPass {
     unsigned long long* log_cnt;   // device counter
     long long log_cap;
     int broken;                    // set by kz_knn_impl when a chunk did not run the dual build (tier change): events incomplete
+    int short_pieces, short_ksel, short_kp;  // > 0: the forward lists are short_pieces lists of 16 per query (the image interleaves the index tiles
+                                   // over the ranges, kz_knn_dual.h), the finalize kernel selects short_ksel of their entries
     double main_ms;
     // called by kz_knn_impl right behind the launch of the LAST chunk's sweep (the event log is complete once that kernel has
     // run): kz_knn_dual enqueues the reverse direction's chain on the context's second stream there, so that it runs beside the
@@ -1215,6 +1217,16 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             long_pieces = S;
         }
     }
+    // SHORT-LIST ROUTE of the dual pass (27 .. 54 neighbours, also 13 .. 26): the same construction the other way round -- lists
+    // of 16 over k / 6 index ranges instead of one list of 32 / 64 per query.  The K' = 16 kernel keeps three workgroups per CU
+    // and its merges short; a range that holds 16 or more of a query's nearest rows is seen by the certification (piece_bound).
+    // The caller has dealt the index tiles over the ranges (kz_knn_dual.h): near rows of a query sit in ALL ranges alike.
+    const int KP_class = KP;
+    if (dual && dual->short_pieces > 0 && KP > dual->short_kp && kp_min <= dual->short_kp) {
+        KP = dual->short_kp;
+        KSEL = dual->short_ksel;
+        long_pieces = dual->short_pieces;
+    }
     const bool exact_only = KP == 0;
     if (exact_only) {
         if (k_eff > KZ_EXACT_MAX_K) {
@@ -1271,7 +1283,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // query rows are processed in chunks so that the candidate lists stay below ~1 GiB: 524288 rows for K' >= 64, up to four
     // times as many for shorter lists (1 M x 250 k, K' = 16: one launch instead of two -- one tail round, one read-back, one
     // re-search of the uncertified rows)
-    const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (KP <= 16 ? 4 : (KP <= 32 ? 2 : 1));
+    const int KP_mem = KP_class > KP ? KP_class : KP;   // (short-list route: several lists of 16 -- the chunk of the replaced list length)
+    const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (KP_mem <= 16 ? 4 : (KP_mem <= 32 ? 2 : 1));
     double main_ms = 0, fin_ms = 0, fb_ms = 0;
     int64_t n_fail_total = 0, n_escalated = 0;
     double max_err_ratio = 0.0;

@@ -89,27 +89,52 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
     }
 }
 
-// Sample image.  Image tile j' <- tile stride * j of A's image, where j runs through the sample tiles part by part: part p =
-// sample tiles p, p + P, p + 2 P, ... (the first s_tiles % P parts hold one tile more).  One workgroup per tile; P = 1: j = j'.
-__global__ __launch_bounds__(256) void kz_dual_sample_kernel(const uint4* __restrict__ packed, const float* __restrict__ bias,
-                                                             int tile_q, int stride, int s_tiles, int P,
-                                                             uint4* __restrict__ s_packed, float* __restrict__ s_bias) {
-    const int jp = blockIdx.x;
-    const int q = s_tiles / P, r = s_tiles - q * P;
-    int part, i;
-    if (jp < r * (q + 1)) {
-        part = jp / (q + 1);
-        i = jp - part * (q + 1);
+// Rows dealt over P parts: position r' of a sequence of N rows <- row j, with j running through the parts one after the other,
+// part p = rows p, p + P, p + 2 P, ... (the first N % P parts hold one row more).  P = 1: j = r'.
+__device__ __forceinline__ int64_t kz_dual_dealt_row(int64_t rp, int64_t N, int P) {
+    const int64_t q = N / P, r = N - q * P;
+    int64_t part, i;
+    if (rp < r * (q + 1)) {
+        part = rp / (q + 1);
+        i = rp - part * (q + 1);
     } else {
-        const int j2 = jp - r * (q + 1);
+        const int64_t j2 = rp - r * (q + 1);
         part = r + j2 / q;
         i = j2 - (part - r) * q;
     }
-    const int64_t src = (int64_t)(part + P * i) * stride;
-    const uint4* sp = packed + src * tile_q;
-    uint4* dp = s_packed + (int64_t)jp * tile_q;
-    for (int e = threadIdx.x; e < tile_q; e += 256) dp[e] = sp[e];
-    if (threadIdx.x < KZ_TILE) s_bias[(int64_t)jp * KZ_TILE + threadIdx.x] = bias[src * KZ_TILE + threadIdx.x];
+    return part + P * i;
+}
+
+// Sample image: the rows of every stride-th tile of A's image, dealt over P parts ROW BY ROW (data stored cluster by cluster has
+// all near rows of a query in one stretch of A; dealt, every part holds its share of them).  One workgroup per image tile; a
+// row of the fp16 image is 2 nsr fragments of 16 bytes, one per (slice, plane) block of its tile.
+__global__ __launch_bounds__(256) void kz_dual_sample_kernel(const uint4* __restrict__ packed, const float* __restrict__ bias,
+                                                             int nsr, int stride, int s_tiles, int P,
+                                                             uint4* __restrict__ s_packed, float* __restrict__ s_bias) {
+    const int jp = blockIdx.x;
+    const int n_frag = 2 * nsr * KZ_TILE;   // 16-byte fragments of a tile: [slice][plane][row]
+    for (int e = threadIdx.x; e < n_frag; e += 256) {
+        const int row = e & (KZ_TILE - 1), blk = e >> 7;
+        const int64_t j = kz_dual_dealt_row((int64_t)jp * KZ_TILE + row, (int64_t)s_tiles * KZ_TILE, P);
+        const int64_t src_tile = (j >> 7) * stride;
+        s_packed[(int64_t)jp * n_frag + e] = packed[src_tile * n_frag + blk * KZ_TILE + (j & (KZ_TILE - 1))];
+        if (blk == 0) s_bias[(int64_t)jp * KZ_TILE + row] = bias[src_tile * KZ_TILE + (j & (KZ_TILE - 1))];
+    }
+}
+
+// Short-list route of the main sweep: the TILES of the sorted order are dealt over P index ranges (rows with neighbouring
+// thresholds tend to be neighbours of the same queries); the last, possibly partial, tile stays the last.  Whole tiles, not
+// rows: the sweep's per-tile test wants the 128 rows of a tile to be neighbours in threshold (dealt row by row a tile spans
+// 128 P sorted ranks -- 500k x 500k, k = 50: the log of passed groups overflowed its 1.5 x estimate).
+__global__ void kz_dual_interleave_kernel(const int* __restrict__ perm, const float* __restrict__ theta_s, int64_t n, int64_t n_pad,
+                                          int P, int* __restrict__ perm_out, float* __restrict__ theta_out) {
+    const int64_t rp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rp >= n_pad) return;
+    const int64_t tiles = n_pad / KZ_TILE - 1;   // the tiles that move
+    const int64_t jp = rp / KZ_TILE;
+    const int64_t src = jp < tiles ? kz_dual_dealt_row(jp, tiles, P) * KZ_TILE + (rp & (KZ_TILE - 1)) : rp;
+    perm_out[rp] = src < n ? perm[src] : -1;
+    theta_out[rp] = src < n ? theta_s[src] : INFINITY;
 }
 
 __global__ void kz_dual_fill_kernel(float* __restrict__ out, int64_t n, float v) {
@@ -117,13 +142,18 @@ __global__ void kz_dual_fill_kernel(float* __restrict__ out, int64_t n, float v)
     if (i < n) out[i] = v;
 }
 
-// per-tile minimum of the sorted thresholds, broadcast over the tile's rows (the kernel copies the first 64 floats of a
-// tile and reads one).  Rows are in DESCENDING order: the minimum of a tile is its last real row.
+// per-tile minimum of the thresholds in image order, broadcast over the tile's rows (the kernel copies the first 64 floats of a
+// tile and reads one).  (Rows behind the end carry +inf.)
 __global__ void kz_dual_tilemin_kernel(const float* __restrict__ theta_sorted, int64_t n, int64_t n_pad, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
-    const int64_t tile_end = (i / KZ_TILE + 1) * KZ_TILE;
-    out[i] = theta_sorted[(tile_end < n ? tile_end : n) - 1];
+    const int64_t t0 = (i / KZ_TILE) * KZ_TILE;
+    const int lane = threadIdx.x & 63;
+    // (blocks of 256 threads = two whole tiles; the 64 lanes of a wave share a tile)
+    float m = fminf(theta_sorted[t0 + lane], theta_sorted[t0 + 64 + lane]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+    out[i] = m;
 }
 
 // Load balance of the query side.  How many events a query row takes part in is heavy-tailed (hubness: rows near the data
@@ -492,7 +522,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // ---- sample sweep's lists.  The threshold is the rank-th best sample key, and the rank-th best of ANY set of distinct sample
     // rows is a valid (lower) threshold.  The sweep therefore never needs lists of K' entries: the sample is cut into `pieces`
     // parts with a list of 16 (32) each, 2 rank entries in all.  A part holds rank / pieces +- sqrt(rank / pieces) of a row's rank
-    // best -- provided the parts are alike: part p takes the sample tiles p, p + pieces, p + 2 pieces, ... (a contiguous range
+    // best -- provided the parts are alike: part p takes the sample ROWS p, p + pieces, p + 2 pieces, ... (a contiguous range
     // would hold ALL the near rows of a query when the data is stored cluster by cluster, its list of 16 would overflow and the
     // threshold fall to the far rows).  The K' = 16 kernel keeps three workgroups per CU and short merges: 500k x 500k, k = 50:
     // reverse direction 51.0 -> 46.4 ms per step, same event counts.
@@ -509,7 +539,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // ---- sample image: every stride-th tile of A's fp16 image (tiles are contiguous runs of n_slices x 4 KiB), dealt over the parts
     KZ_DUAL_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
     hipLaunchKernelGGL(kz_dual_sample_kernel, dim3((unsigned)s_tiles), dim3(256), 0, ctx->stream, (const uint4*)ia->packed, ia->bias,
-                       (int)(tile_bytes / 16), stride, (int)s_tiles, force_s > 0 ? force_s : 1, (uint4*)s_packed, s_bias);
+                       n_slices, stride, (int)s_tiles, force_s > 0 ? force_s : 1, (uint4*)s_packed, s_bias);
     KZ_DUAL_HIP(hipGetLastError());
     KZ_DUAL_HIP(hipMemsetAsync(ev_cnt, 0, (size_t)b_pad * 4, ctx->stream));
     KZ_DUAL_HIP(hipMemsetAsync(d_cnt, 0, 1024, ctx->stream));
@@ -574,6 +604,23 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     } else
 #endif
     KZ_DUAL_RC(kz_sort_pairs_f32_i32(ctx, theta, theta_s, iota, perm, (int)b->n, 1));
+    // ---- short-list route of the main sweep (kz_knn_impl): k / 6 lists of 16 per query instead of one of 32 / 64.  Rows with
+    // neighbouring thresholds tend to be neighbours of the same queries, so the sorted tiles are dealt over the index ranges.
+    int main_pieces = 0;
+    if (ctx->dual_short_main && KP > 16 && KP <= 64) {
+        // (a range of at least 64 tiles: the k nearest rows of a query must be spread over many more tiles than there are ranges)
+        const int per = ctx->dual_short_div * (ctx->dual_short_kp / 16);
+        const int P = (k + per - 1) / per;
+        if (P >= 2 && P * ctx->dual_short_kp <= 256 && KP > ctx->dual_short_kp && b_tiles - 1 >= (int64_t)ctx->dual_short_min_tiles * P) main_pieces = P;
+    }
+    if (main_pieces > 0) {
+        // (iota and theta -- the sort's inputs -- are free now: they take the dealt order)
+        hipLaunchKernelGGL(kz_dual_interleave_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, perm, theta_s, b->n,
+                           b_pad, main_pieces, iota, theta);
+        KZ_DUAL_HIP(hipGetLastError());
+        int* ti = perm; perm = iota; iota = ti;
+        float* tf = theta_s; theta_s = theta; theta = tf;
+    }
     hipLaunchKernelGGL(kz_dual_tilemin_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, theta_s, b->n, b_pad, theta_min);
     KZ_DUAL_HIP(hipGetLastError());
     KZ_DUAL_RC(kz_himage_pack_permuted(b, perm, p_packed, p_bias));
@@ -597,6 +644,9 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     dp.log_meta = log_meta;
     dp.log_cnt = d_cnt;
     dp.log_cap = log_cap;
+    dp.short_pieces = main_pieces;
+    dp.short_ksel = k + 16;
+    dp.short_kp = ctx->dual_short_kp;
     // ---- the reverse direction's chain: events -> lists -> ordinary finalize with B as the query side.  Enqueued on the
     // context's SECOND stream from inside kz_knn_impl, right behind the sweep (KzDualPass::post_sweep): it shares no buffer
     // with what the first stream does meanwhile (finalize of A's lists, fail-counter read-back, re-search of uncertified rows)

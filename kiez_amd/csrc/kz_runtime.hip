@@ -50,6 +50,10 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_deal = 1;
     c->dual_overlap = 1;
     c->dual_sample_short = 1;
+    c->dual_short_main = 1;
+    c->dual_short_kp = 16;
+    c->dual_short_min_tiles = 64;
+    c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
     c->lds_pad = 0;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
@@ -120,6 +124,17 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "dual_max_gb") == 0) {
         KZ_REQUIRE(value >= 0, "dual_max_gb must be >= 0");
         c->dual_max_gb = value;
+    } else if (strcmp(name, "dual_short_main") == 0) {
+        c->dual_short_main = value != 0 ? 1 : 0;
+    } else if (strcmp(name, "dual_short_min_tiles") == 0) {
+        KZ_REQUIRE(value >= 1, "kz_ctx_set_option: dual_short_min_tiles must be >= 1");
+        c->dual_short_min_tiles = (int)value;
+    } else if (strcmp(name, "dual_short_kp") == 0) {
+        KZ_REQUIRE(value == 16 || value == 32, "kz_ctx_set_option: dual_short_kp must be 16 or 32");
+        c->dual_short_kp = (int)value;
+    } else if (strcmp(name, "dual_short_div") == 0) {
+        KZ_REQUIRE(value >= 1 && value <= 16, "kz_ctx_set_option: dual_short_div must be in [1, 16]");
+        c->dual_short_div = (int)value;
     } else if (strcmp(name, "dual_sample_short") == 0) {
         c->dual_sample_short = value != 0 ? 1 : 0;
     } else if (strcmp(name, "dual_overlap") == 0) {

@@ -34,10 +34,11 @@ for case in range(n_cases):
         return base[rng.integers(0, len(base), n)]
     a, b = gen(na).astype(dtype), gen(nb).astype(dtype)
     opt = (int(rng.choice([1, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 0, 4096, 16384])), int(rng.integers(0, 2)),
-           int(rng.integers(0, 2)), int(rng.integers(0, 2)))   # ..., wide workgroups for the shared sweep, reverse chain on the second stream
+           int(rng.integers(0, 2)), int(rng.integers(0, 2)),   # ..., wide workgroups for the shared sweep, reverse chain on the second stream
+           int(rng.choice([64, 3, 3, 8])), int(rng.integers(0, 2)))   # short-list route: smallest index range in tiles; short sample lists
     if only >= 0 and case != only:
         continue
-    print(f"case {case}: na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} stride/chunk/deal/wide/overlap {opt}", flush=True)
+    print(f"case {case}: na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} stride/chunk/deal/wide/overlap/short-min/short-sample {opt}", flush=True)
     ctx.set_option("dual_stride", opt[0])
     ctx.set_option("chunk_rows", opt[1])
     ctx.set_option("dual_deal", opt[2])
@@ -50,6 +51,8 @@ for case in range(n_cases):
     ctx.set_option("dual_force", 1)
     ctx.set_option("h_wide", opt[3])          # (the two reference searches above ran the narrow builds)
     ctx.set_option("dual_overlap", opt[4])
+    ctx.set_option("dual_short_min_tiles", opt[5])
+    ctx.set_option("dual_sample_short", opt[6])
     (xd, xi, sa), (yd, yi, sb) = N.knn_dual(ctx, am, bm, k)
     ctx.set_option("h_wide", 0)
     ok = (np.array_equal(r1[1].numpy(), xi.numpy()) and np.array_equal(r1[0].numpy(), xd.numpy())
@@ -58,8 +61,9 @@ for case in range(n_cases):
     if not ok or ratio >= 1.0:
         bad += 1
     print(("ok " if ok else "BAD"), f"na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} dual {sa['dual']}/{sb['dual']} "
-          f"ev/row {sb['n_events'] / nb:.1f} esc {sb['n_escalated_rows']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
-for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1), ("h_wide", 0), ("dual_overlap", 1)):
+          f"ev/row {sb['n_events'] / nb:.1f} esc {sa['n_escalated_rows']}/{sb['n_escalated_rows']} splits {sa['n_splits']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
+for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1), ("h_wide", 0), ("dual_overlap", 1),
+                ("dual_short_min_tiles", 64), ("dual_sample_short", 1)):
     ctx.set_option(name, v)
 print("cases", n_cases, "bad", bad)
 sys.exit(1 if bad else 0)
