@@ -1041,10 +1041,10 @@ struct KzPass {
 // query tiles -- one work item = one unit x one index range, w4.x = its first tile -- and converted back to tiles for the list
 // layout (a region ends on a unit boundary, the last one at the last tile).
 static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, int max_pieces, int KP, int tier, int64_t fail_rows,
-                           KzPass* out, int tpw = 1, int force_pieces = 0) {
+                           KzPass* out, int tpw = 1, int force_pieces = 0, int min_pieces = 0) {
     KzPlan pl;
     kz_plan_pass(n_qtiles, n_ytiles, slots, max_pieces, (tier == KZ_TIER_H ? 1 : 2) * KP, tier == KZ_TIER_F32 ? 2 : 1,
-                 tier == KZ_TIER_H ? 1 : 0, tpw, force_pieces > 0 ? force_pieces : ctx->force_splits, ctx->min_splits, &pl);
+                 tier == KZ_TIER_H ? 1 : 0, tpw, force_pieces > 0 ? force_pieces : ctx->force_splits, min_pieces > ctx->min_splits ? min_pieces : ctx->min_splits, &pl);
     const KzListLayout& lay = pl.lay;
     const int W = pl.W;
     const size_t list_elems = pl.list_elems;
@@ -1236,6 +1236,16 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         KP = 128;   // (list geometry of the scratch block only; no list kernel runs)
     }
     if (KP < kp_min) KP = kp_min < 128 ? kp_min : 128;   // (list lengths are 16 / 32 / 64 / 128)
+    // kp_min = -1 (escalated rows of a K' = 16 pass): MORE LISTS instead of longer ones -- a list of 16 per index range over at
+    // least four ranges, the finalize kernel selecting k + 16 of their entries.  The bound of the certification becomes the
+    // largest 16th-best key of a RANGE (a quarter of the index or less) instead of the 16th-best key of the whole index: the
+    // margin in ranks a failed row needs, with the K' = 16 kernel and a quarter of the entries to merge (14 rows of a 1M-row
+    // index: 0.75 + 0.62 ms with lists of 64 over 64 ranges).
+    int min_pieces_call = 0;
+    if (kp_min == -1 && KP == 16 && !exact_only && KSEL == 0 && index->n_tiles >= 16) {
+        KSEL = k_eff + 16;
+        min_pieces_call = 4;
+    }
     if (stats) memset(stats, 0, sizeof(*stats));
     if (q_count == 0) return KZ_OK;
     KZ_HIP(hipSetDevice(ctx->device));
@@ -1313,7 +1323,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         KzPass ps;
         // (long-k route: exactly long_pieces index ranges per query tile, one round)
         int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1), KP, tier, cq_count, &ps,
-                                 tier == KZ_TIER_H ? tpw_h : 1, (tier == KZ_TIER_F32 && long_pieces > 8) ? 8 : long_pieces);
+                                 tier == KZ_TIER_H ? tpw_h : 1, (tier == KZ_TIER_F32 && long_pieces > 8) ? 8 : long_pieces, min_pieces_call);
         if (rc != KZ_OK) return rc;
         const KzListLayout& lay = ps.lay;
         const int W = ps.W;
@@ -1499,7 +1509,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             const bool widen = tier == KZ_TIER_H && KP < 128;
             kz_knn_stats st2;
             rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids,
-                                  widen ? 0 : 1, widen ? (KP * 4 < 128 ? KP * 4 : 128) : 0, fp.out_dist, fp.out_ind, &st2, &ms);
+                                  widen ? 0 : 1, widen ? (KP == 16 && KSEL == 0 && ctx->esc_short ? -1 : (KP * 4 < 128 ? KP * 4 : 128)) : 0, fp.out_dist,
+                                  fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;
             n_escalated += n_fail + st2.n_escalated_rows;

@@ -778,7 +778,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             dp.broken = 1;   // the log itself overflowed: events are missing for unknown rows
         } else if (n_fail > 0) {
             // rows of B with an overflowing buffer or an uncertified list: the ordinary search, longer lists when they are few
-            const int kp_min = ((int64_t)n_fail * 8 > b->n || KP >= 128) ? 0 : (KP * 4 < 128 ? KP * 4 : 128);
+            // (K' = 16: more lists instead of longer ones, kz_knn_impl kp_min = -1)
+            const int kp_min = ((int64_t)n_fail * 8 > b->n || KP >= 128) ? 0 : (KP == 16 && ctx->esc_short ? -1 : (KP * 4 < 128 ? KP * 4 : 128));
             kz_knn_stats st2;
             KZ_DUAL_RC(kz_escalate_rows(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, -1, kp_min, d_dist_ba, d_ind_ba, &st2, &ms));
             st_ba.fallback_ms = ms;

@@ -51,6 +51,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_overlap = 1;
     c->dual_sample_short = 1;
     c->dual_short_main = 1;
+    c->esc_short = 1;
     c->dual_short_kp = 16;
     c->dual_short_min_tiles = 64;
     c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
@@ -126,6 +127,8 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
         c->dual_max_gb = value;
     } else if (strcmp(name, "dual_short_main") == 0) {
         c->dual_short_main = value != 0 ? 1 : 0;
+    } else if (strcmp(name, "esc_short") == 0) {
+        c->esc_short = value != 0 ? 1 : 0;
     } else if (strcmp(name, "dual_short_min_tiles") == 0) {
         KZ_REQUIRE(value >= 1, "kz_ctx_set_option: dual_short_min_tiles must be >= 1");
         c->dual_short_min_tiles = (int)value;
