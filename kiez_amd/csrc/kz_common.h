@@ -20,6 +20,7 @@ struct kz_ctx {
     hipEvent_t ev[12];   // [0..7] work on `stream`, [8..11] the reverse direction of kz_knn_dual on `stream2`
     hipStream_t stream2; // second stream: kz_knn_dual runs the reverse direction's event chain beside the forward direction's finalize
     double eps_scale;
+    int qgroup;            // query tiles per group of the work table (0 = automatic: 24, an XCD's worth of workgroups for the fp16 kernel)
     int force_splits;
     int h_wps;        // tuning knob: 2 = run the fp16 kernel's two-workgroups-per-CU build also where three would fit
     int long_k;       // 1 (default): 111 .. ~540 neighbours per query on the fused kernels (kz_knn_impl "long-k route"); 0: exact kernels

@@ -1078,7 +1078,11 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
         ctx->h_stage_flip ^= 1;
         int4* hw = (int4*)((char*)ctx->h_stage + (ctx->h_stage_flip ? ctx->h_stage_bytes / 2 : 0));
         static_assert(sizeof(KzWorkItem) == sizeof(int4), "work items are uploaded as int4");
-        kz_plan_fill_work(pl, n_ytiles, tpw, (KzWorkItem*)hw);
+        // (fp16 kernel: query groups of four times what an XCD holds, see kz_plan_fill_work; "qgroup" overrides.  500k x 500k,
+        //  ten ranges per query tile, main kernel: 24: 109.3 ms, 96: 107.6, 384: 102.5, 768 .. 4096: 101.9 .. 103.2)
+        const int per_xcd = (slots + 7) / 8;
+        const int qgroup = ctx->qgroup > 0 ? ctx->qgroup : (tier == KZ_TIER_H && 4 * per_xcd > KZ_QGROUP ? 4 * per_xcd : KZ_QGROUP);
+        kz_plan_fill_work(pl, n_ytiles, tpw, (KzWorkItem*)hw, qgroup);
         KZ_HIP(hipMemcpyAsync(out->d_work, hw, (size_t)W * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     }
     return KZ_OK;

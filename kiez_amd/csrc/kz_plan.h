@@ -117,8 +117,10 @@ static inline void kz_plan_pass(int n_qtiles, int n_ytiles, int slots, int max_p
 // The work table of a plan: hw[W].  Logical order inside a region: groups of KZ_QGROUP query units, inside a group
 // split-major.  The workgroups resident on one XCD then cover few query tiles (their fragments stay in the 4 MiB L2) times a
 // few index ranges (each index tile is fetched once and hit by the whole group); items are spread over block ids so that
-// blocks with equal (id % 8) -- one XCD -- take consecutive items.
-static inline void kz_plan_fill_work(const KzPlan& pl, int n_ytiles, int tpw, KzWorkItem* hw) {
+// blocks with equal (id % 8) -- one XCD -- take consecutive items.  `qgroup`: the fp16 kernel keeps its query fragments in
+// registers, so its groups are several times what an XCD holds -- with many index ranges per query tile (short-list
+// route: 10) the workgroups resident on an XCD then stream ONE range together instead of four.
+static inline void kz_plan_fill_work(const KzPlan& pl, int n_ytiles, int tpw, KzWorkItem* hw, int qgroup = KZ_QGROUP) {
     auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
     auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
     for (int r = 0; r < pl.lay.n_regions; ++r) {
@@ -127,7 +129,7 @@ static inline void kz_plan_fill_work(const KzPlan& pl, int n_ytiles, int tpw, Kz
         if (cnt == 0) continue;
         const int len = split_len(sp);
         const int nsp = split_cnt(sp);
-        const int G = KZ_QGROUP < nq ? KZ_QGROUP : nq;
+        const int G = qgroup < nq ? qgroup : nq;
         int next = 0;
         for (int label = 0; label < 8; ++label) {
             for (int i = 0; i < cnt; ++i) {

@@ -127,6 +127,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
         c->dual_max_gb = value;
     } else if (strcmp(name, "dual_short_main") == 0) {
         c->dual_short_main = value != 0 ? 1 : 0;
+    } else if (strcmp(name, "qgroup") == 0) {
+        KZ_REQUIRE(value >= 0 && value <= 4096, "kz_ctx_set_option: qgroup must be in [0, 4096]");
+        c->qgroup = (int)value;
     } else if (strcmp(name, "esc_short") == 0) {
         c->esc_short = value != 0 ? 1 : 0;
     } else if (strcmp(name, "dual_short_min_tiles") == 0) {
