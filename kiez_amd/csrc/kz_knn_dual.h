@@ -61,15 +61,19 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
         valid[u] = e < M && in_idx[l0 + e] >= 0;
         rnk[u] = 0;
     }
+    // rank of every entry = the number of valid entries in front of it: entry oe is broadcast from its lane through a scalar
+    // register (v_readlane: jj is uniform) -- not through the LDS crossbar -- and only the 64-entry blocks that exist are ranked
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int lim = min(64, M - 64 * v);
         for (int jj = 0; jj < lim; ++jj) {
-            const float ox = __shfl(x[v], jj, 64);
-            const int ov = __shfl(valid[v], jj, 64);
+            const float ox = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x[v]), jj));
+            const int ov = __builtin_amdgcn_readlane(valid[v], jj);
+            if (!ov) continue;   // (uniform)
             const int oe = jj + 64 * v;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rnk[u] += (ov && (ox > x[u] || (ox == x[u] && oe < lane + 64 * u))) ? 1 : 0;
+            for (int u = 0; u < 4; ++u)
+                if (64 * u < M) rnk[u] += (ox > x[u] || (ox == x[u] && oe < lane + 64 * u)) ? 1 : 0;
         }
     }
     float tau = -INFINITY;

@@ -1,4 +1,6 @@
-timeout 1800 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 900 python3 tools/fuzz_dual.py 120 41 2>&1 | tail -1
-timeout 900 python3 tools/fuzz_tiers.py 80 9 2>&1 | tail -1
-timeout 900 python3 tools/fuzz_api.py 60 5 2>&1 | tail -1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for w in c3 ns; do
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/v_ks_$w -- python3 bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-others > gpurun_out/v_$w.json 2> gpurun_out/v_err.txt
+python3 tools/show.py gpurun_out/v_$w.json | cut -c1-200
+f=$(find gpurun_out/v_ks_$w -name "*kernel_stats.csv" | head -1); grep -E "theta|select_kernel|scatter" $f | cut -c1-60,160-260; rm -rf gpurun_out/v_ks_$w
+done
