@@ -1005,6 +1005,8 @@ constexpr int KZ_EXACT_MAX_K = 4096;   // neighbours per query on the exact-only
 static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout& lay, int KP, int64_t q_count, int dtype) {
     for (int rg = 0; rg < lay.n_regions; ++rg) {
         const int64_t lo = (int64_t)(rg > 0 ? lay.qt_end[rg - 1] : 0) * KZ_TILE - fp.list_row0;
+        // (neighbouring regions with the same number of ranges -- forced ranges: all of them -- go out as ONE launch)
+        while (rg + 1 < lay.n_regions && lay.pieces[rg + 1] == lay.pieces[rg]) ++rg;
         const int64_t hi = (int64_t)lay.qt_end[rg] * KZ_TILE - fp.list_row0;
         fp.q_first = lo < 0 ? 0 : lo;
         fp.q_last = hi > q_count ? q_count : hi;
