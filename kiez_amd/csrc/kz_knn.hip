@@ -1513,9 +1513,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             // float32-operand kernel.  The inner call sends its own uncertified rows further down (float32 operands,
             // exact float64 kernels).  Results are scattered back.
             const bool widen = tier == KZ_TIER_H && KP < 128;
+            // (short-list route: the rows it cannot certify are mostly the ones a list of K' could not certify either -- they go
+            //  where that list's failures would have gone, lists four times K', not through a list of K' first)
+            const int KP_esc = KP_class > KP ? KP_class : KP;
             kz_knn_stats st2;
             rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids,
-                                  widen ? 0 : 1, widen ? (KP == 16 && KSEL == 0 && ctx->esc_short ? -1 : (KP * 4 < 128 ? KP * 4 : 128)) : 0, fp.out_dist,
+                                  widen ? 0 : 1, widen ? (KP == 16 && KSEL == 0 && ctx->esc_short ? -1 : (KP_esc * 4 < 128 ? KP_esc * 4 : 128)) : 0, fp.out_dist,
                                   fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;
