@@ -30,9 +30,12 @@ struct kz_ctx {
     int precision;    // 0: fp16 first pass where eligible (default), 2: split-bf16 first pass, 1: float32 operands only
     int dual_stride;  // kz_knn_dual: every dual_stride-th tile of the query side is in the threshold sample (0: no dual pass, 1: automatic)
     int dual_deal;    // tuning knob: 1 (default) = the dual pass deals the query rows into load-balanced tiles, 0 = natural order
+    int esc_bf;            // 1 (default): rows the fp16 tier cannot certify with its longest lists go to the split-bf16 operands before the float32 ones
     int esc_short;         // 1 (default): uncertified rows of a K' = 16 pass are searched again with lists of 16 over >= 4 index ranges; 0: with lists of 64
     int dual_short_main;   // 1 (default): the main sweep of kz_knn_dual keeps k / dual_short_div lists of 16 per query instead of one of 32 / 64; 0: one list of K'
     int dual_short_div;    // (default 5)
+    int dual_rev_long;     // 1 (default): the reverse direction of kz_knn_dual keeps lists of 2 K' (K' >= 32)
+    int dual_short_extra;  // ... of whose entries the finalize kernel selects k + this many (default 48)
     int dual_short_kp;     // list length of that route: 16 (default) or 32
     int dual_short_min_tiles;   // ... taken when an index range has at least this many tiles (default 64; test knob)
     int dual_sample_short; // 1 (default): the sample sweep of kz_knn_dual uses lists of 16 (32) over several index ranges whatever K' is; 0: lists of K'

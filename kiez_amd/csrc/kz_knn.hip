@@ -1502,15 +1502,17 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (tier != KZ_TIER_F32 && (int64_t)n_fail * 4 > cq_count) {
             // more than a quarter of the chunk's rows could not be certified under this tier's margin: this data needs the
             // float32 operands; redo the chunk (and run the rest of the call) with the float32-MFMA kernel
-            tier = KZ_TIER_F32;
+            // (from the fp16 tier: the split-bf16 operands first -- three products per multiply-add instead of the float32 pipe's
+            //  sixteenth of the rate, and a bound 2^-16-ish instead of 2^-11-ish; the long-k route's list geometry is fp16 / float32 only)
+            tier = (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0) ? KZ_TIER_BF : KZ_TIER_F32;
             n_escalated += cq_count;
             continue;
         }
         if (tier != KZ_TIER_F32 && n_fail > 0) {
             // Escalate only the uncertified rows: gather them into a dense query block and search it again -- fp16 tier
             // with lists shorter than 128: same operands, lists four times as long (no new image of the index: 14 rows
-            // of a 1M-row index cost 0.4 ms this way against 7 ms for packing its float32 image); otherwise the
-            // float32-operand kernel.  The inner call sends its own uncertified rows further down (float32 operands,
+            // of a 1M-row index cost 0.4 ms this way against 7 ms for packing its float32 image); otherwise the split-bf16
+            // operands (from the fp16 tier), then the float32-operand kernel.  The inner call sends its own uncertified rows further down (float32 operands,
             // exact float64 kernels).  Results are scattered back.
             const bool widen = tier == KZ_TIER_H && KP < 128;
             // (short-list route: the rows it cannot certify are mostly the ones a list of K' could not certify either -- they go
@@ -1518,7 +1520,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             const int KP_esc = KP_class > KP ? KP_class : KP;
             kz_knn_stats st2;
             rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids,
-                                  widen ? 0 : 1, widen ? (KP == 16 && KSEL == 0 && ctx->esc_short ? -1 : (KP_esc * 4 < 128 ? KP_esc * 4 : 128)) : 0, fp.out_dist,
+                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0 ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short ? -1 : (KP_esc * 4 < 128 ? KP_esc * 4 : 128)) : 0, fp.out_dist,
                                   fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;

@@ -374,6 +374,11 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // threshold are there by construction (at rank k a row whose k best all happen to be sample rows -- probability stride^-k:
     // 4-25 % of the rows at k = 1 -- could not be certified and was searched again)
     const int rank = k + 1 < KP ? k + 1 : KP;
+    // list length of the REVERSE direction (the K' best events of a row): twice K' for K' >= 32 -- the events are there anyway
+    // (~(k + 1) stride per row), the re-rank gathers only the candidates within 2 eps of the k-th key whatever the list length
+    // is, and the certification's bound falls from the 64th to the 128th best key: on clustered data (many near-equal
+    // distances) far fewer rows are searched again (400k x 400k, k = 50, 40 clusters: 42.7k -> 0 rows, call 162 -> 134 ms; uniform 500k x 500k: +0.9 ms)
+    const int KPr = (KP >= 32 && ctx->dual_rev_long) ? (2 * KP < 128 ? 2 * KP : 128) : KP;
     const int n_slices = b->kg / 4;
     // every stride-th tile of A is in the sample.  Automatic (dual_stride = 1): the sample sweep costs T / stride, the events
     // (log, scatter, select, slower sweep) ~0.10 ns each with |B| k stride of them: stride = sqrt(T / (|B| k 0.07 ns)), T ~ 2 |A| |B| d / 1e15 s
@@ -492,8 +497,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&theta);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&floor_);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&qnb);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * KP * 4, (void**)&col_key);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * KP * 4, (void**)&col_idx);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * KPr * 4, (void**)&col_key);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * KPr * 4, (void**)&col_idx);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&ev_cnt);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * 4, (void**)&fail_list);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * ev_cap * 8, (void**)&ev);
@@ -649,7 +654,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     dp.log_cnt = d_cnt;
     dp.log_cap = log_cap;
     dp.short_pieces = main_pieces;
-    dp.short_ksel = k + 16;
+    dp.short_ksel = k + ctx->dual_short_extra < main_pieces * ctx->dual_short_kp ? k + ctx->dual_short_extra : main_pieces * ctx->dual_short_kp;
     dp.short_kp = ctx->dual_short_kp;
     // ---- the reverse direction's chain: events -> lists -> ordinary finalize with B as the query side.  Enqueued on the
     // context's SECOND stream from inside kz_knn_impl, right behind the sweep (KzDualPass::post_sweep): it shares no buffer
@@ -661,7 +666,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         float *theta_s, *qnb, *p_bias, *col_key, *floor_; int *row_map, *ev_cnt, *perm, *col_idx, *fail_list, *fail_count_b;
         uint2* ev; int ev_cap, KP, k; int64_t b_tiles; double* d_dist_ba; int64_t* d_ind_ba;
     } rv = {ctx, a, b, ia, ib, log_keys, log_meta, d_cnt, log_cap, theta_s, qnb, p_bias, col_key, floor_, row_map, ev_cnt, perm,
-            col_idx, fail_list, fail_count_b, ev, ev_cap, KP, k, b_tiles, d_dist_ba, d_ind_ba};
+            col_idx, fail_list, fail_count_b, ev, ev_cap, KPr, k, b_tiles, d_dist_ba, d_ind_ba};
     auto enqueue_reverse = [](void* user) -> int {
         RevCtx& r = *(RevCtx*)user;
         kz_ctx* ctx = r.ctx;
@@ -771,7 +776,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         st_ba.main_kernel_ms = sample_ms + ms;   // sample sweep + scatter + select: what this direction cost besides the shared sweep
         KZ_DUAL_HIP(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
         st_ba.finalize_ms = ms;
-        st_ba.list_len = KP;
+        st_ba.list_len = KPr;
         st_ba.n_splits = 1;
         st_ba.first_pass = KZ_TIER_H;
         st_ba.dual = 1;
@@ -783,7 +788,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         } else if (n_fail > 0) {
             // rows of B with an overflowing buffer or an uncertified list: the ordinary search, longer lists when they are few
             // (K' = 16: more lists instead of longer ones, kz_knn_impl kp_min = -1)
-            const int kp_min = ((int64_t)n_fail * 8 > b->n || KP >= 128) ? 0 : (KP == 16 && ctx->esc_short ? -1 : (KP * 4 < 128 ? KP * 4 : 128));
+            const int kp_min = ((int64_t)n_fail * 8 > b->n || KPr >= 128) ? 0 : (KPr == 16 && ctx->esc_short ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
             kz_knn_stats st2;
             KZ_DUAL_RC(kz_escalate_rows(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, -1, kp_min, d_dist_ba, d_ind_ba, &st2, &ms));
             st_ba.fallback_ms = ms;

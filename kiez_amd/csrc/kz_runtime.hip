@@ -52,7 +52,10 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_sample_short = 1;
     c->dual_short_main = 1;
     c->esc_short = 1;
+    c->esc_bf = 1;
     c->dual_short_kp = 16;
+    c->dual_short_extra = 48;   // (400k x 400k, k = 50, 40 clusters: rows searched again 27.9k at 16, 10.7k from 32 on; uniform data: no difference)
+    c->dual_rev_long = 1;
     c->dual_short_min_tiles = 64;
     c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
     c->lds_pad = 0;
@@ -130,11 +133,18 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "qgroup") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 4096, "kz_ctx_set_option: qgroup must be in [0, 4096]");
         c->qgroup = (int)value;
+    } else if (strcmp(name, "esc_bf") == 0) {
+        c->esc_bf = value != 0 ? 1 : 0;
     } else if (strcmp(name, "esc_short") == 0) {
         c->esc_short = value != 0 ? 1 : 0;
     } else if (strcmp(name, "dual_short_min_tiles") == 0) {
         KZ_REQUIRE(value >= 1, "kz_ctx_set_option: dual_short_min_tiles must be >= 1");
         c->dual_short_min_tiles = (int)value;
+    } else if (strcmp(name, "dual_rev_long") == 0) {
+        c->dual_rev_long = value != 0 ? 1 : 0;
+    } else if (strcmp(name, "dual_short_extra") == 0) {
+        KZ_REQUIRE(value >= 1 && value <= 200, "kz_ctx_set_option: dual_short_extra must be in [1, 200]");
+        c->dual_short_extra = (int)value;
     } else if (strcmp(name, "dual_short_kp") == 0) {
         KZ_REQUIRE(value == 16 || value == 32, "kz_ctx_set_option: dual_short_kp must be 16 or 32");
         c->dual_short_kp = (int)value;

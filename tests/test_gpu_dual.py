@@ -20,7 +20,7 @@ def ctx():
     c.set_option("dual_force", 1)   # the test shapes are far below the size at which the shared sweep pays
     yield c
     for name, value in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("eps_scale", 1.0), ("precision", 0), ("dual_max_gb", 0),
-                        ("dual_overlap", 1), ("dual_sample_short", 1), ("dual_short_main", 1), ("dual_short_min_tiles", 64), ("esc_short", 1),
+                        ("dual_overlap", 1), ("dual_sample_short", 1), ("dual_short_main", 1), ("dual_short_min_tiles", 64), ("esc_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1),
                         ("qgroup", 0)):
         c.set_option(name, value)
 
@@ -287,9 +287,16 @@ def test_reverse_rows_of_a_k64_search_that_fail_are_researched_with_a_valid_list
     """Regression (found by tools/fuzz_dual.py): K' = 64 with a few percent of uncertified reverse rows (exact duplicates)
     asked the re-search for lists of 4 x 64 = 256 entries; list lengths end at 128."""
     a, b = _data("duplicates", 21114, 200, 51, np.float32), _data("duplicates", 32829, 200, 52, np.float32)
-    sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 54, "sqeuclidean")
+    ctx.set_option("dual_rev_long", 0)   # (reverse lists of K' = 64 as then; with the default 128 every row of this case is certified)
+    try:
+        sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 54, "sqeuclidean")
+    finally:
+        ctx.set_option("dual_rev_long", 1)
     _assert_same(sep, dual)
-    assert s_ba["n_escalated_rows"] > 0
+    assert s_ba["n_escalated_rows"] > 0 and s_ba["list_len"] == 64
+    sep2, dual2, _, s_ba2 = _both_ways(ctx, a, b, 54, "sqeuclidean")
+    _assert_same(sep2, dual2)
+    assert s_ba2["list_len"] == 128 and s_ba2["n_escalated_rows"] <= s_ba["n_escalated_rows"]
 
 
 def test_footprint_gate_and_cache_trim(ctx):

@@ -9,6 +9,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 ctx = N.Context.get()
+import os
+for _o in os.environ.get("KZ_OPTS", "").split():
+    ctx.set_option(_o.split("=")[0], float(_o.split("=")[1]))
 rng = np.random.default_rng(5)
 
 
@@ -34,7 +37,7 @@ for metric in ("cosine",):
         am, bm = N.DeviceMatrix(ctx, a, metric), N.DeviceMatrix(ctx, b, metric)
         res = {}
         for short in (0, 1, 0, 1):
-            ctx.set_option("dual_short_main", short)
+            ctx.set_option("dual_short_main", short & 1)
             ctx.sync()
             t0 = time.perf_counter()
             (xd, xi, sa), (yd, yi, sb) = N.knn_dual(ctx, am, bm, k)
