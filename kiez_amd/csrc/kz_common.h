@@ -34,7 +34,7 @@ struct kz_ctx {
     int esc_short;         // 1 (default): uncertified rows of a K' = 16 pass are searched again with lists of 16 over >= 4 index ranges; 0: with lists of 64
     int dual_short_main;   // 1 (default): the main sweep of kz_knn_dual keeps k / dual_short_div lists of 16 per query instead of one of 32 / 64; 0: one list of K'
     int dual_short_div;    // (default 5)
-    int dual_rev_long;     // 1 (default): the reverse direction of kz_knn_dual keeps lists of 2 K' (K' >= 32)
+    int dual_rev_long;     // 1 (default): the reverse direction of kz_knn_dual keeps lists of 2 K'
     int dual_short_extra;  // ... of whose entries the finalize kernel selects k + this many (default 48)
     int dual_short_kp;     // list length of that route: 16 (default) or 32
     int dual_short_min_tiles;   // ... taken when an index range has at least this many tiles (default 64; test knob)

@@ -345,6 +345,9 @@ __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* si
 #endif
 constexpr int KZ_FIN_ROWS = KZ_FIN_ROWS_N;
 constexpr int KZ_FIN_MAXM = 4096;  // list entries per query: 4 waves x (4096*8 + 128*28) B = 142 KiB of LDS at most
+// Rows a K' = 16 pass could not certify: few (the usual handful) -> more lists of 16, it is all latency; many (hard data) -> lists
+// of 64, which certify more of them in one go (400k x 400k, k = 10, clusters of very different density: 140 against 112 ms)
+constexpr int KZ_ESC_SHORT_MAX_ROWS = 2048;
 constexpr int KZ_MAX_PIECES = 64;  // index ranges per query tile (each range keeps its own K'-entry list per query)
 static int kz_max_pieces(int KP, int halves) {
     const int m = KZ_FIN_MAXM / (halves * KP);
@@ -1249,7 +1252,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // index: 0.75 + 0.62 ms with lists of 64 over 64 ranges).
     int min_pieces_call = 0;
     if (kp_min == -1 && KP == 16 && !exact_only && KSEL == 0 && index->n_tiles >= 16) {
-        KSEL = k_eff + 16;
+        KSEL = k_eff + 48;   // (<= 60 of the >= 64 entries)
         min_pieces_call = 4;
     }
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -1518,9 +1521,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             // (short-list route: the rows it cannot certify are mostly the ones a list of K' could not certify either -- they go
             //  where that list's failures would have gone, lists four times K', not through a list of K' first)
             const int KP_esc = KP_class > KP ? KP_class : KP;
+            // (... when they are many.  A handful -- uniform data: ~2e-4 of the queries, those whose near rows crowd one range --
+            //  is certified by one list of K' at a quarter of the cost: 500k x 500k, k = 50: 4.5 -> ms per step)
+            const bool crowding_only = KP_class > KP && n_fail <= KZ_ESC_SHORT_MAX_ROWS;
             kz_knn_stats st2;
             rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids,
-                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0 ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short ? -1 : (KP_esc * 4 < 128 ? KP_esc * 4 : 128)) : 0, fp.out_dist,
+                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0 ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (crowding_only ? KP_esc : (KP_esc * 4 < 128 ? KP_esc * 4 : 128))) : 0, fp.out_dist,
                                   fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;

@@ -374,11 +374,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // threshold are there by construction (at rank k a row whose k best all happen to be sample rows -- probability stride^-k:
     // 4-25 % of the rows at k = 1 -- could not be certified and was searched again)
     const int rank = k + 1 < KP ? k + 1 : KP;
-    // list length of the REVERSE direction (the K' best events of a row): twice K' for K' >= 32 -- the events are there anyway
+    // list length of the REVERSE direction (the K' best events of a row): twice K' -- the events are there anyway
     // (~(k + 1) stride per row), the re-rank gathers only the candidates within 2 eps of the k-th key whatever the list length
     // is, and the certification's bound falls from the 64th to the 128th best key: on clustered data (many near-equal
-    // distances) far fewer rows are searched again (400k x 400k, k = 50, 40 clusters: 42.7k -> 0 rows, call 162 -> 134 ms; uniform 500k x 500k: +0.9 ms)
-    const int KPr = (KP >= 32 && ctx->dual_rev_long) ? (2 * KP < 128 ? 2 * KP : 128) : KP;
+    // distances) far fewer rows are searched again (400k x 400k, k = 50, 40 clusters: 42.7k -> 0 rows, call 162 -> 134 ms; uniform 500k x 500k: +0.9 ms; k = 10: 12.4k -> 0 rows, 104 -> 97 ms, and ns 105.9 -> 104.4 ms per step:
+    // its ~25 uncertified reverse rows per step are gone)
+    const int KPr = ctx->dual_rev_long ? (2 * KP < 128 ? 2 * KP : 128) : KP;
     const int n_slices = b->kg / 4;
     // every stride-th tile of A is in the sample.  Automatic (dual_stride = 1): the sample sweep costs T / stride, the events
     // (log, scatter, select, slower sweep) ~0.10 ns each with |B| k stride of them: stride = sqrt(T / (|B| k 0.07 ns)), T ~ 2 |A| |B| d / 1e15 s
@@ -788,7 +789,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         } else if (n_fail > 0) {
             // rows of B with an overflowing buffer or an uncertified list: the ordinary search, longer lists when they are few
             // (K' = 16: more lists instead of longer ones, kz_knn_impl kp_min = -1)
-            const int kp_min = ((int64_t)n_fail * 8 > b->n || KPr >= 128) ? 0 : (KPr == 16 && ctx->esc_short ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
+            const int kp_min = ((int64_t)n_fail * 8 > b->n || KPr >= 128) ? 0 : (KPr == 16 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
             kz_knn_stats st2;
             KZ_DUAL_RC(kz_escalate_rows(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, -1, kp_min, d_dist_ba, d_ind_ba, &st2, &ms));
             st_ba.fallback_ms = ms;
