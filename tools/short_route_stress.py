@@ -31,7 +31,7 @@ def gen(kind, n):
     raise ValueError(kind)
 
 
-for metric in ("cosine",):
+for metric in (os.environ.get("KZ_METRIC", "cosine"),):
     for kind in ("normal", "clusters, stored cluster by cluster", "clusters, shuffled", "clusters of very different density"):
         a, b = gen(kind, n).astype(np.float32), gen(kind, n + 1000).astype(np.float32)
         am, bm = N.DeviceMatrix(ctx, a, metric), N.DeviceMatrix(ctx, b, metric)
