@@ -1251,9 +1251,13 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // margin in ranks a failed row needs, with the K' = 16 kernel and a quarter of the entries to merge (14 rows of a 1M-row
     // index: 0.75 + 0.62 ms with lists of 64 over 64 ranges).
     int min_pieces_call = 0;
-    if (kp_min == -1 && KP == 16 && !exact_only && KSEL == 0 && index->n_tiles >= 16) {
-        KSEL = k_eff + 48;   // (<= 60 of the >= 64 entries)
-        min_pieces_call = 4;
+    if (kp_min == -1) {
+        if (KP == 16 && !exact_only && KSEL == 0 && index->n_tiles >= 16) {
+            KSEL = k_eff + 48;   // (<= 60 of the >= 64 entries)
+            min_pieces_call = 4;
+        } else if (!exact_only && KP < 64) {
+            KP = 64;   // (an index of a few tiles: lists of 64 -- every re-search must ask for MORE than the pass that failed)
+        }
     }
     if (stats) memset(stats, 0, sizeof(*stats));
     if (q_count == 0) return KZ_OK;
@@ -1496,21 +1500,14 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fin_ms += ms;
         last_splits = lay.pieces[0];
         last_blocks = W;
-        if (dual && tier == KZ_TIER_H && (int64_t)n_fail * 4 > cq_count) {
-            // the chunk is a range of image rows in the dual pass' own order: it cannot simply be redone with the float32
-            // kernel -- the caller (kz_knn_dual) runs both directions the ordinary way instead
-            dual->broken = 2;
-            return KZ_OK;
-        }
-        if (tier != KZ_TIER_F32 && (int64_t)n_fail * 4 > cq_count) {
-            // more than a quarter of the chunk's rows could not be certified under this tier's margin: this data needs the
-            // float32 operands; redo the chunk (and run the rest of the call) with the float32-MFMA kernel
-            // (from the fp16 tier: the split-bf16 operands first -- three products per multiply-add instead of the float32 pipe's
-            //  sixteenth of the rate, and a bound 2^-16-ish instead of 2^-11-ish; the long-k route's list geometry is fp16 / float32 only)
-            tier = (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0) ? KZ_TIER_BF : KZ_TIER_F32;
-            n_escalated += cq_count;
-            continue;
-        }
+        // More than a quarter of the chunk's rows uncertified: this data needs better operands -- the REST of the call starts at
+        // the next tier (not in the dual pass: its kernel exists for the fp16 tier only).  THIS chunk's uncertified rows go down
+        // like any others: searching a quarter (or all) of the rows again at the next tier is never more work than redoing the
+        // whole chunk there, which is what an earlier version did -- and abandoned the shared sweep altogether (500k x 62.5k, k = 50, 40
+        // tight clusters: 579 -> 540 ms cluster by cluster, 528 -> 348 ms shuffled; nearly every row of that set needs better operands).
+        int tier_next = tier;
+        if (!dual && tier != KZ_TIER_F32 && (int64_t)n_fail * 4 > cq_count)
+            tier_next = (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0) ? KZ_TIER_BF : KZ_TIER_F32;
         if (tier != KZ_TIER_F32 && n_fail > 0) {
             // Escalate only the uncertified rows: gather them into a dense query block and search it again -- fp16 tier
             // with lists shorter than 128: same operands, lists four times as long (no new image of the index: 14 rows
@@ -1534,6 +1531,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             n_fail_total += st2.n_fallback_rows;
             if (st2.max_err_ratio > max_err_ratio) max_err_ratio = st2.max_err_ratio;
             c0 += max_rows_per_chunk;
+            tier = tier_next;
             continue;
         }
         n_fail_total += n_fail;
