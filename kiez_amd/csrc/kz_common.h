@@ -32,6 +32,7 @@ struct kz_ctx {
     int dual_deal;    // tuning knob: 1 (default) = the dual pass deals the query rows into load-balanced tiles, 0 = natural order
     int esc_bf;            // 1 (default): rows the fp16 tier cannot certify with its longest lists go to the split-bf16 operands before the float32 ones
     int esc_short;         // 1 (default): uncertified rows of a K' = 16 pass are searched again with lists of 16 over >= 4 index ranges; 0: with lists of 64
+    int short_ord;         // 1 (default): the ordinary fp16 kernel takes the short-list route too (a dealt second image of the index)
     int dual_short_main;   // 1 (default): the main sweep of kz_knn_dual keeps k / dual_short_div lists of 16 per query instead of one of 32 / 64; 0: one list of K'
     int dual_short_div;    // (default 5)
     int dual_rev_long;     // 1 (default): the reverse direction of kz_knn_dual keeps lists of 2 K'
@@ -74,12 +75,33 @@ struct kz_center {
 };
 
 // fp16 operand image of a matrix (first pass of the fused kernel, kz_knn_h16.h), built lazily by kz_knn
+// Rows dealt over P parts: position r' of a sequence of N rows <- row j, with j running through the parts one after the other,
+// part p = rows p, p + P, p + 2 P, ... (the first N % P parts hold one row more).  P = 1: j = r'.
+__host__ __device__ __forceinline__ int64_t kz_dealt_row(int64_t rp, int64_t N, int P) {
+    const int64_t q = N / P, r = N - q * P;
+    int64_t part, i;
+    if (rp < r * (q + 1)) {
+        part = rp / (q + 1);
+        i = rp - part * (q + 1);
+    } else {
+        const int64_t j2 = rp - r * (q + 1);
+        part = r + j2 / q;
+        i = j2 - (part - r) * q;
+    }
+    return part + P * i;
+}
+
 struct kz_himage {
     kz_center* center;
     unsigned short* packed;  // [n_tiles][nsr][2 planes][128 rows][8] fp16: plane p = k 8p..8p+7 of the 16-k slice
     float* bias;             // [n_tiles*128] accumulator init -S^2 |x_c|^2 / 2 (pad rows: -inf)
     double* rowq;            // [n][3] unscaled: |x_c|^2, |x_h|, |x_c - x_h|  (x_c = float32(x - mu), x_h = fp16 operand / S)
     double* d_max;           // device [3]: max |x_h|, max |x_c - x_h|, max |x_c|^2 over the rows
+    // a second image with the rows DEALT over dealt_P index ranges (kz_himage_dealt; short-list route of the ordinary kernel)
+    int dealt_P;
+    unsigned short* dealt_packed;
+    float* dealt_bias;
+    int* dealt_perm;         // [n_tiles*128] matrix row of image row r (-1 behind the end)
 };
 
 struct kz_matrix {
@@ -108,6 +130,7 @@ int kz_matrix_image_f32(kz_matrix* m);
 int kz_matrix_image_bf(kz_matrix* m);
 int kz_himage_ensure(kz_matrix* query, kz_matrix* index);
 int kz_himage_pack_permuted(kz_matrix* m, const int* d_perm, unsigned short* packed, float* bias);
+int kz_himage_dealt(kz_matrix* m, int P);
 // stable sort of (float key, int value) pairs on the context's stream (kz_sort.hip)
 int kz_sort_pairs_f32_i32(kz_ctx* ctx, const float* keys_in, float* keys_out, const int* vals_in, int* vals_out, int n, int descending);
 int kz_matrix_check(kz_matrix* m);

@@ -1199,6 +1199,10 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     KZ_REQUIRE(query->metric == index->metric, "kz_knn: query and index were packed for different metrics");
     KZ_REQUIRE(q_begin >= 0 && q_count >= 0 && q_begin + q_count <= query->n, "kz_knn: query row range out of bounds");
     KZ_REQUIRE(k >= 1, "kz_knn: Expected k > 0. Got %d", k);
+    // kp_min >= 1000: lists of kp_min - 1000, and NOT the short-list route (the re-search of rows that route could not certify:
+    // every re-search must differ from the pass that failed)
+    const bool no_short = kp_min >= 1000;
+    if (no_short) kp_min -= 1000;
     const int k_eff = k + (exclude_self ? 1 : 0);
     KZ_REQUIRE((int64_t)k_eff <= index->n, "kz_knn: Expected n_neighbors %s n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld",
                exclude_self ? "<" : "<=", k, (long long)index->n);
@@ -1283,6 +1287,28 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         const int rc = kz_himage_ensure(query, index);
         if (rc != KZ_OK) return rc;
     }
+    // SHORT-LIST ROUTE of the ordinary kernel: as in the dual pass, lists of 16 over P index ranges instead of one list of 32 /
+    // 64 / 128 per query -- on a second image of the index whose ROWS are dealt over the ranges (kz_himage_dealt; in the caller's
+    // row order the near rows of a query may all sit in one stretch).  P lists hold at least as many entries as the list they
+    // replace; taken when a range has at least 64 tiles.  (The long lists' kernels stay for small indexes and for k > 80.)
+    const int KP_class2 = KP;   // (the list length this call would use without the route)
+    bool short_ord = false;
+    if (!dual && !no_short && tier == KZ_TIER_H && ctx->short_ord && KP > 16 && KSEL == 0 && !exact_only) {
+        int P = (k_eff + ctx->dual_short_div - 1) / ctx->dual_short_div;
+        if (P < KP / 16) P = KP / 16;
+        const int sel = k_eff + (KP >= 128 ? 80 : 48) < P * 16 ? k_eff + (KP >= 128 ? 80 : 48) : P * 16;
+        if (P <= 16 && (int64_t)index->n_tiles >= (int64_t)ctx->dual_short_min_tiles * P && sel >= k_eff) {
+            const int rc = kz_himage_dealt(index, P);
+            if (rc == KZ_OK) {
+                short_ord = true;
+                KP = 16;
+                KSEL = sel;
+                long_pieces = P;
+            } else if (rc != KZ_ERR_NOMEM) {
+                return rc;
+            }   // (no memory for the second image: the long list)
+        }
+    }
     int slots_cache[3] = {0, 0, 0};
     int tpw_h = 1;   // query tiles per workgroup of the fp16 kernel this call runs (wide builds: 2 or 3)
     auto slots_for = [&](int t, int* out) -> int {
@@ -1350,8 +1376,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         memset(&cp, 0, sizeof(cp));
         if (tier == KZ_TIER_H) {
             cp.qpack = (const float*)query->himg->packed;
-            cp.ypack = (const float*)index->himg->packed;
-            cp.ybias = index->himg->bias;
+            cp.ypack = (const float*)(short_ord ? index->himg->dealt_packed : index->himg->packed);
+            cp.ybias = short_ord ? index->himg->dealt_bias : index->himg->bias;
         } else {
             cp.qpack = tier == KZ_TIER_BF ? (const float*)query->packed_bf : query->packed;
             cp.ypack = tier == KZ_TIER_BF ? (const float*)index->packed_bf : index->packed;
@@ -1433,6 +1459,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         }
         fp.out_dist = d_dist + c0 * (int64_t)k;
         fp.out_ind = d_ind + c0 * (int64_t)k;
+        if (tier == KZ_TIER_H && short_ord) fp.idx_map = index->himg->dealt_perm;   // the lists hold rows of the dealt index image
         if (tier == KZ_TIER_H && dual) {
             fp.idx_map = dual->perm;      // the lists hold rows of the sorted index image
             fp.row_map = dual->row_map;   // the chunk is a range of IMAGE rows: results and failures go by matrix row
@@ -1517,13 +1544,13 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             const bool widen = tier == KZ_TIER_H && KP < 128;
             // (short-list route: the rows it cannot certify are mostly the ones a list of K' could not certify either -- they go
             //  where that list's failures would have gone, lists four times K', not through a list of K' first)
-            const int KP_esc = KP_class > KP ? KP_class : KP;
+            const int KP_esc = short_ord ? KP_class2 : (KP_class > KP ? KP_class : KP);
             // (... when they are many.  A handful -- uniform data: ~2e-4 of the queries, those whose near rows crowd one range --
             //  is certified by one list of K' at a quarter of the cost: 500k x 500k, k = 50: 4.5 -> ms per step)
-            const bool crowding_only = KP_class > KP && n_fail <= KZ_ESC_SHORT_MAX_ROWS;
+            const bool crowding_only = KP_esc > KP && n_fail <= KZ_ESC_SHORT_MAX_ROWS;
             kz_knn_stats st2;
             rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids,
-                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0 ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (crowding_only ? KP_esc : (KP_esc * 4 < 128 ? KP_esc * 4 : 128))) : 0, fp.out_dist,
+                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0 ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KP_esc > KP ? 1000 : 0) + (crowding_only ? KP_esc : (KP_esc * 4 < 128 ? KP_esc * 4 : 128))) : 0, fp.out_dist,
                                   fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;
@@ -1531,6 +1558,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             n_fail_total += st2.n_fallback_rows;
             if (st2.max_err_ratio > max_err_ratio) max_err_ratio = st2.max_err_ratio;
             c0 += max_rows_per_chunk;
+            if (tier_next != tier && short_ord) {   // (the other tiers' kernels keep one list of K' per query)
+                short_ord = false;
+                KP = KP_class2;
+                KSEL = 0;
+                long_pieces = 0;
+            }
             tier = tier_next;
             continue;
         }

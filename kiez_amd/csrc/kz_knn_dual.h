@@ -93,22 +93,6 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
     }
 }
 
-// Rows dealt over P parts: position r' of a sequence of N rows <- row j, with j running through the parts one after the other,
-// part p = rows p, p + P, p + 2 P, ... (the first N % P parts hold one row more).  P = 1: j = r'.
-__device__ __forceinline__ int64_t kz_dual_dealt_row(int64_t rp, int64_t N, int P) {
-    const int64_t q = N / P, r = N - q * P;
-    int64_t part, i;
-    if (rp < r * (q + 1)) {
-        part = rp / (q + 1);
-        i = rp - part * (q + 1);
-    } else {
-        const int64_t j2 = rp - r * (q + 1);
-        part = r + j2 / q;
-        i = j2 - (part - r) * q;
-    }
-    return part + P * i;
-}
-
 // Sample image: the rows of every stride-th tile of A's image, dealt over P parts ROW BY ROW (data stored cluster by cluster has
 // all near rows of a query in one stretch of A; dealt, every part holds its share of them).  One workgroup per image tile; a
 // row of the fp16 image is 2 nsr fragments of 16 bytes, one per (slice, plane) block of its tile.
@@ -119,7 +103,7 @@ __global__ __launch_bounds__(256) void kz_dual_sample_kernel(const uint4* __rest
     const int n_frag = 2 * nsr * KZ_TILE;   // 16-byte fragments of a tile: [slice][plane][row]
     for (int e = threadIdx.x; e < n_frag; e += 256) {
         const int row = e & (KZ_TILE - 1), blk = e >> 7;
-        const int64_t j = kz_dual_dealt_row((int64_t)jp * KZ_TILE + row, (int64_t)s_tiles * KZ_TILE, P);
+        const int64_t j = kz_dealt_row((int64_t)jp * KZ_TILE + row, (int64_t)s_tiles * KZ_TILE, P);
         const int64_t src_tile = (j >> 7) * stride;
         s_packed[(int64_t)jp * n_frag + e] = packed[src_tile * n_frag + blk * KZ_TILE + (j & (KZ_TILE - 1))];
         if (blk == 0) s_bias[(int64_t)jp * KZ_TILE + row] = bias[src_tile * KZ_TILE + (j & (KZ_TILE - 1))];
@@ -136,7 +120,7 @@ __global__ void kz_dual_interleave_kernel(const int* __restrict__ perm, const fl
     if (rp >= n_pad) return;
     const int64_t tiles = n_pad / KZ_TILE - 1;   // the tiles that move
     const int64_t jp = rp / KZ_TILE;
-    const int64_t src = jp < tiles ? kz_dual_dealt_row(jp, tiles, P) * KZ_TILE + (rp & (KZ_TILE - 1)) : rp;
+    const int64_t src = jp < tiles ? kz_dealt_row(jp, tiles, P) * KZ_TILE + (rp & (KZ_TILE - 1)) : rp;
     perm_out[rp] = src < n ? perm[src] : -1;
     theta_out[rp] = src < n ? theta_s[src] : INFINITY;
 }

@@ -422,6 +422,9 @@ void kz_himage_free(kz_matrix* m) {
     kz_pool_free(m->ctx, im->bias, 0);
     kz_pool_free(m->ctx, im->rowq, 0);
     kz_pool_free(m->ctx, im->d_max, 0);
+    kz_pool_free(m->ctx, im->dealt_packed, 0);
+    kz_pool_free(m->ctx, im->dealt_bias, 0);
+    kz_pool_free(m->ctx, im->dealt_perm, 0);
     kz_center_release(m->ctx, im->center);
     delete im;
     m->himg = nullptr;
@@ -515,6 +518,45 @@ int kz_himage_pack_permuted(kz_matrix* m, const int* d_perm, unsigned short* pac
                            m->n, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, packed, bias, (double*)nullptr,
                            (unsigned long long*)nullptr, d_perm);
     KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
+// A second fp16 image of m with its rows dealt over P index ranges (range p = rows p, p + P, p + 2 P, ...; kz_dealt_row): the
+// short-list route of the ordinary kernel keeps one list of 16 per query and RANGE, and the ranges must be alike -- in the
+// caller's row order the near rows of a query may all sit in one stretch of the matrix (data stored cluster by cluster).
+// Same centre, same scale, bit-identical operands and biases, row for row; cached on the image (one P at a time).
+__global__ void kz_dealt_perm_kernel(int64_t n, int64_t n_pad, int P, int* __restrict__ perm) {
+    const int64_t rp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rp < n_pad) perm[rp] = rp < n ? (int)kz_dealt_row(rp, n, P) : -1;
+}
+
+int kz_himage_dealt(kz_matrix* m, int P) {
+    kz_ctx* ctx = m->ctx;
+    KZ_REQUIRE(m->himg && P >= 2 && (int64_t)P <= m->n, "kz_himage_dealt: no fp16 image / bad range count");
+    kz_himage* im = m->himg;
+    if (im->dealt_P == P) return KZ_OK;
+    const int nsr = m->kg / 4;
+    const int64_t n_pad = m->n_tiles * KZ_TILE;
+    if (!im->dealt_packed) {
+        if (kz_pool_alloc(ctx, (size_t)n_pad * (size_t)nsr * 32 + 32 * 4096, (void**)&im->dealt_packed) != KZ_OK ||
+            kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&im->dealt_bias) != KZ_OK ||
+            kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&im->dealt_perm) != KZ_OK) {
+            kz_pool_free(ctx, im->dealt_packed, 0);
+            kz_pool_free(ctx, im->dealt_bias, 0);
+            kz_pool_free(ctx, im->dealt_perm, 0);
+            im->dealt_packed = nullptr;
+            im->dealt_bias = nullptr;
+            im->dealt_perm = nullptr;
+            im->dealt_P = 0;
+            return KZ_ERR_NOMEM;
+        }
+    }
+    im->dealt_P = 0;
+    hipLaunchKernelGGL(kz_dealt_perm_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, m->n, n_pad, P, im->dealt_perm);
+    KZ_HIP(hipGetLastError());
+    const int rc = kz_himage_pack_permuted(m, im->dealt_perm, im->dealt_packed, im->dealt_bias);
+    if (rc != KZ_OK) return rc;
+    im->dealt_P = P;
     return KZ_OK;
 }
 

@@ -52,6 +52,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_sample_short = 1;
     c->dual_short_main = 1;
     c->esc_short = 1;
+    c->short_ord = 1;
     c->esc_bf = 1;
     c->dual_short_kp = 16;
     c->dual_short_extra = 48;   // (400k x 400k, k = 50, 40 clusters: rows searched again 27.9k at 16, 10.7k from 32 on; uniform data: no difference)
@@ -133,6 +134,8 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "qgroup") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 4096, "kz_ctx_set_option: qgroup must be in [0, 4096]");
         c->qgroup = (int)value;
+    } else if (strcmp(name, "short_ord") == 0) {
+        c->short_ord = value != 0 ? 1 : 0;
     } else if (strcmp(name, "esc_bf") == 0) {
         c->esc_bf = value != 0 ? 1 : 0;
     } else if (strcmp(name, "esc_short") == 0) {

@@ -1,0 +1,94 @@
+"""Short-list route of the ORDINARY kernel (kz_knn.hip "SHORT-LIST ROUTE of the ordinary kernel"): 13 .. 80 neighbours per query as
+lists of 16 over P index ranges of a second, row-dealt image of the index, instead of one list of 32 / 64 / 128.  The reference
+has no counterpart (scikit-learn's brute force keeps one heap per query, sklearn_nearest_neighbors.py:96-101): the result must be
+the float64 neighbour order all the same.  Needs an MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx():
+    from kiez_amd import _native as N
+    c = N.Context.get()
+    yield c
+    for name, value in (("short_ord", 1), ("dual_short_min_tiles", 64), ("eps_scale", 1.0)):
+        c.set_option(name, value)
+
+
+def _data(kind, n, d, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.random((n, d)).astype(np.float32)
+    if kind == "cluster by cluster":   # all near rows of a query in ONE stretch of the matrix
+        centres = rng.standard_normal((12, d))
+        sizes = rng.multinomial(n, np.ones(12) / 12)
+        return np.concatenate([centres[c] + 0.5 * rng.standard_normal((sizes[c], d)) for c in range(12)]).astype(np.float32)
+    if kind == "duplicates":
+        base = rng.random((max(n // 9, 8), d))
+        return base[rng.integers(0, len(base), n)].astype(np.float32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,metric", [("uniform", "euclidean"), ("cluster by cluster", "cosine"), ("duplicates", "sqeuclidean")])
+@pytest.mark.parametrize("k", [13, 26, 50, 64, 80])
+def test_route_on_and_off_give_the_same_neighbours_and_the_oracle_agrees(ctx, kind, metric, k):
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    q, y = _data(kind, 3000, 48, 1), _data(kind, 30000, 48, 2)
+    qm, ym = N.DeviceMatrix(ctx, q, metric), N.DeviceMatrix(ctx, y, metric)
+    ctx.set_option("dual_short_min_tiles", 8)    # (235 index tiles: the route is taken with ranges of >= 8 tiles)
+    ctx.set_option("short_ord", 0)
+    d0, i0, s0 = N.knn(ctx, qm, ym, k)
+    ctx.set_option("short_ord", 1)
+    d1, i1, s1 = N.knn(ctx, qm, ym, k)
+    assert s0["list_len"] in (32, 64, 128) and s1["list_len"] == 16 and s1["n_splits"] >= max(2, (k + 4) // 5), (s0, s1)
+    np.testing.assert_array_equal(i1.numpy(), i0.numpy())
+    np.testing.assert_array_equal(d1.numpy(), d0.numpy())
+    if kind != "duplicates":
+        rows = np.arange(0, len(q), 15)
+        q64, y64 = (q.astype(np.float64), y.astype(np.float64)) if metric == "cosine" else (q, y)
+        np.testing.assert_array_equal(i1.numpy()[rows], O.knn_exact(q64[rows], y64, k, metric)[1])
+
+
+@pytest.mark.parametrize("k", [20, 50])
+def test_route_in_single_source_mode_strips_the_query_itself(ctx, k):
+    """exclude_self: the query's own row is a row of the DEALT image under another number -- the finalize kernel translates the
+    list entries back before it strips it (neighbor_algorithm_base.py:119 is_self_querying)."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    y = _data("cluster by cluster", 20000, 40, 3)
+    ym = N.DeviceMatrix(ctx, y, "euclidean")
+    ctx.set_option("dual_short_min_tiles", 8)
+    d1, i1, s1 = N.knn(ctx, ym, ym, k, exclude_self=True)
+    assert s1["list_len"] == 16
+    i = i1.numpy()
+    assert (i != np.arange(len(y))[:, None]).all()
+    rows = np.arange(0, len(y), 97)
+    np.testing.assert_array_equal(i[rows], O.knn_exact(y, y, k, "euclidean", exclude_self=True)[1][rows])
+
+
+def test_rows_the_route_cannot_certify_go_down_and_come_back_right(ctx):
+    """eps_scale large enough that many rows fail the fp16 certification: they are searched again with LONG lists (never the
+    same geometry twice), then with better operands; same neighbours as without the route."""
+    from kiez_amd import _native as N
+    q, y = _data("uniform", 2000, 32, 5), _data("uniform", 40000, 32, 6)
+    qm, ym = N.DeviceMatrix(ctx, q, "euclidean"), N.DeviceMatrix(ctx, y, "euclidean")
+    ctx.set_option("dual_short_min_tiles", 8)
+    out = {}
+    for short in (0, 1):
+        ctx.set_option("short_ord", short)
+        res = []
+        for eps in (1.0, 40.0, 1e9):
+            ctx.set_option("eps_scale", eps)
+            d, i, st = N.knn(ctx, qm, ym, 30)
+            res.append((i.numpy(), d.numpy(), st["n_escalated_rows"] + st["n_fallback_rows"]))
+        ctx.set_option("eps_scale", 1.0)
+        out[short] = res
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    assert out[1][2][2] >= 2000     # eps_scale = 1e9: every row reaches the exact float64 kernels
+    for r in out[1][1:]:
+        np.testing.assert_array_equal(r[0], out[1][0][0])
