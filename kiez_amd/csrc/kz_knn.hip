@@ -1296,6 +1296,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     if (!dual && !no_short && tier == KZ_TIER_H && ctx->short_ord && KP > 16 && KSEL == 0 && !exact_only) {
         int P = (k_eff + ctx->dual_short_div - 1) / ctx->dual_short_div;
         if (P < KP / 16) P = KP / 16;
+        if (kp_min >= 128) P = 16;   // (a re-search that asks for lists of 128: all the ranges the finalize kernel's fast selection takes)
         const int sel = k_eff + (KP >= 128 ? 80 : 48) < P * 16 ? k_eff + (KP >= 128 ? 80 : 48) : P * 16;
         if (P <= 16 && (int64_t)index->n_tiles >= (int64_t)ctx->dual_short_min_tiles * P && sel >= k_eff) {
             const int rc = kz_himage_dealt(index, P);
@@ -1545,12 +1546,14 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             // (short-list route: the rows it cannot certify are mostly the ones a list of K' could not certify either -- they go
             //  where that list's failures would have gone, lists four times K', not through a list of K' first)
             const int KP_esc = short_ord ? KP_class2 : (KP_class > KP ? KP_class : KP);
-            // (... when they are many.  A handful -- uniform data: ~2e-4 of the queries, those whose near rows crowd one range --
-            //  is certified by one list of K' at a quarter of the cost: 500k x 500k, k = 50: 4.5 -> ms per step)
+            // (... when they are many: lists of 128 -- which the callee turns into 16 lists of 16 on the dealt image when the index
+            //  is large: more ranges than this pass had, so not the same search again.  A handful -- uniform data: ~2e-4 of the
+            //  queries, those whose near rows crowd one range -- is certified by ONE list of K' at a quarter of the cost: 500k x
+            //  500k, k = 50: 4.7 -> 1.7 ms per step)
             const bool crowding_only = KP_esc > KP && n_fail <= KZ_ESC_SHORT_MAX_ROWS;
             kz_knn_stats st2;
             rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids,
-                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0 ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KP_esc > KP ? 1000 : 0) + (crowding_only ? KP_esc : (KP_esc * 4 < 128 ? KP_esc * 4 : 128))) : 0, fp.out_dist,
+                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0 ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : ((KP_esc > KP && (crowding_only || long_pieces >= 16)) ? 1000 : 0) + (crowding_only ? KP_esc : (KP_esc * 4 < 128 ? KP_esc * 4 : 128))) : 0, fp.out_dist,
                                   fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;

@@ -20,7 +20,7 @@ def main():
     bad = 0
     for c in range(n_cases):
         d = int(rng.choice([3, 16, 17, 31, 33, 48, 64, 65, 96, 100, 128, 129, 150, 176, 192, 200, 224, 240, 256, 257, 300, 384, 385, 500]))
-        n_t = int(rng.choice([60, 127, 128, 129, 500, 1000, 2049, 4000]))
+        n_t = int(rng.choice([60, 127, 128, 129, 500, 1000, 2049, 4000, 9000, 20000]))
         n_s = int(rng.choice([1, 31, 128, 130, 700, 1500]))
         metric = str(rng.choice(["euclidean", "sqeuclidean", "cosine"]))
         dtype = np.float32 if rng.rand() < 0.6 else np.float64
@@ -32,6 +32,10 @@ def main():
         s = t if single else gen(n_s, d).astype(dtype)
         if metric == "cosine":
             s, t = s.astype(np.float64), (s if single else t).astype(np.float64)
+        # short-list route of the ordinary kernel forced onto small index ranges; a bound that sends rows down the tiers
+        min_tiles, eps = int(rng.choice([64, 2, 2, 4])), float(rng.choice([1.0, 1.0, 1.0, 30.0]))
+        ctx.set_option("dual_short_min_tiles", min_tiles)
+        ctx.set_option("eps_scale", eps)
         res = {}
         for prec in (0, 2, 1):   # fp16 first pass (default), split-bf16, float32 operands only
             ctx.set_option("precision", prec)
@@ -42,6 +46,8 @@ def main():
                 res[prec] = (dd.numpy(), ii.numpy(), st)
             finally:
                 ctx.set_option("precision", 0)
+        ctx.set_option("dual_short_min_tiles", 64)
+        ctx.set_option("eps_scale", 1.0)
         ok = all(np.array_equal(res[0][1], res[p][1]) and np.array_equal(res[0][0], res[p][0]) for p in (1, 2))
         if len(s) * n_t <= 2_000_000:
             od, oi = O.knn_exact(s, t, k, O.canonical_metric(metric), exclude_self=single)
@@ -49,7 +55,7 @@ def main():
         tag = "ok " if ok else "BAD"
         bad += 0 if ok else 1
         print(tag, f"n_s={len(s)} n_t={n_t} d={d} {metric} {np.dtype(dtype).name} k={k} single={single}",
-              "tier", res[0][2]["first_pass"], "esc", res[0][2]["n_escalated_rows"], "fb", res[0][2]["n_fallback_rows"],
+              "tier", res[0][2]["first_pass"], "lists", res[0][2]["n_splits"], "x", res[0][2]["list_len"], f"min_tiles {min_tiles} eps {eps}", "esc", res[0][2]["n_escalated_rows"], "fb", res[0][2]["n_fallback_rows"],
               "ratio %.3f" % res[0][2]["max_err_ratio"])
     print("cases", n_cases, "bad", bad)
     sys.exit(1 if bad else 0)
