@@ -1542,7 +1542,10 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             // of a 1M-row index cost 0.4 ms this way against 7 ms for packing its float32 image); otherwise the split-bf16
             // operands (from the fp16 tier), then the float32-operand kernel.  The inner call sends its own uncertified rows further down (float32 operands,
             // exact float64 kernels).  Results are scattered back.
-            const bool widen = tier == KZ_TIER_H && KP < 128;
+            // (more than half of the chunk uncertified: the fp16 operands are the wrong tool for this data, longer lists of the
+            //  same keys will not help most of them -- straight to the split-bf16 operands)
+            const bool fp16_hard = tier == KZ_TIER_H && ctx->esc_bf && (int64_t)n_fail * 2 > cq_count && (long_pieces == 0 || short_ord || (dual && dual->short_pieces > 0));
+            const bool widen = tier == KZ_TIER_H && KP < 128 && !fp16_hard;
             // (short-list route: the rows it cannot certify are mostly the ones a list of K' could not certify either -- they go
             //  where that list's failures would have gone, lists four times K', not through a list of K' first)
             const int KP_esc = short_ord ? KP_class2 : (KP_class > KP ? KP_class : KP);
@@ -1553,7 +1556,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             const bool crowding_only = KP_esc > KP && n_fail <= KZ_ESC_SHORT_MAX_ROWS;
             kz_knn_stats st2;
             rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids,
-                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0 ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : ((KP_esc > KP && (crowding_only || long_pieces >= 16)) ? 1000 : 0) + (crowding_only ? KP_esc : (KP_esc * 4 < 128 ? KP_esc * 4 : 128))) : 0, fp.out_dist,
+                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && (long_pieces == 0 || fp16_hard) ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : ((KP_esc > KP && (crowding_only || long_pieces >= 16)) ? 1000 : 0) + (crowding_only ? KP_esc : (KP_esc * 4 < 128 ? KP_esc * 4 : 128))) : 0, fp.out_dist,
                                   fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;

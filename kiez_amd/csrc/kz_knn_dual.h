@@ -775,7 +775,9 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             // (K' = 16: more lists instead of longer ones, kz_knn_impl kp_min = -1)
             const int kp_min = ((int64_t)n_fail * 8 > b->n || KPr >= 128) ? 0 : (KPr == 16 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
             kz_knn_stats st2;
-            KZ_DUAL_RC(kz_escalate_rows(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, -1, kp_min, d_dist_ba, d_ind_ba, &st2, &ms));
+            // (more than half of B's rows: fp16 is the wrong tier for this data -- the split-bf16 operands at once)
+            const int prec = ((int64_t)n_fail * 2 > b->n && ctx->esc_bf) ? 2 : -1;
+            KZ_DUAL_RC(kz_escalate_rows(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, prec, prec == 2 ? 0 : kp_min, d_dist_ba, d_ind_ba, &st2, &ms));
             st_ba.fallback_ms = ms;
             st_ba.n_escalated_rows = n_fail + st2.n_escalated_rows;
             st_ba.n_fallback_rows = st2.n_fallback_rows;
