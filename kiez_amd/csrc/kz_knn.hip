@@ -1291,7 +1291,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // 64 / 128 per query -- on a second image of the index whose ROWS are dealt over the ranges (kz_himage_dealt; in the caller's
     // row order the near rows of a query may all sit in one stretch).  P lists hold at least as many entries as the list they
     // replace; taken when a range has at least 64 tiles.  (The long lists' kernels stay for small indexes and for k > 80.)
-    const int KP_class2 = KP;   // (the list length this call would use without the route)
+    const int KP_long = KP;   // (the list length this call would use without the route)
     bool short_ord = false;
     if (!dual && !no_short && tier == KZ_TIER_H && ctx->short_ord && KP > 16 && KSEL == 0 && !exact_only) {
         int P = (k_eff + ctx->dual_short_div - 1) / ctx->dual_short_div;
@@ -1548,16 +1548,30 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             const bool widen = tier == KZ_TIER_H && KP < 128 && !fp16_hard;
             // (short-list route: the rows it cannot certify are mostly the ones a list of K' could not certify either -- they go
             //  where that list's failures would have gone, lists four times K', not through a list of K' first)
-            const int KP_esc = short_ord ? KP_class2 : (KP_class > KP ? KP_class : KP);
+            const int KP_esc = short_ord ? KP_long : (KP_class > KP ? KP_class : KP);
             // (... when they are many: lists of 128 -- which the callee turns into 16 lists of 16 on the dealt image when the index
             //  is large: more ranges than this pass had, so not the same search again.  A handful -- uniform data: ~2e-4 of the
             //  queries, those whose near rows crowd one range -- is certified by ONE list of K' at a quarter of the cost: 500k x
             //  500k, k = 50: 4.7 -> 1.7 ms per step)
             const bool crowding_only = KP_esc > KP && n_fail <= KZ_ESC_SHORT_MAX_ROWS;
+            // what the re-search asks for: (operand tier, list length) -- never what this pass just tried
+            int next_prec, next_kp;
+            if (!widen) {   // fp16 with its longest lists, or fp16 altogether, has failed: better operands, this call's own list length
+                next_prec = (tier == KZ_TIER_H && ctx->esc_bf && (long_pieces == 0 || fp16_hard)) ? 2 : 1;
+                next_kp = 0;
+            } else if (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS) {
+                next_prec = 0;
+                next_kp = -1;   // a handful of rows of a K' = 16 pass: more lists of 16
+            } else {
+                const int len = crowding_only ? KP_esc : (KP_esc * 4 < 128 ? KP_esc * 4 : 128);
+                // (after a short-list pass: one LONG list -- unless many rows failed and the callee can still add ranges)
+                const bool long_only = KP_esc > KP && (crowding_only || long_pieces >= 16);
+                next_prec = 0;
+                next_kp = (long_only ? 1000 : 0) + len;
+            }
             kz_knn_stats st2;
-            rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids,
-                                  widen ? 0 : (tier == KZ_TIER_H && ctx->esc_bf && (long_pieces == 0 || fp16_hard) ? 2 : 1), widen ? (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : ((KP_esc > KP && (crowding_only || long_pieces >= 16)) ? 1000 : 0) + (crowding_only ? KP_esc : (KP_esc * 4 < 128 ? KP_esc * 4 : 128))) : 0, fp.out_dist,
-                                  fp.out_ind, &st2, &ms);
+            rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids, next_prec,
+                                  next_kp, fp.out_dist, fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;
             n_escalated += n_fail + st2.n_escalated_rows;
@@ -1566,7 +1580,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             c0 += max_rows_per_chunk;
             if (tier_next != tier && short_ord) {   // (the other tiers' kernels keep one list of K' per query)
                 short_ord = false;
-                KP = KP_class2;
+                KP = KP_long;
                 KSEL = 0;
                 long_pieces = 0;
             }
