@@ -377,11 +377,13 @@ __device__ __forceinline__ int kz_rank_select(const float* ekey, const int* eidx
     for (int v = 0; v < E; ++v) {
         n_valid += __popcll(__ballot(xi[v] >= 0));
         const int lim = min(64, M - 64 * v);
-        for (int jj = 0; jj < lim; ++jj) {  // jj is wave-uniform: the broadcasts are v_readlane, not ds_bpermute
-            const float ox = __shfl(x[v], jj, 64);
-            const int oi = __shfl(xi[v], jj, 64);
+        for (int jj = 0; jj < lim; ++jj) {  // jj is wave-uniform: the broadcasts are v_readlane (spelled out: __shfl compiled to ds_bpermute)
+            const int oi = __builtin_amdgcn_readlane(xi[v], jj);
+            if (oi < 0) continue;   // (uniform)
+            const float ox = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x[v]), jj));
 #pragma unroll
-            for (int u = 0; u < E; ++u) rank[u] += (oi >= 0 && (ox > x[u] || (ox == x[u] && oi < xi[u]))) ? 1 : 0;
+            for (int u = 0; u < E; ++u)
+                if (64 * u < M) rank[u] += (ox > x[u] || (ox == x[u] && oi < xi[u])) ? 1 : 0;
         }
     }
 #pragma unroll

@@ -1,7 +1,7 @@
-timeout 2400 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4
-timeout 1500 python3 tools/fuzz_dual.py 200 701 2>&1 | tail -1
-timeout 1500 python3 tools/fuzz_api.py 150 704 2>&1 | tail -1
-for w in ns c3 c4s c1 c2; do
-timeout 300 python3 bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-others > gpurun_out/v_$w.json 2> gpurun_out/v_err.txt
-python3 tools/show.py gpurun_out/v_$w.json | cut -c1-150
+timeout 900 python3 -X faulthandler -m pytest tests/test_gpu_parity.py tests/test_gpu_dual.py tests/test_gpu_short_lists.py -x -q 2>&1 | grep -v "^Extension" | tail -2
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for w in c3 ns; do
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/v_ks_$w -- python3 bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-others > gpurun_out/v_$w.json 2> gpurun_out/v_err.txt
+python3 tools/show.py gpurun_out/v_$w.json | cut -c1-140
+f=$(find gpurun_out/v_ks_$w -name "*kernel_stats.csv" | head -1); grep -E "finalize" $f | cut -c1-50,60-130; rm -rf gpurun_out/v_ks_$w
 done
