@@ -461,15 +461,17 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     }
     // top-KS of the M entries by (key desc, idx asc)
     int V = 0;
-    if (M <= 256) {
+    if (M <= 512) {
         // E entries per lane: the rank of an entry among the valid entries is a count over uniform-lane broadcasts
         // (v_readlane), no cross-lane reduction chains; entries with rank < KS land in ck/ci already ordered
         if (M <= 64)
             V = kz_rank_select<1>(ekey, eidx, M, KS, ck, ci, lane);
         else if (M <= 128)
             V = kz_rank_select<2>(ekey, eidx, M, KS, ck, ci, lane);
-        else
+        else if (M <= 256)
             V = kz_rank_select<4>(ekey, eidx, M, KS, ck, ci, lane);
+        else
+            V = kz_rank_select<8>(ekey, eidx, M, KS, ck, ci, lane);
     } else {
         for (int r = 0; r < KS; ++r) {
             float bk = -INFINITY;
@@ -1232,8 +1234,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             long_pieces = S;
         }
     }
-    // SHORT-LIST ROUTE of the dual pass (27 .. 54 neighbours, also 13 .. 26): the same construction the other way round -- lists
-    // of 16 over k / 6 index ranges instead of one list of 32 / 64 per query.  The K' = 16 kernel keeps three workgroups per CU
+    // SHORT-LIST ROUTE of the dual pass (13 .. 110 neighbours): the same construction the other way round -- lists
+    // of 16 over k / 5 index ranges instead of one list of 32 / 64 / 128 per query.  The K' = 16 kernel keeps three workgroups per CU
     // and its merges short; a range that holds 16 or more of a query's nearest rows is seen by the certification (piece_bound).
     // The caller has dealt the index tiles over the ranges (kz_knn_dual.h): near rows of a query sit in ALL ranges alike.
     const int KP_class = KP;
@@ -1292,7 +1294,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // SHORT-LIST ROUTE of the ordinary kernel: as in the dual pass, lists of 16 over P index ranges instead of one list of 32 /
     // 64 / 128 per query -- on a second image of the index whose ROWS are dealt over the ranges (kz_himage_dealt; in the caller's
     // row order the near rows of a query may all sit in one stretch).  P lists hold at least as many entries as the list they
-    // replace; taken when a range has at least 64 tiles.  (The long lists' kernels stay for small indexes and for k > 80.)
+    // replace; taken when a range has at least 64 tiles.  (The long lists' kernels stay for small indexes.)
     const int KP_long = KP;   // (the list length this call would use without the route)
     bool short_ord = false;
     if (!dual && !no_short && tier == KZ_TIER_H && ctx->short_ord && KP > 16 && KSEL == 0 && !exact_only) {
@@ -1300,7 +1302,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (P < KP / 16) P = KP / 16;
         if (kp_min >= 128) P = 16;   // (a re-search that asks for lists of 128: all the ranges the finalize kernel's fast selection takes)
         const int sel = k_eff + (KP >= 128 ? 80 : 48) < P * 16 ? k_eff + (KP >= 128 ? 80 : 48) : P * 16;
-        if (P <= 16 && (int64_t)index->n_tiles >= (int64_t)ctx->dual_short_min_tiles * P && sel >= k_eff) {
+        if (P <= 32 && (int64_t)index->n_tiles >= (int64_t)ctx->dual_short_min_tiles * P && sel >= k_eff) {   // (<= 512 entries: kz_rank_select<8>)
             const int rc = kz_himage_dealt(index, P);
             if (rc == KZ_OK) {
                 short_ord = true;

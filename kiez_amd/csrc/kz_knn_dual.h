@@ -598,14 +598,14 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     } else
 #endif
     KZ_DUAL_RC(kz_sort_pairs_f32_i32(ctx, theta, theta_s, iota, perm, (int)b->n, 1));
-    // ---- short-list route of the main sweep (kz_knn_impl): k / 6 lists of 16 per query instead of one of 32 / 64.  Rows with
+    // ---- short-list route of the main sweep (kz_knn_impl): k / 5 lists of 16 per query instead of one of 32 / 64 / 128.  Rows with
     // neighbouring thresholds tend to be neighbours of the same queries, so the sorted tiles are dealt over the index ranges.
     int main_pieces = 0;
-    if (ctx->dual_short_main && KP > 16 && KP <= 64) {
+    if (ctx->dual_short_main && KP > 16) {
         // (a range of at least 64 tiles: the k nearest rows of a query must be spread over many more tiles than there are ranges)
         const int per = ctx->dual_short_div * (ctx->dual_short_kp / 16);
         const int P = (k + per - 1) / per;
-        if (P >= 2 && P * ctx->dual_short_kp <= 256 && KP > ctx->dual_short_kp && b_tiles - 1 >= (int64_t)ctx->dual_short_min_tiles * P) main_pieces = P;
+        if (P >= 2 && P * ctx->dual_short_kp <= 512 && KP > ctx->dual_short_kp && b_tiles - 1 >= (int64_t)ctx->dual_short_min_tiles * P) main_pieces = P;
     }
     if (main_pieces > 0) {
         // (iota and theta -- the sort's inputs -- are free now: they take the dealt order)

@@ -360,13 +360,13 @@ def test_short_sample_lists_on_cluster_ordered_rows(ctx, k):
 
 
 @pytest.mark.parametrize("kind,metric", [("uniform", "euclidean"), ("normal", "cosine"), ("clustered", "euclidean"), ("duplicates", "sqeuclidean")])
-@pytest.mark.parametrize("k", [13, 26, 27, 50, 54])
+@pytest.mark.parametrize("k", [13, 26, 27, 50, 54, 100])
 def test_short_list_route_of_the_main_sweep(ctx, kind, metric, k):
     """13 .. 54 neighbours: the main sweep keeps k / 5 lists of 16 per query over dealt index ranges instead of one list of 32 / 64
     (kz_knn.hip "SHORT-LIST ROUTE").  Forced onto small inputs (ranges of 3 tiles, where a query's near rows DO crowd into single
     ranges and rows go down the tiers): both directions must equal two ordinary searches, and a row sample the oracle."""
     from kiez_amd import _native as N
-    a, b = _data(kind, 9000, 40, 7, np.float32), _data(kind, 7000, 40, 8, np.float32)
+    a, b = _data(kind, 9000, 40, 7, np.float32), _data(kind, 7000 if k <= 54 else 12000, 40, 8, np.float32)
     ctx.set_option("dual_short_min_tiles", 3)
     try:
         ref, got, s_ab, s_ba = _both_ways(ctx, a, b, k, metric)
@@ -376,7 +376,7 @@ def test_short_list_route_of_the_main_sweep(ctx, kind, metric, k):
     if kind in ("uniform", "normal"):   # (clustered rows at this size need the float32 operands, tied distances at the K'-th place
         # cannot be certified: there the pass hands over to two searches -- the results must be right all the same)
         assert s_ab["dual"] == 1 and s_ba["dual"] == 1, (s_ab, s_ba)
-        assert s_ab["n_splits"] == (k + 4) // 5, s_ab
+        assert (k + 4) // 5 - 1 <= s_ab["n_splits"] <= (k + 4) // 5, s_ab   # (ranges of whole tiles: 94 tiles in 20 ranges of 5 are 19)
     for x, y in zip(ref, got):
         np.testing.assert_array_equal(x, y)
     if kind != "duplicates":   # (exact duplicates: the order among equal distances is the library's, not scikit-learn's)

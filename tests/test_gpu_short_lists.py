@@ -1,4 +1,4 @@
-"""Short-list route of the ORDINARY kernel (kz_knn.hip "SHORT-LIST ROUTE of the ordinary kernel"): 13 .. 80 neighbours per query as
+"""Short-list route of the ORDINARY kernel (kz_knn.hip "SHORT-LIST ROUTE of the ordinary kernel"): 13 .. 110 neighbours per query as
 lists of 16 over P index ranges of a second, row-dealt image of the index, instead of one list of 32 / 64 / 128.  The reference
 has no counterpart (scikit-learn's brute force keeps one heap per query, sklearn_nearest_neighbors.py:96-101): the result must be
 the float64 neighbour order all the same.  Needs an MI355X: `pytest -m gpu`."""
@@ -32,7 +32,7 @@ def _data(kind, n, d, seed):
 
 
 @pytest.mark.parametrize("kind,metric", [("uniform", "euclidean"), ("cluster by cluster", "cosine"), ("duplicates", "sqeuclidean")])
-@pytest.mark.parametrize("k", [13, 26, 50, 64, 80])
+@pytest.mark.parametrize("k", [13, 26, 50, 64, 80, 100, 110])
 def test_route_on_and_off_give_the_same_neighbours_and_the_oracle_agrees(ctx, kind, metric, k):
     from kiez_amd import _native as N
     from oracle import kiez_oracle as O
@@ -43,7 +43,7 @@ def test_route_on_and_off_give_the_same_neighbours_and_the_oracle_agrees(ctx, ki
     d0, i0, s0 = N.knn(ctx, qm, ym, k)
     ctx.set_option("short_ord", 1)
     d1, i1, s1 = N.knn(ctx, qm, ym, k)
-    assert s0["list_len"] in (32, 64, 128) and s1["list_len"] == 16 and s1["n_splits"] >= max(2, (k + 4) // 5), (s0, s1)
+    assert s0["list_len"] in (32, 64, 128) and s1["list_len"] == 16 and s1["n_splits"] >= max(2, (k + 4) // 5 - 1), (s0, s1)   # (k = 110: 22 lists, 352 entries)
     np.testing.assert_array_equal(i1.numpy(), i0.numpy())
     np.testing.assert_array_equal(d1.numpy(), d0.numpy())
     if kind != "duplicates":
