@@ -32,13 +32,14 @@ struct kz_ctx {
     int dual_deal;    // tuning knob: 1 (default) = the dual pass deals the query rows into load-balanced tiles, 0 = natural order
     int esc_bf;            // 1 (default): rows the fp16 tier cannot certify with its longest lists go to the split-bf16 operands before the float32 ones
     int esc_short;         // 1 (default): uncertified rows of a K' = 16 pass are searched again with lists of 16 over >= 4 index ranges; 0: with lists of 64
+    int short_ord_min_tiles;   // ... when an index range has at least this many tiles (default 48)
     int short_ord;         // 1 (default): the ordinary fp16 kernel takes the short-list route too (a dealt second image of the index)
     int dual_short_main;   // 1 (default): the main sweep of kz_knn_dual keeps k / dual_short_div lists of 16 per query instead of one of 32 / 64; 0: one list of K'
     int dual_short_div;    // (default 5)
     int dual_rev_long;     // 1 (default): the reverse direction of kz_knn_dual keeps lists of 2 K'
     int dual_short_extra;  // ... of whose entries the finalize kernel selects k + this many (default 48)
     int dual_short_kp;     // list length of that route: 16 (default) or 32
-    int dual_short_min_tiles;   // ... taken when an index range has at least this many tiles (default 64; test knob)
+    int dual_short_min_tiles;   // ... taken when an index range has at least this many tiles (default 128; test knob)
     int dual_sample_short; // 1 (default): the sample sweep of kz_knn_dual uses lists of 16 (32) over several index ranges whatever K' is; 0: lists of K'
     int dual_overlap; // 1 (default): kz_knn_dual runs the reverse direction's chain on the second stream beside the forward finalize; 0: behind it
     double dual_max_gb; // kz_knn_dual: transient footprint budget in GiB (0 = the built-in 32)

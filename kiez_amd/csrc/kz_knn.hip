@@ -1294,7 +1294,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // SHORT-LIST ROUTE of the ordinary kernel: as in the dual pass, lists of 16 over P index ranges instead of one list of 32 /
     // 64 / 128 per query -- on a second image of the index whose ROWS are dealt over the ranges (kz_himage_dealt; in the caller's
     // row order the near rows of a query may all sit in one stretch).  P lists hold at least as many entries as the list they
-    // replace; taken when a range has at least 64 tiles.  (The long lists' kernels stay for small indexes.)
+    // replace; taken when a range has at least 48 tiles (measured down to 49: k = 100 on 125k index rows 15.3 -> 8.2 ms, k = 50 on
+    // 83k rows 11.3 -> 9.6, k = 26 on 60k rows 6.9 -> 6.5).  (The long lists' kernels stay for small indexes.)
     const int KP_long = KP;   // (the list length this call would use without the route)
     bool short_ord = false;
     if (!dual && !no_short && tier == KZ_TIER_H && ctx->short_ord && KP > 16 && KSEL == 0 && !exact_only) {
@@ -1302,7 +1303,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (P < KP / 16) P = KP / 16;
         if (kp_min >= 128) P = 16;   // (a re-search that asks for lists of 128: all the ranges the finalize kernel's fast selection takes)
         const int sel = k_eff + (KP >= 128 ? 80 : 48) < P * 16 ? k_eff + (KP >= 128 ? 80 : 48) : P * 16;
-        if (P <= 32 && (int64_t)index->n_tiles >= (int64_t)ctx->dual_short_min_tiles * P && sel >= k_eff) {   // (<= 512 entries: kz_rank_select<8>)
+        if (P <= 32 && (int64_t)index->n_tiles >= (int64_t)ctx->short_ord_min_tiles * P && sel >= k_eff) {   // (<= 512 entries: kz_rank_select<8>)
             const int rc = kz_himage_dealt(index, P);
             if (rc == KZ_OK) {
                 short_ord = true;

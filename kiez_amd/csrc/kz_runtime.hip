@@ -57,7 +57,10 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_short_kp = 16;
     c->dual_short_extra = 48;   // (400k x 400k, k = 50, 40 clusters: rows searched again 27.9k at 16, 10.7k from 32 on; uniform data: no difference)
     c->dual_rev_long = 1;
-    c->dual_short_min_tiles = 64;
+    // (500k x nb, k = 50, uniform, tiles per range -> shared sweep without / with the route: 49: 33.7 / 39.9 ms, 65: 39.4 / 45.6,
+    //  78: 45.3 / 52.5, 98: 53.0 / 56.9, 133: 66.7 / 66.5, 195: 92.5 / 88.7, 390 (C3): -6 %)
+    c->dual_short_min_tiles = 128;
+    c->short_ord_min_tiles = 48;
     c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
     c->lds_pad = 0;
     c->precision = 0;
@@ -140,6 +143,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
         c->esc_bf = value != 0 ? 1 : 0;
     } else if (strcmp(name, "esc_short") == 0) {
         c->esc_short = value != 0 ? 1 : 0;
+    } else if (strcmp(name, "short_ord_min_tiles") == 0) {
+        KZ_REQUIRE(value >= 1, "kz_ctx_set_option: short_ord_min_tiles must be >= 1");
+        c->short_ord_min_tiles = (int)value;
     } else if (strcmp(name, "dual_short_min_tiles") == 0) {
         KZ_REQUIRE(value >= 1, "kz_ctx_set_option: dual_short_min_tiles must be >= 1");
         c->dual_short_min_tiles = (int)value;

@@ -20,7 +20,7 @@ def ctx():
     c.set_option("dual_force", 1)   # the test shapes are far below the size at which the shared sweep pays
     yield c
     for name, value in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("eps_scale", 1.0), ("precision", 0), ("dual_max_gb", 0),
-                        ("dual_overlap", 1), ("dual_sample_short", 1), ("dual_short_main", 1), ("dual_short_min_tiles", 64), ("esc_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1),
+                        ("dual_overlap", 1), ("dual_sample_short", 1), ("dual_short_main", 1), ("dual_short_min_tiles", 128), ("esc_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1),
                         ("qgroup", 0)):
         c.set_option(name, value)
 
@@ -371,7 +371,7 @@ def test_short_list_route_of_the_main_sweep(ctx, kind, metric, k):
     try:
         ref, got, s_ab, s_ba = _both_ways(ctx, a, b, k, metric)
     finally:
-        ctx.set_option("dual_short_min_tiles", 64)
+        ctx.set_option("dual_short_min_tiles", 128)
         ctx.set_option("dual_force", 0)
     if kind in ("uniform", "normal"):   # (clustered rows at this size need the float32 operands, tied distances at the K'-th place
         # cannot be certified: there the pass hands over to two searches -- the results must be right all the same)

@@ -13,7 +13,7 @@ def ctx():
     from kiez_amd import _native as N
     c = N.Context.get()
     yield c
-    for name, value in (("short_ord", 1), ("dual_short_min_tiles", 64), ("eps_scale", 1.0)):
+    for name, value in (("short_ord", 1), ("short_ord_min_tiles", 48), ("eps_scale", 1.0)):
         c.set_option(name, value)
 
 
@@ -38,7 +38,7 @@ def test_route_on_and_off_give_the_same_neighbours_and_the_oracle_agrees(ctx, ki
     from oracle import kiez_oracle as O
     q, y = _data(kind, 3000, 48, 1), _data(kind, 30000, 48, 2)
     qm, ym = N.DeviceMatrix(ctx, q, metric), N.DeviceMatrix(ctx, y, metric)
-    ctx.set_option("dual_short_min_tiles", 8)    # (235 index tiles: the route is taken with ranges of >= 8 tiles)
+    ctx.set_option("short_ord_min_tiles", 8)    # (235 index tiles: the route is taken with ranges of >= 8 tiles)
     ctx.set_option("short_ord", 0)
     d0, i0, s0 = N.knn(ctx, qm, ym, k)
     ctx.set_option("short_ord", 1)
@@ -60,7 +60,7 @@ def test_route_in_single_source_mode_strips_the_query_itself(ctx, k):
     from oracle import kiez_oracle as O
     y = _data("cluster by cluster", 20000, 40, 3)
     ym = N.DeviceMatrix(ctx, y, "euclidean")
-    ctx.set_option("dual_short_min_tiles", 8)
+    ctx.set_option("short_ord_min_tiles", 8)
     d1, i1, s1 = N.knn(ctx, ym, ym, k, exclude_self=True)
     assert s1["list_len"] == 16
     i = i1.numpy()
@@ -75,7 +75,7 @@ def test_rows_the_route_cannot_certify_go_down_and_come_back_right(ctx):
     from kiez_amd import _native as N
     q, y = _data("uniform", 2000, 32, 5), _data("uniform", 40000, 32, 6)
     qm, ym = N.DeviceMatrix(ctx, q, "euclidean"), N.DeviceMatrix(ctx, y, "euclidean")
-    ctx.set_option("dual_short_min_tiles", 8)
+    ctx.set_option("short_ord_min_tiles", 8)
     out = {}
     for short in (0, 1):
         ctx.set_option("short_ord", short)

@@ -35,7 +35,7 @@ for case in range(n_cases):
     a, b = gen(na).astype(dtype), gen(nb).astype(dtype)
     opt = (int(rng.choice([1, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 0, 4096, 16384])), int(rng.integers(0, 2)),
            int(rng.integers(0, 2)), int(rng.integers(0, 2)),   # ..., wide workgroups for the shared sweep, reverse chain on the second stream
-           int(rng.choice([64, 3, 3, 8])), int(rng.integers(0, 2)),   # short-list route: smallest index range in tiles; short sample lists
+           int(rng.choice([128, 3, 3, 8])), int(rng.integers(0, 2)),   # short-list route: smallest index range in tiles; short sample lists
            int(rng.integers(0, 2)), int(rng.choice([16, 48, 48, 100])), int(rng.integers(0, 2)))   # reverse lists of 2 K'; entries selected beyond k; bf16 tier in the chain
     if only >= 0 and case != only:
         continue
@@ -53,6 +53,7 @@ for case in range(n_cases):
     ctx.set_option("h_wide", opt[3])          # (the two reference searches above ran the narrow builds)
     ctx.set_option("dual_overlap", opt[4])
     ctx.set_option("dual_short_min_tiles", opt[5])
+    ctx.set_option("short_ord_min_tiles", min(opt[5], 48))
     ctx.set_option("dual_sample_short", opt[6])
     ctx.set_option("dual_rev_long", opt[7])
     ctx.set_option("dual_short_extra", opt[8])
@@ -67,7 +68,7 @@ for case in range(n_cases):
     print(("ok " if ok else "BAD"), f"na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} dual {sa['dual']}/{sb['dual']} "
           f"ev/row {sb['n_events'] / nb:.1f} esc {sa['n_escalated_rows']}/{sb['n_escalated_rows']} splits {sa['n_splits']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
 for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1), ("h_wide", 0), ("dual_overlap", 1),
-                ("dual_short_min_tiles", 64), ("dual_sample_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1)):
+                ("dual_short_min_tiles", 128), ("short_ord_min_tiles", 48), ("dual_sample_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1)):
     ctx.set_option(name, v)
 print("cases", n_cases, "bad", bad)
 sys.exit(1 if bad else 0)

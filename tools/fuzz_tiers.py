@@ -34,7 +34,7 @@ def main():
             s, t = s.astype(np.float64), (s if single else t).astype(np.float64)
         # short-list route of the ordinary kernel forced onto small index ranges; a bound that sends rows down the tiers
         min_tiles, eps = int(rng.choice([64, 2, 2, 4])), float(rng.choice([1.0, 1.0, 1.0, 30.0]))
-        ctx.set_option("dual_short_min_tiles", min_tiles)
+        ctx.set_option("short_ord_min_tiles", min_tiles)
         ctx.set_option("eps_scale", eps)
         res = {}
         for prec in (0, 2, 1):   # fp16 first pass (default), split-bf16, float32 operands only
@@ -46,7 +46,7 @@ def main():
                 res[prec] = (dd.numpy(), ii.numpy(), st)
             finally:
                 ctx.set_option("precision", 0)
-        ctx.set_option("dual_short_min_tiles", 64)
+        ctx.set_option("short_ord_min_tiles", 48)
         ctx.set_option("eps_scale", 1.0)
         ok = all(np.array_equal(res[0][1], res[p][1]) and np.array_equal(res[0][0], res[p][0]) for p in (1, 2))
         if len(s) * n_t <= 2_000_000:

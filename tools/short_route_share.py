@@ -37,4 +37,4 @@ for kind in ("uniform", "normal", "cluster by cluster", "clusters shuffled"):
         same = np.array_equal(ref[0], xi.numpy()) and np.array_equal(ref[1], yi.numpy())
         print(f"{kind:20s} min_tiles {mt:3d}: {ms:7.1f} ms dual {sa['dual']}/{sb['dual']} main {sa['main_kernel_ms']:.1f} splits {sa['n_splits']} "
               f"re-searched {sa['n_escalated_rows']}/{sb['n_escalated_rows']} same {same}", flush=True)
-ctx.set_option("dual_short_min_tiles", 64)
+ctx.set_option("dual_short_min_tiles", 128)
