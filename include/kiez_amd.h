@@ -91,7 +91,7 @@ int kz_ctx_trim(kz_ctx* ctx);
  * "dual_short_main": 1 (default) = so does its main sweep for 13 .. 110 neighbours (k / "dual_short_div" lists of 16 per query, taken
  * when an index range has at least "dual_short_min_tiles" tiles; "dual_short_kp": 16 or 32); "esc_short": 1 (default) = rows a
  * K' = 16 pass could not certify are searched again with more lists of 16 instead of lists of 64; "qgroup": query tiles per group
- * of the work table (0 = automatic); "short_ord": 1 (default) = the ordinary search takes the short-list route too (13 .. 110
+ * of the work table (0 = automatic); "short_ord": 1 (default) = the ordinary search takes the short-list route too (13 .. 320
  * neighbours, a second row-dealt image of the index, ranges of at least "short_ord_min_tiles" tiles); "dual_rev_long": 1 (default) = reverse lists of twice the list length;
  * "esc_bf": 1 (default) = split-bf16 operands before the float32 ones for rows the fp16 tier cannot certify. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);

@@ -1296,14 +1296,18 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // row order the near rows of a query may all sit in one stretch).  P lists hold at least as many entries as the list they
     // replace; taken when a range has at least 48 tiles (measured down to 49: k = 100 on 125k index rows 15.3 -> 8.2 ms, k = 50 on
     // 83k rows 11.3 -> 9.6, k = 26 on 60k rows 6.9 -> 6.5).  (The long lists' kernels stay for small indexes.)
-    const int KP_long = KP;   // (the list length this call would use without the route)
+    const int KP_long = KP, KSEL_long = KSEL, pieces_long = long_pieces;   // (the list geometry this call would use without the route)
     bool short_ord = false;
-    if (!dual && !no_short && tier == KZ_TIER_H && ctx->short_ord && KP > 16 && KSEL == 0 && !exact_only) {
+    // (the long-k route up to 320 neighbours as well: k / 5 <= 64 lists of 16 instead of 4 .. 14 lists of 128 -- 50k x 500k x 200, main
+    //  kernel: k = 128 32.4 -> 12.5 ms, k = 160 35.4 -> 13.3; beyond 32 lists the finalize kernel selects by repeated arg-max)
+    const bool longk_lists = KSEL > 0 && long_pieces > 0 && KP == 128 && kp_min <= 0 && k_eff <= 320;
+    if (!dual && !no_short && tier == KZ_TIER_H && ctx->short_ord && KP > 16 && (KSEL == 0 || longk_lists) && !exact_only) {
         int P = (k_eff + ctx->dual_short_div - 1) / ctx->dual_short_div;
         if (P < KP / 16) P = KP / 16;
         if (kp_min >= 128) P = 16;   // (a re-search that asks for lists of 128: all the ranges the finalize kernel's fast selection takes)
         const int sel = k_eff + (KP >= 128 ? 80 : 48) < P * 16 ? k_eff + (KP >= 128 ? 80 : 48) : P * 16;
-        if (P <= 32 && (int64_t)index->n_tiles >= (int64_t)ctx->short_ord_min_tiles * P && sel >= k_eff) {   // (<= 512 entries: kz_rank_select<8>)
+        if (P <= (longk_lists ? 64 : 32) && (int64_t)index->n_tiles >= (int64_t)ctx->short_ord_min_tiles * P && sel >= k_eff &&
+            4 * kz_fin_wave_bytes(P * 16, sel) <= 160 * 1024) {   // (<= 512 entries: kz_rank_select<8>)
             const int rc = kz_himage_dealt(index, P);
             if (rc == KZ_OK) {
                 short_ord = true;
@@ -1586,8 +1590,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             if (tier_next != tier && short_ord) {   // (the other tiers' kernels keep one list of K' per query)
                 short_ord = false;
                 KP = KP_long;
-                KSEL = 0;
-                long_pieces = 0;
+                KSEL = KSEL_long;
+                long_pieces = pieces_long;
             }
             tier = tier_next;
             continue;

@@ -92,3 +92,23 @@ def test_rows_the_route_cannot_certify_go_down_and_come_back_right(ctx):
     assert out[1][2][2] >= 2000     # eps_scale = 1e9: every row reaches the exact float64 kernels
     for r in out[1][1:]:
         np.testing.assert_array_equal(r[0], out[1][0][0])
+
+
+@pytest.mark.parametrize("k", [111, 128, 160, 200, 320])
+def test_long_k_route_with_lists_of_sixteen(ctx, k):
+    """111 .. 320 neighbours on an index large enough: k / 5 lists of 16 (up to 64: 1024 entries per query) instead of the long-k
+    route's lists of 128; same neighbours either way, and the oracle's."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    q, y = _data("cluster by cluster", 1500, 32, 11), _data("cluster by cluster", 40000, 32, 12)
+    qm, ym = N.DeviceMatrix(ctx, q, "euclidean"), N.DeviceMatrix(ctx, y, "euclidean")
+    ctx.set_option("short_ord_min_tiles", 4)
+    ctx.set_option("short_ord", 0)
+    d0, i0, s0 = N.knn(ctx, qm, ym, k)
+    ctx.set_option("short_ord", 1)
+    d1, i1, s1 = N.knn(ctx, qm, ym, k)
+    assert s0["list_len"] == 128 and s1["list_len"] == 16 and s1["n_splits"] >= (k + 4) // 5 - 1, (s0, s1)
+    np.testing.assert_array_equal(i1.numpy(), i0.numpy())
+    np.testing.assert_array_equal(d1.numpy(), d0.numpy())
+    rows = np.arange(0, len(q), 25)
+    np.testing.assert_array_equal(i1.numpy()[rows], O.knn_exact(q[rows], y, k, "euclidean")[1])

@@ -50,12 +50,14 @@ def main():
             s, t = s.astype(np.float64), (s if single else t).astype(np.float64)
         kk = min(k, len(t) - 2)
         ctx.set_option("precision", prec)
+        ctx.set_option("short_ord_min_tiles", int(rng.choice([48, 1, 2, 4])))   # lists of 16 on the dealt image, forced onto small ranges
         try:
             ym = N.DeviceMatrix(ctx, t, metric)
             qm = ym if single else N.DeviceMatrix(ctx, s, metric)
             dd, ii, st = N.knn(ctx, qm, ym, kk, exclude_self=single)
         finally:
             ctx.set_option("precision", 0)
+            ctx.set_option("short_ord_min_tiles", 48)
         od, oi = O.knn_exact(s, t, kk, O.canonical_metric(metric), exclude_self=single)
         ok = np.array_equal(ii.numpy(), oi) if kind != "dups" else np.allclose(dd.numpy(), od, rtol=1e-6, atol=1e-6)
         ok = ok and np.allclose(dd.numpy(), od, rtol=1e-6, atol=1e-6) and st["max_err_ratio"] < 1.0
