@@ -473,38 +473,90 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         else
             V = kz_rank_select<8>(ekey, eidx, M, KS, ck, ci, lane);
     } else {
-        for (int r = 0; r < KS; ++r) {
-            float bk = -INFINITY;
-            int bi = 0x7fffffff, be = -1;
-            for (int e = lane; e < M; e += 64) {
-                const float x = ekey[e];
-                const int xi = eidx[e];
-                if (xi >= 0 && (x > bk || (x == bk && xi < bi))) {
-                    bk = x;
-                    bi = xi;
-                    be = e;
-                }
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ok = __shfl_xor(bk, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                const int oe = __shfl_xor(be, off, 64);
-                if (oe >= 0 && (be < 0 || ok > bk || (ok == bk && oi < bi))) {
-                    bk = ok;
-                    bi = oi;
-                    be = oe;
-                }
-            }
-            if (be < 0) break;  // uniform: every lane holds the same winner
-            if (lane == 0) {
-                ck[r] = bk;
-                ci[r] = bi;
-                eidx[be] = -1;  // consumed
-            }
-            V = r + 1;
-            kz_wave_sync();
+        // More than 512 entries (long-k route): radix select of the KS-th largest key over the keys as sortable integers (32
+        // counting passes over the entries), the entries above it compacted, ties at it by ascending row, and the KS selected
+        // entries rank-sorted into ck / ci -- O(32 M + KS^2) / 64 steps per lane instead of the KS arg-max rounds over all M
+        // entries this branch used to run (k = 500, 21 lists of 128: 221 of the call's 282 ms were those rounds).
+        unsigned* uk = reinterpret_cast<unsigned*>(ekey);   // (the keys are not needed as floats any more)
+        auto key_of = [](unsigned u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); };
+        int nv = 0;
+#pragma nounroll
+        for (int e = lane; e < M; e += 64) {
+            unsigned bts = __float_as_uint(ekey[e]);
+            if (bts == 0x80000000u) bts = 0u;   // (-0 = +0)
+            const bool valid = eidx[e] >= 0;
+            uk[e] = valid ? (bts ^ ((bts >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
+            nv += valid ? 1 : 0;
         }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) nv += __shfl_xor(nv, off, 64);
+        kz_wave_sync();
+        float* tk = reinterpret_cast<float*>(cv);   // (cv / sv are written after the selection: KS doubles hold KS keys + KS rows)
+        int* ti = reinterpret_cast<int*>(tk + KS);
+        int nsel = 0;
+        unsigned thr = 0u;
+        const bool all = nv <= KS;
+        if (!all) {
+#pragma nounroll
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned cand = thr | (1u << bit);
+                int c = 0;
+#pragma nounroll
+                for (int e0 = 0; e0 < M; e0 += 64) {
+                    const int e = e0 + lane;
+                    c += (int)__popcll(__ballot(e < M && eidx[e] >= 0 && uk[e] >= cand));
+                }
+                if (c >= KS) thr = cand;
+            }
+        }
+#pragma nounroll
+        for (int e0 = 0; e0 < M; e0 += 64) {   // entries above the threshold (all valid entries when there are at most KS)
+            const int e = e0 + lane;
+            const bool sel = e < M && eidx[e] >= 0 && (all || uk[e] > thr);
+            const unsigned long long mask = __ballot(sel);
+            if (sel) {
+                const int pos = nsel + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                tk[pos] = key_of(uk[e]);
+                ti[pos] = eidx[e];
+            }
+            nsel += (int)__popcll(mask);
+        }
+        if (!all) {   // the remaining places go to the entries AT the threshold with the smallest rows
+            int last = -1;
+            while (nsel < KS) {
+                int best = 0x7fffffff;
+#pragma nounroll
+                for (int e = lane; e < M; e += 64) {
+                    const int xi = eidx[e];
+                    if (xi >= 0 && uk[e] == thr && xi > last && xi < best) best = xi;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+                if (best == 0x7fffffff) break;   // (cannot happen: at least KS entries are >= thr)
+                if (lane == 0) {
+                    tk[nsel] = key_of(thr);
+                    ti[nsel] = best;
+                }
+                last = best;
+                ++nsel;
+            }
+        }
+        kz_wave_sync();
+#pragma nounroll
+        for (int c = lane; c < nsel; c += 64) {   // rank sort: (key descending, row ascending), as the rounds produced it
+            const float kc = tk[c];
+            const int ic = ti[c];
+            int r = 0;
+#pragma nounroll
+            for (int o = 0; o < nsel; ++o) {
+                const float ko = tk[o];
+                const int io = ti[o];
+                r += (ko > kc || (ko == kc && io < ic)) ? 1 : 0;
+            }
+            ck[r] = kc;
+            ci[r] = ic;
+        }
+        V = nsel;
     }
     kz_wave_sync();
 
