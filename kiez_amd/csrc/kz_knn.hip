@@ -397,7 +397,7 @@ __device__ __forceinline__ int kz_rank_select(const float* ekey, const int* eidx
 }
 
 // One query, one wave (only wave-level synchronisation inside).
-template <typename T>
+template <typename T, int FROWS>
 __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const int64_t q, const int lane, char* wbase) {
     const int KS = p.KSEL > 0 ? p.KSEL : p.KP;   // candidates selected and re-ranked
     double* cv = reinterpret_cast<double*>(wbase);
@@ -620,7 +620,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         Vr = cnt < k_eff ? k_eff : cnt;
     }
 
-    // exact float64 re-rank of the Vr candidates, KZ_FIN_ROWS rows in flight per pass (independent gathers and butterfly sums
+    // exact float64 re-rank of the Vr candidates, FROWS rows in flight per pass (independent gathers and butterfly sums
     // overlap); the per-candidate arithmetic is exactly kz_wave_dot / kz_wave_dot_normalized (kz_common.h)
     const T* yraw = reinterpret_cast<const T*>(p.yraw);
     const bool vec = kz_row_vec_ok(qptr, p.d) && kz_row_vec_ok(yraw, p.d);
@@ -629,7 +629,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 #else
     if (sizeof(T) == 4 && vec && p.d <= 256 && Vr > 0) {
 #endif   // (Vr == 0: a reverse-direction row without a single event)
-        // float32 rows of up to 256 elements (one 16-byte load per lane and row): the loads of the NEXT group of KZ_FIN_ROWS
+        // float32 rows of up to 256 elements (one 16-byte load per lane and row): the loads of the NEXT group of FROWS
         // candidates are issued before the current group's fma chains and butterfly sums -- same arithmetic in the same order
         // as the generic loop below (and as kz_wave_dot), only the memory latency of group g+1 hides under the sums of group g
         const int k0 = 4 * lane;
@@ -642,18 +642,18 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                 for (int e = 0; e < 4; ++e) qk[e] = qk[e] / qs;
             }
         }
-        auto issue = [&](int c0, float4 (&buf)[KZ_FIN_ROWS], double (&ysb)[KZ_FIN_ROWS]) {
+        auto issue = [&](int c0, float4 (&buf)[FROWS], double (&ysb)[FROWS]) {
 #pragma unroll
-            for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+            for (int u = 0; u < FROWS; ++u) {
                 const int yi = ci[min(c0 + u, Vr - 1)];
                 ysb[u] = p.ysqn[yi];
                 buf[u] = act ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(yraw) + (int64_t)yi * p.d + k0)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        auto reduce = [&](int c0, const float4 (&buf)[KZ_FIN_ROWS], const double (&ysb)[KZ_FIN_ROWS]) {
+        auto reduce = [&](int c0, const float4 (&buf)[FROWS], const double (&ysb)[FROWS]) {
 #pragma unroll
-            for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+            for (int u = 0; u < FROWS; ++u) {
                 const double yk[4] = {(double)buf[u].x, (double)buf[u].y, (double)buf[u].z, (double)buf[u].w};
                 double a = 0.0;
                 if (act) {
@@ -678,7 +678,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 #if KZ_FIN_DEPTH == 3
         // three groups in flight (a rotating set of three register buffers, the loop unrolled by three: no copies): the gathers
         // of groups g + 1 and g + 2 are under way while group g is reduced
-        constexpr int R = KZ_FIN_ROWS;
+        constexpr int R = FROWS;
         float4 b0[R], b1[R], b2[R];
         double y0[R], y1[R], y2[R];
         issue(0, b0, y0);
@@ -695,16 +695,16 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
             if ((c0 += R) >= Vr) break;
         }
 #else
-        float4 cur[KZ_FIN_ROWS], nxt[KZ_FIN_ROWS];
-        double ys_c[KZ_FIN_ROWS], ys_n[KZ_FIN_ROWS];
+        float4 cur[FROWS], nxt[FROWS];
+        double ys_c[FROWS], ys_n[FROWS];
         issue(0, cur, ys_c);
-        for (int c0 = 0; c0 < Vr; c0 += KZ_FIN_ROWS) {
-            const bool more = c0 + KZ_FIN_ROWS < Vr;   // wave-uniform
-            if (more) issue(c0 + KZ_FIN_ROWS, nxt, ys_n);
+        for (int c0 = 0; c0 < Vr; c0 += FROWS) {
+            const bool more = c0 + FROWS < Vr;   // wave-uniform
+            if (more) issue(c0 + FROWS, nxt, ys_n);
             reduce(c0, cur, ys_c);
             if (more) {
 #pragma unroll
-                for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+                for (int u = 0; u < FROWS; ++u) {
                     cur[u] = nxt[u];
                     ys_c[u] = ys_n[u];
                 }
@@ -712,11 +712,11 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         }
 #endif
     } else
-    for (int c0 = 0; c0 < Vr; c0 += KZ_FIN_ROWS) {
-        const T* yp[KZ_FIN_ROWS];
-        double ys[KZ_FIN_ROWS], acc[KZ_FIN_ROWS];
+    for (int c0 = 0; c0 < Vr; c0 += FROWS) {
+        const T* yp[FROWS];
+        double ys[FROWS], acc[FROWS];
 #pragma unroll
-        for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+        for (int u = 0; u < FROWS; ++u) {
             const int yi = ci[min(c0 + u, Vr - 1)];
             yp[u] = yraw + (int64_t)yi * p.d;
             ys[u] = p.ysqn[yi];
@@ -730,7 +730,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                 for (int e = 0; e < 4; ++e) qk[e] = qk[e] / qs;
             }
 #pragma unroll
-            for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+            for (int u = 0; u < FROWS; ++u) {
                 double yk[4];
                 kz_row4(yp[u], k0, p.d, vec, yk);
                 if (p.metric == KZ_COSINE) {
@@ -743,7 +743,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
             }
         }
 #pragma unroll
-        for (int u = 0; u < KZ_FIN_ROWS; ++u) {
+        for (int u = 0; u < FROWS; ++u) {
             const double dot = kz_wave_sum(acc[u]);
             double v;
             if (p.metric == KZ_COSINE) {
@@ -836,8 +836,12 @@ constexpr int KZ_FIN_QPB = 4;
 #ifndef KZ_FIN_WAVES
 #define KZ_FIN_WAVES 7  // minimum waves per SIMD the finalize kernel is compiled for (see KZ_FIN_ROWS_N above; at 8 waves / 64 VGPRs it spills)
 #endif
-template <typename T>
-__global__ __launch_bounds__(256, KZ_FIN_WAVES) void kz_knn_finalize_kernel(KnnFinParams p) {
+// FROWS / MINW: candidate rows gathered per group and the occupancy compiled for.  <1, KZ_FIN_WAVES> is the kernel of every
+// ordinary pass (a dozen to ~50 gathered rows per query: waves in flight beat rows in flight per wave); <8, 2> serves the long-k
+// route (hundreds of gathered rows per query, one workgroup per CU for its LDS anyway: the gathers of a query were a chain of
+// ~k / 2 round trips).
+template <typename T, int FROWS, int MINW>
+__global__ __launch_bounds__(256, MINW) void kz_knn_finalize_kernel(KnnFinParams p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -845,7 +849,7 @@ __global__ __launch_bounds__(256, KZ_FIN_WAVES) void kz_knn_finalize_kernel(KnnF
     for (int rep = 0; rep < KZ_FIN_QPB / 4; ++rep) {
         const int64_t q = p.q_first + (int64_t)blockIdx.x * KZ_FIN_QPB + rep * 4 + wave;
         if (q >= p.q_last) break;  // whole wave leaves; only wave-level sync inside
-        kz_finalize_query<T>(p, q, lane, wbase);
+        kz_finalize_query<T, FROWS>(p, q, lane, wbase);
         kz_wave_sync();
     }
 }
@@ -1073,14 +1077,18 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
         fp.max_m = lay.pieces[rg] * lay.halves * KP;
         const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
         const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, fp.KSEL > 0 ? fp.KSEL : KP);
-        if (fin_lds > 65536) {
-            const void* fk = dtype == KZ_F32 ? (const void*)kz_knn_finalize_kernel<float> : (const void*)kz_knn_finalize_kernel<double>;
-            KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
-        }
-        if (dtype == KZ_F32)
-            hipLaunchKernelGGL(kz_knn_finalize_kernel<float>, dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
+        const bool wide = (fp.KSEL > 0 ? fp.KSEL : KP) > 160;   // the long-k route
+        const void* fk = dtype == KZ_F32 ? (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>)
+                                         : (wide ? (const void*)kz_knn_finalize_kernel<double, 4, 2> : (const void*)kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>);
+        if (fin_lds > 65536) KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
+        if (dtype == KZ_F32 && wide)
+            hipLaunchKernelGGL((kz_knn_finalize_kernel<float, 8, 2>), dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
+        else if (dtype == KZ_F32)
+            hipLaunchKernelGGL((kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>), dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
+        else if (wide)
+            hipLaunchKernelGGL((kz_knn_finalize_kernel<double, 4, 2>), dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
         else
-            hipLaunchKernelGGL(kz_knn_finalize_kernel<double>, dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
+            hipLaunchKernelGGL((kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>), dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
     }
     KZ_HIP(hipGetLastError());
     return KZ_OK;
