@@ -480,7 +480,6 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         unsigned* uk = reinterpret_cast<unsigned*>(ekey);   // (the keys are not needed as floats any more)
         auto key_of = [](unsigned u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); };
         int nv = 0;
-#pragma nounroll
         for (int e = lane; e < M; e += 64) {
             unsigned bts = __float_as_uint(ekey[e]);
             if (bts == 0x80000000u) bts = 0u;   // (-0 = +0)
@@ -497,11 +496,9 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         unsigned thr = 0u;
         const bool all = nv <= KS;
         if (!all) {
-#pragma nounroll
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned cand = thr | (1u << bit);
                 int c = 0;
-#pragma nounroll
                 for (int e0 = 0; e0 < M; e0 += 64) {
                     const int e = e0 + lane;
                     c += (int)__popcll(__ballot(e < M && eidx[e] >= 0 && uk[e] >= cand));
@@ -509,7 +506,6 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                 if (c >= KS) thr = cand;
             }
         }
-#pragma nounroll
         for (int e0 = 0; e0 < M; e0 += 64) {   // entries above the threshold (all valid entries when there are at most KS)
             const int e = e0 + lane;
             const bool sel = e < M && eidx[e] >= 0 && (all || uk[e] > thr);
@@ -525,7 +521,6 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
             int last = -1;
             while (nsel < KS) {
                 int best = 0x7fffffff;
-#pragma nounroll
                 for (int e = lane; e < M; e += 64) {
                     const int xi = eidx[e];
                     if (xi >= 0 && uk[e] == thr && xi > last && xi < best) best = xi;
@@ -542,12 +537,11 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
             }
         }
         kz_wave_sync();
-#pragma nounroll
         for (int c = lane; c < nsel; c += 64) {   // rank sort: (key descending, row ascending), as the rounds produced it
             const float kc = tk[c];
             const int ic = ti[c];
             int r = 0;
-#pragma nounroll
+#pragma unroll 4
             for (int o = 0; o < nsel; ++o) {
                 const float ko = tk[o];
                 const int io = ti[o];
