@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: source queries/s over fit + kneighbors (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c1|c2|c3|c3s|c4s|c1g] [--no-others]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--workload ns|c1|c2|c3|c3s|c4s|c4|c1g|hard] [--no-others]
     python bench.py --openea EMB_DIR KG_DIR [--steps K] [--warmup W]      (real entity-alignment embeddings)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment LAUNCHES ITSELF: the parent (which never touches a
+GPU) starts `python -m torch.distributed.run ... bench.py <same arguments>` as a child process, one rank per GPU, forwards
+rank 0's JSON line and exits with the child's code.
+`--scaling weak` (default): every rank owns a 250k-row source shard of the workload ("ns": 8 GPUs = 2M x 1M).
+`--scaling strong`: the TOTAL source is fixed -- default workload BASELINE.json configuration 4 at its stated size (2M x 1M,
+d = 300, k = 10, CSLS), rank r owns rows row_slice(2M, r, N); N = 1 is the whole configuration on one GPU.
 
 A "step" is one full `fit(source, target)` + `kneighbors(k)` over synthetic embeddings that are already resident in
 HBM (the reference's `rng.rand` data, float32).  Default workload = the shape BASELINE.json quotes its target on, one
@@ -40,11 +46,17 @@ WORKLOADS = {
            "C3: 500k x 500k, d=200, cosine, k=50, MutualProximity empiric"),
     "c4s": (250_000, 1_000_000, 300, "euclidean", 10, 10, "CSLS", {},
             "C4 per-GPU share: 250k source rows x 1M target, d=300, k=10, CSLS"),
+    "c4": (2_000_000, 1_000_000, 300, "euclidean", 10, 10, "CSLS", {},
+           "C4 at its stated size: 2M source rows x 1M target, d=300, k=10, CSLS (strong scaling: the 2M rows are split over the ranks)"),
     "ns": (250_000, 1_000_000, 200, "euclidean", 10, 10, "CSLS", {},
            "north-star target shape (BASELINE.json), per-GPU share: 250k source rows x 1M target, d=200, k=10, CSLS"),
     "c1g": (100_000, 100_000, 128, "euclidean", 10, 10, None, {},
             "C1 on gaussian data (rng.randn) for contrast with uniform: 100k x 100k, d=128, euclidean, k=10, hubness=None"),
+    "hard": (300_000, 301_000, 64, "cosine", 50, 50, "MutualProximity", {"method": "empiric"},
+             "data that is hard for the fp16 first pass (40 tight gaussian clusters far from the centre, rows stored cluster by "
+             "cluster; tools/short_route_stress.py): 300k x 301k, d=64, cosine, k=50, MutualProximity empiric"),
 }
+METRIC = "source queries/sec (fit+kneighbors) + recall@k vs reference, 1/2/4/8 GPU"   # BASELINE.json's metric
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, 'Peak BF16/FP16 MFMA ~2.5 PF dense'
 TIER_NAME = {0: "f32", 1: "bf16x2", 2: "f16"}
@@ -141,7 +153,7 @@ def cpu_baseline(source, target, metric, K, k, hub, hub_kw, budget_flop=6e11):
     return out
 
 
-def sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, rows=128):
+def sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, rows=1024):
     """Result check that also works where the oracle cannot run the whole fit (1M-row reverse pass): a row sample of BOTH
     kNN passes against the oracle's exact float64 search, then the oracle's rescale + final sort on the sampled source rows
     fed with the (sample-verified) fit state of this run."""
@@ -173,7 +185,7 @@ def sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, ro
         elif h in ("mutualproximity", "mp") and hub_kw.get("method") in ("exact", "empiric"):
             d_t2s, i_t2s = st["dist_t2s"].cpu().numpy(), st["ind_t2s"].cpu().numpy()
             out["fit_state_rows_identical"] = int((i_t2s[sel_t] == ri).all(axis=1).sum())
-            sub = min(rows, 32)   # the oracle loop allocates n_t floats per candidate
+            sub = min(rows, 256)
             fd, fi, got_d, got_i, sel_s = fd[:sub], fi[:sub], got_d[:sub], got_i[:sub], sel_s[:sub]
             out["rows"] = int(sub)
             hr = O.mp_empiric_transform(fd, fi, d_t2s, i_t2s)
@@ -181,24 +193,50 @@ def sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, ro
             return None
         od, oi = O.sort_topk(hr, fi, k)
     same = (got_i == oi).all(axis=1)
-    if hub and hub.lower().startswith("mutual"):
-        # MP-empiric values are multiples of 1/K: rows whose candidates include the query id are knife-edge
-        same |= (fi == sel_s[:, None]).any(axis=1)
+    if hub and hub.lower().startswith("mutual") and hub_kw.get("method") in ("exact", "empiric"):
+        # MP-empiric values are multiples of 1/K; a row whose candidate list contains the query's own id is a knife edge
+        # (the reference compares a pair's forward and reverse BLAS value with a strict '>').  Those rows are
+        # counted apart, never ORed into "identical": index_rows_identical counts the other rows only.
+        knife = (fi == sel_s[:, None]).any(axis=1)
+        out.update(knife_edge_rows=int(knife.sum()), knife_edge_rows_identical=int((same & knife).sum()),
+                   rows_not_knife_edge=int((~knife).sum()))
+        same &= ~knife
     out.update(index_rows_identical=int(same.sum()),
                recall_at_k=float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got_i, oi)])),
                max_rel_dist_err=float(np.max(np.abs(got_d - od) / np.maximum(np.abs(od), 1e-12))))
     return out
 
 
-def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True):
-    """Generate the data, run warm-up + timed steps, return (summary dict, host arrays) on every rank."""
-    from kiez_amd.distributed import ShardedKiez
-    n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[name]
-    # synthetic data in the reference's style (kiez/kiez.py:50-52): rng.rand, source first, then target
-    rng = np.random.RandomState(0 if rank == 0 else 1000 + rank)
+def synth_rows(name, seed, rows, d):
+    """Synthetic float32 embeddings of one workload, generated in blocks (no [rows, d] float64 transient).  Default: the
+    reference's `rng.rand` (kiez/kiez.py:50-52); names ending in "g": `rng.randn`; "hard": 40 tight gaussian clusters far from
+    the centre, stored cluster by cluster (tools/short_route_stress.py)."""
+    rng = np.random.RandomState(seed)
+    out = np.empty((rows, d), dtype=np.float32)
+    if name == "hard":
+        centres = np.random.RandomState(5).standard_normal((40, d)) * 3     # the same centres on both sides
+        sizes = rng.multinomial(rows, np.ones(40) / 40)
+        b = 0
+        for c in range(40):
+            out[b:b + sizes[c]] = centres[c] + 0.4 * rng.standard_normal((sizes[c], d))
+            b += sizes[c]
+        return out
     gen = rng.randn if name.endswith("g") else rng.rand
-    source_h = gen(n_s, d).astype(np.float32)
-    target_h = gen(n_t, d).astype(np.float32) if rank == 0 else None
+    for b in range(0, rows, 250_000):
+        out[b:b + 250_000] = gen(min(250_000, rows - b), d)
+    return out
+
+
+def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, scaling="weak", check_rows=1024):
+    """Generate the data, run warm-up + timed steps, return (summary dict, host arrays) on every rank.
+    scaling = "weak": every rank owns WORKLOADS[name][0] source rows; "strong": that many rows in total, split over the ranks."""
+    from kiez_amd.distributed import ShardedKiez, row_slice
+    n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[name]
+    n_s_total = n_s * world if scaling == "weak" else n_s
+    if scaling == "strong":
+        n_s = row_slice(n_s_total, rank, world)[1]
+    source_h = synth_rows(name, 0 if rank == 0 else 1000 + rank, n_s, d)
+    target_h = synth_rows(name, 77, n_t, d) if rank == 0 else None
     source = eng.to_engine(source_h)
     target = eng.to_engine(target_h) if rank == 0 else None
     eng.sync()
@@ -238,7 +276,7 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True):
     def fence():
         if dist.is_initialized():
             dist.barrier()
-        torch.cuda.synchronize()
+        eng.sync()
 
     try:
         res = None
@@ -271,7 +309,8 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True):
     peak = PEAK_F32_MFMA_TFLOPS if tier == 0 else PEAK_BF16_MFMA_TFLOPS
     summary = {
         "name": name, "desc": desc, "n_s": n_s, "n_t": n_t, "d": d, "metric": metric, "K": K, "k": k, "hub": hub, "hub_kw": hub_kw,
-        "elapsed": elapsed, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "value": n_s * world * steps / elapsed,
+        "n_s_total": n_s_total, "scaling": scaling,
+        "elapsed": elapsed, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "value": n_s_total * steps / elapsed,
         "tier": tier, "peak": peak, "achieved": achieved, "n_launch": n_launch, "kernel_s": kernel_s, "flops": flops,
         "fallback_rows": int(sum(st["n_fallback_rows"] for _, _, st in knn_log)),
         "escalated_rows": int(sum(st.get("n_escalated_rows", 0) for _, _, st in knn_log)),
@@ -288,7 +327,7 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True):
     }
     chk = None
     if check and rank == 0 and world == 1:
-        chk = sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw)
+        chk = sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, rows=check_rows)
     summary["check"] = chk
     return summary, (source_h, target_h), res
 
@@ -398,16 +437,16 @@ def run_openea(args):
     return line
 
 
-def main():
-    # Keep stdout clean for the ONE JSON line: librccl prints a start-up banner to fd 1 when the communicator is created.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: ns (weak scaling), c4 (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: every rank owns the workload's source rows (default); strong: the workload's source rows are split "
+                         "over the ranks (default workload: BASELINE.json configuration 4 at its stated size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle sample check")
     ap.add_argument("--no-others", action="store_true", help="do not run the other BASELINE configurations after the main workload")
@@ -419,17 +458,74 @@ def main():
     ap.add_argument("--openea-hubness", default="CSLS")
     ap.add_argument("--openea-metric", default="euclidean")
     ap.add_argument("--openea-k", type=int, default=10)
-    args = ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true",
+                    help="NOT a measurement: run the launch / rendezvous / sharding / collective / reporting path of this script on "
+                         "the CPU test engine (tests/cpu_engine.py) over gloo with a tiny shape; `value` is null.  For machines "
+                         "without a GPU (tests/test_bench_launch.py)")
+    args = ap.parse_args(argv)
+    if args.workload is None:
+        args.workload = "c4" if args.scaling == "strong" else "ns"
+    return args
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process tree (one process per GPU,
+    `python -m torch.distributed.run`), forward rank 0's JSON line (the child inherits stdout) and return the child's exit code.
+    Called before anything in this process has touched a GPU; this process never does."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    import torch.distributed as dist
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # started through torch.distributed.run
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    # Keep stdout clean for the ONE JSON line: librccl prints a start-up banner to fd 1 when the communicator is created.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch.distributed as dist
+    if args.launch_check:
+        # launch-path check on the CPU test engine (no GPU in this process): gloo, tiny shape, no measurement
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1 or launched:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        from kiez_amd.distributed import Comm
+        from tests.cpu_engine import OracleEngine
+        eng = OracleEngine()
+        eng.last_stats = {"main_kernel_ms": 0.0, "n_fallback_rows": 0, "finalize_ms": 0.0, "fallback_ms": 0.0}
+        eng.last_stats_reverse = dict(eng.last_stats)
+        comm = Comm(time_collectives=True)
+        WORKLOADS["launch-check"] = (2000 if args.scaling == "weak" else 4001, 1500, 16, "euclidean", 5, 5, "CSLS", {},
+                                     "launch check (CPU test engine over gloo; NOT a measurement)")
+        s, _, _ = run_workload("launch-check", eng, comm, dist, rank, world, args.steps, args.warmup, check=False, scaling=args.scaling)
+        if rank == 0:
+            line = {"metric": METRIC, "value": None, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": s["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                    "dtype": None, "data": "synthetic", "launch_check": True,
+                    "config": {"workload": s["desc"], "n_source_total": s["n_s_total"], "n_source_this_rank": s["n_s"], "n_target": s["n_t"],
+                               "engine": "tests/cpu_engine.py over gloo -- launch path only, value deliberately null"},
+                    "collective_ms_per_step": s["collective_ms_per_step"], "collective_traffic_per_step": s["collective_traffic_per_step"]}
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -451,7 +547,7 @@ def main():
         eng.ctx.set_option(name, float(val))
 
     main_s, (source_h, target_h), _ = run_workload(args.workload, eng, comm, dist, rank, world, args.steps, args.warmup,
-                                                   check=not args.no_check)
+                                                   check=not args.no_check, scaling=args.scaling)
     n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[args.workload]
 
     line = None
@@ -460,7 +556,7 @@ def main():
         tier = s["tier"]
         traffic, traffic_dispatches = pmc_traffic(args.workload, s)
         line = {
-            "metric": "source queries/sec (fit+kneighbors) + recall@k vs reference, 1/2/4/8 GPU",  # BASELINE.json's metric
+            "metric": METRIC,
             "recall_at_k": (s["check"] or {}).get("recall_at_k"),   # against the oracle on a row sample (None if not checked)
             "value": s["value"],
             "unit": "queries/s",
@@ -469,11 +565,11 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": s["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": TIER_NAME[tier],
             "data": "synthetic",
-            "config": {"workload": desc, "n_source_per_gpu": n_s, "n_target": n_t, "d": d, "metric": metric,
+            "config": {"workload": desc, "n_source_total": s["n_s_total"], "n_source_per_gpu": s["n_s_total"] // world, "n_target": n_t, "d": d, "metric": metric,
                        "n_candidates": K, "k": k, "hubness": hub, "hubness_kwargs": hub_kw,
                        "inputs": "float32 rng.rand, resident in HBM; results left in HBM",
                        "parallelism": f"source row-sharded x{world}, target replicated"
@@ -527,15 +623,17 @@ def main():
     del source_h, target_h
     if world == 1 and not args.no_others:
         others = {}
-        for name in ("c1", "c2", "c3", "c4s", "ns"):
+        # c4 = configuration 4 at its stated size on this one GPU (the N = 1 anchor of `--scaling strong`; ~1.3 s per step: fewer
+        # steps); c1g / hard = the same kernels on gaussian and on clustered data (how often the tier chain runs is data dependent)
+        for name in ("c1", "c2", "c3", "c4s", "c4", "ns", "c1g", "hard"):
             if name == args.workload:
                 continue
             try:
                 # (each workload starts from an empty buffer cache: what the previous one left behind is of the wrong sizes and
                 #  only turns this one's first releases into hipFree calls)
                 eng.ctx.trim()
-                osum, _, _ = run_workload(name, eng, comm, dist, rank, world, args.other_steps, args.other_warmup,
-                                          check=not args.no_check)
+                o_steps, o_warm = (min(args.other_steps, 3), min(args.other_warmup, 1)) if name == "c4" else (args.other_steps, args.other_warmup)
+                osum, _, _ = run_workload(name, eng, comm, dist, rank, world, o_steps, o_warm, check=not args.no_check)
                 others[name] = short(osum)
             except Exception as e:  # pragma: no cover  (a secondary workload must never cost the main line)
                 others[name] = {"error": f"{type(e).__name__}: {e}"}

@@ -12,6 +12,7 @@ class _Mat:
     def __init__(self, rows, metric):
         self.rows = rows.numpy()
         self.metric = metric
+        self.shape = tuple(self.rows.shape)   # (as kiez_amd._native.DeviceMatrix)
 
 
 class OracleEngine:
