@@ -64,6 +64,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
     c->lds_pad = 0;
     c->precision = 0;
+    c->pack_sweep = 1;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
         c->precision = (strcmp(pv, "fp32") == 0 || strcmp(pv, "1") == 0) ? 1 : ((strcmp(pv, "bf16") == 0 || strcmp(pv, "2") == 0) ? 2 : 0);
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -76,9 +77,9 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     }
     KZ_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     for (int i = 0; i < 12; ++i) KZ_HIP(hipEventCreate(&c->ev[i]));
-    KZ_HIP(hipMalloc((void**)&c->d_counters, 64 * sizeof(int)));
+    KZ_HIP(hipMalloc((void**)&c->d_counters, KZ_COUNTER_INTS * sizeof(int)));
     KZ_HIP(hipHostMalloc((void**)&c->h_counters, 64 * sizeof(int), hipHostMallocDefault));
-    KZ_HIP(hipMemsetAsync(c->d_counters, 0, 64 * sizeof(int), c->stream));
+    KZ_HIP(hipMemsetAsync(c->d_counters, 0, KZ_COUNTER_INTS * sizeof(int), c->stream));
     KZ_HIP(hipStreamSynchronize(c->stream));
     *out = c;
     return KZ_OK;
@@ -104,6 +105,7 @@ int kz_ctx_trim(kz_ctx* c) {
     KZ_REQUIRE(c != nullptr, "kz_ctx_trim: null context");
     KZ_HIP(hipSetDevice(c->device));
     KZ_HIP(hipStreamSynchronize(c->stream));
+    if (c->stream2) KZ_HIP(hipStreamSynchronize(c->stream2));   // (kz_knn_dual's reverse chain: nothing it uses may be freed under it)
     for (int i = 0; i < c->pool_n; ++i) (void)hipFree(c->pool[i].ptr);
     c->pool_n = 0;
     c->pool_bytes = 0;
@@ -189,6 +191,8 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "lds_pad") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
         c->lds_pad = (int)value;
+    } else if (strcmp(name, "pack_sweep") == 0) {
+        c->pack_sweep = value != 0 ? 1 : 0;
     } else if (strcmp(name, "min_splits") == 0) {
         KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
         c->min_splits = (int)value;
@@ -242,8 +246,16 @@ int kz_memcpy_d2d(kz_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
 }  // extern "C"
 
 // ---- stream-ordered buffer pool ---------------------------------------------------------------------
-// All work of a context runs on ONE stream, so handing a released buffer to the next allocation of a similar size is
-// ordered behind its last use; this avoids hipFree (device-wide sync) + hipMalloc on every fit().
+// The work of a context runs on ONE stream, so handing a released buffer to the next allocation of a similar size is
+// ordered behind its last use; this avoids hipFree (device-wide sync) + hipMalloc on every fit().  The one exception is
+// kz_knn_dual's reverse chain on the second stream: kz_knn_dual holds every buffer that chain uses until it has synchronised
+// stream2 itself; everything here that FREES device memory (eviction, the retry after a failed hipMalloc, a scratch block that
+// grows, kz_ctx_trim) waits for BOTH streams first, so that no helper called while the chain is in flight can pull memory from
+// under it.
+static void kz_sync_streams(kz_ctx* c) {
+    (void)hipStreamSynchronize(c->stream);
+    if (c->stream2 && c->stream2 != c->stream) (void)hipStreamSynchronize(c->stream2);
+}
 static const size_t KZ_POOL_MAX_BYTES = (size_t)48 << 30;   // of 288 GB
 
 static void kz_live_add(kz_ctx* c, void* ptr, size_t bytes) {
@@ -285,7 +297,7 @@ int kz_pool_alloc(kz_ctx* c, size_t bytes, void** out) {
     void* base = nullptr;
     hipError_t e = hipMalloc(&base, need);
     if (e != hipSuccess) {  // release the cache and retry once
-        (void)hipStreamSynchronize(c->stream);
+        kz_sync_streams(c);
         for (int i = 0; i < c->pool_n; ++i) (void)hipFree(c->pool[i].ptr);
         c->pool_n = 0;
         c->pool_bytes = 0;
@@ -309,7 +321,7 @@ void kz_pool_free(kz_ctx* c, void* ptr, size_t /*bytes*/) {
         // gigabytes (seen: 260 ms per fit after other workloads had run in the same process)
         bool synced = false;
         while (c->pool_n > 0 && (c->pool_n >= 64 || c->pool_bytes + cap > KZ_POOL_MAX_BYTES)) {
-            if (!synced) (void)hipStreamSynchronize(c->stream);
+            if (!synced) kz_sync_streams(c);
             synced = true;
             (void)hipFree(c->pool[0].ptr);
             c->pool_bytes -= c->pool[0].bytes;
@@ -322,13 +334,13 @@ void kz_pool_free(kz_ctx* c, void* ptr, size_t /*bytes*/) {
         c->pool_bytes += cap;
         return;
     }
-    (void)hipStreamSynchronize(c->stream);
+    kz_sync_streams(c);
     (void)hipFree(ptr);
 }
 
 int kz_scratch(kz_ctx* c, size_t bytes, void** out) {
     if (bytes > c->scratch_bytes) {
-        KZ_HIP(hipStreamSynchronize(c->stream));
+        kz_sync_streams(c);
         if (c->scratch) KZ_HIP(hipFree(c->scratch));
         c->scratch = nullptr;
         c->scratch_bytes = 0;

@@ -32,6 +32,9 @@ for k, d in agg.items():
 PY
   rm -rf "$OUT/$name"
 }
+# PASSES="fetch write tcc grbm" selects passes (default: all)
+sel() { [ -z "${PASSES:-}" ] || [[ " $PASSES " == *" $1 "* ]]; }
+orig_run=$(declare -f run); eval "${orig_run/run ()/run_pass ()}"; run() { sel "$1" && run_pass "$@"; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run sq3 SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VALU_MFMA_MOPS_F16
