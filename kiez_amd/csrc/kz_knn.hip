@@ -1458,6 +1458,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         cp.dbg = nullptr;
         if (tier == KZ_TIER_H && ctx->pack_sweep) {
             cp.pack_pos = ctx->d_counters + KZ_PACK_POS_OFF;
+            cp.pack_mode = ctx->pack_sweep;
             KZ_HIP(hipMemsetAsync(cp.pack_pos, 0, 256 * sizeof(int), ctx->stream));
         }
 #ifdef KZ_STAMP

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     // lone sweep.  The workgroups sharing an XCD are labelled by blockIdx.x % 8 (round-robin placement, MI355X_MICROARCH.md).
     int t_start = t_begin;
     if (p.pack_pos) {
-        const int pos = __builtin_nontemporal_load(p.pack_pos + (blockIdx.x & 7) * 32);   // (one L2 read, never from a stale scalar cache line)
+        const int label = p.pack_mode == 2 ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (blockIdx.x & 7);   // (2: HW_REG_XCC_ID[3:0])
+        const int pos = __builtin_nontemporal_load(p.pack_pos + label * 32);   // (one L2 read, never from a stale scalar cache line)
         const int posu = __builtin_amdgcn_readfirstlane(pos);
         if (posu > t_begin && posu < t_end) t_start = posu;
     }
@@ -288,7 +289,9 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
             typedef __attribute__((address_space(4))) const volatile unsigned long long kz_karg_u64;
             const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
             int* pp = (int*)*(kz_karg_u64*)(ka + offsetof(KnnCandParams, pack_pos));
-            if (tid == 0) __builtin_nontemporal_store(tile, pp + (blockIdx.x & 7) * 32);
+            const int mode = *(__attribute__((address_space(4))) const volatile int*)(ka + offsetof(KnnCandParams, pack_mode));
+            const int label = mode == 2 ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (blockIdx.x & 7);
+            if (tid == 0) __builtin_nontemporal_store(tile, pp + label * 32);
             __builtin_amdgcn_sched_barrier(0);
         }
         {

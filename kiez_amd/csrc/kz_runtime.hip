@@ -192,7 +192,8 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
         KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
         c->lds_pad = (int)value;
     } else if (strcmp(name, "pack_sweep") == 0) {
-        c->pack_sweep = value != 0 ? 1 : 0;
+        KZ_REQUIRE(value == 0 || value == 1 || value == 2, "pack_sweep must be 0 (off), 1 (XCD label = blockIdx.x % 8) or 2 (HW_REG_XCC_ID)");
+        c->pack_sweep = (int)value;
     } else if (strcmp(name, "min_splits") == 0) {
         KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
         c->min_splits = (int)value;
