@@ -115,9 +115,15 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     // lone sweep.  The workgroups sharing an XCD are labelled by blockIdx.x % 8 (round-robin placement, MI355X_MICROARCH.md).
     int t_start = t_begin;
     if (p.pack_pos) {
-        const int label = p.pack_mode == 2 ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (blockIdx.x & 7);   // (2: HW_REG_XCC_ID[3:0])
-        const int pos = __builtin_nontemporal_load(p.pack_pos + label * 32);   // (one L2 read, never from a stale scalar cache line)
-        const int posu = __builtin_amdgcn_readfirstlane(pos);
+        // ONE lane reads the word (other workgroups keep writing it: four waves reading for themselves could see four values)
+        // and hands it to the workgroup through LDS
+        kz_lds_i32* sh = (kz_lds_i32*)(smem + Cfg::SYNC_OFF) + 8;
+        if (threadIdx.x == 0) {
+            const int label = p.pack_mode == 2 ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (blockIdx.x & 7);   // (2: HW_REG_XCC_ID[3:0])
+            *sh = __builtin_nontemporal_load(p.pack_pos + label * 32);   // (one L2 read, never from a stale scalar cache line)
+        }
+        __syncthreads();
+        const int posu = __builtin_amdgcn_readfirstlane(*sh);
         if (posu > t_begin && posu < t_end) t_start = posu;
     }
     // WIDE: waves 4 b .. 4 b + 3 take query tile wd.x + b; a workgroup at the end of the launch may reach past its last
