@@ -45,11 +45,10 @@ struct kz_ctx {
     double dual_max_gb; // kz_knn_dual: transient footprint budget in GiB (0 = the built-in 32)
     int dual_force;   // test knob: run the dual pass also where it does not pay (few query rows)
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
-    int pack_sweep;   // 1 (default): workgroups of the fp16 kernel join their XCD's sweep where it is (kz_knn_h16.h "PACK SWEEP"); 0: every sweep starts at its first tile
     // scratch (grown on demand, reused across calls)
     void* scratch;
     size_t scratch_bytes;
-    int* d_counters;  // small device int array (fail counter, flags; [KZ_PACK_POS_OFF, + 256): the pack-sweep positions)
+    int* d_counters;  // small device int array (fail counter, flags)
     int* h_counters;  // pinned host mirror
     int n_cus;        // compute units of the device
     void* h_stage;    // pinned host staging for the per-call work table
@@ -64,7 +63,6 @@ struct kz_ctx {
     size_t live_bytes[KZ_LIVE_MAX];
 };
 
-constexpr int KZ_COUNTER_INTS = 512, KZ_PACK_POS_OFF = 256;
 int kz_pool_alloc(kz_ctx* ctx, size_t bytes, void** out);   // returns KZ_OK / KZ_ERR_NOMEM
 void kz_pool_free(kz_ctx* ctx, void* ptr, size_t bytes);
 

@@ -1456,11 +1456,6 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         cp.out_key = out_key;
         cp.out_idx = out_idx;
         cp.dbg = nullptr;
-        if (tier == KZ_TIER_H && ctx->pack_sweep) {
-            cp.pack_pos = ctx->d_counters + KZ_PACK_POS_OFF;
-            cp.pack_mode = ctx->pack_sweep;
-            KZ_HIP(hipMemsetAsync(cp.pack_pos, 0, 256 * sizeof(int), ctx->stream));
-        }
 #ifdef KZ_STAMP
         cp.dbg = (unsigned long long*)(ctx->d_counters + 16);
         KZ_HIP(hipMemsetAsync(cp.dbg, 0, 12 * sizeof(unsigned long long), ctx->stream));

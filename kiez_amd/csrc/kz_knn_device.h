@@ -108,10 +108,6 @@ struct KnnCandParams {
     void* log_meta;                // [log_cap] x 8 B
     unsigned long long* log_cnt;
     long long log_cap;
-    // pack sweep (fp16 kernel): [8 x 32] ints, zeroed before the launch -- per XCD label (blockIdx.x % 8) the index tile its
-    // workgroups are at; nullptr = every workgroup sweeps its range from the first tile (kz_knn_h16.h "PACK SWEEP")
-    int* pack_pos;
-    int pack_mode;   // which workgroups share a position word: 1 = equal blockIdx.x % 8, 2 = equal HW_REG_XCC_ID
 };
 
 constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows

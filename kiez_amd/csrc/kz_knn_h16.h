@@ -107,25 +107,6 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     const int4 wd = p.work[blockIdx.x];
     const int t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
-    // PACK SWEEP (KnnCandParams::pack_pos): the range is swept CYCLICALLY from the index tile the workgroups of this XCD are at
-    // right now -- t_start .. t_end - 1, then t_begin .. t_start - 1 -- instead of from t_begin.  The lists do not depend on the
-    // order of the tiles; the L2 does: a workgroup dispatched while its XCD's other ~95 are in the middle of the range joins them
-    // where they are (every index tile is then fetched into the XCD's L2 once for all of them) instead of streaming the range
-    // alone, 1000 tiles behind.  Speed only: any start tile inside the range is correct, a stale or foreign value just means a
-    // lone sweep.  The workgroups sharing an XCD are labelled by blockIdx.x % 8 (round-robin placement, MI355X_MICROARCH.md).
-    int t_start = t_begin;
-    if (p.pack_pos) {
-        // ONE lane reads the word (other workgroups keep writing it: four waves reading for themselves could see four values)
-        // and hands it to the workgroup through LDS
-        kz_lds_i32* sh = (kz_lds_i32*)(smem + Cfg::SYNC_OFF) + 8;
-        if (threadIdx.x == 0) {
-            const int label = p.pack_mode == 2 ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (blockIdx.x & 7);   // (2: HW_REG_XCC_ID[3:0])
-            *sh = __builtin_nontemporal_load(p.pack_pos + label * 32);   // (one L2 read, never from a stale scalar cache line)
-        }
-        __syncthreads();
-        const int posu = __builtin_amdgcn_readfirstlane(*sh);
-        if (posu > t_begin && posu < t_end) t_start = posu;
-    }
     // WIDE: waves 4 b .. 4 b + 3 take query tile wd.x + b; a workgroup at the end of the launch may reach past its last
     // tile: those waves sweep along (barriers, and nothing else, need them) on the last valid tile's rows with every
     // threshold at +inf -- no event, no list traffic, no output
@@ -192,8 +173,7 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     // offset: two scalar adds per slice instead of a clamped 64-bit index computation); slices are issued strictly in
     // order, and the ring runs up to R + P slices past the end of the sweep -- into the next tiles of the image or into
     // the padding kz_himage_build allocates behind it (those slots are never read).
-    const char* dma_src = reinterpret_cast<const char*>(p.ypack) + ((int64_t)t_start * NSR) * 4096;   // uniform
-    int dma_left = (t_end - t_start) * NSR;   // uniform: slices until the running pointer wraps to the first tile of the range
+    const char* dma_src = reinterpret_cast<const char*>(p.ypack) + ((int64_t)t_begin * NSR) * 4096;   // uniform
     int dma_slot = 0;   // uniform: slot of the next slice to issue
     int dma_turn = 0;   // WIDE: the group of four waves that copies the next slice (the groups take turns)
     const int lane_off = (WIDE ? (tid & 255) : tid) * 16;
@@ -202,18 +182,14 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
         if (!WIDE || tb == dma_turn) kz_glds16_s(dma_src, (unsigned)lane_off, dst);
         if constexpr (WIDE) dma_turn = dma_turn + 1 == TPW ? 0 : dma_turn + 1;
         dma_src += 4096;
-        if (--dma_left == 0) {   // (pack sweep: on to the first tile of the range; a sweep from t_begin wraps only behind its end)
-            dma_src -= (int64_t)(t_end - t_begin) * NSR * 4096;
-            dma_left = (t_end - t_begin) * NSR;
-        }
         dma_slot = (dma_slot + 1) & (R - 1);
     };
 #pragma unroll
     for (int i = 0; i < R; ++i) dma_next();
-    bbuf[(tid & 127)] = p.ybias[(int64_t)t_start * KZ_TILE + (tid & 127)];   // (bias double buffer: by position in the sweep, first tile = 0)
+    bbuf[(t_begin & 1) * 128 + (tid & 127)] = p.ybias[(int64_t)t_begin * KZ_TILE + (tid & 127)];
     KzDualRef du;
     if constexpr (DUAL) {
-        if (tid < 64) tbuf[tid] = p.theta[(int64_t)t_start * KZ_TILE + tid];
+        if (tid < 64) tbuf[tid] = p.theta[(int64_t)t_begin * KZ_TILE + tid];
         du.qrow0 = (p.qt0 + qt) * KZ_TILE + 32 * wq;
         // this query's own offset: read back from LDS in every epilogue (a register held for the whole sweep was spilled at
         // three workgroups per CU, and reloaded behind a wait for the DMA ring)
@@ -238,9 +214,6 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     };
     if (CARRY) fetch_frags(f0, 0);
     int g = 0;
-    int seq = 0;                          // tiles of the sweep done (uniform)
-    const int n_sweep = t_end - t_begin;
-    const bool packed = p.pack_pos != nullptr;
     int th_cur = 0;   // dual pass: threshold buffer of the current tile (uniform)
     f32x16 acc[4];
 #if defined(KZ_EXP) && (KZ_EXP == 8 || KZ_EXP == 9)
@@ -289,17 +262,6 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     auto run_tile = [&](const int tile, auto start_parity) {
         constexpr int P0 = decltype(start_parity)::value;
         KZ_T(t0);
-        // pack sweep: tell the workgroups that will be dispatched to this XCD where its sweep is (every fourth tile, one lane; HERE,
-        // where no accumulator is live, and with the pointer read from the kernel arguments on the spot: nothing is carried)
-        if (packed && (seq & 3) == 0) {
-            typedef __attribute__((address_space(4))) const volatile unsigned long long kz_karg_u64;
-            const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-            int* pp = (int*)*(kz_karg_u64*)(ka + offsetof(KnnCandParams, pack_pos));
-            const int mode = *(__attribute__((address_space(4))) const volatile int*)(ka + offsetof(KnnCandParams, pack_mode));
-            const int label = mode == 2 ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (blockIdx.x & 7);
-            if (tid == 0) __builtin_nontemporal_store(tile, pp + label * 32);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         {
             int h_now = h;
             if constexpr (WPS == 3) {
@@ -307,7 +269,7 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
                 //  three workgroups per CU -- and reloaded behind a wait for the whole DMA ring)
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshrrev_b32 %0, 5, %0" : "=v"(h_now));
             }
-            const float* bp = bbuf + (seq & 1) * 128 + 4 * h_now;
+            const float* bp = bbuf + (tile & 1) * 128 + 4 * h_now;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -331,15 +293,14 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
             // s_waitcnt vmcnt(0): a wait for the whole DMA ring) at the top of every tile
             unsigned off4;
             asm volatile("v_lshrrev_b32 %0, 2, %1" : "=v"(off4) : "v"(lane_off));
-            const int nt = tile + 1 == t_end ? t_begin : tile + 1;   // the next tile of the (cyclic) sweep; behind the last one: any valid tile
             if (wave < 2)
-                kz_glds4_s(p.ybias + (int64_t)nt * KZ_TILE, off4, bbuf + ((seq + 1) & 1) * 128 + wave * 64);
+                kz_glds4_s(p.ybias + (int64_t)min(tile + 1, p.n_ytiles - 1) * KZ_TILE, off4, bbuf + ((tile + 1) & 1) * 128 + wave * 64);
             else if (DUAL && wave == 2)
                 // ... and its smallest thresholds (the rows are sorted by threshold: the epilogue only reads the first), by a
                 // third wave (the -128 floats of its lane offset are folded into the scalar base).  THREE buffers: the value is
                 // read at the END of a tile, so a wave that is already here may not overwrite what a slower wave still reads
                 // for the previous tile; the buffer written here was last read two tiles ago, with a slice barrier in between.
-                kz_glds4_s(p.theta + ((int64_t)nt - 1) * KZ_TILE, off4, tbuf + (th_cur == 2 ? 0 : th_cur + 1) * 64);
+                kz_glds4_s(p.theta + ((int64_t)min(tile + 1, p.n_ytiles - 1) - 1) * KZ_TILE, off4, tbuf + (th_cur == 2 ? 0 : th_cur + 1) * 64);
         }
 #if defined(KZ_EXP) && (KZ_EXP == 8 || KZ_EXP == 9)
         {
@@ -481,7 +442,7 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
             cthr = tbuf[192 + 32 * (tid >> 6) + j] + tbuf[th_cur * 64];   // this query's offset + the tile's smallest theta (rows sorted by theta)
             th_cur = th_cur == 2 ? 0 : th_cur + 1;
         }
-        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, seq == n_sweep - 1, msync, du, cthr, c_merge, n_pass, n_ins, c_e1, c_e2, c_col, n_col);
+        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du, cthr, c_merge, n_pass, n_ins, c_e1, c_e2, c_col, n_col);
         __builtin_amdgcn_sched_barrier(0);
         c_slices += t1 - t0;
         c_epi += __builtin_amdgcn_s_memtime() - t1;
@@ -494,21 +455,16 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
             cthr = tbuf[192 + 32 * (tid >> 6) + j] + tbuf[th_cur * 64];   // this query's offset + the tile's smallest theta (rows sorted by theta)
             th_cur = th_cur == 2 ? 0 : th_cur + 1;
         }
-        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, seq == n_sweep - 1, msync, du, cthr);
+        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du, cthr);
 #endif
-        ++seq;
     };
 
-    int tile = t_start;
+    int tile = t_begin;
     for (;;) {
         run_tile(tile, std::integral_constant<int, 0>{});
-        if (seq >= n_sweep) break;
-        tile = tile + 1 == t_end ? t_begin : tile + 1;
-        if constexpr ((NSR & 1) != 0) {   // (an odd slice count alternates the parity of a tile's first slice)
-            run_tile(tile, std::integral_constant<int, 1>{});
-            if (seq >= n_sweep) break;
-            tile = tile + 1 == t_end ? t_begin : tile + 1;
-        }
+        if (++tile >= t_end) break;
+        run_tile(tile, std::integral_constant<int, (NSR & 1)>{});
+        if (++tile >= t_end) break;
     }
     if constexpr (IN_LDS != 0) {
         // the sweep is over: what lived in LDS goes to the output arrays in the layout kz_knn_finalize_kernel reads

@@ -64,7 +64,6 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
     c->lds_pad = 0;
     c->precision = 0;
-    c->pack_sweep = 1;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
         c->precision = (strcmp(pv, "fp32") == 0 || strcmp(pv, "1") == 0) ? 1 : ((strcmp(pv, "bf16") == 0 || strcmp(pv, "2") == 0) ? 2 : 0);
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -77,9 +76,9 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     }
     KZ_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     for (int i = 0; i < 12; ++i) KZ_HIP(hipEventCreate(&c->ev[i]));
-    KZ_HIP(hipMalloc((void**)&c->d_counters, KZ_COUNTER_INTS * sizeof(int)));
+    KZ_HIP(hipMalloc((void**)&c->d_counters, 64 * sizeof(int)));
     KZ_HIP(hipHostMalloc((void**)&c->h_counters, 64 * sizeof(int), hipHostMallocDefault));
-    KZ_HIP(hipMemsetAsync(c->d_counters, 0, KZ_COUNTER_INTS * sizeof(int), c->stream));
+    KZ_HIP(hipMemsetAsync(c->d_counters, 0, 64 * sizeof(int), c->stream));
     KZ_HIP(hipStreamSynchronize(c->stream));
     *out = c;
     return KZ_OK;
@@ -191,9 +190,6 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "lds_pad") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
         c->lds_pad = (int)value;
-    } else if (strcmp(name, "pack_sweep") == 0) {
-        KZ_REQUIRE(value == 0 || value == 1 || value == 2, "pack_sweep must be 0 (off), 1 (XCD label = blockIdx.x % 8) or 2 (HW_REG_XCC_ID)");
-        c->pack_sweep = (int)value;
     } else if (strcmp(name, "min_splits") == 0) {
         KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
         c->min_splits = (int)value;
