@@ -984,6 +984,9 @@ int kz_hd_launch_kp16(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_b
 int kz_hd_launch_kp32(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
 int kz_hd_launch_kp64(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
 int kz_hd_launch_kp128(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wps, int wide);
+bool kz_h64_supports(int n_slices);   // kz_knn_h64.hip: 64 queries per wave, K' = 16, ordinary (dual = 0) and dual-pass builds
+int kz_h64_occupancy(int n_slices, int dual, int* blocks_per_cu, int lds_pad);
+int kz_h64_launch(int n_slices, int dual, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
 int kz_bf_occupancy_kp16(int n_slices_bf, int* blocks_per_cu, int lds_pad);
 int kz_bf_occupancy_kp32(int n_slices_bf, int* blocks_per_cu, int lds_pad);
 int kz_bf_occupancy_kp64(int n_slices_bf, int* blocks_per_cu, int lds_pad);
@@ -1373,13 +1376,19 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             }   // (no memory for the second image: the long list)
         }
     }
+    // 64 QUERIES PER WAVE (kz_knn_h64.h): the K' = 16 sweeps of 4 .. 13 slices -- half the LDS fragment reads per MFMA and half the
+    // LDS-DMA volume per query of the 32-query kernel; a work item = a unit of two query tiles (tpw = 2).  Option "h_q64" = 0: off.
+    const bool q64 = tier == KZ_TIER_H && KP == 16 && ctx->h_q64 && kz_h64_supports(n_slices) && !exact_only;
     int slots_cache[3] = {0, 0, 0};
     int tpw_h = 1;   // query tiles per workgroup of the fp16 kernel this call runs (wide builds: 2 or 3)
     auto slots_for = [&](int t, int* out) -> int {
         if (slots_cache[t] == 0) {
             int blocks_per_cu = 1;
             int rc0;
-            if (t == KZ_TIER_H && dual)
+            if (t == KZ_TIER_H && q64) {
+                rc0 = kz_h64_occupancy(n_slices, dual ? 1 : 0, &blocks_per_cu, ctx->lds_pad);
+                tpw_h = 2;
+            } else if (t == KZ_TIER_H && dual)
                 KZ_DISPATCH_KP(rc0, kz_hd_occupancy, (n_slices, &blocks_per_cu, &tpw_h, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
             else if (t == KZ_TIER_H)
                 KZ_DISPATCH_KP(rc0, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw_h, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
@@ -1475,8 +1484,13 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             cp.log_meta = dual->log_meta;
             cp.log_cnt = dual->log_cnt;
             cp.log_cap = dual->log_cap;
-            KZ_DISPATCH_KP(rc, kz_hd_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
-        } else if (tier == KZ_TIER_H)
+            if (q64)
+                rc = kz_h64_launch(n_slices, 1, ctx, cp, W);
+            else
+                KZ_DISPATCH_KP(rc, kz_hd_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
+        } else if (tier == KZ_TIER_H && q64)
+            rc = kz_h64_launch(n_slices, 0, ctx, cp, W);
+        else if (tier == KZ_TIER_H)
             KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
         else if (tier == KZ_TIER_BF)
             KZ_DISPATCH_KP(rc, kz_bf_launch, (n_slices, ctx, cp, W));
