@@ -1465,6 +1465,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         cp.out_key = out_key;
         cp.out_idx = out_idx;
         cp.dbg = nullptr;
+        cp.flags = ctx->h64_late ? 1 : 0;
 #ifdef KZ_STAMP
         cp.dbg = (unsigned long long*)(ctx->d_counters + 16);
         KZ_HIP(hipMemsetAsync(cp.dbg, 0, 12 * sizeof(unsigned long long), ctx->stream));
