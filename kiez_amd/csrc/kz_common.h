@@ -44,7 +44,7 @@ struct kz_ctx {
     int dual_overlap; // 1 (default): kz_knn_dual runs the reverse direction's chain on the second stream beside the forward finalize; 0: behind it
     double dual_max_gb; // kz_knn_dual: transient footprint budget in GiB (0 = the built-in 32)
     int dual_force;   // test knob: run the dual pass also where it does not pay (few query rows)
-    int h_q64;        // 1 (default): K' = 16 sweeps of 4 .. 13 slices run the 64-queries-per-wave kernel (kz_knn_h64.h); 0: the 32-query kernel
+    int h_q64;        // 64-queries-per-wave kernel (kz_knn_h64.h) for K' = 16 sweeps of 4 .. 13 slices: 2 (default) = where it pays (kz_knn_impl), 1 = always, 0 = never
     int h64_late;     // tuning knob of that kernel: LDS-DMA copies issued one half slice late (default 0)
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)

@@ -1376,9 +1376,15 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             }   // (no memory for the second image: the long list)
         }
     }
-    // 64 QUERIES PER WAVE (kz_knn_h64.h): the K' = 16 sweeps of 4 .. 13 slices -- half the LDS fragment reads per MFMA and half the
-    // LDS-DMA volume per query of the 32-query kernel; a work item = a unit of two query tiles (tpw = 2).  Option "h_q64" = 0: off.
-    const bool q64 = tier == KZ_TIER_H && KP == 16 && ctx->h_q64 && kz_h64_supports(n_slices) && !exact_only;
+    // 64 QUERIES PER WAVE (kz_knn_h64.h): K' = 16 sweeps of 4 .. 13 slices -- half the LDS fragment reads per MFMA and half the
+    // LDS-DMA volume per query of the 32-query kernel at two waves per SIMD instead of three; a work item = a unit of two query
+    // tiles (tpw = 2).  Measured (profiles/r04_ablation.md section 2): the shared sweep at 13 slices -1.5 % (250k x 1M x 200: 90.6 ->
+    // 89.2 ms), the ordinary kernel +0.8 % there, +8 % at 8 slices, and a launch of fewer than ~4 rounds of units does not fill the
+    // chip (100k x 100k: +30 %).  Option "h_q64": 2 (default) = the shared sweep from 9 slices on over >= 4 rounds of units,
+    // 1 = wherever the kernel is built for (tests), 0 = never.
+    const bool q64_ok = tier == KZ_TIER_H && KP == 16 && kz_h64_supports(n_slices) && !exact_only;
+    const bool q64 = q64_ok && (ctx->h_q64 == 1 || (ctx->h_q64 == 2 && dual && n_slices >= 9 &&
+                                                     (q_count + 2 * KZ_TILE - 1) / (2 * KZ_TILE) >= (int64_t)4 * 2 * ctx->n_cus));
     int slots_cache[3] = {0, 0, 0};
     int tpw_h = 1;   // query tiles per workgroup of the fp16 kernel this call runs (wide builds: 2 or 3)
     auto slots_for = [&](int t, int* out) -> int {

@@ -63,7 +63,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->short_ord_min_tiles = 48;
     c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
     c->lds_pad = 0;
-    c->h_q64 = 1;
+    c->h_q64 = 2;
     c->h64_late = 0;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
@@ -195,7 +195,8 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "h64_late") == 0) {
         c->h64_late = value != 0 ? 1 : 0;
     } else if (strcmp(name, "h_q64") == 0) {
-        c->h_q64 = value != 0 ? 1 : 0;
+        KZ_REQUIRE(value == 0 || value == 1 || value == 2, "h_q64 must be 0 (never), 1 (wherever built) or 2 (automatic)");
+        c->h_q64 = (int)value;
     } else if (strcmp(name, "min_splits") == 0) {
         KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
         c->min_splits = (int)value;
