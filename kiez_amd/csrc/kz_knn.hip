@@ -89,9 +89,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
         __syncthreads();
 
         int g = 0;
-#ifdef KZ_STAMP
-        unsigned long long c_qwait = 0, c_ywait = 0, c_bar = 0;
-#endif
         f32x16 acc[4];
         const float* bias_n = p.ybias + (tid & 127);
         int tile = t_begin;
@@ -103,15 +100,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
         // Lane (j, h) feeds k = 4*(2t+h)+jj for jj = 0..3: the k order inside a slice is permuted identically for
         // A and B, which leaves the dot product unchanged.
         auto slice_step = [&](const float4& bq0, const float4& bq1, const bool stream_q, const int sl_next) {
-#ifdef KZ_STAMP
-            {   // how long does the wave wait for the query fragments issued one slice ago?
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                c_qwait += __builtin_amdgcn_s_memtime() - w0;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
             const int gn = min(g + 1, total - 1);
             const float4* src = ysrc + (int64_t)gn * 512;
             const float4 ya0 = src[tid];
@@ -143,15 +131,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
                 for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifdef KZ_STAMP
-            {   // ... and for the index slice issued at the top of this slice (2 younger query loads may stay in flight)
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                if (stream_q) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                c_ywait += __builtin_amdgcn_s_memtime() - w0;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
             {
                 float4* nb = reinterpret_cast<float4*>(ybuf + ((g + 1) & 1) * 2048);
                 nb[tid] = ya0;
@@ -162,27 +141,14 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
                     qb1 = qn1;
                 }
             }
-#ifdef KZ_STAMP
-            {
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                __syncthreads();
-                c_bar += __builtin_amdgcn_s_memtime() - w0;
-            }
-#else
             // Raw barrier: __syncthreads() is fence + s_barrier and the fence drains vmcnt(0), i.e. it would wait here for
             // the query-fragment loads that are only needed at the top of the next slice.  LDS visibility needs lgkmcnt only.
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
             ++g;
         };
 
-#ifdef KZ_STAMP
-        unsigned long long c_slices = 0, c_epi = 0, c_init = 0, c_e1 = 0, c_e2 = 0;
-#endif
         for (; tile < t_end; ++tile) {
             __builtin_amdgcn_sched_barrier(0);  // do not hoist the next tile's init above the epilogue (64 VGPRs)
-            KZ_T(t0);
             {
                 const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
 #pragma unroll
@@ -198,7 +164,6 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            KZ_T(t1);
             // resident slices: fully unrolled, fragments by static register index
 #pragma unroll
             for (int u = 0; u < NRES; ++u) {
@@ -215,29 +180,8 @@ __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
                 } while (++sl < NS);
             }
             __builtin_amdgcn_sched_barrier(0);
-            KZ_T(t2);
             kz_tile_epilogue<KP>(acc, st, tile, tile == t_end - 1, h);
-#ifdef KZ_STAMP
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            c_init += t1 - t0;
-            c_slices += t2 - t1;
-            c_epi += t3 - t2;
-#endif
         }
-#ifdef KZ_STAMP
-        if (lane == 0 && p.dbg) {
-            atomicAdd(p.dbg + 0, c_slices);
-            atomicAdd(p.dbg + 1, c_epi);
-            atomicAdd(p.dbg + 2, c_init);
-            atomicAdd(p.dbg + 3, (unsigned long long)(t_end - t_begin));
-            atomicAdd(p.dbg + 4, c_e1);
-            atomicAdd(p.dbg + 5, c_e2);
-            atomicAdd(p.dbg + 6, c_qwait);
-            atomicAdd(p.dbg + 7, c_ywait);
-            atomicAdd(p.dbg + 8, c_bar);
-        }
-#endif
     }
 }
 
@@ -1470,12 +1414,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         cp.kg = index->kg;
         cp.out_key = out_key;
         cp.out_idx = out_idx;
-        cp.dbg = nullptr;
         cp.flags = ctx->h64_late ? 1 : 0;
-#ifdef KZ_STAMP
-        cp.dbg = (unsigned long long*)(ctx->d_counters + 16);
-        KZ_HIP(hipMemsetAsync(cp.dbg, 0, 12 * sizeof(unsigned long long), ctx->stream));
-#endif
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         if (exact_only) {
             // every row of the chunk goes to the exact kernels: the "fail list" is 0 .. cq_count-1
@@ -1577,34 +1516,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             memcpy(&unchecked[u]->max_norm, ctx->h_counters + 44 + 10 * u, 8);
             unchecked[u]->checked = true;
         }
-#ifdef KZ_EXP
-        const int n_fail = 0;   // diagnostic builds (tools/ablate.sh): results are wrong by construction, only the first pass is timed
-#else
         const int n_fail = exact_only ? (int)cq_count : ctx->h_counters[8];
-#endif
         {
             double ratio;
             memcpy(&ratio, ctx->h_counters + 10, 8);
             if (ratio > max_err_ratio) max_err_ratio = ratio;
         }
-#ifdef KZ_STAMP
-        {
-            unsigned long long hd[12];
-            KZ_HIP(hipMemcpy(hd, ctx->d_counters + 16, sizeof(hd), hipMemcpyDeviceToHost));
-            const double wt = (double)(hd[3] ? hd[3] : 1);  // wave-tiles
-            if (tier == KZ_TIER_F32) {
-                fprintf(stderr, "[kz stamp] f32 kernel, per wave-tile cycles: slices %.0f  epilogue %.0f  init %.0f  (wave-tiles %llu)\n",
-                        hd[0] / wt, hd[1] / wt, hd[2] / wt, hd[3]);
-                fprintf(stderr, "[kz stamp]   inside slices, per wave-tile: query-frag wait %.0f  index-slice wait %.0f  barrier %.0f\n",
-                        hd[6] / wt, hd[7] / wt, hd[8] / wt);
-            } else {
-                fprintf(stderr, "[kz stamp] %s kernel, per wave-tile cycles: slices %.0f (dma wait %.0f, barrier wait %.0f)  epilogue %.0f "
-                        "(masks %.0f, first scan pass %.0f, merges %.0f; merge passes %.4f, max-lane inserts %.3f; column part %.0f in %.3f of the tiles)  (wave-tiles %llu)\n",
-                        tier == KZ_TIER_H ? "fp16" : "bf16", hd[0] / wt, hd[7] / wt, hd[8] / wt, hd[1] / wt, hd[2] / wt, hd[9] / wt,
-                        hd[4] / wt, hd[5] / wt, hd[6] / wt, hd[10] / wt, hd[11] / wt, hd[3]);
-            }
-        }
-#endif
         float ms = 0;
         KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         main_ms += ms;

@@ -108,9 +108,6 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
     };
     int g = 0;
     f32x16 acc[4];
-#ifdef KZ_STAMP
-    unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0;
-#endif
     // Even NSR: software pipeline over pairs of slices.  Fragment set A holds slice g (even), set B slice g+1; B is
     // fetched under A's MFMAs, the workgroup barrier sits in the middle of B's MFMAs (which only need registers), and
     // the first fragments of the NEXT pair are fetched right behind the barrier, under B's remaining MFMAs -- also
@@ -119,7 +116,6 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
     constexpr bool PIPE = (NSR % 2 == 0) && NSR <= 10;  // the second fragment set costs 32 VGPRs: beyond 10 slices it spills
     if (PIPE) load_frags(ah, al, 0);
     for (int tile = t_begin; tile < t_end; ++tile) {
-        KZ_T(t0);
         {
             const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
 #pragma unroll
@@ -160,20 +156,7 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
                 __builtin_amdgcn_sched_barrier(0);
                 // slices g and g+1 are consumed (their fragments are in registers): after the barrier their slots take
                 // slices g+4 and g+5, while g+2 and g+3 (issued one barrier ago, drained by the fence) become readable
-#ifdef KZ_STAMP
-                {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    const unsigned long long w1 = __builtin_amdgcn_s_memtime();
-                    __syncthreads();
-                    c_dma += w1 - w0;
-                    c_bar += __builtin_amdgcn_s_memtime() - w1;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#else
                 __syncthreads();
-#endif
                 dma_slice(g + 4);
                 dma_slice(g + 5);
                 load_frags(ah, al, g + 2);
@@ -207,31 +190,8 @@ __global__ __launch_bounds__(256, WPS) void kz_knn_cand_bf_kernel(KnnCandParams 
                 ++g;
             }
         }
-#ifdef KZ_STAMP
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync, 0, c_merge, n_pass, n_ins, c_e1, c_e2);
-        __builtin_amdgcn_sched_barrier(0);
-        c_slices += t1 - t0;
-        c_epi += __builtin_amdgcn_s_memtime() - t1;
-#else
         kz_tile_epilogue2<KP, KZ_BF_CAP>(acc, st, bmin, tile, tile == t_end - 1, h, msync, 0);
-#endif
     }
-#ifdef KZ_STAMP
-    if (lane == 0 && p.dbg) {
-        atomicAdd(p.dbg + 0, c_slices);
-        atomicAdd(p.dbg + 1, c_epi);
-        atomicAdd(p.dbg + 3, (unsigned long long)(t_end - t_begin));
-        atomicAdd(p.dbg + 4, c_merge);
-        atomicAdd(p.dbg + 5, n_pass);
-        atomicAdd(p.dbg + 6, n_ins);
-        atomicAdd(p.dbg + 7, c_dma);
-        atomicAdd(p.dbg + 8, c_bar);
-        atomicAdd(p.dbg + 2, c_e1);
-        atomicAdd(p.dbg + 9, c_e2);
-    }
-#endif
 }
 
 
@@ -322,14 +282,10 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
         }
     };
     fetch_frags(f0h, f0l, 0);
-#ifdef KZ_STAMP
-    unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0;
-#endif
 
     // one tile: MFMAs into `cur`; scan of the previous tile's keys in `prev` between the MFMA groups; then its tail
     auto run_tile = [&](f32x16 (&cur)[4], f32x16 (&prev)[4], const bool have_prev, const int tile, auto start_parity) {
         constexpr int P0 = decltype(start_parity)::value;
-        KZ_T(t0);
         {
             const float* bp = bbuf + (tile & 1) * 128 + 4 * h;
 #pragma unroll
@@ -390,18 +346,6 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
             if (g & 1) {
                 // slices g-1 and g are consumed: their slots take slices g-1+RING and g+RING, three barrier periods ahead
                 // of their use (with one wave per SIMD nothing else covers the L2 latency of a late DMA)
-#ifdef KZ_STAMP
-                {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-                    const unsigned long long w1 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_barrier" ::: "memory");
-                    c_dma += w1 - w0;
-                    c_bar += __builtin_amdgcn_s_memtime() - w1;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#else
                 // Until the next barrier this wave READS slices up to g+3 (g+1, g+2 are computed, the fragments of g+3 are
                 // prefetched during g+2).  g+3 and g+4 were issued two barriers ago, so only the 4 wave-loads of the LAST
                 // barrier (slices g+5, g+6) may stay in flight: vmcnt counts in issue order, anything older than the 4
@@ -409,22 +353,13 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
                 // more periods.  vmcnt(8) -- forgetting the one-slice prefetch -- raced: 3 wrong rows in 3000 on a
                 // 1M-row index, caught by the rounding-bound self-check, tests/test_gpu_fullsize.py.)
                 asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
                 dma_slice(g - 1 + KZ_OV_RING);
                 dma_slice(g + KZ_OV_RING);
             }
             ++g;
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifdef KZ_STAMP
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        if (have_prev) kz_tile_epilogue2<KP, KZ_BF_CAP>(prev, st, bmin, tile - 1, false, h, msync, stop, c_merge, n_pass, n_ins, c_e1, c_e2);
-        __builtin_amdgcn_sched_barrier(0);
-        c_slices += t1 - t0;
-        c_epi += __builtin_amdgcn_s_memtime() - t1;
-#else
         if (have_prev) kz_tile_epilogue2<KP, KZ_BF_CAP>(prev, st, bmin, tile - 1, false, h, msync, stop);
-#endif
     };
 
     f32x16 acc0[4], acc1[4];
@@ -434,35 +369,13 @@ __global__ __launch_bounds__(256, 1) void kz_knn_cand_bf_ov_kernel(KnnCandParams
         run_tile(acc0, acc1, have_prev, tile, std::integral_constant<int, 0>{});
         have_prev = true;
         if (++tile >= t_end) {
-#ifdef KZ_STAMP
-            kz_tile_epilogue2<KP, KZ_BF_CAP>(acc0, st, bmin, tile - 1, true, h, msync, 0, c_merge, n_pass, n_ins, c_e1, c_e2);
-#else
             kz_tile_epilogue2<KP, KZ_BF_CAP>(acc0, st, bmin, tile - 1, true, h, msync, 0);
-#endif
             break;
         }
         run_tile(acc1, acc0, true, tile, std::integral_constant<int, (NSR & 1)>{});
         if (++tile >= t_end) {
-#ifdef KZ_STAMP
-            kz_tile_epilogue2<KP, KZ_BF_CAP>(acc1, st, bmin, tile - 1, true, h, msync, 0, c_merge, n_pass, n_ins, c_e1, c_e2);
-#else
             kz_tile_epilogue2<KP, KZ_BF_CAP>(acc1, st, bmin, tile - 1, true, h, msync, 0);
-#endif
             break;
         }
     }
-#ifdef KZ_STAMP
-    if (lane == 0 && p.dbg) {
-        atomicAdd(p.dbg + 0, c_slices);
-        atomicAdd(p.dbg + 1, c_epi);
-        atomicAdd(p.dbg + 3, (unsigned long long)(t_end - t_begin));
-        atomicAdd(p.dbg + 4, c_merge);
-        atomicAdd(p.dbg + 5, n_pass);
-        atomicAdd(p.dbg + 6, n_ins);
-        atomicAdd(p.dbg + 7, c_dma);
-        atomicAdd(p.dbg + 8, c_bar);
-        atomicAdd(p.dbg + 2, c_e1);
-        atomicAdd(p.dbg + 9, c_e2);
-    }
-#endif
 }

@@ -38,12 +38,6 @@ __device__ __forceinline__ float4 kz_nt_load4(const float4* p) {  // non-tempora
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// -DKZ_STAMP: in-kernel s_memtime stamps per section, summed into p.dbg (diagnostic build, never shipped/timed).
-#ifdef KZ_STAMP
-#define KZ_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#else
-#define KZ_T(var)
-#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Stage 1: fused similarity + candidate selection
@@ -100,7 +94,6 @@ struct KnnCandParams {
     int kg;               // k-groups (of 4) per row; slices per tile = kg / 4
     float* out_key;       // per region: [query rows][pieces][2 lane halves][KP]
     int* out_idx;
-    unsigned long long* dbg;  // diagnostic stamp build only (-DKZ_STAMP): cycle sums {slices, epilogue, init, waves}
     // dual pass (fp16 kernel, DUAL build; kz_knn_epi3.h "Dual pass")
     const float* theta;            // [n_ytiles * 128] event threshold per index row (+inf on pad rows)
     const float* qnbias;           // [query rows incl. padding, global row numbers] -bias(q) (+inf on pad rows)
@@ -231,11 +224,6 @@ __device__ __forceinline__ void kz_tile_epilogue(f32x16 (&acc)[4], KzCandState& 
 }
 
 
-#ifdef KZ_STAMP
-#define KZ_EPI2_STAMP_ARGS , unsigned long long& c_merge, unsigned long long& n_pass, unsigned long long& n_ins, unsigned long long& c_e1, unsigned long long& c_e2
-#else
-#define KZ_EPI2_STAMP_ARGS
-#endif
 // Two-level minimum of an unsorted K'-entry list: the list is cut into NB blocks, the minimum of every block (value and
 // position inside the block) is kept in registers.  Replacing the global minimum then touches ONE block: write the new
 // entry, re-read that block (K'/NB keys, one L2 round trip), refresh its minimum -- instead of re-scanning all K' keys.
@@ -339,8 +327,7 @@ __device__ __forceinline__ void kz_merge_logs_shared(KzCandState& st, KzBlockMin
 #define KZ_MERGE_FLAG(CAP) ((CAP) >= 16 ? (CAP) - 8 : (CAP) / 2)
 template <int KP, int CAP>
 __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState& st, KzBlockMin<KP>& bs, const int tile,
-                                                  const bool last_tile, const int h, int* sync, const int resume0 KZ_EPI2_STAMP_ARGS) {
-    KZ_T(te0);
+                                                  const bool last_tile, const int h, int* sync, const int resume0) {
     ++st.tiles_done;
     const bool sched = (st.tiles_done == st.next_merge) || last_tile;  // block-uniform
     {
@@ -348,25 +335,12 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         const bool together = __builtin_amdgcn_readfirstlane(sync[(t - 1) & 3]) != 0;
         if ((threadIdx.x & 63) == 0) sync[(t + 1) & 3] = 0;
         if (together) {
-            KZ_T(tm0);
-#ifdef KZ_STAMP
-            n_ins += __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, st.cnt + __shfl_xor(st.cnt, 32, 64)));
-#endif
             kz_merge_logs_shared<KP>(st, bs);
-#ifdef KZ_STAMP
-            __builtin_amdgcn_sched_barrier(0);
-            c_merge += __builtin_amdgcn_s_memtime() - tm0;
-            n_pass += 1;
-#endif
         }
     }
     if (resume0 >= 16 && !sched) {
         // nothing left to scan (an overlapped scan covered all 16 groups) and no merge due: only the bookkeeping
         if (__any(st.cnt > KZ_MERGE_FLAG(CAP)) && (threadIdx.x & 63) == 0) sync[st.tiles_done & 3] = 1;
-#ifdef KZ_STAMP
-        __builtin_amdgcn_sched_barrier(0);
-        c_e1 += __builtin_amdgcn_s_memtime() - te0;
-#endif
         return;
     }
     float tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));
@@ -386,13 +360,6 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
         asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][4 * g4 + 3]));
         gm[gi] = __builtin_amdgcn_ballot_w64(m > tau_a);
     }
-#ifdef KZ_STAMP
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" :: "s"(gm[0]), "s"(gm[15]));
-    const unsigned long long te1 = __builtin_amdgcn_s_memtime();
-    c_e1 += te1 - te0;
-    bool first_pass = true;
-#endif
     int resume = resume0;  // first group not yet scanned (wave-uniform; > 0 when an overlapped scan already did the rest)
     for (;;) {
         bool need_room = false;
@@ -422,26 +389,9 @@ __device__ __forceinline__ void kz_tile_epilogue2(f32x16 (&acc)[4], KzCandState&
                 }
             }
         }
-#ifdef KZ_STAMP
-        if (first_pass) {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" :: "v"(st.cnt));
-            c_e2 += __builtin_amdgcn_s_memtime() - te1;
-            first_pass = false;
-        }
-#endif
         if (!need_room && !sched) break;
         // merge the log into the list (all lanes of the wave take part; trip counts differ per lane)
-        KZ_T(tm0);
-#ifdef KZ_STAMP
-        n_ins += __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, st.cnt + __shfl_xor(st.cnt, 32, 64)));
-#endif
         kz_merge_logs_shared<KP>(st, bs);
-#ifdef KZ_STAMP
-        __builtin_amdgcn_sched_barrier(0);
-        c_merge += __builtin_amdgcn_s_memtime() - tm0;
-        n_pass += 1;
-#endif
         if (!need_room) break;
         tau_a = fmaxf(st.tau, __shfl_xor(st.tau, 32, 64));  // fresher threshold for the rest of the tile
     }

@@ -591,12 +591,6 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, iota, (int)b_pad);
     hipLaunchKernelGGL(kz_dual_fill_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, theta_s, b_pad, INFINITY);
     KZ_DUAL_HIP(hipGetLastError());
-#ifdef KZ_EXP
-    if (getenv("KZ_DUAL_NOSORT")) {   // diagnostic (with KZ_DUAL_NOEV): the sweep over the image in its natural order
-        KZ_DUAL_HIP(hipMemcpyAsync(perm, iota, (size_t)b->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        KZ_DUAL_HIP(hipMemcpyAsync(theta_s, theta, (size_t)b->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    } else
-#endif
     KZ_DUAL_RC(kz_sort_pairs_f32_i32(ctx, theta, theta_s, iota, perm, (int)b->n, 1));
     // ---- short-list route of the main sweep (kz_knn_impl): k / 5 lists of 16 per query instead of one of 32 / 64 / 128.  Rows with
     // neighbouring thresholds tend to be neighbours of the same queries, so the sorted tiles are dealt over the index ranges.
@@ -618,9 +612,6 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     hipLaunchKernelGGL(kz_dual_tilemin_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, theta_s, b->n, b_pad, theta_min);
     KZ_DUAL_HIP(hipGetLastError());
     KZ_DUAL_RC(kz_himage_pack_permuted(b, perm, p_packed, p_bias));
-#ifdef KZ_EXP
-    if (getenv("KZ_DUAL_NOEV")) hipLaunchKernelGGL(kz_dual_fill_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, theta_min, b_pad, INFINITY);   // diagnostic: a sweep without events
-#endif
     KZ_DUAL_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     float sample_ms = 0;
 

@@ -235,24 +235,7 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
     st.tau = __shfl(st.tau, lane & 31, 64);
 }
 
-#ifdef KZ_STAMP
-#define KZ_EPI3_STAMP_ARGS , unsigned long long& c_merge, unsigned long long& n_pass, unsigned long long& n_ins, unsigned long long& c_e1, unsigned long long& c_e2, unsigned long long& c_col, unsigned long long& n_col
-#define KZ_EPI3_MERGE()                                                  \
-    do {                                                                 \
-        const unsigned long long tm0_ = __builtin_amdgcn_s_memtime();    \
-        n_ins += pool.cnt;                                               \
-        kz_merge_pool3<KP, IN_LDS, DUAL, RECOMP>(st, pool, bs, du);              \
-        __builtin_amdgcn_sched_barrier(0);                               \
-        c_merge += __builtin_amdgcn_s_memtime() - tm0_;                  \
-        n_pass += 1;                                                     \
-    } while (0)
-#elif defined(KZ_EXP) && KZ_EXP == 3
-#define KZ_EPI3_STAMP_ARGS
-#define KZ_EPI3_MERGE() do { st.head = -1; pool.cnt = 0; } while (0)   /* diagnostic build: scan without merges (threshold never rises) */
-#else
-#define KZ_EPI3_STAMP_ARGS
 #define KZ_EPI3_MERGE() kz_merge_pool3<KP, IN_LDS, DUAL, RECOMP>(st, pool, bs, du)
-#endif
 
 // One group of four keys: the lanes in `mask` append it to the pool (positions pool.cnt + rank of the lane in the mask)
 #define KZ_EPI3_APPEND(gi, ev, mask)                                                                                  \
@@ -302,8 +285,7 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
 template <int KP, int CAP, int IN_LDS, bool DUAL, bool RECOMP>
 __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3<IN_LDS>& st, KzWavePool& pool, KzBlockMin3<KP>& bs,
                                                   const int tile, const bool last_tile, kz_lds_i32* sync, const KzDualRef& du,
-                                                  const float cthr KZ_EPI3_STAMP_ARGS) {
-    KZ_T(te0);
+                                                  const float cthr) {
     const int t = ++pool.tiles_done;
     const bool sched = (t == pool.next_merge) || last_tile;  // block-uniform
     if (t == pool.next_merge) {
@@ -341,11 +323,6 @@ __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3
     // really is an event of its row is decided after the launch (kz_dual_scatter_kernel).
     unsigned long long anyc = 0ull;
     if constexpr (DUAL) anyc = __builtin_amdgcn_ballot_w64(m >= cthr);
-#ifdef KZ_STAMP
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long te1 = __builtin_amdgcn_s_memtime();
-    c_e1 += te1 - te0;
-#endif
     if ((anym | anyc) != 0ull) {
         // room needed at most: four entries per (lane, block) pair with an event -- counted from the block maxima (a tile with
         // an event usually has ONE such pair; the older bound, 16 entries per lane with an event, sent many tiles down the
@@ -378,10 +355,6 @@ __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3
             }
             if constexpr (DUAL) {
                 if (anyc != 0ull) {
-#ifdef KZ_STAMP
-                    __builtin_amdgcn_sched_barrier(0);
-                    const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
-#endif
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) {
                         if (__builtin_amdgcn_ballot_w64(bmx[mt] >= cthr) == 0ull) continue;
@@ -393,12 +366,6 @@ __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3
                             if (maskc != 0ull) KZ_EPI3_APPEND_COL(gi, evc, maskc);
                         }
                     }
-#ifdef KZ_STAMP
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("" ::"v"(pool.cnt));
-                    c_col += __builtin_amdgcn_s_memtime() - tc0;
-                    n_col += 1;
-#endif
                 }
             }
         } else {
@@ -453,10 +420,5 @@ __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3
             sync[t & 3] = one;
         }
     }
-#ifdef KZ_STAMP
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::"v"(st.head));
-    c_e2 += __builtin_amdgcn_s_memtime() - te1;
-#endif
     if (sched) KZ_EPI3_MERGE();
 }

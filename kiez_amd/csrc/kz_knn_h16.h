@@ -34,7 +34,7 @@ typedef _Float16 kz_f16x8 __attribute__((ext_vector_type(8)));
 #define KZ_H_DMA_LATE 1
 #endif
 // WIDE: ONE workgroup of 4 x WPS waves per CU instead of WPS workgroups of 4 waves: its WPS query tiles share one ring, so
-// every index slice is copied into the CU's LDS once instead of WPS times.  Measured on the scan-less kernel (tools/ablate.sh
+// every index slice is copied into the CU's LDS once instead of WPS times.  Measured on the scan-less diagnostic kernel of round 3 (profiles/r03_ablation.md section 2; builds
 // 1 5 6 7; 250k x 1M x 200, same box): bare loop 71.2 ms, + slice barriers 71.2 -> 72.9, + the LDS-DMA traffic 83.4 -- and
 // with a third of the DMA volume 75.3: the copies, not the barriers, are what the ring costs, in proportion to their volume.
 // What the wide build gives back: all waves of the CU now run in lockstep -- they reach every barrier and every tile epilogue
@@ -71,13 +71,7 @@ struct KzHCfg {
 };
 
 template <int KP, int NSR, int WPS, bool DUAL = false, bool WIDE = false>
-#if defined(KZ_EXP) && KZ_EXP == 8
-__global__ __launch_bounds__(256, 1) void kz_knn_cand_h_kernel(KnnCandParams p) {   // (diagnostic: one wave per SIMD, 512 registers)
-#elif defined(KZ_EXP) && KZ_EXP == 9
-__global__ __launch_bounds__(256, 2) void kz_knn_cand_h_kernel(KnnCandParams p) {   // (diagnostic: 64 queries per wave at two waves per SIMD)
-#else
 __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn_cand_h_kernel(KnnCandParams p) {
-#endif
     using Cfg = KzHCfg<KP, WPS, NSR, DUAL, WIDE>;
     constexpr int TPW = Cfg::TPW;
     constexpr int R = Cfg::RING, P = Cfg::PERIOD, CAP = Cfg::CAP;
@@ -216,52 +210,10 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     int g = 0;
     int th_cur = 0;   // dual pass: threshold buffer of the current tile (uniform)
     f32x16 acc[4];
-#if defined(KZ_EXP) && (KZ_EXP == 8 || KZ_EXP == 9)
-    // diagnostic build (timing only, results WRONG): the bare loop of a ONE-WAVE-PER-SIMD kernel (9: two waves per SIMD) -- 64 queries per wave (the
-    // index fragment of a slice feeds two MFMAs: half the LDS reads per MFMA), 8 accumulators.  Every wave does TWICE the work
-    // of the shipped kernel on the same grid: compare half its time with exp2.
-    f32x16 acc8[2][4];
-    kz_f16x8 qf8[NSR];
-    {
-#pragma unroll
-        for (int u = 0; u < NSR; ++u)
-            qf8[u] = *reinterpret_cast<const kz_f16x8*>(p.qpack + ((int64_t)(p.qt0 + qt) * NSR + u) * 1024 + (h * KZ_TILE + 32 * ((tid >> 6) ^ 1) + j) * 4);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc8[a][mt][e] = 0.f;
-    }
-#endif
-#if defined(KZ_EXP) && KZ_EXP == 4
-    // diagnostic build (timing only, results WRONG): the bare MFMA + LDS-fragment loop with v_mfma_f32_16x16x32_f16 --
-    // 32 queries x 128 rows per wave = 2 x 8 accumulators of 16x16, one step = 32 k (two slices), ceil(NSR / 2) steps
-    constexpr int NS2 = (NSR + 1) / 2;
-    f32x4v c16[2][8];
-    kz_f16x8 qf2[NS2][2];
-    {
-        const int c = lane >> 4;
-#pragma unroll
-        for (int u2 = 0; u2 < NS2; ++u2)
-#pragma unroll
-            for (int qg = 0; qg < 2; ++qg)
-                qf2[u2][qg] = *reinterpret_cast<const kz_f16x8*>(p.qpack + ((int64_t)(p.qt0 + qt) * NSR + min(2 * u2 + (c >> 1), NSR - 1)) * 1024 +
-                                                                  ((c & 1) * KZ_TILE + 32 * (tid >> 6) + 16 * qg + (lane & 15)) * 4);
-#pragma unroll
-        for (int qg = 0; qg < 2; ++qg)
-#pragma unroll
-            for (int rt = 0; rt < 8; ++rt) c16[qg][rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    }
-#endif
-#ifdef KZ_STAMP
-    unsigned long long c_slices = 0, c_epi = 0, c_merge = 0, n_pass = 0, n_ins = 0, c_dma = 0, c_bar = 0, c_e1 = 0, c_e2 = 0, c_col = 0, n_col = 0;
-#endif
 
     // one tile whose first slice has global parity P0 (compile time: the parity alternates from tile to tile when NSR is odd)
     auto run_tile = [&](const int tile, auto start_parity) {
         constexpr int P0 = decltype(start_parity)::value;
-        KZ_T(t0);
         {
             int h_now = h;
             if constexpr (WPS == 3) {
@@ -302,59 +254,6 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
                 // for the previous tile; the buffer written here was last read two tiles ago, with a slice barrier in between.
                 kz_glds4_s(p.theta + ((int64_t)min(tile + 1, p.n_ytiles - 1) - 1) * KZ_TILE, off4, tbuf + (th_cur == 2 ? 0 : th_cur + 1) * 64);
         }
-#if defined(KZ_EXP) && (KZ_EXP == 8 || KZ_EXP == 9)
-        {
-            kz_f16x8 fa[4], fb4[4];
-            fetch_frags(fa, g);
-#pragma unroll
-            for (int u = 0; u < NSR; ++u) {
-                kz_f16x8 (&cur)[4] = (u & 1) ? fb4 : fa;
-                __builtin_amdgcn_sched_barrier(0);
-                if (u + 1 < NSR) {
-                    if (u & 1)
-                        fetch_frags(fa, g + u + 1);
-                    else
-                        fetch_frags(fb4, g + u + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    acc8[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[mt], qf[u], acc8[0][mt], 0, 0, 0);
-                    acc8[1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[mt], qf8[u], acc8[1][mt], 0, 0, 0);
-                }
-            }
-            g += NSR;
-            asm volatile("" ::"v"(acc8[0][0]), "v"(acc8[0][1]), "v"(acc8[0][2]), "v"(acc8[0][3]));
-            asm volatile("" ::"v"(acc8[1][0]), "v"(acc8[1][1]), "v"(acc8[1][2]), "v"(acc8[1][3]));
-            return;
-        }
-#endif
-#if defined(KZ_EXP) && KZ_EXP == 4
-        {
-            const int c = lane >> 4;
-#pragma unroll
-            for (int u2 = 0; u2 < NS2; ++u2) {
-                const float* fb = ybuf + ((2 * u2 + (c >> 1)) & (R - 1)) * 1024 + ((c & 1) * KZ_TILE + (lane & 15)) * 4;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    kz_f16x8 fr[4];
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) fr[rt] = *reinterpret_cast<const kz_f16x8*>(fb + 64 * (4 * hf + rt));
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                        for (int qg = 0; qg < 2; ++qg)
-                            c16[qg][4 * hf + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[rt], qf2[u2][qg], c16[qg][4 * hf + rt], 0, 0, 0);
-                }
-            }
-            g += NSR;
-            asm volatile("" ::"v"(c16[0][0]), "v"(c16[0][1]), "v"(c16[0][2]), "v"(c16[0][3]), "v"(c16[0][4]), "v"(c16[0][5]), "v"(c16[0][6]), "v"(c16[0][7]));
-            asm volatile("" ::"v"(c16[1][0]), "v"(c16[1][1]), "v"(c16[1][2]), "v"(c16[1][3]), "v"(c16[1][4]), "v"(c16[1][5]), "v"(c16[1][6]), "v"(c16[1][7]));
-            return;
-        }
-#endif
         constexpr bool carry_in = !ONE_SET && (CARRY || (P0 == 1 && (NSR & 1)));
         constexpr bool carry_out = !ONE_SET && (CARRY || (((P0 + NSR) & 1) != 0));
         if (!carry_in && !ONE_SET) {
@@ -393,70 +292,28 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
             // slices g+P+2 .. g+2P+1.  The next period prefetches slices g+2 .. g+P+1: those were issued at the PREVIOUS
             // barrier and are this wave's youngest DMAs, hence vmcnt(0) (any other outstanding operation -- bias load,
             // list traffic of a merge -- only has to finish too).
-#if defined(KZ_EXP) && KZ_EXP == 2
-            if (false) {   // diagnostic build: no slice barrier, no DMA after the prologue (stale LDS data; timing only)
-#else
             // (ONE_SET: nothing is prefetched, a wave at the barrier has read the slices <= g only: the barrier sits one
             //  slice later in the period -- (g + 1) % P == 0 -- and hands out the slots of slices g-P+1 .. g.)
             if ((ONE_SET ? odd : !odd) && (P == 2 || ((g + LAG) & (P - 1)) == 0)) {
-#endif
-#ifdef KZ_STAMP
-                {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    const unsigned long long w1 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_barrier" ::: "memory");
-                    c_dma += w1 - w0;
-                    c_bar += __builtin_amdgcn_s_memtime() - w1;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#else
-#if defined(KZ_EXP) && KZ_EXP == 6
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // diagnostic build: DMA ring without the slice barrier (races; timing only)
-#else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-#endif
                 if constexpr (LATE) {
                     dma_due = 1;   // (issued behind the next slice's MFMAs, see KZ_H_DMA_LATE)
                 } else {
-#if defined(KZ_EXP) && KZ_EXP == 7   // (7: diagnostic build that refills the ring in one period out of three -- a third of the DMA volume; stale data, timing only)
-                    if ((g >> 1) % 3 == 0)
-#endif
                     {
-#if !(defined(KZ_EXP) && KZ_EXP == 5)   // (5: diagnostic build with the slice barrier but no DMA behind the prologue -- stale data; timing only)
 #pragma unroll
                         for (int i = 0; i < P; ++i) dma_next();   // slices g+P+LAG .. g+2P+LAG-1, in order
-#endif
                     }
                 }
             }
             ++g;
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifdef KZ_STAMP
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        float cthr = INFINITY;
-        if constexpr (DUAL) {
-            cthr = tbuf[192 + 32 * (tid >> 6) + j] + tbuf[th_cur * 64];   // this query's offset + the tile's smallest theta (rows sorted by theta)
-            th_cur = th_cur == 2 ? 0 : th_cur + 1;
-        }
-        kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du, cthr, c_merge, n_pass, n_ins, c_e1, c_e2, c_col, n_col);
-        __builtin_amdgcn_sched_barrier(0);
-        c_slices += t1 - t0;
-        c_epi += __builtin_amdgcn_s_memtime() - t1;
-#elif defined(KZ_EXP) && (KZ_EXP == 1 || KZ_EXP == 2 || KZ_EXP == 5 || KZ_EXP == 6 || KZ_EXP == 7)
-        // diagnostic build (tools/ablate.sh, never shipped): no candidate scan at all -- the accumulators are only kept alive
-        asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
-#else
         float cthr = INFINITY;
         if constexpr (DUAL) {
             cthr = tbuf[192 + 32 * (tid >> 6) + j] + tbuf[th_cur * 64];   // this query's offset + the tile's smallest theta (rows sorted by theta)
             th_cur = th_cur == 2 ? 0 : th_cur + 1;
         }
         kz_tile_epilogue3<KP, CAP, IN_LDS, DUAL, RECOMP>(acc, st, pool, bmin, tile, tile == t_end - 1, msync, du, cthr);
-#endif
     };
 
     int tile = t_begin;
@@ -480,20 +337,4 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
             }
         }
     }
-#ifdef KZ_STAMP
-    if (lane == 0 && p.dbg) {
-        atomicAdd(p.dbg + 0, c_slices);
-        atomicAdd(p.dbg + 1, c_epi);
-        atomicAdd(p.dbg + 3, (unsigned long long)(t_end - t_begin));
-        atomicAdd(p.dbg + 4, c_merge);
-        atomicAdd(p.dbg + 5, n_pass);
-        atomicAdd(p.dbg + 6, n_ins);
-        atomicAdd(p.dbg + 7, c_dma);
-        atomicAdd(p.dbg + 8, c_bar);
-        atomicAdd(p.dbg + 2, c_e1);
-        atomicAdd(p.dbg + 9, c_e2);
-        atomicAdd(p.dbg + 10, c_col);
-        atomicAdd(p.dbg + 11, n_col);
-    }
-#endif
 }

@@ -13,12 +13,23 @@ from . import _native as N
 _NO_GOLD = np.iinfo(np.int64).min
 
 
+def _as_row_number(x):
+    """x as an integer if the reference's `==` would match it against an integer row number / neighbour id (ints, and floats with an
+    integral value: 4.0 == 4 and hash(4.0) == hash(4), so `i in gold` and `gold[i] in nn_ind[i][:k]` both accept them), else None."""
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)) and np.isfinite(x) and float(x) == int(x):
+        return int(x)
+    return None
+
+
 def _gold_vector(gold: Dict[Any, Any], n_rows: int) -> np.ndarray:
     """gold target per source row (or _NO_GOLD): one vectorised scatter instead of a Python loop over all rows."""
     out = np.full(n_rows, _NO_GOLD, dtype=np.int64)
-    # (array input: the reference tests `i in gold and gold[i] in nn_ind[i][:k]` with integer row numbers i, so only
-    #  integer keys with integer targets can ever hit; everything still counts in the denominator len(gold))
-    pairs = [(k_, v) for k_, v in gold.items() if isinstance(k_, (int, np.integer)) and isinstance(v, (int, np.integer))]
+    # (array input: the reference tests `i in gold and gold[i] in nn_ind[i][:k]` with integer row numbers i, so only keys and
+    #  targets that compare equal to an integer can ever hit -- ints and integral floats, e.g. gold read with np.loadtxt or from
+    #  a pandas column; everything still counts in the denominator len(gold))
+    pairs = [(a, b) for a, b in ((_as_row_number(k_), _as_row_number(v)) for k_, v in gold.items()) if a is not None and b is not None]
     if pairs:
         keys = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
         vals = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))

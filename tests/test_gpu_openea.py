@@ -55,3 +55,22 @@ def test_bench_openea_mode(tmp_path):
     assert line["data"].startswith("OpenEA") and line["config"]["n_source"] == 4000 and line["value"] > 0
     assert line["check"]["index_rows_identical"] == line["check"]["rows"] and 0.3 < line["hits"]["1"] <= line["hits"]["10"] <= 1.0
     assert line["hits"] == {str(k): v for k, v in line["check"]["hits_reference_formula"].items()}
+
+
+def test_hits_with_float_valued_gold():
+    """gold read with np.loadtxt or from a pandas column holds floats: the reference's `i in gold and gold[i] in nn_ind[i][:k]`
+    (eval_metrics.py:8-13) matches integral floats on both sides (4.0 == 4, equal hashes) and never a fractional one."""
+    from kiez_amd.evaluate import hits
+    rng = np.random.RandomState(3)
+    nn_ind = np.stack([rng.permutation(50)[:10] for _ in range(40)])
+    gold = {}
+    for i in range(0, 40, 2):
+        tgt = int(nn_ind[i][rng.randint(0, 10)]) if i % 4 == 0 else int(rng.randint(0, 50))
+        key = [i, float(i), np.float64(i), np.int32(i)][(i // 2) % 4]
+        gold[key] = [tgt, float(tgt), np.float64(tgt), np.float32(tgt)][(i // 2 + 1) % 4]
+    gold[7] = 3.5            # a fractional target never matches, but counts in len(gold)
+    gold[9.5] = 1            # a fractional key is no row number
+    gold["x"] = 2            # nor is a label
+    ref = _ref_hits(nn_ind, gold, [1, 5, 10])
+    assert ref[10] > 0
+    assert hits(nn_ind, gold) == pytest.approx(ref, abs=0)
