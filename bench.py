@@ -201,9 +201,10 @@ def sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, ro
         out.update(knife_edge_rows=int(knife.sum()), knife_edge_rows_identical=int((same & knife).sum()),
                    rows_not_knife_edge=int((~knife).sum()))
         same &= ~knife
+    plain = np.ones(len(got_d), dtype=bool) if "knife_edge_rows" not in out else ~knife     # (a knife-edge row may differ by one count, 1 / K)
     out.update(index_rows_identical=int(same.sum()),
                recall_at_k=float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got_i, oi)])),
-               max_rel_dist_err=float(np.max(np.abs(got_d - od) / np.maximum(np.abs(od), 1e-12))))
+               max_rel_dist_err=float(np.max(np.abs(got_d[plain] - od[plain]) / np.maximum(np.abs(od[plain]), 1e-12))) if plain.any() else 0.0)
     return out
 
 
@@ -639,6 +640,13 @@ def main():
                 others[name] = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             line["other_workloads"] = others
+            try:
+                # float64 near-ties: pairs of index rows 1/64 .. 16 ulps apart, the reference's own order on them as the golden
+                # (tests/near_ties.py; DESIGN.md section 5: how often the device's float64 order differs from sklearn's, by gap)
+                from tests.near_ties import run_probe
+                line["fp64_order_probe"] = run_probe(eng.ctx)
+            except Exception as e:  # pragma: no cover
+                line["fp64_order_probe"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -134,7 +134,13 @@ int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a, const kz_matrix* b, int k, doub
 /* Host-only (no GPU needed): the work schedule kz_knn builds for a launch with `slots` resident workgroups
  * (DESIGN.md section 3.1 "greedy rounds").  Round r covers round_qtiles[r] query tiles of 128 rows, each swept as
  * round_pieces[r] index ranges of round_piece_tiles[r] tiles of 128 rows (the last range may be shorter).  Arrays
- * hold up to 8 rounds.  k_eff = neighbours kept per query (k + 1 in single-source mode). */
+ * hold up to 8 rounds.  k_eff = neighbours kept per query (k + 1 in single-source mode).
+ * Diagnostic ABI: it plans the CLASSIC route -- one candidate list of K' in {16, 32, 64, 128} per query and index range, one
+ * query tile per workgroup, k_eff <= 110 -- through the same kz_plan_rounds the product calls.  kz_knn itself also takes
+ * routes this function does not describe: several lists of 16 over forced index ranges (13 <= k on a large index, the shared
+ * sweep's forward lists, re-searches), the long-k route (111 .. ~540 neighbours) and work items of two or three query tiles
+ * (wide and 64-query builds); their plans come out of the same kz_plan_pass with other arguments (tests/host/plan_sanitize.cpp
+ * runs those argument ranges under the sanitizers). */
 int kz_knn_plan(int64_t n_query_rows, int64_t n_index_rows, int k_eff, int slots, int force_splits, int min_splits,
                 int* n_rounds, int* round_qtiles, int* round_pieces, int* round_piece_tiles);
 

@@ -1308,7 +1308,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (kp_min >= 128) P = 16;   // (a re-search that asks for lists of 128: all the ranges the finalize kernel's fast selection takes)
         const int sel = k_eff + (KP >= 128 ? 80 : 48) < P * 16 ? k_eff + (KP >= 128 ? 80 : 48) : P * 16;
         if (P <= (longk_lists ? 64 : 32) && (int64_t)index->n_tiles >= (int64_t)ctx->short_ord_min_tiles * P && sel >= k_eff &&
-            4 * kz_fin_wave_bytes(P * 16, sel) <= 160 * 1024) {   // (<= 512 entries: kz_rank_select<8>)
+            4 * kz_fin_wave_bytes(P * 16, sel) <= 160 * 1024) {   // (<= 512 entries: kz_rank_select<8>; up to 1024 -- 33 .. 64 lists of the long-k route -- the radix select)
             const int rc = kz_himage_dealt(index, P);
             if (rc == KZ_OK) {
                 short_ord = true;
