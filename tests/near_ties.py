@@ -6,7 +6,7 @@ from pathlib import Path
 
 import numpy as np
 
-BUCKETS = ((0.0, 1 / 16), (1 / 16, 1 / 4), (1 / 4, 1.0), (1.0, 4.0), (4.0, 1e30))
+BUCKETS = ((0.0, 1 / 16), (1 / 16, 1 / 4), (1 / 4, 1.0), (1.0, 2.0), (2.0, 1e30))
 
 
 def run_probe(ctx=None):

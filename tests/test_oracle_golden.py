@@ -87,3 +87,19 @@ def test_knn_exact_against_sklearn_brute():
     od, oi = O.knn_exact(y, y, 10, "euclidean", exclude_self=True)
     np.testing.assert_array_equal(i, oi)
     np.testing.assert_allclose(d, od, rtol=1e-9, atol=1e-7)
+
+
+def test_oracle_orders_near_ties_as_the_reference_from_two_ulps_on():
+    """tests/golden/near_ties.npz (tools/gen_near_ties.py): pairs of index rows 1/64 .. 16 ulps apart.  From two ulps (of
+    |q|^2 + |y|^2) on, the oracle's float64 expansion must order every pair as the reference did and as exact arithmetic does;
+    below, the order is a property of the summation order (largest gap the oracle gets wrong: 1.04 ulps, the reference: 0.97)."""
+    import numpy as np
+    from pathlib import Path
+    from oracle import kiez_oracle as O
+    fx = np.load(Path(__file__).resolve().parent / "golden" / "near_ties.npz")
+    _, ind = O.knn_exact(fx["query"], fx["index"], 2, "sqeuclidean")
+    assert (np.sort(ind, axis=1) == np.sort(fx["ref_ind"], axis=1)).all()
+    sel = fx["gap_ulps"] >= 2.0
+    assert sel.sum() > 250
+    np.testing.assert_array_equal(ind[sel, 0], fx["ref_ind"][sel, 0])
+    np.testing.assert_array_equal(ind[sel, 0], fx["exact_nearer"][sel])
