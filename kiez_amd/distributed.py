@@ -259,6 +259,41 @@ class Comm:
             self._timed("broadcast", t, lambda: self.dist.broadcast(t, src=src, group=self.group))
         return t
 
+    def broadcast_begin(self, t, src=0):
+        """Start the broadcast of `t` without making the current stream wait for it (RCCL runs it on its own stream); returns a
+        token for `broadcast_end`.  What the caller enqueues in between -- work that does not touch `t` -- runs beside the
+        transfer.  The timer covers begin .. end on the caller's stream (what the step sees of the broadcast)."""
+        if not (self.world > 1 or self.always):
+            return None
+        rec = self._bytes.setdefault("broadcast", [0, 0])
+        rec[0] += 1
+        rec[1] += t.numel() * t.element_size()
+        start = None
+        if self.timed and t.is_cuda:
+            torch = _torch()
+            start = torch.cuda.Event(enable_timing=True)
+            start.record()
+        import time
+        t0 = time.perf_counter()
+        work = self.dist.broadcast(t, src=src, group=self.group, async_op=True)
+        return (work, start, t0, t.is_cuda)
+
+    def broadcast_end(self, token):
+        if token is None:
+            return
+        work, start, t0, on_gpu = token
+        work.wait()   # (GPU: the current stream waits for RCCL's stream; the host does not block)
+        if not self.timed:
+            return
+        if on_gpu:
+            torch = _torch()
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            self._events.append(("broadcast", start, end))
+        else:
+            import time
+            self._wall["broadcast"] = self._wall.get("broadcast", 0.0) + (time.perf_counter() - t0) * 1e3
+
     def all_gather_rows(self, t, counts):
         """Concatenate ragged row blocks [n_r, ...] of all ranks in rank order (padded all_gather)."""
         torch = _torch()
@@ -394,6 +429,7 @@ class ShardedKiez:
         n_s = sum(counts)
         self.single = bool(single_source)
         self._fwd = None
+        bcast = None
         # the target's row count is known BEFORE anything is decided (every rank decides the same way)
         tgt = None
         if self.single:
@@ -420,7 +456,11 @@ class ShardedKiez:
             if bcast_target:
                 d, code = gathered[0][2], gathered[0][3]
                 tgt = tgt0 if comm.rank == 0 else eng.empty((n_t, d), torch.float32 if code == 0 else torch.float64)
-                comm.broadcast(tgt, 0)  # RCCL broadcast of the replicated target over xGMI
+                # RCCL broadcast of the replicated target over xGMI, started here and awaited only where the target is first
+                # needed: the source shard's own preparation (norms of its rows) runs beside the transfer.  (The sweep itself
+                # cannot start on a part of the target: the shared sweep's event thresholds come from a sample that spans all its
+                # rows, and its fp16 image is scaled by the largest centred norm of both matrices -- DESIGN.md section 6.)
+                bcast = comm.broadcast_begin(tgt, 0)
             if tgt.shape[1] != src.shape[1]:
                 raise ValueError("Expected source and target to have the same number of features,"
                                  f" but got source.shape: {tuple(src.shape)} and target.shape: {tuple(tgt.shape)}")
@@ -428,12 +468,16 @@ class ShardedKiez:
                 raise ValueError("source and target must have the same dtype")
         self._keep = (src, src_full, tgt)  # the engine matrices borrow these tensors
         self.n_s, self.n_t = n_s, tgt.shape[0]
+        S_own = None
+        if not need_full_source:
+            S_own = eng.matrix(src, self.metric)     # (beside the broadcast: touches the shard only)
+        comm.broadcast_end(bcast)
         self.T = eng.matrix(tgt, self.metric)
         if need_full_source:
             self.S = self.T if self.single else eng.matrix(src_full, self.metric)
             self.q_begin = self.s_begin   # forward queries are a row range of the full source matrix
         else:
-            self.S = eng.matrix(src, self.metric)
+            self.S = S_own
             self.q_begin = 0
         if self.hub == "none":
             return self

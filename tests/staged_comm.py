@@ -16,6 +16,10 @@ class StagedComm(Comm):
         t.copy_(h)
         return t
 
+    def broadcast_begin(self, t, src=0):
+        self.broadcast(t, src)      # staged: nothing to overlap
+        return None
+
     def all_gather_rows(self, t, counts):
         return super().all_gather_rows(t.cpu(), counts).to(t.device)
 

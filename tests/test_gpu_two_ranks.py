@@ -37,6 +37,10 @@ class _StagedComm(Comm):
         t.copy_(h)
         return t
 
+    def broadcast_begin(self, t, src=0):
+        self.broadcast(t, src)
+        return None
+
     def all_gather_rows(self, t, counts):
         return super().all_gather_rows(t.cpu(), counts).to(t.device)
 
