@@ -31,7 +31,7 @@ for w, f in sorted(latest.items()):
     g = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                      # per-XCD active cycles
     mf = c.get("SQ_INSTS_MFMA", 0.0) or 1.0
     hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
-    tier = "f16" if "cand_h_" in k else ("bf16x2" if "cand_bf" in k else "f32")
+    tier = "f16" if ("cand_h_" in k or "cand_h64_" in k) else ("bf16x2" if "cand_bf" in k else "f32")
     out[f"{w}_{tier}"] = {
         "source": f.name, "kernel": k.replace("void ", ""), "dispatches_averaged": c["_disp"], "avg_ms_under_pmc": c["_avg_ns"] / 1e6,
         "hbm_bytes_per_launch": (c.get("FETCH_SIZE", 0.0) * 2 + c.get("WRITE_SIZE", 0.0)) * 1024,
