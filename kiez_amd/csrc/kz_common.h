@@ -45,7 +45,6 @@ struct kz_ctx {
     double dual_max_gb; // kz_knn_dual: transient footprint budget in GiB (0 = the built-in 32)
     int dual_force;   // test knob: run the dual pass also where it does not pay (few query rows)
     int h_q64;        // 64-queries-per-wave kernel (kz_knn_h64.h) for K' = 16 sweeps of 4 .. 13 slices: 2 (default) = where it pays (kz_knn_impl), 1 = always, 0 = never
-    int h_mfma16;     // 1: K' = 16 sweeps run the v_mfma_f32_16x16x32_f16 build (kz_knn_hx.h); 0 (default): the 32x32x16 kernels
     int h64_late;     // tuning knob of that kernel: LDS-DMA copies issued one half slice late (default 0)
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)

@@ -931,9 +931,6 @@ int kz_hd_launch_kp128(int n_slices, kz_ctx* ctx, const KnnCandParams& p, int n_
 bool kz_h64_supports(int n_slices);   // kz_knn_h64.hip: 64 queries per wave, K' = 16, ordinary (dual = 0) and dual-pass builds
 int kz_h64_occupancy(int n_slices, int dual, int* blocks_per_cu, int lds_pad);
 int kz_h64_launch(int n_slices, int dual, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
-bool kz_hx_supports(int n_slices);    // kz_knn_hx.hip: the v_mfma_f32_16x16x32_f16 build, K' = 16
-int kz_hx_occupancy(int n_slices, int dual, int wps, int* blocks_per_cu, int lds_pad);
-int kz_hx_launch(int n_slices, int dual, int wps, kz_ctx* ctx, const KnnCandParams& p, int n_blocks);
 int kz_bf_occupancy_kp16(int n_slices_bf, int* blocks_per_cu, int lds_pad);
 int kz_bf_occupancy_kp32(int n_slices_bf, int* blocks_per_cu, int lds_pad);
 int kz_bf_occupancy_kp64(int n_slices_bf, int* blocks_per_cu, int lds_pad);
@@ -1332,8 +1329,6 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     const bool q64_ok = tier == KZ_TIER_H && KP == 16 && kz_h64_supports(n_slices) && !exact_only;
     const bool q64 = q64_ok && (ctx->h_q64 == 1 || (ctx->h_q64 == 2 && dual && n_slices >= 9 &&
                                                      (q_count + 2 * KZ_TILE - 1) / (2 * KZ_TILE) >= (int64_t)4 * 2 * ctx->n_cus));
-    // 16x16x32 MFMA build (kz_knn_hx.h): K' = 16 sweeps; option "h_mfma16" (experiment: profiles/r04_ablation.md section 5)
-    const bool hx = !q64 && tier == KZ_TIER_H && KP == 16 && ctx->h_mfma16 && kz_hx_supports(n_slices) && !exact_only;
     int slots_cache[3] = {0, 0, 0};
     int tpw_h = 1;   // query tiles per workgroup of the fp16 kernel this call runs (wide builds: 2 or 3)
     auto slots_for = [&](int t, int* out) -> int {
@@ -1343,9 +1338,6 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             if (t == KZ_TIER_H && q64) {
                 rc0 = kz_h64_occupancy(n_slices, dual ? 1 : 0, &blocks_per_cu, ctx->lds_pad);
                 tpw_h = 2;
-            } else if (t == KZ_TIER_H && hx) {
-                rc0 = kz_hx_occupancy(n_slices, dual ? 1 : 0, ctx->h_wps, &blocks_per_cu, ctx->lds_pad);
-                tpw_h = 1;
             } else if (t == KZ_TIER_H && dual)
                 KZ_DISPATCH_KP(rc0, kz_hd_occupancy, (n_slices, &blocks_per_cu, &tpw_h, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
             else if (t == KZ_TIER_H)
@@ -1440,14 +1432,10 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             cp.log_cap = dual->log_cap;
             if (q64)
                 rc = kz_h64_launch(n_slices, 1, ctx, cp, W);
-            else if (hx)
-                rc = kz_hx_launch(n_slices, 1, ctx->h_wps, ctx, cp, W);
             else
                 KZ_DISPATCH_KP(rc, kz_hd_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
         } else if (tier == KZ_TIER_H && q64)
             rc = kz_h64_launch(n_slices, 0, ctx, cp, W);
-        else if (tier == KZ_TIER_H && hx)
-            rc = kz_hx_launch(n_slices, 0, ctx->h_wps, ctx, cp, W);
         else if (tier == KZ_TIER_H)
             KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
         else if (tier == KZ_TIER_BF)
