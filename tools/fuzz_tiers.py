@@ -36,6 +36,8 @@ def main():
         min_tiles, eps = int(rng.choice([64, 2, 2, 4])), float(rng.choice([1.0, 1.0, 1.0, 30.0]))
         ctx.set_option("short_ord_min_tiles", min_tiles)
         ctx.set_option("eps_scale", eps)
+        q64 = int(rng.randint(0, 2))          # fp16 pass on the 64-queries-per-wave kernel where it is built (K' = 16, 4 .. 13 slices)
+        ctx.set_option("h_q64", q64)
         res = {}
         for prec in (0, 2, 1):   # fp16 first pass (default), split-bf16, float32 operands only
             ctx.set_option("precision", prec)
@@ -48,6 +50,7 @@ def main():
                 ctx.set_option("precision", 0)
         ctx.set_option("short_ord_min_tiles", 48)
         ctx.set_option("eps_scale", 1.0)
+        ctx.set_option("h_q64", 2)
         ok = all(np.array_equal(res[0][1], res[p][1]) and np.array_equal(res[0][0], res[p][0]) for p in (1, 2))
         if len(s) * n_t <= 2_000_000:
             od, oi = O.knn_exact(s, t, k, O.canonical_metric(metric), exclude_self=single)
@@ -55,7 +58,7 @@ def main():
         tag = "ok " if ok else "BAD"
         bad += 0 if ok else 1
         print(tag, f"n_s={len(s)} n_t={n_t} d={d} {metric} {np.dtype(dtype).name} k={k} single={single}",
-              "tier", res[0][2]["first_pass"], "lists", res[0][2]["n_splits"], "x", res[0][2]["list_len"], f"min_tiles {min_tiles} eps {eps}", "esc", res[0][2]["n_escalated_rows"], "fb", res[0][2]["n_fallback_rows"],
+              "tier", res[0][2]["first_pass"], "lists", res[0][2]["n_splits"], "x", res[0][2]["list_len"], f"min_tiles {min_tiles} eps {eps} q64 {q64}", "esc", res[0][2]["n_escalated_rows"], "fb", res[0][2]["n_fallback_rows"],
               "ratio %.3f" % res[0][2]["max_err_ratio"])
     print("cases", n_cases, "bad", bad)
     sys.exit(1 if bad else 0)
