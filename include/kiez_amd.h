@@ -93,7 +93,10 @@ int kz_ctx_trim(kz_ctx* ctx);
  * K' = 16 pass could not certify are searched again with more lists of 16 instead of lists of 64; "qgroup": query tiles per group
  * of the work table (0 = automatic); "short_ord": 1 (default) = the ordinary search takes the short-list route too (13 .. 320
  * neighbours, a second row-dealt image of the index, ranges of at least "short_ord_min_tiles" tiles); "dual_rev_long": 1 (default) = reverse lists of twice the list length;
- * "esc_bf": 1 (default) = split-bf16 operands before the float32 ones for rows the fp16 tier cannot certify. */
+ * "esc_bf": 1 (default) = split-bf16 operands before the float32 ones for rows the fp16 tier cannot certify;
+ * "h_q64": the 64-queries-per-wave build of the fp16 kernel (K' = 16, 4 .. 13 slices): 2 (default) = where it pays (the shared
+ * sweep from 9 slices on over >= 4 rounds of work items), 1 = wherever it is built, 0 = never; "h64_late": its LDS-DMA copies
+ * issued one half slice late (tuning knob, default 0).  Every route gives identical results. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 
 int kz_malloc(kz_ctx* ctx, size_t bytes, void** d_ptr);
