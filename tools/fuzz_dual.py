@@ -1,5 +1,6 @@
 """GPU box: randomised shapes for kz_knn_dual (shared sweep forced) against two kz_knn calls, bit for bit.
    python3 tools/fuzz_dual.py [n_cases] [seed]"""
+import os
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -7,7 +8,8 @@ from kiez_amd import _native as N
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # run just this case (the random stream is advanced through the others)
+_o = sys.argv[3] if len(sys.argv) > 3 else "-1"          # run just this case, or the cases "first-last" (the random stream is advanced through the others)
+only_first, only = (int(_o.split("-")[0]), int(_o.split("-")[1])) if "-" in _o[1:] else (int(_o), int(_o))
 scale = int(sys.argv[4]) if len(sys.argv) > 4 else 1     # multiplies the row counts (10: up to 600 k x 400 k)
 ctx = N.Context.get()
 bad = 0
@@ -37,7 +39,10 @@ for case in range(n_cases):
            int(rng.integers(0, 2)), int(rng.integers(0, 2)),   # ..., wide workgroups for the shared sweep, reverse chain on the second stream
            int(rng.choice([128, 3, 3, 8])), int(rng.integers(0, 2)),   # short-list route: smallest index range in tiles; short sample lists
            int(rng.integers(0, 2)), int(rng.choice([16, 48, 48, 100])), int(rng.integers(0, 2)))   # reverse lists of 2 K'; entries selected beyond k; bf16 tier in the chain
-    if only >= 0 and case != only:
+    q64 = int(rng.integers(0, 3))             # 64-queries-per-wave kernel: 0 nowhere, 1 in the reference searches only, 2 in the shared sweep only
+    if os.environ.get("KZ_FUZZ_Q64") is not None:
+        q64 = int(os.environ["KZ_FUZZ_Q64"])
+    if only >= 0 and not (only_first <= case <= only):
         continue
     print(f"case {case}: na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} stride/chunk/deal/wide/overlap/short-min/short-sample/rev-long/extra/bf {opt}", flush=True)
     ctx.set_option("dual_stride", opt[0])
@@ -45,7 +50,6 @@ for case in range(n_cases):
     ctx.set_option("dual_deal", opt[2])
     am, bm = N.DeviceMatrix(ctx, a, metric), N.DeviceMatrix(ctx, b, metric)
     ctx.set_option("dual_force", 0)
-    q64 = int(rng.integers(0, 3))             # 64-queries-per-wave kernel: 0 nowhere, 1 in the reference searches only, 2 in the shared sweep only
     ctx.set_option("h_q64", 1 if q64 == 1 else 0)
     r1 = N.knn(ctx, am, bm, k); ctx.sync()
     if only >= 0: print("  a->b done", r1[2]["n_escalated_rows"], r1[2]["n_fallback_rows"], flush=True)
@@ -66,6 +70,26 @@ for case in range(n_cases):
     ctx.set_option("h_q64", 2)
     ok = (np.array_equal(r1[1].numpy(), xi.numpy()) and np.array_equal(r1[0].numpy(), xd.numpy())
           and np.array_equal(r2[1].numpy(), yi.numpy()) and np.array_equal(r2[0].numpy(), yd.numpy()))
+    if not ok:
+        # diagnosis of a failing case: the reference searches once more on the other kernel, the oracle on the differing rows
+        from oracle import kiez_oracle as O
+        ctx.set_option("dual_force", 0)
+        ctx.set_option("h_q64", 0 if q64 == 1 else 1)
+        o1 = N.knn(ctx, am, bm, k); o2 = N.knn(ctx, bm, am, k)
+        ctx.set_option("h_q64", 2)
+        for name, ref, alt, dual_i, qa, ya in (("a->b", r1, o1, xi, a, b), ("b->a", r2, o2, yi, b, a)):
+            ri, ai, di = ref[1].numpy(), alt[1].numpy(), dual_i.numpy()
+            rows = np.nonzero((ri != di).any(axis=1))[0]
+            print(f"  {name}: rows where reference != dual: {len(rows)}; reference(other kernel) != dual: {int((ai != di).any(axis=1).sum())}; "
+                  f"reference != reference(other kernel): {int((ri != ai).any(axis=1).sum())}", flush=True)
+            if len(rows):
+                mc = O.canonical_metric(metric)
+                q64_ = qa[rows[:8]].astype(np.float64) if mc == "cosine" else qa[rows[:8]]
+                y64_ = ya.astype(np.float64) if mc == "cosine" else ya
+                od, oi = O.knn_exact(q64_, y64_, k, mc)
+                for j, r in enumerate(rows[:8]):
+                    print(f"    row {r}: oracle==reference {np.array_equal(oi[j], ri[r])} oracle==dual {np.array_equal(oi[j], di[r])} "
+                          f"first diff col {int(np.nonzero(ri[r] != di[r])[0][0])} ref {ri[r][:6]} dual {di[r][:6]} oracle {oi[j][:6]} dist {od[j][:4]}", flush=True)
     ratio = max(sa["max_err_ratio"], sb["max_err_ratio"])
     if not ok or ratio >= 1.0:
         bad += 1
