@@ -195,7 +195,10 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     kz_f16x8 qf[NSR];
 #pragma unroll
     for (int u = 0; u < NSR; ++u) qf[u] = *reinterpret_cast<const kz_f16x8*>(qbase + u * 1024);
-    __syncthreads();   // (drains vmcnt(0): the whole prologue ring has landed)
+    // the whole prologue ring must have landed before anyone reads it: said explicitly (the copies are inline asm, invisible to the
+    // compiler's barrier; every wave's bias-row store above happens to wait for them too -- kz_knn_h64.h shows what happens without)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     const float* fbase = ybuf + (h * KZ_TILE + j) * 4;  // this lane's fragment inside a slot: plane h, row j (+ 32 mt)
     // two static fragment sets selected by the parity of the global slice counter (no register copies)

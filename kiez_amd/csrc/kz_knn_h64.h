@@ -150,7 +150,12 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_h64_kernel(KnnCandParams p
         qf[0][u] = *reinterpret_cast<const kz_f16x8*>(qbase + u * 1024);
         qf[1][u] = *reinterpret_cast<const kz_f16x8*>(qbase + u * 1024 + 32 * 4);
     }
-    __syncthreads();   // (drains vmcnt(0): the whole prologue ring has landed)
+    // the whole prologue ring must have landed before anyone reads it.  The copies are inline asm: the compiler's barrier does not
+    // know them, and only waves with a load-dependent LDS store of their own in front of it (wave 0's bias rows; every wave in the
+    // dual build) would wait for them by accident -- at 4 slices (8 query-fragment loads) waves 1 .. 3 of the ordinary build did
+    // reach the barrier with copies in flight: 1 - 4 wrong rows in ~1 % of randomised runs (tools/fuzz_dual.py, round 4).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     const float* fbase = ybuf + (h * 64 + j) * 4;   // this lane's fragment inside a slot: plane h, row j (+ 32 rb)
     kz_f16x8 f0[2], f1[2];
