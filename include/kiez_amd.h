@@ -96,7 +96,9 @@ int kz_ctx_trim(kz_ctx* ctx);
  * "esc_bf": 1 (default) = split-bf16 operands before the float32 ones for rows the fp16 tier cannot certify;
  * "h_q64": the 64-queries-per-wave build of the fp16 kernel (K' = 16, 4 .. 13 slices): 2 (default) = where it pays (the shared
  * sweep from 9 slices on over >= 4 rounds of work items), 1 = wherever it is built, 0 = never; "h64_late": its LDS-DMA copies
- * issued one half slice late (tuning knob, default 0).  Every route gives identical results. */
+ * issued one half slice late (tuning knob, default 0); "tier_probe": rows of the strided sample a large ordinary search (>= 5e10
+ * distance pairs) sends through the fp16 pass first -- more than half of them uncertified and the call starts at the split-bf16
+ * operands instead of paying for a whole fp16 sweep (default 4096, 0 = off).  Every route gives identical results. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 
 int kz_malloc(kz_ctx* ctx, size_t bytes, void** d_ptr);

@@ -988,6 +988,11 @@ __global__ void kz_iota_kernel(int* __restrict__ out, int n) {
     if (i < n) out[i] = i;
 }
 
+__global__ void kz_strided_rows_kernel(int* __restrict__ out, int n, int64_t stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)((int64_t)i * stride);
+}
+
 __global__ __launch_bounds__(256) void kz_scatter_rows_kernel(const double* __restrict__ sd, const int64_t* __restrict__ si,
                                                               const int* __restrict__ rows, int n_rows, int k,
                                                               double* __restrict__ od, int64_t* __restrict__ oi) {
@@ -1299,6 +1304,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // 83k rows 11.3 -> 9.6, k = 26 on 60k rows 6.9 -> 6.5).  (The long lists' kernels stay for small indexes.)
     const int KP_long = KP, KSEL_long = KSEL, pieces_long = long_pieces;   // (the list geometry this call would use without the route)
     bool short_ord = false;
+    float probe_ms = 0;   // (tier probe, below: reported with the fallback time)
     // (the long-k route up to 320 neighbours as well: k / 5 <= 64 lists of 16 instead of 4 .. 14 lists of 128 -- 50k x 500k x 200, main
     //  kernel: k = 128 32.4 -> 12.5 ms, k = 160 35.4 -> 13.3; beyond 32 lists the finalize kernel selects by repeated arg-max)
     const bool longk_lists = KSEL > 0 && long_pieces > 0 && KP == 128 && kp_min <= 0 && k_eff <= 320;
@@ -1318,6 +1324,37 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             } else if (rc != KZ_ERR_NOMEM) {
                 return rc;
             }   // (no memory for the second image: the long list)
+        }
+    }
+    // TIER PROBE.  Data that is hard for fp16 as a whole (tight clusters far from the centre: nearly every row fails the first pass'
+    // certification) used to pay for a complete fp16 sweep and its finalize before anything went down the tiers (bench.py "hard":
+    // 2 x 31.6 of 150 ms per step).  A large ordinary search therefore first sends a STRIDED sample of its query rows (4096 rows:
+    // representative whatever the row order) through the fp16 pass as an escalation-style sub-search; if more than half of them
+    // cannot be certified, the call starts at the split-bf16 tier.  The sample's results are written to their places (the main
+    // pass writes the same values again).  Cost on data that is fine: ~1.4 % of a 300k-row sweep + ~0.3 ms; only top-level
+    // searches of >= 5e10 distance pairs and >= 64k query rows take it (C1 / C2 do not).  Option "tier_probe" = 0: off.
+    if (tier == KZ_TIER_H && !dual && precision_override < 0 && kp_min == 0 && !exact_only && ctx->tier_probe > 0 && ctx->esc_bf &&
+        q_count >= (int64_t)16 * ctx->tier_probe && (double)q_count * (double)index->n >= 5e10 && ctx->chunk_rows == 0) {
+        const int n_probe = ctx->tier_probe;
+        int* plist = nullptr;
+        int rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);
+        if (rc != KZ_OK) return rc;
+        hipLaunchKernelGGL(kz_strided_rows_kernel, dim3((unsigned)((n_probe + 255) / 256)), dim3(256), 0, ctx->stream, plist, n_probe,
+                           q_count / n_probe);
+        kz_knn_stats stp;
+        float pms = 0;
+        rc = kz_escalate_rows(ctx, query, q_begin, plist, n_probe, index, k, exclude_self, d_self_ids, 0, 0, d_dist, d_ind, &stp, &pms);
+        kz_pool_free(ctx, plist, 0);
+        if (rc != KZ_OK) return rc;
+        probe_ms = pms;
+        if (stp.n_escalated_rows * 2 > n_probe) {
+            tier = KZ_TIER_BF;
+            if (short_ord) {   // (the other tiers' kernels keep one list of K' per query)
+                short_ord = false;
+                KP = KP_long;
+                KSEL = KSEL_long;
+                long_pieces = pieces_long;
+            }
         }
     }
     // 64 QUERIES PER WAVE (kz_knn_h64.h): K' = 16 sweeps of 4 .. 13 slices -- half the LDS fragment reads per MFMA and half the
@@ -1357,7 +1394,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // re-search of the uncertified rows)
     const int KP_mem = KP_class > KP ? KP_class : KP;   // (short-list route: several lists of 16 -- the chunk of the replaced list length)
     const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (KP_mem <= 16 ? 4 : (KP_mem <= 32 ? 2 : 1));
-    double main_ms = 0, fin_ms = 0, fb_ms = 0;
+    double main_ms = 0, fin_ms = 0, fb_ms = probe_ms;
     int64_t n_fail_total = 0, n_escalated = 0;
     double max_err_ratio = 0.0;
     int last_splits = 1, last_blocks = 0, first_tier = tier;

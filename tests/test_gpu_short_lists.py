@@ -112,3 +112,37 @@ def test_long_k_route_with_lists_of_sixteen(ctx, k):
     np.testing.assert_array_equal(d1.numpy(), d0.numpy())
     rows = np.arange(0, len(q), 25)
     np.testing.assert_array_equal(i1.numpy()[rows], O.knn_exact(q[rows], y, k, "euclidean")[1])
+
+
+def test_tier_probe_starts_hard_data_at_the_split_bf16_tier():
+    """Data that is hard for fp16 as a whole (tight clusters far from the centre: every row fails the first pass' certification): a
+    strided 4096-row probe finds that out and the search starts at the split-bf16 tier instead of paying for a whole fp16 sweep;
+    easy data of the same size keeps the fp16 pass.  Identical results either way (sklearn_nearest_neighbors.py:96-101)."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    ctx = N.Context.get()
+    rng = np.random.RandomState(5)
+    d, n_q, n_i = 64, 300_000, 200_000
+    centres = rng.standard_normal((40, d)) * 3
+
+    def clustered(n):
+        sizes = rng.multinomial(n, np.ones(40) / 40)
+        return np.concatenate([centres[c] + 0.4 * rng.standard_normal((sizes[c], d)) for c in range(40)]).astype(np.float32)
+    try:
+        for kind, q, y in (("hard", clustered(n_q), clustered(n_i)), ("easy", rng.rand(n_q, d).astype(np.float32), rng.rand(n_i, d).astype(np.float32))):
+            qm, ym = N.DeviceMatrix(ctx, q, "euclidean"), N.DeviceMatrix(ctx, y, "euclidean")
+            ctx.set_option("tier_probe", 4096)
+            d1, i1, s1 = N.knn(ctx, qm, ym, 10)
+            ctx.set_option("tier_probe", 0)
+            d0, i0, s0 = N.knn(ctx, qm, ym, 10)
+            assert s0["first_pass"] == 2                                     # without the probe: always the fp16 pass first
+            assert s1["first_pass"] == (1 if kind == "hard" else 2), (kind, s1)
+            np.testing.assert_array_equal(i1.numpy(), i0.numpy())
+            np.testing.assert_array_equal(d1.numpy(), d0.numpy())
+            rows = np.arange(0, n_q, n_q // 300)[:300]
+            od, oi = O.knn_exact(q[rows], y, 10, "euclidean")
+            np.testing.assert_array_equal(i1.numpy()[rows], oi)
+            if kind == "hard":
+                assert s0["n_escalated_rows"] > n_q // 2
+    finally:
+        ctx.set_option("tier_probe", 4096)
