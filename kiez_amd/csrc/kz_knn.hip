@@ -992,11 +992,6 @@ __global__ void kz_strided_rows_kernel(int* __restrict__ out, int n, int64_t str
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int)((int64_t)i * stride);
 }
-// out[i] = first + (i * step) mod n: a permutation of first .. first + n - 1 when gcd(step, n) = 1
-__global__ void kz_permuted_rows_kernel(int* __restrict__ out, int n, int first, int64_t step) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = first + (int)(((int64_t)i * step) % n);
-}
 
 __global__ __launch_bounds__(256) void kz_scatter_rows_kernel(const double* __restrict__ sd, const int64_t* __restrict__ si,
                                                               const int* __restrict__ rows, int n_rows, int k,
@@ -1353,57 +1348,13 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (rc != KZ_OK) return rc;
         probe_ms = pms;
         if (stp.n_escalated_rows * 2 > n_probe) {
-            // Hard for fp16: every row to the split-bf16 tier -- as escalation-style sub-searches over the rows in a STRIDE-PERMUTED
-            // order.  Data that fails as a whole is clustered data, and rows stored cluster by cluster make every query tile hit
-            // its own cluster's stretch of the index at once (bursts of list events in all four waves together): the same kernel
-            // on the same 300k rows took 43.8 ms in row order and 30.2 ms in the arbitrary order of a fail list.
-            double t_main = 0, t_fin = 0, t_fb = pms, worst = 0;
-            int64_t n_esc = 0, n_fb = 0;
-            const int64_t CH = 524288;
-            int first_pass_sub = KZ_TIER_BF, list_len_sub = KP_long, splits_sub = 1, blocks_sub = 0;
-            for (int64_t c0 = 0; c0 < q_count; c0 += CH) {
-                const int n = (int)(q_count - c0 < CH ? q_count - c0 : CH);
-                static const int primes[] = {4099, 4111, 4127, 4129, 4133, 4139, 4153, 4157, 4159, 4177};
-                int64_t step = 1;
-                for (int pi = 0; pi < 10; ++pi)
-                    if (n % primes[pi] != 0) {
-                        step = primes[pi] % n;
-                        break;
-                    }
-                if (step == 0) step = 1;
-                int* rl = nullptr;
-                rc = kz_pool_alloc(ctx, (size_t)n * sizeof(int), (void**)&rl);
-                if (rc != KZ_OK) return rc;
-                hipLaunchKernelGGL(kz_permuted_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rl, n, (int)c0, step);
-                kz_knn_stats st2;
-                float ms2 = 0;
-                rc = kz_escalate_rows(ctx, query, q_begin, rl, n, index, k, exclude_self, d_self_ids, 2, 0, d_dist, d_ind, &st2, &ms2);
-                kz_pool_free(ctx, rl, 0);
-                if (rc != KZ_OK) return rc;
-                t_main += st2.main_kernel_ms;
-                t_fin += st2.finalize_ms;
-                t_fb += ms2 - st2.main_kernel_ms - st2.finalize_ms > 0 ? ms2 - st2.main_kernel_ms - st2.finalize_ms : 0;
-                n_esc += st2.n_escalated_rows;
-                n_fb += st2.n_fallback_rows;
-                if (st2.max_err_ratio > worst) worst = st2.max_err_ratio;
-                first_pass_sub = st2.first_pass;
-                list_len_sub = st2.list_len;
-                splits_sub = st2.n_splits;
-                blocks_sub = st2.n_blocks;
+            tier = KZ_TIER_BF;
+            if (short_ord) {   // (the other tiers' kernels keep one list of K' per query)
+                short_ord = false;
+                KP = KP_long;
+                KSEL = KSEL_long;
+                long_pieces = pieces_long;
             }
-            if (stats) {
-                stats->main_kernel_ms = t_main;
-                stats->finalize_ms = t_fin;
-                stats->fallback_ms = t_fb;
-                stats->n_fallback_rows = n_fb;
-                stats->list_len = list_len_sub;
-                stats->n_splits = splits_sub;
-                stats->n_blocks = blocks_sub;
-                stats->first_pass = first_pass_sub;
-                stats->n_escalated_rows = n_esc;
-                stats->max_err_ratio = worst > stp.max_err_ratio ? worst : stp.max_err_ratio;
-            }
-            return KZ_OK;
         }
     }
     // 64 QUERIES PER WAVE (kz_knn_h64.h): K' = 16 sweeps of 4 .. 13 slices -- half the LDS fragment reads per MFMA and half the
