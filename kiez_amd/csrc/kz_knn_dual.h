@@ -357,7 +357,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // the threshold of a row is its (k + 1)-th best sample key: the sample rows are rows of a, so k rows STRICTLY above the
     // threshold are there by construction (at rank k a row whose k best all happen to be sample rows -- probability stride^-k:
     // 4-25 % of the rows at k = 1 -- could not be certified and was searched again)
-    const int rank = k + 1 < KP ? k + 1 : KP;
+    // "dual_rank" (tuning knob; 0 = k + 1): a LOWER rank r -- with the sample thinned to match -- keeps the expected r x stride
+    // events per row while the sample sweep shrinks; the k rows are then no longer there by construction: a row with fewer than k
+    // events (count of rows above the r-th order statistic of a stride-fold sample: mean r stride, deviation sqrt(r) stride) comes
+    // out of the finalize kernel uncertified (V < k) and is searched again like any other.
+    int rank = k + 1 < KP ? k + 1 : KP;
+    if (ctx->dual_rank > 0 && ctx->dual_rank < rank) rank = ctx->dual_rank;
     // list length of the REVERSE direction (the K' best events of a row): twice K' -- the events are there anyway
     // (~(k + 1) stride per row), the re-rank gathers only the candidates within 2 eps of the k-th key whatever the list length
     // is, and the certification's bound falls from the 64th to the 128th best key: on clustered data (many near-equal

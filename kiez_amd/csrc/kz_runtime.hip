@@ -66,6 +66,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->h_q64 = 2;
     c->h64_late = 0;
     c->tier_probe = 4096;
+    c->dual_rank = 0;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
         c->precision = (strcmp(pv, "fp32") == 0 || strcmp(pv, "1") == 0) ? 1 : ((strcmp(pv, "bf16") == 0 || strcmp(pv, "2") == 0) ? 2 : 0);
@@ -193,6 +194,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "lds_pad") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
         c->lds_pad = (int)value;
+    } else if (strcmp(name, "dual_rank") == 0) {
+        KZ_REQUIRE(value >= 0 && value <= 128, "dual_rank must be in [0, 128]");
+        c->dual_rank = (int)value;
     } else if (strcmp(name, "tier_probe") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 65536, "tier_probe must be in [0, 65536]");
         c->tier_probe = (int)value;
