@@ -335,6 +335,52 @@ static int kz_knn_dual_separately(kz_ctx* ctx, kz_matrix* a, kz_matrix* b, int k
     return rc;
 }
 
+// Rank of the sample key that becomes a row's event threshold (kz_knn_dual "rank").  Model, per candidate rank r: stride s =
+// sqrt(T / (|B| r c_ev)) clamped as kz_knn_dual clamps it; cost = T / s (sample sweep) + c_ev |B| r s (events: log, scatter, select,
+// the slower sweep) + P_fail |B| c_row (rows with fewer than k events, searched again; c_row = three times a row's share of a
+// sweep: small batches run well below the sweep's rate); P_fail = P(Gamma(r) < (k - r + 1) / (s - 1)) -- the lower tail of the
+// negative binomial count of non-sample rows above the r-th best of an s-fold sample.  Ranks with P_fail > 1e-3 are out.
+static inline int kz_dual_pick_rank(int k, int rank_safe, double t_sweep_ms, double a_n, double b_n) {
+    const double c_ev = 0.10e-6;   // ms per event (kz_knn_dual's stride model)
+    auto stride_of = [&](int r) {
+        const double s_opt = sqrt(t_sweep_ms / (b_n * r * c_ev));
+        double st = s_opt < 4.0 ? 4.0 : (s_opt > 32.0 ? 32.0 : floor(s_opt + 0.5));
+        const double s_max = floor(4096.0 / ((double)r + 7.0 * sqrt((double)r) + 1.0));
+        return st > s_max ? s_max : st;
+    };
+    auto p_fail = [&](int r, double st) {
+        if (r >= k + 1) return 0.0;
+        const double x = (double)(k - r + 1) / (st - 1.0);   // Gamma(r, 1) must reach this
+        // P(Gamma(r) < x) = e^-x sum_{j >= r} x^j / j!
+        double term = exp(-x);
+        for (int j = 1; j <= r; ++j) term *= x / j;
+        double sum = 0.0;
+        for (int j = r; j < r + 200 && term > 1e-300; ++j) {
+            sum += term;
+            term *= x / (j + 1);
+        }
+        return sum < 1.0 ? sum : 1.0;
+    };
+    const double c_row = 3.0 * t_sweep_ms / a_n;
+    int best = rank_safe;
+    double best_cost = 1e300;
+    // (floor: a quarter of the safe rank and 8 -- below, the model's gains were not there when measured: 250k x 1M, k = 10: rank
+    //  8 -> 106.9 ms per step, rank 6 -> 108.6, k + 1 = 11 -> 108.7; a sample of a few hundred tiles is a short sweep)
+    int r_min = (rank_safe + 3) / 4 > 8 ? (rank_safe + 3) / 4 : 8;
+    if (r_min > rank_safe) r_min = rank_safe;
+    for (int r = rank_safe; r >= r_min; --r) {
+        const double st = stride_of(r);
+        const double pf = p_fail(r, st);
+        if (pf > 1e-3) break;   // (P_fail grows as r falls)
+        const double cost = t_sweep_ms / st + c_ev * b_n * r * st + pf * b_n * c_row;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = r;
+        }
+    }
+    return best;
+}
+
 extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b_c, int k, double* d_dist_ab, int64_t* d_ind_ab,
                            double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba) {
     kz_matrix* a = const_cast<kz_matrix*>(a_c);
@@ -357,12 +403,19 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // the threshold of a row is its (k + 1)-th best sample key: the sample rows are rows of a, so k rows STRICTLY above the
     // threshold are there by construction (at rank k a row whose k best all happen to be sample rows -- probability stride^-k:
     // 4-25 % of the rows at k = 1 -- could not be certified and was searched again)
-    // "dual_rank" (tuning knob; 0 = k + 1): a LOWER rank r -- with the sample thinned to match -- keeps the expected r x stride
-    // events per row while the sample sweep shrinks; the k rows are then no longer there by construction: a row with fewer than k
-    // events (count of rows above the r-th order statistic of a stride-fold sample: mean r stride, deviation sqrt(r) stride) comes
-    // out of the finalize kernel uncertified (V < k) and is searched again like any other.
-    int rank = k + 1 < KP ? k + 1 : KP;
-    if (ctx->dual_rank > 0 && ctx->dual_rank < rank) rank = ctx->dual_rank;
+    // ... that is the SAFE rank.  Round 4: the threshold sits at a LOWER rank r of a thinner sample (stride ~ 1 / sqrt(r)): sample
+    // sweep and events per row (~ r stride) both shrink with sqrt(r).  The k rows are then no longer there by construction: the
+    // number of non-sample rows above the r-th best sample key is negative binomial (r, 1 / stride) -- ~ Gamma(r) x (stride - 1),
+    // whatever the data looks like -- and a row that gets fewer than k events comes out of the finalize kernel uncertified (V < k)
+    // and is searched again like any other.  r = the cheapest rank whose share of such rows stays below 1e-3 (kz_dual_pick_rank);
+    // 500k x 500k, k = 50: rank 51 -> 12, stride 6 -> 12: step 162.9 -> 142.7 ms, rows searched again unchanged (~750); k = 10:
+    // rank 11 -> 8: ns 108.7 -> 106.9 ms.  Option "dual_rank": 0 = automatic, -1 = k + 1, > 0 = that rank.
+    const int rank_safe = k + 1 < KP ? k + 1 : KP;
+    int rank = rank_safe;
+    if (ctx->dual_rank > 0)
+        rank = ctx->dual_rank < rank_safe ? ctx->dual_rank : rank_safe;
+    else if (ctx->dual_rank == 0 && ctx->dual_stride == 1)
+        rank = kz_dual_pick_rank(k, rank_safe, 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12, (double)a->n, (double)b->n);
     // list length of the REVERSE direction (the K' best events of a row): twice K' -- the events are there anyway
     // (~(k + 1) stride per row), the re-rank gathers only the candidates within 2 eps of the k-th key whatever the list length
     // is, and the certification's bound falls from the 64th to the 128th best key: on clustered data (many near-equal

@@ -195,7 +195,7 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
         KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
         c->lds_pad = (int)value;
     } else if (strcmp(name, "dual_rank") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 128, "dual_rank must be in [0, 128]");
+        KZ_REQUIRE(value >= -1 && value <= 128, "dual_rank must be -1 (k + 1), 0 (automatic) or in [1, 128]");
         c->dual_rank = (int)value;
     } else if (strcmp(name, "tier_probe") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 65536, "tier_probe must be in [0, 65536]");
