@@ -99,7 +99,7 @@ def test_reverse_direction_uses_the_sweep_on_a_shape_where_it_pays(ctx):
     sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 10, "euclidean")
     _assert_same(sep, dual)
     assert s_ab["dual"] == 1 and s_ba["dual"] == 1
-    assert 5 * 10 < s_ba["n_events"] / len(b) < 40 * 10     # k stride, stride chosen from the shapes within [4, 32]
+    assert 4 * 8 < s_ba["n_events"] / len(b) < 40 * 10      # rank x stride: rank chosen within [8, k + 1], stride within [4, 32]
     assert s_ba["n_logged_groups"] < 1.3 * s_ba["n_events"]   # the per-tile threshold (rows sorted by threshold) is nearly exact
     assert s_ba["n_escalated_rows"] < 0.01 * len(b)
 
@@ -381,3 +381,21 @@ def test_short_list_route_of_the_main_sweep(ctx, kind, metric, k):
         np.testing.assert_array_equal(x, y)
     if kind != "duplicates":   # (exact duplicates: the order among equal distances is the library's, not scikit-learn's)
         _oracle_sample(a, b, k, metric, got)
+
+
+@pytest.mark.parametrize("rank", [-1, 0, 3, 1])
+def test_threshold_rank_below_k_plus_one(ctx, rank):
+    """`dual_rank`: the event threshold of a row at a LOWER rank of a thinner sample.  The k rows are then no longer among the events by
+    construction: rows that get fewer than k events must come back uncertified and be searched again -- identical results for every
+    rank, down to rank 1 (where a good share of the rows falls short)."""
+    ctx.set_option("dual_rank", rank)
+    try:
+        a, b = _data("uniform", 60000, 48, 21, np.float32), _data("uniform", 9000, 48, 22, np.float32)
+        sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 10, "euclidean")
+        _assert_same(sep, dual)
+        _oracle_sample(a, b, 10, "euclidean", dual)
+        assert s_ba["dual"] == 1
+        if rank == 1:
+            assert s_ba["n_escalated_rows"] > 0      # rows short of events went down the ordinary way
+    finally:
+        ctx.set_option("dual_rank", 0)
