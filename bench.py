@@ -325,6 +325,8 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
         "shared_sweeps": len(rev_log),
         "reverse_extra_ms_per_step": sum(r["main_kernel_ms"] + r["finalize_ms"] + r["fallback_ms"] for r in rev_log) / max(steps, 1),
         "reverse_events_per_row": (sum(r["n_events"] for r in rev_log) / max(len(rev_log), 1) / max(min(n_s, n_t), 1)) if rev_log else 0.0,
+        # rows of the reverse direction searched again (an overflowing event buffer, fewer than k events, an uncertified list)
+        "reverse_escalated_rows": int(sum(r.get("n_escalated_rows", 0) for r in rev_log)),
     }
     chk = None
     if check and rank == 0 and world == 1:
@@ -373,7 +375,7 @@ def short(summary):
             "finalize_avg_ms": s["finalize_avg_ms"], "certification_fallback_rows": s["fallback_rows"],
             "escalated_rows": s["escalated_rows"], "fallback_total_ms": s["fallback_total_ms"],
             "max_err_over_eps": s["max_err_ratio"], "steps": s["steps"], "shared_sweeps": s["shared_sweeps"],
-            "reverse_extra_ms_per_step": s["reverse_extra_ms_per_step"], "check": s["check"]}
+            "reverse_extra_ms_per_step": s["reverse_extra_ms_per_step"], "reverse_escalated_rows": s["reverse_escalated_rows"], "check": s["check"]}
 
 
 def run_openea(args):
@@ -593,7 +595,7 @@ def main():
                          "note": ("algorithmic flop = 2 n_q n_i d per launch, counted ONCE for a launch that serves both search "
                                   "directions (kz_knn_dual): the reference evaluates that distance matrix twice")},
             "shared_sweep": {"launches": s["shared_sweeps"], "reverse_extra_ms_per_step": s["reverse_extra_ms_per_step"],
-                             "reverse_events_per_row": s["reverse_events_per_row"]},
+                             "reverse_events_per_row": s["reverse_events_per_row"], "reverse_escalated_rows": s["reverse_escalated_rows"]},
             "certification_fallback_rows": s["fallback_rows"],
             "escalated_rows": s["escalated_rows"],
             "rounding_bound_self_check": {"max_err_over_eps": s["max_err_ratio"],
