@@ -36,7 +36,7 @@ def main():
     variants = [v.strip() for v in args.variants.split(";")]
     out = {}
     for w in args.workloads.split(","):
-        rec = {v: {"step": [], "main": [], "esc": [], "fb": [], "check": None} for v in variants}
+        rec = {v: {"step": [], "main": [], "esc": [], "resc": [], "fb": [], "check": None} for v in variants}
         for r in range(args.rounds):
             for v in variants:
                 opts = dict(o.split("=") for o in filter(None, v.split(",")))
@@ -47,13 +47,14 @@ def main():
                 rec[v]["step"].append(s["ms_per_step"])
                 rec[v]["main"].append(s["kernel_s"] / max(s["n_launch"], 1) * 1e3)
                 rec[v]["esc"].append(s["escalated_rows"])
+                rec[v]["resc"].append(s.get("reverse_escalated_rows", 0))
                 rec[v]["fb"].append(s["fallback_rows"])
                 if s["check"] is not None:
                     rec[v]["check"] = s["check"]
         for v in variants:
             st, mn = sorted(rec[v]["step"]), sorted(rec[v]["main"])
             print(f"{w:5s} [{v or 'defaults':40s}] step med {st[len(st) // 2]:8.3f} min {st[0]:8.3f} | main med {mn[len(mn) // 2]:8.3f} min {mn[0]:8.3f}"
-                  f" | esc {rec[v]['esc'][-1]} fb {rec[v]['fb'][-1]} | rounds step {[round(x, 2) for x in rec[v]['step']]} main {[round(x, 2) for x in rec[v]['main']]}"
+                  f" | esc {rec[v]['esc'][-1]} rev-esc {rec[v]['resc'][-1]} fb {rec[v]['fb'][-1]} | rounds step {[round(x, 2) for x in rec[v]['step']]} main {[round(x, 2) for x in rec[v]['main']]}"
                   + (f" | check {rec[v]['check']}" if rec[v]["check"] else ""), flush=True)
         out[w] = rec
     if args.json:
