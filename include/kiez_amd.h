@@ -98,7 +98,9 @@ int kz_ctx_trim(kz_ctx* ctx);
  * sweep from 9 slices on over >= 4 rounds of work items), 1 = wherever it is built, 0 = never; "h64_late": its LDS-DMA copies
  * issued one half slice late (tuning knob, default 0); "tier_probe": rows of the strided sample a large ordinary search (>= 5e10
  * distance pairs) sends through the fp16 pass first -- more than half of them uncertified and the call starts at the split-bf16
- * operands instead of paying for a whole fp16 sweep (default 4096, 0 = off).  Every route gives identical results. */
+ * operands instead of paying for a whole fp16 sweep (default 4096, 0 = off); "dual_rank": rank of the sample key that becomes a
+ * row's event threshold in kz_knn_dual (0 = automatic: the cheapest rank that leaves fewer than 1e-3 of the rows short of k
+ * events -- those are searched again; -1 = the safe k + 1; > 0 = that rank).  Every route gives identical results. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 
 int kz_malloc(kz_ctx* ctx, size_t bytes, void** d_ptr);
