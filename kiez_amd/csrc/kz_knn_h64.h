@@ -1,10 +1,12 @@
 // fp16 first pass, 64 QUERIES PER WAVE (K' = 16): the kernel of kz_knn_h16.h with half the LDS traffic per multiply-add.
 //
 // kz_knn_h16.h gives a wave 32 queries x 128 index rows: per 16-k slice it reads four 1 KiB fragments of the index from LDS for
-// four MFMAs, and a workgroup's 4 KiB LDS-DMA copy of the slice serves 128 queries.  Measured there (profiles/r03_ablation.md
-// section 2): the bare MFMA + fragment loop runs at 0.58 of the matrix peak, the DMA ring costs another 14-17 % IN PROPORTION TO
-// ITS VOLUME -- per slice step a CU reads 48 KiB of fragments and takes 12 KiB of copies while each SIMD owes 384 matrix cycles:
-// the LDS pipeline, not the matrix pipe, is what the loop waits for.
+// four MFMAs, and a workgroup's 4 KiB LDS-DMA copy of the slice serves 128 queries; round 3's ablation had the DMA ring cost
+// 14-17 % in proportion to its volume and a bare-loop probe of 64-query waves 7-14 % faster per flop.  What this kernel measured
+// once it was a whole kernel (profiles/r04_ablation.md sections 2, 3): a tie -- -1.5 % on the shared sweep at 13 slices, +1 ... +9 %
+// on ordinary sweeps -- because the sweeps sit on the chip's power limit, not on the LDS pipeline: matrix-pipe busy x clock is the
+// same 1.05 GHz for both structures (this one: an emptier pipe at a higher clock).  It runs where it wins (kz_knn_impl: the shared
+// sweep from 9 slices on, large launches) and stays otherwise as that evidence.
 //
 // Here a wave owns 64 queries x 64 index rows (HALF a tile): four accumulators acc[rb][qh] (rb = 32-row block, qh = 32-query
 // half), and per 16-k step of a half tile TWO 1 KiB fragments feed FOUR MFMAs (each index fragment meets both query halves):
