@@ -203,12 +203,26 @@ __global__ __launch_bounds__(256) void kz_mp_empiric_kernel(const double* __rest
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the reverse list of candidate j + 1 (its ids: one or two per lane; the last distance for the fill value) is fetched while
+    // candidate j is processed: the loop is a chain of dependent gathers otherwise (one wave per query, 50 round trips to HBM)
+    long long idn[2] = {-1, -1};
+    double lastn = 0.0;
+    const double* rdn = nullptr;
+    auto prefetch = [&](const int jn) {
+        const int64_t cn = c_i[jn];
+        rdn = dist_t2s + cn * (int64_t)Kt;
+        const int64_t* rin = ind_t2s + cn * (int64_t)Kt;
+        lastn = rdn[Kt - 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) idn[u] = lane + 64 * u < Kt ? rin[lane + 64 * u] : -1;
+    };
+    prefetch(0);
     for (int j = 0; j < K; ++j) {
         const double dj = d_i[j];
-        const int64_t cj = c_i[j];
-        const double* rd = dist_t2s + cj * (int64_t)Kt;
-        const int64_t* ri = ind_t2s + cj * (int64_t)Kt;
-        const double fill = rd[Kt - 1] + 1e-6;
+        const double* rd = rdn;
+        const double fill = lastn + 1e-6;
+        const long long idc[2] = {idn[0], idn[1]};
+        if (j + 1 < K) prefetch(j + 1);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             if (lane + 64 * u < K) T[lane + 64 * u] = fill;
@@ -216,8 +230,11 @@ __global__ __launch_bounds__(256) void kz_mp_empiric_kernel(const double* __rest
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // every reverse-list entry p looks its id up among the sorted candidate ids
-        for (int pp = lane; pp < Kt; pp += 64) {
-            const long long id = ri[pp];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pp = lane + 64 * u;
+            if (pp >= Kt) continue;
+            const long long id = idc[u];
             int lo = 0, hi = K - 1, pos = -1;
             while (lo <= hi) {
                 const int mid = (lo + hi) >> 1;
@@ -576,7 +593,7 @@ int kz_mp_empiric(kz_ctx* ctx, const double* d_dist, const int64_t* d_ind, int64
     KZ_CHECK_NK("kz_mp_empiric");
     KZ_REQUIRE(d_dist && d_ind && d_dist_t2s && d_ind_t2s && d_out, "kz_mp_empiric: null argument");
     KZ_REQUIRE(Kt >= 1 && n_t >= 1, "kz_mp_empiric: bad reverse list shape");
-    if (K <= KZ_MP_MAXK) {
+    if (K <= KZ_MP_MAXK && Kt <= KZ_MP_MAXK) {   // (one or two candidates / reverse-list entries per lane)
         hipLaunchKernelGGL(kz_mp_empiric_kernel, kz_grid1d(n, 4), dim3(256), 0, ctx->stream, d_dist, d_ind, n, K, d_dist_t2s,
                            d_ind_t2s, n_t, Kt, d_out);
     } else {
