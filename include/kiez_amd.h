@@ -111,7 +111,8 @@ int kz_memcpy_d2d(kz_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 
 /* ---- index construction: replaces SklearnNN._fit (sklearn_nearest_neighbors.py:83-94) ------------------ */
 /* rows [n, d]: rows_on_device = 0 host memory (copied into HBM), 1 device memory (copied), 2 device memory BORROWED
- * (read in place; the caller keeps the buffer alive and unchanged until kz_matrix_destroy).  Computes the float64 row
+ * (read in place; the caller keeps the buffer alive and unchanged until kz_matrix_destroy), 3 device memory borrowed as a ROW
+ * SOURCE only (no norms, no operand images: accepted by kz_dsl_fit as `source`, refused by every search entry point).  Computes the float64 row
  * norms; the MFMA operand images (fp16 / split-bf16 / float32 tiles) are built by the first kz_knn that needs them.
  * NaN/inf input is an error (KZ_ERR_NONFINITE; scikit-learn rejects those inputs too): reported here for host rows, by
  * the first kz_knn / kz_knn_dual that searches the matrix for device rows (this call then waits for nothing). */

@@ -267,7 +267,7 @@ class DeviceMatrix:
     """kz_matrix: an embedding matrix in HBM (exact rows + float64 norms + MFMA operand images: float32 and split-bf16)."""
 
     def __init__(self, ctx: Context, data, metric: str, device_ptr: Optional[int] = None, shape=None, dtype=None,
-                 borrow: bool = False, keepalive=None):
+                 borrow: bool = False, keepalive=None, rows_only: bool = False):
         """`device_ptr` + `borrow=True`: zero-copy -- the matrix reads the caller's HBM buffer in place (kz_matrix_create
         rows_on_device = 2); `keepalive` (the tensor / array that owns it) is held until the matrix is destroyed and must
         not be modified meanwhile (the reference holds its inputs the same way, neighbor_algorithm_base.py:95-96)."""
@@ -289,7 +289,10 @@ class DeviceMatrix:
             self.shape = tuple(shape)
             self.dtype = np.dtype(dtype)
             self._keepalive = keepalive if borrow else None
-            _check(ctx.lib.kz_matrix_create(ctx.handle, _P(device_ptr), 2 if borrow else 1, self.shape[0], self.shape[1],
+            if rows_only and not borrow:
+                raise ValueError("rows_only needs a borrowed device buffer")
+            # (rows_only: kz_matrix_create rows_on_device = 3 -- a row source for kz_dsl_fit, nothing computed, not searchable)
+            _check(ctx.lib.kz_matrix_create(ctx.handle, _P(device_ptr), (3 if rows_only else 2) if borrow else 1, self.shape[0], self.shape[1],
                                             KZ_F32 if self.dtype == np.float32 else KZ_F64, METRIC_IDS[metric], C.byref(h)),
                    "kz_matrix_create")
         self.handle = h

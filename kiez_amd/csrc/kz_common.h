@@ -117,7 +117,8 @@ struct kz_matrix {
     int kg;           // d_pad / 4 (number of 4-wide k-groups), d_pad = round_up(d, 16)
     int kg_bf;        // same for the split-bf16 image (currently equal to kg)
     void* raw;        // [n, d] dtype, row-major (exact data, used by the float64 re-rank)
-    bool raw_borrowed;  // raw is the caller's buffer (kz_matrix_create rows_on_device = 2), not ours to free
+    bool raw_borrowed;  // raw is the caller's buffer (kz_matrix_create rows_on_device = 2 / 3), not ours to free
+    bool raw_only;      // rows_on_device = 3: rows only -- no norms, no operand images: a row SOURCE (kz_dsl_fit), not searchable
     float* packed;    // [n_tiles][kg][128][4] float32 MFMA operand image (NULL until kz_matrix_image_f32)
     unsigned short* packed_bf;  // [n_tiles][kg/4][4 planes][128][8] bf16 split image: planes hi(k 0-7), hi(k 8-15), lo, lo
                                 // (NULL until kz_matrix_image_bf)

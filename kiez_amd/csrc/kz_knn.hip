@@ -1203,6 +1203,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                        int64_t* d_ind, kz_knn_stats* stats, KzDualPass* dual) {
     KZ_REQUIRE(ctx && query && index && d_dist && d_ind, "kz_knn: null argument");
     KZ_REQUIRE(query->ctx == ctx && index->ctx == ctx, "kz_knn: matrices belong to a different context");
+    KZ_REQUIRE(!query->raw_only && !index->raw_only, "kz_knn: a rows-only matrix (kz_matrix_create rows_on_device = 3) cannot be searched");
     KZ_REQUIRE(query->d == index->d, "kz_knn: feature dimensions differ (%lld vs %lld)", (long long)query->d,
                (long long)index->d);
     KZ_REQUIRE(query->dtype == index->dtype, "kz_knn: query and index must have the same dtype");

@@ -388,6 +388,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     KZ_REQUIRE(ctx && a && b && d_dist_ab && d_ind_ab && d_dist_ba && d_ind_ba, "kz_knn_dual: null argument");
     KZ_REQUIRE(a != b, "kz_knn_dual: the two matrices must be different objects (a single matrix is searched with kz_knn)");
     KZ_REQUIRE(a->ctx == ctx && b->ctx == ctx, "kz_knn_dual: matrices belong to a different context");
+    KZ_REQUIRE(!a->raw_only && !b->raw_only, "kz_knn_dual: a rows-only matrix (kz_matrix_create rows_on_device = 3) cannot be searched");
     KZ_REQUIRE(a->d == b->d, "kz_knn_dual: feature dimensions differ (%lld vs %lld)", (long long)a->d, (long long)b->d);
     KZ_REQUIRE(a->dtype == b->dtype, "kz_knn_dual: the matrices must have the same dtype");
     KZ_REQUIRE(a->metric == b->metric, "kz_knn_dual: the matrices were packed for different metrics");

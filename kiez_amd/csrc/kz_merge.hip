@@ -90,6 +90,7 @@ extern "C" {
 int kz_pair_values(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t q_count, const kz_matrix* index,
                    const int64_t* d_ind, int k, double* d_val) {
     KZ_REQUIRE(ctx && query && index && d_ind && d_val, "kz_pair_values: null argument");
+    KZ_REQUIRE(query && index && !query->raw_only && !index->raw_only, "kz_pair_values: null or rows-only matrix");
     KZ_REQUIRE(query->d == index->d && query->dtype == index->dtype && query->metric == index->metric,
                "kz_pair_values: query/index mismatch (d %lld vs %lld)", (long long)query->d, (long long)index->d);
     KZ_REQUIRE(q_begin >= 0 && q_count >= 0 && q_begin + q_count <= query->n && k >= 1, "kz_pair_values: bad row range");

@@ -612,7 +612,7 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     KZ_REQUIRE(dtype == KZ_F32 || dtype == KZ_F64, "kz_matrix_create: dtype must be KZ_F32 or KZ_F64");
     KZ_REQUIRE(metric == KZ_EUCLIDEAN || metric == KZ_SQEUCLIDEAN || metric == KZ_COSINE,
                "kz_matrix_create: unknown metric %d", metric);
-    KZ_REQUIRE(rows_on_device >= 0 && rows_on_device <= 2, "kz_matrix_create: rows_on_device must be 0, 1 or 2");
+    KZ_REQUIRE(rows_on_device >= 0 && rows_on_device <= 3, "kz_matrix_create: rows_on_device must be 0, 1, 2 or 3");
     KZ_HIP(hipSetDevice(ctx->device));
     kz_matrix* m = new kz_matrix();
     memset(m, 0, sizeof(*m));
@@ -632,8 +632,16 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
         kz_matrix_destroy(m);
         return code;
     };
-    m->raw_borrowed = rows_on_device == 2;
+    m->raw_borrowed = rows_on_device >= 2;
     if (m->raw_borrowed) m->raw = const_cast<void*>(rows);
+    if (rows_on_device == 3) {
+        // rows only (a row SOURCE for kz_dsl_fit's centroid gather: the multi-rank DSL path gathers the source shards for that one
+        // kernel): nothing is computed, allocated or waited for; every search entry point refuses the matrix
+        m->raw_only = true;
+        m->checked = true;
+        *out = m;
+        return KZ_OK;
+    }
     if ((!m->raw_borrowed && kz_pool_alloc(ctx, raw_bytes, &m->raw) != KZ_OK) ||
         kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&m->bias) != KZ_OK || kz_pool_alloc(ctx, (size_t)n * 8, (void**)&m->sqn) != KZ_OK ||
         kz_pool_alloc(ctx, 64, (void**)&m->d_stats) != KZ_OK) {

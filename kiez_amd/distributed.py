@@ -80,13 +80,13 @@ class HipEngine:
         return t.cpu().numpy()
 
     # -- compute ----------------------------------------------------------------------------------
-    def matrix(self, rows, metric: str):
+    def matrix(self, rows, metric: str, rows_only: bool = False):
         N = self.N
         assert rows.dtype in (self.torch.float32, self.torch.float64)
         dt = np.float32 if rows.dtype == self.torch.float32 else np.float64
         # zero-copy: the matrix reads the tensor's HBM in place and keeps the tensor alive
         return N.DeviceMatrix(self.ctx, None, metric, device_ptr=rows.data_ptr(), shape=tuple(rows.shape), dtype=dt, borrow=True,
-                              keepalive=rows)
+                              keepalive=rows, rows_only=rows_only)
 
     def knn(self, qm, q_begin: int, q_count: int, im, k: int, exclude_self: bool):
         torch, N = self.torch, self.N
@@ -518,7 +518,8 @@ class ShardedKiez:
                     # but only for this gather kernel -- the second sweep stays saved
                     src_full = comm.all_gather_rows(src, counts)
                     self._keep = self._keep + (src_full,)
-                    S_fit = eng.matrix(src_full, self.metric)
+                    # (a row source only: no norms, no operand images of the gathered rows)
+                    S_fit = eng.matrix(src_full, self.metric, rows_only=True)
             else:
                 d_t2s, i_t2s = d_rev, i_rev
         else:

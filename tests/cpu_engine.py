@@ -30,7 +30,7 @@ class OracleEngine:
     def to_numpy(self, t):
         return t.numpy()
 
-    def matrix(self, rows, metric):
+    def matrix(self, rows, metric, rows_only=False):
         return _Mat(rows, metric)
 
     def knn(self, qm, q_begin, q_count, im, k, exclude_self):

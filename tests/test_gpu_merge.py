@@ -148,3 +148,30 @@ def test_more_than_128_candidates_through_the_api(K):
                 assert knife_edge_topk_ok(od[r], oi[r], d[r], i[r], r, K, ri), (hub, r)
         np.testing.assert_array_equal(i[keep], oi[keep], err_msg=str((hub, kw)))
         np.testing.assert_allclose(d[keep], od[keep], rtol=1e-5, atol=1e-6 if hub == "DisSimLocal" else 1e-9, err_msg=str((hub, kw)))
+
+
+def test_rows_only_matrix_is_a_row_source_and_nothing_else():
+    """kz_matrix_create rows_on_device = 3: the gathered source of the multi-rank DSL path -- rows for kz_dsl_fit's centroid gather
+    (dis_sim.py:96-101), no norms, no operand images; every search entry point refuses it."""
+    import ctypes as C
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    ctx = N.Context.get()
+    rng = np.random.RandomState(4)
+    s, t = rng.rand(3000, 40).astype(np.float32), rng.rand(2500, 40).astype(np.float32)
+    s_dev = ctx.to_device(s)
+    sm_rows = N.DeviceMatrix(ctx, None, "euclidean", device_ptr=s_dev.ptr.value, shape=s.shape, dtype=np.float32, borrow=True,
+                             keepalive=s_dev, rows_only=True)
+    sm, tm = N.DeviceMatrix(ctx, s, "euclidean"), N.DeviceMatrix(ctx, t, "euclidean")
+    _, i_t2s, _ = N.knn(ctx, tm, sm, 10)
+    out_a, out_b = ctx.empty((len(t),), np.float64), ctx.empty((len(t),), np.float64)
+    for src, out in ((sm, out_a), (sm_rows, out_b)):
+        N._check(ctx.lib.kz_dsl_fit(ctx.handle, i_t2s.ptr, len(t), 10, src.handle, tm.handle, 0, out.ptr), "kz_dsl_fit")
+    np.testing.assert_array_equal(out_a.numpy(), out_b.numpy())
+    np.testing.assert_allclose(out_b.numpy(), O.dsl_fit(i_t2s.numpy(), s.astype(np.float64), t.astype(np.float64)), rtol=1e-12)
+    with pytest.raises(RuntimeError, match="rows-only"):
+        N.knn(ctx, tm, sm_rows, 5)
+    with pytest.raises(RuntimeError, match="rows-only"):
+        N.knn_dual(ctx, sm_rows, tm, 5)
+    with pytest.raises(ValueError):
+        N.DeviceMatrix(ctx, None, "euclidean", device_ptr=s_dev.ptr.value, shape=s.shape, dtype=np.float32, borrow=False, rows_only=True)
