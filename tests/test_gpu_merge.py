@@ -169,9 +169,9 @@ def test_rows_only_matrix_is_a_row_source_and_nothing_else():
         N._check(ctx.lib.kz_dsl_fit(ctx.handle, i_t2s.ptr, len(t), 10, src.handle, tm.handle, 0, out.ptr), "kz_dsl_fit")
     np.testing.assert_array_equal(out_a.numpy(), out_b.numpy())
     np.testing.assert_allclose(out_b.numpy(), O.dsl_fit(i_t2s.numpy(), s.astype(np.float64), t.astype(np.float64)), rtol=1e-12)
-    with pytest.raises(RuntimeError, match="rows-only"):
+    with pytest.raises(ValueError, match="rows-only"):
         N.knn(ctx, tm, sm_rows, 5)
-    with pytest.raises(RuntimeError, match="rows-only"):
+    with pytest.raises(ValueError, match="rows-only"):
         N.knn_dual(ctx, sm_rows, tm, 5)
     with pytest.raises(ValueError):
         N.DeviceMatrix(ctx, None, "euclidean", device_ptr=s_dev.ptr.value, shape=s.shape, dtype=np.float32, borrow=False, rows_only=True)
