@@ -95,8 +95,7 @@ int kz_ctx_trim(kz_ctx* ctx);
  * neighbours, a second row-dealt image of the index, ranges of at least "short_ord_min_tiles" tiles); "dual_rev_long": 1 (default) = reverse lists of twice the list length;
  * "esc_bf": 1 (default) = split-bf16 operands before the float32 ones for rows the fp16 tier cannot certify;
  * "h_q64": the 64-queries-per-wave build of the fp16 kernel (K' = 16, 4 .. 13 slices): 2 (default) = where it pays (the shared
- * sweep from 9 slices on over >= 4 rounds of work items), 1 = wherever it is built, 0 = never; "h64_late": its LDS-DMA copies
- * issued one half slice late (tuning knob, default 0); "tier_probe": rows of the strided sample a large ordinary search (>= 5e10
+ * sweep from 9 slices on over >= 4 rounds of work items), 1 = wherever it is built, 0 = never; "tier_probe": rows of the strided sample a large ordinary search (>= 5e10
  * distance pairs) sends through the fp16 pass first -- more than half of them uncertified and the call starts at the split-bf16
  * operands instead of paying for a whole fp16 sweep (default 4096, 0 = off); "dual_rank": rank of the sample key that becomes a
  * row's event threshold in kz_knn_dual (0 = automatic: the cheapest rank that leaves fewer than 1e-3 of the rows short of k

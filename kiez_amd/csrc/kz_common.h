@@ -47,7 +47,6 @@ struct kz_ctx {
     int h_q64;        // 64-queries-per-wave kernel (kz_knn_h64.h) for K' = 16 sweeps of 4 .. 13 slices: 2 (default) = where it pays (kz_knn_impl), 1 = always, 0 = never
     int dual_rank;    // kz_knn_dual: rank of the sample key that becomes a row's event threshold (0 = automatic, -1 = k + 1, > 0 = that rank; kz_knn_dual.h)
     int tier_probe;   // rows of the strided sample a large ordinary search sends through the fp16 pass first (0 = off; default 4096): more than half uncertified -> the call starts at split-bf16
-    int h64_late;     // tuning knob of that kernel: LDS-DMA copies issued one half slice late (default 0)
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)
     void* scratch;

@@ -1452,7 +1452,6 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         cp.kg = index->kg;
         cp.out_key = out_key;
         cp.out_idx = out_idx;
-        cp.flags = ctx->h64_late ? 1 : 0;
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         if (exact_only) {
             // every row of the chunk goes to the exact kernels: the "fail list" is 0 .. cq_count-1

@@ -101,7 +101,6 @@ struct KnnCandParams {
     void* log_meta;                // [log_cap] x 8 B
     unsigned long long* log_cnt;
     long long log_cap;
-    int flags;                     // kz_knn_h64.h: bit 0 = LDS-DMA copies issued one half slice late
 };
 
 constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows

@@ -167,8 +167,6 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_h64_kernel(KnnCandParams p
         f[1] = *reinterpret_cast<const kz_f16x8*>(fb + 128);
     };
     fetch_frags(f0, 0);
-    const bool late = (p.flags & 1) != 0;
-    int dma_due = 0;
     int g = 0;        // half slices done (uniform)
     int seq = 0;      // half tiles done (uniform)
     int th_cur = 0;   // dual pass: threshold buffer of the current half tile (uniform)
@@ -234,21 +232,10 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_h64_kernel(KnnCandParams p
             // fragments of all half slices <= g + 1 in registers, so the slots of g-P+2 .. g+1 take g+P+2 .. g+2P+1 (this wave's
             // share: the two of its parity).  The next period prefetches g+2 .. g+P+1: issued at the PREVIOUS barrier, hence
             // vmcnt(0).
-            if (late && dma_due) {
-                // (KnnCandParams::flags bit 0: the copies the PREVIOUS half slice's barrier released are issued here, behind this
-                //  half slice's MFMAs, where the wave has no LDS read of its own in flight -- KZ_H_DMA_LATE of kz_knn_h16.h)
-#pragma unroll
-                for (int i = 0; i < P / 2; ++i) dma_next();
-                dma_due = 0;
-            }
             if (((g + 2) & (P - 1)) == 0) {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (late) {
-                    dma_due = 1;
-                } else {
 #pragma unroll
-                    for (int i = 0; i < P / 2; ++i) dma_next();
-                }
+                for (int i = 0; i < P / 2; ++i) dma_next();   // (issued one half slice later, behind the next MFMAs: +3 ... +4 % -- measured, not kept)
             }
             ++g;
         }

@@ -64,7 +64,6 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
     c->lds_pad = 0;
     c->h_q64 = 2;
-    c->h64_late = 0;
     c->tier_probe = 4096;
     c->dual_rank = 0;
     c->precision = 0;
@@ -200,8 +199,6 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "tier_probe") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 65536, "tier_probe must be in [0, 65536]");
         c->tier_probe = (int)value;
-    } else if (strcmp(name, "h64_late") == 0) {
-        c->h64_late = value != 0 ? 1 : 0;
     } else if (strcmp(name, "h_q64") == 0) {
         KZ_REQUIRE(value == 0 || value == 1 || value == 2, "h_q64 must be 0 (never), 1 (wherever built) or 2 (automatic)");
         c->h_q64 = (int)value;

@@ -19,7 +19,7 @@ def ctx():
     c = N.Context.get()
     c.set_option("h_q64", 1)
     yield c
-    for name, value in (("h_q64", 2), ("h64_late", 0), ("dual_force", 0), ("force_splits", 0), ("chunk_rows", 0)):
+    for name, value in (("h_q64", 2), ("dual_force", 0), ("force_splits", 0), ("chunk_rows", 0)):
         c.set_option(name, value)
 
 
