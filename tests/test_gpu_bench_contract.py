@@ -1,0 +1,37 @@
+"""The driver's contract for `bench.py` (task statement): ONE JSON line on stdout with the metric BASELINE.json names, whole-job
+throughput, `roofline` and `cpu_baseline` objects -- checked on a short run of the default workload on the GPU."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_default_bench_line_has_what_the_driver_reads():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--no-others"], capture_output=True, text=True,
+                       timeout=1500, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    base = json.loads((ROOT / "BASELINE.json").read_text())
+    assert line["metric"] == base["metric"] and line["unit"] == "queries/s" and line["higher_is_better"] is True
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["data"] == "synthetic" and line["dtype"] in ("f16", "bf16x2", "f32")
+    cfg = line["config"]
+    assert "workload" in cfg and cfg["d"] == 200 and cfg["n_target"] == 1_000_000 and cfg["k"] == 10 and cfg["hubness"] == "CSLS"
+    assert abs(line["value"] - cfg["n_source_total"] * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) / line["value"] < 1e-6
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.2 < rf["frac"] < 0.7
+    assert abs(rf["achieved"] - rf["algorithmic_flop_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12) / rf["achieved"] < 1e-6
+    assert rf["avg_launch_ms"] < line["ms_per_step"]                      # the dominant kernel is inside the step
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "queries/s"
+    chk = line["check"]
+    assert chk["rows"] == 1024 and chk["index_rows_identical"] == 1024 and chk["recall_at_k"] == 1.0
+    assert line["certification_fallback_rows"] == 0 and line["rounding_bound_self_check"]["max_err_over_eps"] < 1.0
