@@ -238,6 +238,11 @@ int kz_hit_positions(kz_ctx* ctx, const int64_t* d_ind, const int64_t* d_gold, i
 /* float64 -> float32 cast of an [count] array (cosine + float32 inputs keep the reference's output dtype). */
 int kz_cast_f64_f32(kz_ctx* ctx, const double* d_in, float* d_out, int64_t count);
 
+/* Self-test hook (tests/test_gpu_fast_div.py): the shared-reciprocal division of the cosine re-rank (kz_div_shared, kz_common.h)
+ * against the plain float64 division on `count` pseudo-random pairs (numerator a float32 value, divisor a norm >= |a|; `mode`
+ * 1: numerators and divisors with all-ones / single-bit significands mixed in); *h_mismatch = pairs whose bits differ. */
+int kz_selftest_div(kz_ctx* ctx, int64_t count, uint64_t seed, int mode, int64_t* h_mismatch);
+
 #ifdef __cplusplus
 }
 #endif

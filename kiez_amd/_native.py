@@ -87,6 +87,7 @@ SYMBOLS = [
     ("kz_split_self", C.c_int, [_P, _P, _P, _I64, C.c_int, _I64, _P, _P, _P, _P]),
     ("kz_knn_plan", C.c_int, [_I64, _I64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                               C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("kz_selftest_div", C.c_int, [_P, _I64, C.c_uint64, C.c_int, C.POINTER(_I64)]),
     ("kz_row_stats", C.c_int, [_P, _P, _I64, C.c_int, _P, _P, _P]),
     ("kz_csls", C.c_int, [_P, _P, _P, _I64, C.c_int, _P, _P]),
     ("kz_local_scaling", C.c_int, [_P, _P, _P, _I64, C.c_int, _P, C.c_int, _P]),

@@ -177,6 +177,36 @@ __global__ void kz_hit_positions_kernel(const int64_t* __restrict__ ind, const i
     atomicAdd(hist + pos, 1ull);
 }
 
+// ---- self-test of kz_div_shared (kz_common.h): pseudo-random pairs, the bits of the shared-reciprocal quotient against a / b ----
+__device__ __forceinline__ unsigned long long kz_mix64(unsigned long long z) {   // (splitmix64 finaliser)
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ void kz_selftest_div_kernel(long long count, unsigned long long seed, int mode, unsigned long long* __restrict__ bad) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n_bad = 0;
+    for (long long i = i0; i < count; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long r0 = kz_mix64(seed + 2ull * (unsigned long long)i), r1 = kz_mix64(seed + 2ull * (unsigned long long)i + 1ull);
+        // numerator: a float32 value with a random significand, magnitude 2^-40 .. 2^20, either sign (mode 1: every 4th one has an
+        // all-ones or a single-bit significand)
+        unsigned man = (unsigned)(r0 & 0x7fffffu);
+        if (mode == 1 && ((r0 >> 23) & 3u) == 0u) man = ((r0 >> 25) & 1u) ? 0x7fffffu : (1u << ((r0 >> 26) % 23u));
+        const unsigned ex = 127u - 40u + (unsigned)((r0 >> 32) % 61u);
+        const float af = __uint_as_float((unsigned)((r0 >> 63) << 31) | (ex << 23) | man);
+        const double a = (double)af;
+        // divisor: |a| times a factor in [1, 2^12) with a random 52-bit significand (a row norm is at least every element)
+        unsigned long long bman = r1 & 0xfffffffffffffull;
+        if (mode == 1 && ((r1 >> 52) & 3u) == 0u) bman = ((r1 >> 54) & 1u) ? 0xfffffffffffffull : (1ull << ((r1 >> 55) % 52u));
+        const double f = __longlong_as_double((long long)(((1023ull + ((r1 >> 58) % 12ull)) << 52) | bman));
+        const double b = fabs(a) * f;
+        const double rcp = 1.0 / b;
+        const double q = kz_div_shared(a, b, rcp), ref = a / b;
+        n_bad += (__double_as_longlong(q) != __double_as_longlong(ref)) ? 1ull : 0ull;
+    }
+    if (n_bad) atomicAdd(bad, n_bad);
+}
+
 extern "C" {
 
 int kz_hit_positions(kz_ctx* ctx, const int64_t* d_ind, const int64_t* d_gold, int64_t n, int cols, int64_t* d_hist) {
@@ -288,6 +318,20 @@ int kz_kocc_select(kz_ctx* ctx, const int64_t* d_kocc, int64_t n, int mode, doub
     KZ_HIP(hipMemcpyAsync(&hc, dc, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
     KZ_HIP(hipStreamSynchronize(ctx->stream));
     *h_count = (int64_t)hc;
+    return KZ_OK;
+}
+
+int kz_selftest_div(kz_ctx* ctx, int64_t count, uint64_t seed, int mode, int64_t* h_mismatch) {
+    KZ_REQUIRE(ctx && h_mismatch && count >= 0 && (mode == 0 || mode == 1), "kz_selftest_div: bad argument");
+    KZ_HIP(hipSetDevice(ctx->device));
+    unsigned long long* dc = (unsigned long long*)(ctx->d_counters + 44);
+    KZ_HIP(hipMemsetAsync(dc, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(kz_selftest_div_kernel, dim3(ctx->n_cus * 8), dim3(256), 0, ctx->stream, (long long)count, (unsigned long long)seed, mode, dc);
+    KZ_HIP(hipGetLastError());
+    unsigned long long hc = 0;
+    KZ_HIP(hipMemcpyAsync(&hc, dc, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+    KZ_HIP(hipStreamSynchronize(ctx->stream));
+    *h_mismatch = (int64_t)hc;
     return KZ_OK;
 }
 

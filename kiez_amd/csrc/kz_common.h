@@ -45,12 +45,18 @@ struct kz_ctx {
     double dual_max_gb; // kz_knn_dual: transient footprint budget in GiB (0 = the built-in 32)
     int dual_force;   // test knob: run the dual pass also where it does not pay (few query rows)
     int h_q64;        // 64-queries-per-wave kernel (kz_knn_h64.h) for K' = 16 sweeps of 4 .. 13 slices: 2 (default) = where it pays (kz_knn_impl), 1 = always, 0 = never
+    int fin_fast_div; // finalize kernel, cosine: shared-reciprocal division (kz_div_shared)
+    int list_floor;   // kz_knn_dual: 1 = the forward lists of the shared sweep start at a population floor (kz_knn_dual.h "POPULATION FLOOR")
+    int floor_probe;  // ... rows of the probe behind it
+    double floor_margin;  // ... the largest shortfall of the probe below the model, times this
     int dual_rank;    // kz_knn_dual: rank of the sample key that becomes a row's event threshold (0 = automatic, -1 = k + 1, > 0 = that rank; kz_knn_dual.h)
     int tier_probe;   // rows of the strided sample a large ordinary search sends through the fp16 pass first (0 = off; default 4096): more than half uncertified -> the call starts at split-bf16
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)
     void* scratch;
     size_t scratch_bytes;
+    float* floor_buf;      // seeded lists of an ordinary search: one float per padded query row (kz_knn.hip "POPULATION FLOOR")
+    size_t floor_bytes;
     int* d_counters;  // small device int array (fail counter, flags)
     int* h_counters;  // pinned host mirror
     int n_cus;        // compute units of the device
@@ -161,6 +167,7 @@ void kz_set_error(const char* fmt, ...);
     } while (0)
 
 int kz_scratch(kz_ctx* ctx, size_t bytes, void** out);
+int kz_floor_buf(kz_ctx* ctx, size_t bytes, float** out);
 
 // ---------------------------------------------------------------------------------------------------
 // Canonical wave-cooperative float64 dot product.  Every exact distance in the library (row norms, the
@@ -211,6 +218,22 @@ __device__ __forceinline__ double kz_wave_dot(const T* __restrict__ a, const T* 
         for (int u = 0; u < 4; ++u) acc = fma(x[u], y[u], acc);
     }
     return kz_wave_sum(acc);
+}
+
+// a / b for MANY numerators over one divisor, bit for bit the IEEE quotient: rcp = 1.0 / b (correctly rounded, computed once),
+// q0 = RN(a rcp) is within 2 ulp of a / b; one residual step makes it faithful (q1 = RN(q0 + (a - b q0) rcp): the value before
+// the rounding is within 2^-51 ulp of a / b); for a faithful q1 the residual a - b q1 is exact and RN(q1 + (a - b q1) rcp) is
+// the correctly rounded quotient (Markstein, "Computation of elementary functions on the IBM RISC System/6000 processor", 1990,
+// theorem on the final step of a division with a correctly rounded reciprocal).  Five multiply-adds against the eleven
+// instructions (one of them a quarter-rate reciprocal) of the compiler's division.  Valid while nothing under- or overflows: here
+// a is a float32 value or 0 and b the row's norm >= |a| (or 1.0 for a zero row), so |a / b| <= 1 and the residuals stay far
+// above the subnormal range; the caller takes the plain division when rcp is not finite (b = 0).  tests/test_gpu_fast_div.py compares the two on
+// 2^30 pairs.
+__device__ __forceinline__ double kz_div_shared(double a, double b, double rcp) {
+    const double q0 = a * rcp;
+    const double q1 = fma(fma(-q0, b, a), rcp, q0);
+    const double q2 = fma(fma(-q1, b, a), rcp, q1);
+    return q2;
 }
 
 // cosine: sum_k (a_k / na) * (b_k / nb) with the per-element divisions scikit-learn's normalize() performs

@@ -10,6 +10,8 @@
 //                           distances, sort, strip the query itself (single-source mode), write [q, k].
 //   3. kz_exact_*           exact float64 brute force for the (rare) rows that could not be certified.
 // Result: neighbour order == order of the float64 distances the reference computes; no approximation.
+#include <vector>
+
 #include "kz_common.h"
 
 #include "kz_knn_device.h"
@@ -196,6 +198,7 @@ struct KnnFinParams {
     const int* in_idx;
     KzListLayout lay;     // list layout (kz_list_base)
     int max_m;            // largest entry count of a query in this launch (sizes the dynamic LDS)
+    int fast_div;         // cosine re-rank: y_k / |y| as kz_div_shared (one reciprocal per candidate row; same bits as the division)
     int64_t q_first, q_last;  // local query range [q_first, q_last) handled by this launch
     int KP;               // entries per list (per query and index range)
     int KSEL;             // candidates the finalize kernel selects from a query's lists and re-ranks (0: = KP).  Larger than KP on the
@@ -225,6 +228,9 @@ struct KnnFinParams {
     // dual pass, reverse direction (kz_knn_dual.h): the list holds the K' best EVENTS of the row; rows outside the events
     // have an approximate key below excl_floor[q] (+inf: the row's events are incomplete, it must fail)
     const float* excl_floor;
+    // seeded lists (KnnCandParams::qfloor): [q_begin + q] the key the query's lists started from -- rows that never entered a list
+    // have an approximate key at or below it
+    const float* list_floor;
     int dual_col;
     const int* idx_map;   // dual pass, forward direction: list entry r stands for index row idx_map[r] (NULL: identity)
     const int* row_map;   // dual pass, forward direction: the query image is permuted too -- image row r is matrix row row_map[r];
@@ -385,7 +391,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     // Long-k route (KS > KP): the union of the per-range lists holds the KS best approximate keys only if no range
     // contributes more than its list can hold.  A FULL list may have evicted rows: everything outside it has a key <= its
     // smallest entry -- the largest such value over the full lists joins the certification bound below.
-    float piece_bound = -INFINITY;
+    float piece_bound = p.list_floor ? p.list_floor[p.q_begin + q] : -INFINITY;
     if (KS > KP) {
         for (int l0 = 0; l0 < M; l0 += KP) {   // (uniform; KP is a multiple of 16, lists are at most 128 entries)
             float mn = INFINITY;
@@ -596,8 +602,20 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                 double a = 0.0;
                 if (act) {
                     if (p.metric == KZ_COSINE) {
+                        bool done = false;
+                        if (p.fast_div) {
+                            const double rcp = 1.0 / ysb[u];   // (wave-uniform: every lane holds the same row norm)
+                            const int rcp_hi = __builtin_amdgcn_readfirstlane((int)((unsigned long long)__double_as_longlong(rcp) >> 32));
+                            if ((rcp_hi & 0x7ff00000) != 0x7ff00000) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e] / ysb[u], a);
+                                for (int e = 0; e < 4; ++e) a = fma(qk[e], kz_div_shared(yk[e], ysb[u], rcp), a);
+                                done = true;
+                            }
+                        }
+                        if (!done) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e] / ysb[u], a);
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e], a);
@@ -1021,6 +1039,7 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
         fp.q_last = hi > q_count ? q_count : hi;
         if (fp.q_last <= fp.q_first) continue;
         fp.max_m = lay.pieces[rg] * lay.halves * KP;
+        fp.fast_div = ctx->fin_fast_div;
         const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
         const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, fp.KSEL > 0 ? fp.KSEL : KP);
         const bool wide = (fp.KSEL > 0 ? fp.KSEL : KP) > 160;   // the long-k route
@@ -1103,6 +1122,98 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
     return KZ_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// POPULATION FLOOR (seeded lists).  A list that starts empty (threshold -inf) takes K' (1 + ln(n / K')) events per query over a
+// sweep, half of them in the first few tiles.  A strided probe of the query rows (an escalation-style sub-search: the tier
+// probe of an ordinary search, a probe of its own in kz_knn_dual; exact float64 results, written to their places) shows where
+// the k-th best key of a row lies as a function of |q_c|^2: least squares over the probe, the floor = the model minus the
+// largest shortfall seen (times "floor_margin").  Every list of the main sweep then STARTS at its row's floor
+// (KnnCandParams::qfloor), and the finalize kernel counts the floor into its bound on the rows outside the lists
+// (KnnFinParams::list_floor).  A row whose k-th key lies below its floor ends with fewer than k candidates, is not certified
+// and is searched again like any other uncertified row: the floor decides how many rows take that path, never a result.  Whatever
+// the data looks like, a row falls short of the largest shortfall among P probe rows with probability 1 / (P + 1) (the rows are
+// exchangeable): at most ~n / P rows of a call take the detour.
+// ---------------------------------------------------------------------------------------------------
+// probe row i = matrix row i * stride: (|q_c|^2, exact key of its k-th neighbour) from the probe's float64 distances.
+// key = (|q_c|^2 - d^2) / 2 with d^2 = the squared distance (cosine: 2 x distance, rows are unit vectors).
+__global__ void kz_floor_pairs_kernel(const double* __restrict__ dist, const double* __restrict__ rowq, int n_probe, int64_t stride, int k,
+                                      int metric, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_probe) return;
+    const int64_t r = (int64_t)i * stride;
+    const double v = dist[r * k + k - 1];
+    const double d2 = metric == KZ_EUCLIDEAN ? v * v : (metric == KZ_COSINE ? 2.0 * v : v);
+    const double x = rowq[r * 3];
+    out[2 * i] = x;
+    out[2 * i + 1] = 0.5 * (x - d2);
+}
+// floor of list row p (matrix row row_map[p]) in the units of the sweep's approximate keys: the model's key minus the
+// margin, minus the rounding bound of this row's approximate keys (the finalize kernel's eps_q), scaled and rounded down.
+// Pad rows: +inf (no events at all).
+__global__ void kz_floor_rows_kernel(const int* __restrict__ row_map, int64_t n, int64_t n_pad, const double* __restrict__ rowq,
+                                     const double* __restrict__ y_hmax, const double* __restrict__ hscale, double alpha, double beta,
+                                     double margin, double eps_mult, double gamma_acc, float* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pad) return;
+    const int64_t r = row_map ? (int64_t)row_map[p] : (p < n ? p : -1);   // (no map: the rows in their own order)
+    if (r < 0) {
+        out[p] = INFINITY;
+        return;
+    }
+    const double qc2 = rowq[r * 3 + 0], qh = rowq[r * 3 + 1], qr = rowq[r * 3 + 2];
+    const double Yh = y_hmax[0], Ry = y_hmax[1], Yc2 = y_hmax[2];
+    const double qc = sqrt(qc2), yc = sqrt(Yc2);
+    const double eps = eps_mult * (qr * Yh + qh * Ry + qr * Ry + gamma_acc * (0.5 * Yc2 + qh * Yh) +
+                                   1.1920928955078125e-07 * (qc + yc) * (qc + yc) + 1e-12 * (0.5 * Yc2 + qc2));
+    const double f = (alpha + beta * qc2 - margin - eps) / hscale[1];
+    float ff = (float)f;
+    if ((double)ff > f) ff = nextafterf(ff, -INFINITY);
+    out[p] = ff;
+}
+
+static inline double kz_gamma_acc_h(int kg) { return 2.0 * (double)(kg * 4 + 16) * 5.9604644775390625e-08; }
+// model = {alpha, beta, margin}; *ok = false when the probe's values are not finite (no floor then).  `dist`: [.., k] results whose
+// row i * stride is probe row i; rowq: the query image's per-row statistics, same row numbering.  Waits for the stream.
+static int kz_floor_model(kz_ctx* ctx, const double* dist, const double* rowq, int n_probe, int64_t stride, int k, int metric, double* model,
+                          bool* ok) {
+    double* d_pairs = nullptr;
+    int rc = kz_pool_alloc(ctx, (size_t)n_probe * 16, (void**)&d_pairs);
+    if (rc != KZ_OK) return rc;
+    std::vector<double> hp((size_t)n_probe * 2);
+    hipLaunchKernelGGL(kz_floor_pairs_kernel, dim3((unsigned)((n_probe + 255) / 256)), dim3(256), 0, ctx->stream, dist, rowq, n_probe, stride, k,
+                       metric, d_pairs);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(hp.data(), d_pairs, (size_t)n_probe * 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    kz_pool_free(ctx, d_pairs, 0);
+    if (e != hipSuccess) {
+        kz_set_error("kz_knn: floor probe failed: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    double sx = 0, sy = 0;
+    for (int i = 0; i < n_probe; ++i) {
+        sx += hp[2 * i];
+        sy += hp[2 * i + 1];
+    }
+    const double mx = sx / n_probe, my = sy / n_probe;
+    double sxx = 0, sxy = 0;
+    for (int i = 0; i < n_probe; ++i) {
+        sxx += (hp[2 * i] - mx) * (hp[2 * i] - mx);
+        sxy += (hp[2 * i] - mx) * (hp[2 * i + 1] - my);
+    }
+    const double beta = sxx > 0 ? sxy / sxx : 0.0, alpha = my - beta * mx;
+    double short_max = 0;
+    for (int i = 0; i < n_probe; ++i) {
+        const double r = alpha + beta * hp[2 * i] - hp[2 * i + 1];   // the model above the row's k-th key by r
+        if (r > short_max) short_max = r;
+    }
+    model[0] = alpha;
+    model[1] = beta;
+    model[2] = short_max * ctx->floor_margin;
+    *ok = (alpha - alpha == 0.0) && (beta - beta == 0.0) && (model[2] - model[2] == 0.0);
+    return KZ_OK;
+}
+
 // Escalation of uncertified rows: gather rows cq_begin + fail_list[0 .. n_fail) of `query` into a dense block, search it
 // again (kz_knn_impl with the given precision / minimum list length; that call sends ITS uncertified rows further down)
 // and scatter the results into out_dist / out_ind at the rows' positions.  Ends with a stream synchronisation.
@@ -1115,6 +1226,7 @@ struct KzDualPass {
     const int* perm;               // [index rows] matrix row of image row r: list entries are translated by the finalize kernel
     const float* theta;            // [index tiles * 128] per row of the sorted image: the smallest threshold of its tile
     const float* qnbias;           // [query tiles * 128]
+    const float* qfloor;           // [query tiles * 128] or nullptr: seeded forward lists (kz_knn_dual.h "population floor")
     void* log_keys;
     void* log_meta;
     unsigned long long* log_cnt;   // device counter
@@ -1287,7 +1399,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // truncating internal adds (the operand rounding is measured per row, kz_pack.hip).
     const double gamma_f32 = ((double)(index->kg * 4 + 16) * 5.9604644775390625e-08 + 1e-12) * ctx->eps_scale;
     const double gamma_bf = kz_bf16_gamma(index->kg_bf * 4) * ctx->eps_scale;
-    const double gamma_acc_h = 2.0 * (double)(index->kg * 4 + 16) * 5.9604644775390625e-08;
+    const double gamma_acc_h = kz_gamma_acc_h(index->kg);
 
     // ---- tier of this call ------------------------------------------------------------------------------------------
     const int precision = precision_override >= 0 ? precision_override : ctx->precision;
@@ -1334,6 +1446,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // cannot be certified, the call starts at the split-bf16 tier.  The sample's results are written to their places (the main
     // pass writes the same values again).  Cost on data that is fine: ~1.4 % of a 300k-row sweep + ~0.3 ms; only top-level
     // searches of >= 5e10 distance pairs and >= 64k query rows take it (C1 / C2 do not).  Option "tier_probe" = 0: off.
+    float* qfloor_ord = nullptr;   // seeded lists of an ordinary search (the context's buffer: nothing to release)
     if (tier == KZ_TIER_H && !dual && precision_override < 0 && kp_min == 0 && !exact_only && ctx->tier_probe > 0 && ctx->esc_bf &&
         q_count >= (int64_t)16 * ctx->tier_probe && (double)q_count * (double)index->n >= 5e10 && ctx->chunk_rows == 0) {
         const int n_probe = ctx->tier_probe;
@@ -1355,6 +1468,21 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 KP = KP_long;
                 KSEL = KSEL_long;
                 long_pieces = pieces_long;
+            }
+        } else if (ctx->list_floor) {
+            // POPULATION FLOOR (above kz_escalate_rows): the probe's results are the model's input
+            double model[3];
+            bool ok = false;
+            rc = kz_floor_model(ctx, d_dist, query->himg->rowq + q_begin * 3, n_probe, q_count / n_probe, k, metric, model, &ok);
+            if (rc != KZ_OK) return rc;
+            const int64_t n_pad = (int64_t)query->n_tiles * KZ_TILE;
+            if (ok) rc = kz_floor_buf(ctx, (size_t)n_pad * 4, &qfloor_ord);
+            if (rc != KZ_OK) return rc;
+            if (qfloor_ord) {
+                hipLaunchKernelGGL(kz_floor_rows_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)nullptr, query->n,
+                                   n_pad, query->himg->rowq, index->himg->d_max, index->himg->center->d_scale, model[0], model[1], model[2],
+                                   ctx->eps_scale, gamma_acc_h, qfloor_ord);
+                KZ_HIP(hipGetLastError());
             }
         }
     }
@@ -1452,6 +1580,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         cp.kg = index->kg;
         cp.out_key = out_key;
         cp.out_idx = out_idx;
+        if (tier == KZ_TIER_H && !dual) cp.qfloor = qfloor_ord;
         KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         if (exact_only) {
             // every row of the chunk goes to the exact kernels: the "fail list" is 0 .. cq_count-1
@@ -1463,6 +1592,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             cp.ybias = dual->ybias;
             cp.theta = dual->theta;
             cp.qnbias = dual->qnbias;
+            cp.qfloor = dual->qfloor;
             cp.log_keys = dual->log_keys;
             cp.log_meta = dual->log_meta;
             cp.log_cnt = dual->log_cnt;
@@ -1521,9 +1651,11 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fp.out_dist = d_dist + c0 * (int64_t)k;
         fp.out_ind = d_ind + c0 * (int64_t)k;
         if (tier == KZ_TIER_H && short_ord) fp.idx_map = index->himg->dealt_perm;   // the lists hold rows of the dealt index image
+        if (tier == KZ_TIER_H && !dual) fp.list_floor = qfloor_ord;
         if (tier == KZ_TIER_H && dual) {
             fp.idx_map = dual->perm;      // the lists hold rows of the sorted index image
             fp.row_map = dual->row_map;   // the chunk is a range of IMAGE rows: results and failures go by matrix row
+            fp.list_floor = dual->qfloor;
             fp.out_dist = d_dist;
             fp.out_ind = d_ind;
         }

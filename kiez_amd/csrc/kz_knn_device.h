@@ -101,6 +101,10 @@ struct KnnCandParams {
     void* log_meta;                // [log_cap] x 8 B
     unsigned long long* log_cnt;
     long long log_cap;
+    // seeded lists (fp16 kernels): [query rows incl. padding, global row numbers] a list starts FULL of (qfloor, no row) entries
+    // instead of (-inf, no row): keys at or below the floor never become events.  The finalize kernel gets the same array
+    // (KnnFinParams::list_floor) and counts the floor into the bound on the rows outside the lists.  nullptr: -inf.
+    const float* qfloor;
 };
 
 constexpr int KZ_CAND_LDS_BASE = 16384 + 1024;  // 2 index slices + 2 bias rows

@@ -489,7 +489,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     const long long log_cap = (long long)((double)b->n * rank * stride * 1.5) + (1 << 20);
 
     unsigned short *s_packed = nullptr, *p_packed = nullptr, *q_packed = nullptr;
-    float *s_bias = nullptr, *p_bias = nullptr, *q_bias = nullptr, *q_key = nullptr, *q_key_s = nullptr, *theta = nullptr, *theta_s = nullptr, *theta_min = nullptr, *floor_ = nullptr, *qnb = nullptr, *col_key = nullptr;
+    float *s_bias = nullptr, *p_bias = nullptr, *q_bias = nullptr, *q_key = nullptr, *q_key_s = nullptr, *theta = nullptr, *theta_s = nullptr, *theta_min = nullptr, *floor_ = nullptr, *qnb = nullptr, *col_key = nullptr, *qfloor = nullptr;
     int *ev_cnt = nullptr, *col_idx = nullptr, *fail_list = nullptr, *iota = nullptr, *perm = nullptr, *q_iota = nullptr, *q_sorted = nullptr, *row_map = nullptr;
     uint2* ev = nullptr;
     void *log_keys = nullptr, *log_meta = nullptr;
@@ -513,6 +513,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         kz_pool_free(ctx, theta, 0);
         kz_pool_free(ctx, floor_, 0);
         kz_pool_free(ctx, qnb, 0);
+        kz_pool_free(ctx, qfloor, 0);
         kz_pool_free(ctx, col_key, 0);
         kz_pool_free(ctx, ev_cnt, 0);
         kz_pool_free(ctx, col_idx, 0);
@@ -572,6 +573,35 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         }                     \
     } while (0)
 
+    // ---- POPULATION FLOOR of the forward lists (kz_knn.hip "POPULATION FLOOR"): a strided probe of A's rows -- an escalation-style
+    // sub-search, exact float64 results written to their places -- gives the model; the floors are filled in once the dealt
+    // order of A's rows (row_map) exists.
+    double floor_model[3] = {0, 0, 0};
+    bool have_floor = false;
+    if (ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe) {
+        const int n_probe = ctx->floor_probe;
+        const int64_t pstride = a->n / n_probe;
+        int* plist = nullptr;
+        rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);
+        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&qfloor);
+        kz_knn_stats stp;
+        float pms = 0;
+        if (rc == KZ_OK) {
+            hipLaunchKernelGGL(kz_strided_rows_kernel, dim3((unsigned)((n_probe + 255) / 256)), dim3(256), 0, ctx->stream, plist, n_probe, pstride);
+            rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, 0, d_dist_ab, d_ind_ab, &stp, &pms);
+        }
+        kz_pool_free(ctx, plist, 0);
+        if (rc == KZ_OK) rc = kz_floor_model(ctx, d_dist_ab, ia->rowq, n_probe, pstride, k, a->metric, floor_model, &have_floor);
+        if (rc != KZ_OK) {
+            release();
+            return rc;
+        }
+        if (!have_floor) {
+            kz_pool_free(ctx, qfloor, 0);
+            qfloor = nullptr;
+        }
+    }
+
     // ---- sample sweep's lists.  The threshold is the rank-th best sample key, and the rank-th best of ANY set of distinct sample
     // rows is a valid (lower) threshold.  The sweep therefore never needs lists of K' entries: the sample is cut into `pieces`
     // parts with a list of 16 (32) each, 2 rank entries in all.  A part holds rank / pieces +- sqrt(rank / pieces) of a row's rank
@@ -609,6 +639,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     KZ_DUAL_HIP(hipGetLastError());
     KZ_DUAL_RC(kz_himage_pack_permuted(a, row_map, q_packed, q_bias));
     hipLaunchKernelGGL(kz_dual_negbias_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_bias, a->n, a_pad, qnb);
+    if (qfloor) {
+        hipLaunchKernelGGL(kz_floor_rows_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, row_map, a->n, a_pad, ia->rowq,
+                           ib->d_max, ib->center->d_scale, floor_model[0], floor_model[1], floor_model[2], ctx->eps_scale,
+                           kz_gamma_acc_h(b->kg), qfloor);
+        KZ_DUAL_HIP(hipGetLastError());
+    }
 
     // ---- sample sweep: B x sample(A) with the ordinary kernel, lists of at most 256 entries per row -----------------------
     {
@@ -684,6 +720,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     dp.perm = perm;
     dp.theta = theta_min;
     dp.qnbias = qnb;
+    dp.qfloor = qfloor;
     dp.log_keys = log_keys;
     dp.log_meta = log_meta;
     dp.log_cnt = d_cnt;

@@ -149,9 +149,9 @@ struct KzBlockMin3 {
     static constexpr int NB = KP >= 64 ? 8 : 4;
     static constexpr int BS = KP / NB;
     float bm[NB];
-    __device__ __forceinline__ void init() {
+    __device__ __forceinline__ void init(const float v) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) bm[i] = -INFINITY;
+        for (int i = 0; i < NB; ++i) bm[i] = v;
     }
 };
 

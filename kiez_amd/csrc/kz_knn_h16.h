@@ -136,10 +136,12 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     KzWavePool pool;
     pool.keys = (__attribute__((address_space(3))) f32x4e*)(smem + Cfg::POOLK_OFF) + wave * CAP;
     pool.meta = (__attribute__((address_space(3))) i32x2e*)(smem + Cfg::POOLM_OFF) + wave * CAP;
+    // (seeded lists: KnnCandParams::qfloor)
+    const float fl = p.qfloor ? p.qfloor[(int64_t)(p.qt0 + qt) * KZ_TILE + 32 * wq_v + j] : -INFINITY;
     if (h == 0 && valid) {  // the list belongs to the query: lane-half 0 owns it (kz_merge_logs3)
 #pragma unroll 4
         for (int e = 0; e < KP; ++e) {
-            st.list.kp()[e * KzListRef<IN_LDS>::KSTRIDE] = -INFINITY;
+            st.list.kp()[e * KzListRef<IN_LDS>::KSTRIDE] = fl;
             st.list.ip()[e * KzListRef<IN_LDS>::ISTRIDE] = -1;
         }
     }
@@ -154,9 +156,9 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
         }
         return;
     }
-    st.tau = valid ? -INFINITY : INFINITY;
+    st.tau = valid ? fl : INFINITY;
     KzBlockMin3<KP> bmin;
-    bmin.init();
+    bmin.init(fl);
     st.head = -1;
     pool.cnt = 0;
     pool.tiles_done = 0;

@@ -83,11 +83,14 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_h64_kernel(KnnCandParams p
     KzWavePool pool;
     pool.keys = (__attribute__((address_space(3))) f32x4e*)(smem + Cfg::POOLK_OFF) + wave * CAP;
     pool.meta = (__attribute__((address_space(3))) i32x2e*)(smem + Cfg::POOLM_OFF) + wave * CAP;
+    // (seeded lists: KnnCandParams::qfloor)
+    const int64_t frow = (int64_t)(p.qt0 + qt) * KZ_TILE + r0_v + j;
+    const float fl0 = p.qfloor ? p.qfloor[frow] : -INFINITY, fl1 = p.qfloor ? p.qfloor[frow + 32] : -INFINITY;
     if (h == 0 && valid) {
 #pragma unroll 4
         for (int e = 0; e < KP; ++e) {
-            st.list.kp()[e * 128] = -INFINITY;
-            st.list.kp()[e * 128 + 32] = -INFINITY;
+            st.list.kp()[e * 128] = fl0;
+            st.list.kp()[e * 128 + 32] = fl1;
             st.list.ip()[e * 128] = -1;
             st.list.ip()[e * 128 + 32] = -1;
         }
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void kz_knn_cand_h64_kernel(KnnCandParams p
         }
         return;
     }
-    st.tau[0] = st.tau[1] = valid ? -INFINITY : INFINITY;
+    st.tau[0] = valid ? fl0 : INFINITY;
+    st.tau[1] = valid ? fl1 : INFINITY;
     st.head[0] = st.head[1] = -1;
     pool.cnt = 0;
     pool.tiles_done = 0;

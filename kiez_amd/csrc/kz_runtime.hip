@@ -66,6 +66,10 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->h_q64 = 2;
     c->tier_probe = 4096;
     c->dual_rank = 0;
+    c->list_floor = 0;
+    c->fin_fast_div = 1;
+    c->floor_probe = 4096;
+    c->floor_margin = 1.3;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
         c->precision = (strcmp(pv, "fp32") == 0 || strcmp(pv, "1") == 0) ? 1 : ((strcmp(pv, "bf16") == 0 || strcmp(pv, "2") == 0) ? 2 : 0);
@@ -92,6 +96,7 @@ int kz_ctx_destroy(kz_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->floor_buf) (void)hipFree(c->floor_buf);
     for (int i = 0; i < c->pool_n; ++i) (void)hipFree(c->pool[i].ptr);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -111,6 +116,11 @@ int kz_ctx_trim(kz_ctx* c) {
     for (int i = 0; i < c->pool_n; ++i) (void)hipFree(c->pool[i].ptr);
     c->pool_n = 0;
     c->pool_bytes = 0;
+    if (c->floor_buf) {
+        (void)hipFree(c->floor_buf);
+        c->floor_buf = nullptr;
+        c->floor_bytes = 0;
+    }
     if (c->scratch) {
         (void)hipFree(c->scratch);
         c->scratch = nullptr;
@@ -193,6 +203,18 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "lds_pad") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
         c->lds_pad = (int)value;
+    } else if (strcmp(name, "fin_fast_div") == 0) {
+        KZ_REQUIRE(value == 0 || value == 1, "fin_fast_div must be 0 or 1");
+        c->fin_fast_div = (int)value;
+    } else if (strcmp(name, "list_floor") == 0) {
+        KZ_REQUIRE(value == 0 || value == 1, "list_floor must be 0 or 1");
+        c->list_floor = (int)value;
+    } else if (strcmp(name, "floor_probe") == 0) {
+        KZ_REQUIRE(value >= 0 && value <= 65536, "floor_probe must be in [0, 65536]");
+        c->floor_probe = (int)value;
+    } else if (strcmp(name, "floor_margin") == 0) {
+        KZ_REQUIRE(value >= 0 && value <= 1e6, "floor_margin must be in [0, 1e6]");
+        c->floor_margin = value;
     } else if (strcmp(name, "dual_rank") == 0) {
         KZ_REQUIRE(value >= -1 && value <= 128, "dual_rank must be -1 (k + 1), 0 (automatic) or in [1, 128]");
         c->dual_rank = (int)value;
@@ -345,6 +367,25 @@ void kz_pool_free(kz_ctx* c, void* ptr, size_t /*bytes*/) {
     }
     kz_sync_streams(c);
     (void)hipFree(ptr);
+}
+
+// the context's floor buffer (grown on demand, released with the context / kz_ctx_trim)
+int kz_floor_buf(kz_ctx* c, size_t bytes, float** out) {
+    if (bytes > c->floor_bytes) {
+        kz_sync_streams(c);
+        if (c->floor_buf) (void)hipFree(c->floor_buf);
+        c->floor_buf = nullptr;
+        c->floor_bytes = 0;
+        const size_t want = bytes + bytes / 4;
+        const hipError_t e = hipMalloc((void**)&c->floor_buf, want);
+        if (e != hipSuccess) {
+            kz_set_error("floor buffer allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+            return KZ_ERR_NOMEM;
+        }
+        c->floor_bytes = want;
+    }
+    *out = c->floor_buf;
+    return KZ_OK;
 }
 
 int kz_scratch(kz_ctx* c, size_t bytes, void** out) {

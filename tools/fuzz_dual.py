@@ -42,6 +42,9 @@ for case in range(n_cases):
     q64 = int(rng.integers(0, 3))             # 64-queries-per-wave kernel: 0 nowhere, 1 in the reference searches only, 2 in the shared sweep only
     if os.environ.get("KZ_FUZZ_Q64") is not None:
         q64 = int(os.environ["KZ_FUZZ_Q64"])
+    fl = (int(rng.integers(0, 2)), int(rng.choice([64, 256, 2048])), float(rng.choice([0.3, 1.3, 1.3, 3.0])))   # seeded lists: on / probe rows / margin
+    if os.environ.get("KZ_FUZZ_FLOOR") is not None:
+        fl = (int(os.environ["KZ_FUZZ_FLOOR"]),) + fl[1:]
     if only >= 0 and not (only_first <= case <= only):
         continue
     print(f"case {case}: na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} stride/chunk/deal/wide/overlap/short-min/short-sample/rev-long/extra/bf {opt}", flush=True)
@@ -50,6 +53,7 @@ for case in range(n_cases):
     ctx.set_option("dual_deal", opt[2])
     am, bm = N.DeviceMatrix(ctx, a, metric), N.DeviceMatrix(ctx, b, metric)
     ctx.set_option("dual_force", 0)
+    ctx.set_option("list_floor", 0)
     ctx.set_option("h_q64", 1 if q64 == 1 else 0)
     r1 = N.knn(ctx, am, bm, k); ctx.sync()
     if only >= 0: print("  a->b done", r1[2]["n_escalated_rows"], r1[2]["n_fallback_rows"], flush=True)
@@ -65,7 +69,11 @@ for case in range(n_cases):
     ctx.set_option("dual_short_extra", opt[8])
     ctx.set_option("esc_bf", opt[9])
     ctx.set_option("h_q64", 1 if q64 == 2 else 0)
+    ctx.set_option("list_floor", fl[0])
+    ctx.set_option("floor_probe", fl[1])
+    ctx.set_option("floor_margin", fl[2])
     (xd, xi, sa), (yd, yi, sb) = N.knn_dual(ctx, am, bm, k)
+    ctx.set_option("list_floor", 0)
     ctx.set_option("h_wide", 0)
     ctx.set_option("h_q64", 2)
     ok = (np.array_equal(r1[1].numpy(), xi.numpy()) and np.array_equal(r1[0].numpy(), xd.numpy())
@@ -94,9 +102,9 @@ for case in range(n_cases):
     if not ok or ratio >= 1.0:
         bad += 1
     print(("ok " if ok else "BAD"), f"na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} dual {sa['dual']}/{sb['dual']} "
-          f"q64 {q64} ev/row {sb['n_events'] / nb:.1f} esc {sa['n_escalated_rows']}/{sb['n_escalated_rows']} splits {sa['n_splits']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
+          f"q64 {q64} floor {fl} ev/row {sb['n_events'] / nb:.1f} esc {sa['n_escalated_rows']}/{sb['n_escalated_rows']} splits {sa['n_splits']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
 for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1), ("h_wide", 0), ("dual_overlap", 1),
-                ("dual_short_min_tiles", 128), ("short_ord_min_tiles", 48), ("dual_sample_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1)):
+                ("dual_short_min_tiles", 128), ("short_ord_min_tiles", 48), ("dual_sample_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1), ("list_floor", 1), ("floor_probe", 2048), ("floor_margin", 1.3)):
     ctx.set_option(name, v)
 print("cases", n_cases, "bad", bad)
 sys.exit(1 if bad else 0)
