@@ -573,35 +573,6 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         }                     \
     } while (0)
 
-    // ---- POPULATION FLOOR of the forward lists (kz_knn.hip "POPULATION FLOOR"): a strided probe of A's rows -- an escalation-style
-    // sub-search, exact float64 results written to their places -- gives the model; the floors are filled in once the dealt
-    // order of A's rows (row_map) exists.
-    double floor_model[3] = {0, 0, 0};
-    bool have_floor = false;
-    if (ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe) {
-        const int n_probe = ctx->floor_probe;
-        const int64_t pstride = a->n / n_probe;
-        int* plist = nullptr;
-        rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);
-        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&qfloor);
-        kz_knn_stats stp;
-        float pms = 0;
-        if (rc == KZ_OK) {
-            hipLaunchKernelGGL(kz_strided_rows_kernel, dim3((unsigned)((n_probe + 255) / 256)), dim3(256), 0, ctx->stream, plist, n_probe, pstride);
-            rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, 0, d_dist_ab, d_ind_ab, &stp, &pms);
-        }
-        kz_pool_free(ctx, plist, 0);
-        if (rc == KZ_OK) rc = kz_floor_model(ctx, d_dist_ab, ia->rowq, n_probe, pstride, k, a->metric, floor_model, &have_floor);
-        if (rc != KZ_OK) {
-            release();
-            return rc;
-        }
-        if (!have_floor) {
-            kz_pool_free(ctx, qfloor, 0);
-            qfloor = nullptr;
-        }
-    }
-
     // ---- sample sweep's lists.  The threshold is the rank-th best sample key, and the rank-th best of ANY set of distinct sample
     // rows is a valid (lower) threshold.  The sweep therefore never needs lists of K' entries: the sample is cut into `pieces`
     // parts with a list of 16 (32) each, 2 rank entries in all.  A part holds rank / pieces +- sqrt(rank / pieces) of a row's rank
@@ -639,12 +610,6 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     KZ_DUAL_HIP(hipGetLastError());
     KZ_DUAL_RC(kz_himage_pack_permuted(a, row_map, q_packed, q_bias));
     hipLaunchKernelGGL(kz_dual_negbias_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_bias, a->n, a_pad, qnb);
-    if (qfloor) {
-        hipLaunchKernelGGL(kz_floor_rows_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, row_map, a->n, a_pad, ia->rowq,
-                           ib->d_max, ib->center->d_scale, floor_model[0], floor_model[1], floor_model[2], ctx->eps_scale,
-                           kz_gamma_acc_h(b->kg), qfloor);
-        KZ_DUAL_HIP(hipGetLastError());
-    }
 
     // ---- sample sweep: B x sample(A) with the ordinary kernel, lists of at most 256 entries per row -----------------------
     {
@@ -709,6 +674,41 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     KZ_DUAL_RC(kz_himage_pack_permuted(b, perm, p_packed, p_bias));
     KZ_DUAL_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     float sample_ms = 0;
+    // ---- POPULATION FLOOR of the forward lists (kz_knn.hip "POPULATION FLOOR"): a strided probe of A's rows -- an escalation-style
+    // sub-search, exact float64 results written to their places -- gives the model.  It runs HERE, behind the enqueued sample sweep and sorts: the host
+    // side of the probe (allocations, its work table, the waits for its counters) passes while the GPU works those off.
+    double floor_model[3] = {0, 0, 0};
+    bool have_floor = false;
+    if (ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe) {
+        const int n_probe = ctx->floor_probe;
+        const int64_t pstride = a->n / n_probe;
+        int* plist = nullptr;
+        rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);
+        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&qfloor);
+        kz_knn_stats stp;
+        float pms = 0;
+        if (rc == KZ_OK) {
+            hipLaunchKernelGGL(kz_strided_rows_kernel, dim3((unsigned)((n_probe + 255) / 256)), dim3(256), 0, ctx->stream, plist, n_probe, pstride);
+            rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, 0, d_dist_ab, d_ind_ab, &stp, &pms);
+        }
+        kz_pool_free(ctx, plist, 0);
+        if (rc == KZ_OK) rc = kz_floor_model(ctx, d_dist_ab, ia->rowq, n_probe, pstride, k, a->metric, floor_model, &have_floor);
+        if (rc != KZ_OK) {
+            release();
+            return rc;
+        }
+        if (!have_floor) {
+            kz_pool_free(ctx, qfloor, 0);
+            qfloor = nullptr;
+        }
+    }
+
+    if (qfloor) {
+        hipLaunchKernelGGL(kz_floor_rows_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, row_map, a->n, a_pad, ia->rowq,
+                           ib->d_max, ib->center->d_scale, floor_model[0], floor_model[1], floor_model[2], ctx->eps_scale,
+                           kz_gamma_acc_h(b->kg), qfloor);
+        KZ_DUAL_HIP(hipGetLastError());
+    }
 
     // ---- main sweep: A x B, lists of A's rows + event log of B's rows ---------------------------------------------------------
     KzDualPass dp;

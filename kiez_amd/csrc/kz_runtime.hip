@@ -66,9 +66,9 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->h_q64 = 2;
     c->tier_probe = 4096;
     c->dual_rank = 0;
-    c->list_floor = 0;
+    c->list_floor = 1;
     c->fin_fast_div = 1;
-    c->floor_probe = 4096;
+    c->floor_probe = 1024;
     c->floor_margin = 1.3;
     c->precision = 0;
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16

@@ -104,7 +104,7 @@ for case in range(n_cases):
     print(("ok " if ok else "BAD"), f"na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} dual {sa['dual']}/{sb['dual']} "
           f"q64 {q64} floor {fl} ev/row {sb['n_events'] / nb:.1f} esc {sa['n_escalated_rows']}/{sb['n_escalated_rows']} splits {sa['n_splits']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
 for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1), ("h_wide", 0), ("dual_overlap", 1),
-                ("dual_short_min_tiles", 128), ("short_ord_min_tiles", 48), ("dual_sample_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1), ("list_floor", 1), ("floor_probe", 2048), ("floor_margin", 1.3)):
+                ("dual_short_min_tiles", 128), ("short_ord_min_tiles", 48), ("dual_sample_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1), ("list_floor", 1), ("floor_probe", 1024), ("floor_margin", 1.3)):
     ctx.set_option(name, v)
 print("cases", n_cases, "bad", bad)
 sys.exit(1 if bad else 0)
