@@ -1550,8 +1550,20 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         // ---- schedule: which workgroup sweeps which (query tile, index-tile range): kz_prepare_pass above --------------
         KzPass ps;
         // (long-k route: exactly long_pieces index ranges per query tile, one round)
+        int force_pieces = (tier == KZ_TIER_F32 && long_pieces > 8) ? 8 : long_pieces;
+        if (tier == KZ_TIER_H && short_ord && force_pieces > 0) {
+            // a SMALL launch on the short-list route (a re-search of a few hundred uncertified rows, a probe): P ranges per query
+            // tile leave most of the chip idle (216 rows x 10 ranges: 20 workgroups sweeping 390 tiles each, 1.98 ms) -- every
+            // range is cut further, s P lists of 16 per query (the finalize kernel selects from any number of lists), as long as
+            // a piece keeps at least 8 tiles and a query at most 64 lists
+            const int units = (n_qtiles + tpw_h - 1) / tpw_h;
+            int sub = slots / (units * force_pieces);
+            if (sub > KZ_MAX_PIECES / force_pieces) sub = KZ_MAX_PIECES / force_pieces;
+            if (sub > n_ytiles / (8 * force_pieces)) sub = n_ytiles / (8 * force_pieces);
+            if (sub > 1 && 4 * kz_fin_wave_bytes(force_pieces * sub * 16, KSEL) <= 160 * 1024) force_pieces *= sub;
+        }
         int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1), KP, tier, cq_count, &ps,
-                                 tier == KZ_TIER_H ? tpw_h : 1, (tier == KZ_TIER_F32 && long_pieces > 8) ? 8 : long_pieces, min_pieces_call);
+                                 tier == KZ_TIER_H ? tpw_h : 1, force_pieces, min_pieces_call);
         if (rc != KZ_OK) return rc;
         const KzListLayout& lay = ps.lay;
         const int W = ps.W;
