@@ -578,6 +578,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         // as the generic loop below (and as kz_wave_dot), only the memory latency of group g+1 hides under the sums of group g
         const int k0 = 4 * lane;
         const bool act = k0 < p.d;
+        const int k0r = act ? k0 : 0;
         double qk[4] = {0.0, 0.0, 0.0, 0.0};
         if (act) {
             kz_row4(qptr, k0, p.d, true, qk);
@@ -589,10 +590,14 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         auto issue = [&](int c0, float4 (&buf)[FROWS], double (&ysb)[FROWS]) {
 #pragma unroll
             for (int u = 0; u < FROWS; ++u) {
+                // (no branch around a load, and no load under a condition: with loads on some paths only the compiler waits for
+                //  ALL outstanding loads -- s_waitcnt vmcnt(0), the group just issued included -- before the first use of the
+                //  current group, and the prefetch hides nothing (the loop ran at latency + arithmetic per candidate).  Lanes
+                //  past the end of the row read its first elements and never use them; the group past the last one is the last
+                //  candidate again.)
                 const int yi = ci[min(c0 + u, Vr - 1)];
                 ysb[u] = p.ysqn[yi];
-                buf[u] = act ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(yraw) + (int64_t)yi * p.d + k0)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                buf[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(yraw) + (int64_t)yi * p.d + k0r);
             }
         };
         auto reduce = [&](int c0, const float4 (&buf)[FROWS], const double (&ysb)[FROWS]) {
@@ -638,15 +643,15 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         float4 b0[R], b1[R], b2[R];
         double y0[R], y1[R], y2[R];
         issue(0, b0, y0);
-        if (R < Vr) issue(R, b1, y1);
+        issue(R, b1, y1);
         for (int c0 = 0;;) {   // (all conditions wave-uniform)
-            if (c0 + 2 * R < Vr) issue(c0 + 2 * R, b2, y2);
+            issue(c0 + 2 * R, b2, y2);
             reduce(c0, b0, y0);
             if ((c0 += R) >= Vr) break;
-            if (c0 + 2 * R < Vr) issue(c0 + 2 * R, b0, y0);
+            issue(c0 + 2 * R, b0, y0);
             reduce(c0, b1, y1);
             if ((c0 += R) >= Vr) break;
-            if (c0 + 2 * R < Vr) issue(c0 + 2 * R, b1, y1);
+            issue(c0 + 2 * R, b1, y1);
             reduce(c0, b2, y2);
             if ((c0 += R) >= Vr) break;
         }
@@ -654,17 +659,12 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         float4 cur[FROWS], nxt[FROWS];
         double ys_c[FROWS], ys_n[FROWS];
         issue(0, cur, ys_c);
-        for (int c0 = 0; c0 < Vr; c0 += FROWS) {
-            const bool more = c0 + FROWS < Vr;   // wave-uniform
-            if (more) issue(c0 + FROWS, nxt, ys_n);
+        for (int c0 = 0; c0 < Vr; c0 += 2 * FROWS) {   // (unrolled by two: the buffers swap roles, no copies)
+            issue(c0 + FROWS, nxt, ys_n);
             reduce(c0, cur, ys_c);
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < FROWS; ++u) {
-                    cur[u] = nxt[u];
-                    ys_c[u] = ys_n[u];
-                }
-            }
+            if (c0 + FROWS >= Vr) break;
+            issue(c0 + 2 * FROWS, cur, ys_c);
+            reduce(c0 + FROWS, nxt, ys_n);
         }
 #endif
     } else
