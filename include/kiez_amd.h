@@ -99,7 +99,12 @@ int kz_ctx_trim(kz_ctx* ctx);
  * distance pairs) sends through the fp16 pass first -- more than half of them uncertified and the call starts at the split-bf16
  * operands instead of paying for a whole fp16 sweep (default 4096, 0 = off); "dual_rank": rank of the sample key that becomes a
  * row's event threshold in kz_knn_dual (0 = automatic: the cheapest rank that leaves fewer than 1e-3 of the rows short of k
- * events -- those are searched again; -1 = the safe k + 1; > 0 = that rank).  Every route gives identical results. */
+ * events -- those are searched again; -1 = the safe k + 1; > 0 = that rank); "list_floor": 1 (default) = the candidate lists of a
+ * large sweep start at a per-row floor modelled on a probe of the query rows ("floor_probe" rows of a in kz_knn_dual, default 1024;
+ * the tier probe's rows in an ordinary search) instead of at -inf: keys at or below the floor never become list events, rows left
+ * with fewer than k candidates are searched again ("floor_margin", default 1.3, scales the model's safety margin; 0 = none);
+ * "fin_fast_div": 1 (default) = the cosine re-rank divides through one reciprocal per candidate row (bit-identical to the
+ * division).  Every route gives identical results. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 
 int kz_malloc(kz_ctx* ctx, size_t bytes, void** d_ptr);

@@ -46,6 +46,7 @@ struct kz_ctx {
     int dual_force;   // test knob: run the dual pass also where it does not pay (few query rows)
     int h_q64;        // 64-queries-per-wave kernel (kz_knn_h64.h) for K' = 16 sweeps of 4 .. 13 slices: 2 (default) = where it pays (kz_knn_impl), 1 = always, 0 = never
     int fin_fast_div; // finalize kernel, cosine: shared-reciprocal division (kz_div_shared)
+    double probe_min_pairs;  // ordinary searches below this many distance pairs take neither the tier probe nor a floor (5e10)
     int list_floor;   // kz_knn_dual: 1 = the forward lists of the shared sweep start at a population floor (kz_knn_dual.h "POPULATION FLOOR")
     int floor_probe;  // ... rows of the probe behind it
     double floor_margin;  // ... the largest shortfall of the probe below the model, times this

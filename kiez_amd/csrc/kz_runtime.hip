@@ -66,6 +66,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->h_q64 = 2;
     c->tier_probe = 4096;
     c->dual_rank = 0;
+    c->probe_min_pairs = 5e10;
     c->list_floor = 1;
     c->fin_fast_div = 1;
     c->floor_probe = 1024;
@@ -206,6 +207,9 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "fin_fast_div") == 0) {
         KZ_REQUIRE(value == 0 || value == 1, "fin_fast_div must be 0 or 1");
         c->fin_fast_div = (int)value;
+    } else if (strcmp(name, "probe_min_pairs") == 0) {
+        KZ_REQUIRE(value >= 0, "probe_min_pairs must be >= 0");
+        c->probe_min_pairs = value;
     } else if (strcmp(name, "list_floor") == 0) {
         KZ_REQUIRE(value == 0 || value == 1, "list_floor must be 0 or 1");
         c->list_floor = (int)value;
