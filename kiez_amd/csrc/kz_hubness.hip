@@ -157,47 +157,58 @@ __global__ void kz_mp_normal_kernel(const double* __restrict__ dist, const int64
 //   out[i,j] = 1 - #{m : d[i,m] > d[i,j] and T_j[m] > d[i,j]} / K
 //   T_j[m]   = dist_t2s[c_j, p] if ind_t2s[c_j, p] == c_m (c_m is a TARGET id matched against SOURCE ids: the
 //              reference's behaviour) else dist_t2s[c_j, Kt-1] + 1e-6
-// The K candidate ids of the query are rank-sorted once into LDS; for every j the Kt reverse-list ids of c_j are
-// looked up by binary search (K log K instead of K^2 id compares per j) and scattered into T.
+// The K candidate ids of the query go into a hash table in LDS once; for every j the Kt reverse-list ids of c_j are looked
+// up in it (K Kt probes instead of K^2 Kt id compares) and their distances scattered into T.
 constexpr int KZ_MP_MAXK = 128;
 
 __global__ __launch_bounds__(256) void kz_mp_empiric_kernel(const double* __restrict__ dist, const int64_t* __restrict__ ind,
                                                             int64_t n, int K, const double* __restrict__ dist_t2s,
                                                             const int64_t* __restrict__ ind_t2s, int64_t n_t, int Kt,
                                                             double* __restrict__ out) {
-    __shared__ long long s_sorted[4][KZ_MP_MAXK];  // candidate ids in ascending order
-    __shared__ double s_T[4][KZ_MP_MAXK];          // T_j indexed by SORTED candidate position
+    __shared__ long long s_cand[4][KZ_MP_MAXK];   // candidate ids, by candidate
+    __shared__ int s_tab[4][2 * KZ_MP_MAXK];      // open-addressing hash table over them: slot -> candidate, -1 = empty
+    __shared__ double s_T[4][KZ_MP_MAXK];         // T_j, by candidate
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     if (i >= n) return;  // whole wave; only wave-level synchronisation below
     const double* d_i = dist + i * (int64_t)K;
     const int64_t* c_i = ind + i * (int64_t)K;
-    long long* sorted = s_sorted[wave];
+    long long* cand = s_cand[wave];
+    int* tab = s_tab[wave];
     double* T = s_T[wave];
-    // this lane's candidates m = lane, lane + 64: distance, id, rank of the id among the K ids
+    constexpr unsigned HMASK = 2 * KZ_MP_MAXK - 1;
+    auto slot_of = [](const long long id) {
+        return (((unsigned)(unsigned long long)id ^ (unsigned)((unsigned long long)id >> 32)) * 0x9E3779B1u) >> 24;   // (8 bits: 256 slots)
+    };
+    static_assert(2 * KZ_MP_MAXK == 256, "slot_of keeps 8 bits");
+    // this lane's candidates m = lane, lane + 64: distance and id
     double dm[2] = {0.0, 0.0};
     long long cm[2] = {0, 0};
-    int rk[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int m = lane + 64 * u;
         if (m < K) {
             dm[u] = d_i[m];
             cm[u] = c_i[m];
+            cand[m] = cm[u];
         }
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tab[lane + 64 * t] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // The candidate ids go into a hash table (at most 128 keys in 256 slots, linear probing): a look-up is one or two probes
+    // instead of the log2 K steps of a binary search over the sorted ids -- the kernel is bound by its instruction count (K
+    // look-ups of Kt ids per query), not by the lists it gathers (profiles/r04_ablation.md section 11) -- and nothing has to be
+    // sorted first (that was K dependent loads of c_i[o] per query).  (The ids of one kNN row are distinct.)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int m = lane + 64 * u;
         if (m < K) {
-            int r = 0;
-            for (int o = 0; o < K; ++o) {
-                const long long co = c_i[o];
-                r += (co < cm[u] || (co == cm[u] && o < m)) ? 1 : 0;
-            }
-            rk[u] = r;
-            sorted[r] = cm[u];
+            unsigned h = slot_of(cm[u]);
+            while (atomicCAS(&tab[h], -1, m) != -1) h = (h + 1) & HMASK;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -229,33 +240,31 @@ __global__ __launch_bounds__(256) void kz_mp_empiric_kernel(const double* __rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // every reverse-list entry p looks its id up among the sorted candidate ids
+        // every reverse-list entry p looks its id up among the candidate ids
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int pp = lane + 64 * u;
             if (pp >= Kt) continue;
             const long long id = idc[u];
-            int lo = 0, hi = K - 1, pos = -1;
-            while (lo <= hi) {
-                const int mid = (lo + hi) >> 1;
-                const long long v = sorted[mid];
-                if (v == id) {
-                    pos = mid;
+            unsigned h = slot_of(id);
+            int pos = -1;
+            for (;;) {
+                const int m = tab[h];
+                if (m < 0) break;
+                if (cand[m] == id) {
+                    pos = m;
                     break;
                 }
-                if (v < id) lo = mid + 1; else hi = mid - 1;
+                h = (h + 1) & HMASK;
             }
             if (pos >= 0) T[pos] = rd[pp];  // ids inside one kNN row are distinct: at most one writer per position
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int cnt = 0;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (lane + 64 * u < K && dm[u] > dj && T[rk[u]] > dj) ++cnt;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        // (a count over the wave: two ballots, no cross-lane exchange through LDS)
+        const int cnt = (int)__popcll(__ballot(lane < K && dm[0] > dj && T[lane] > dj)) +
+                        (int)__popcll(__ballot(lane + 64 < K && dm[1] > dj && T[(lane + 64) & (KZ_MP_MAXK - 1)] > dj));
         if (lane == 0) out[i * (int64_t)K + j] = 1.0 - (double)cnt / (double)K;
         __builtin_amdgcn_wave_barrier();
     }
