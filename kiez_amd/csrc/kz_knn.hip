@@ -287,11 +287,15 @@ __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* si
 // depth 3 at 5 waves (4 spilled) 3.57 / 7.60; rows 1 depth 2 at 7 waves (70 VGPRs, no spill) 3.03 / 7.37; rows 1 depth 3 at 7
 // (6 spilled) 3.14 / 7.25; rows 4 depth 3 at 3 waves 4.96 / 9.59.  Waves in flight beat rows in flight per wave: the phases
 // around the gather loop (list load, rank select, rank sort) of one query hide under the gathers of the other waves' queries.
+// Round 4 (the loads of the loop issued without branches, so that the prefetch overlaps at all; the per-query values in scalar
+// registers: 71 -> 59 VGPRs), finalize time over 4 steps of C3 + 4 of ns, reverse chain not overlapped: rows 1 depth 2 at 8 waves
+// 69.2 ms; rows 2 depth 2 at 7 (70 VGPRs) 69.1; rows 1 depth 3 at 7 69.5; **rows 1 depth 3 at 8 (64 VGPRs, no spill) 67.4**; rows 2
+// depth 3 at 6 72.9.
 #ifndef KZ_FIN_ROWS_N
 #define KZ_FIN_ROWS_N 1
 #endif
 #ifndef KZ_FIN_DEPTH
-#define KZ_FIN_DEPTH 2
+#define KZ_FIN_DEPTH 3
 #endif
 constexpr int KZ_FIN_ROWS = KZ_FIN_ROWS_N;
 constexpr int KZ_FIN_MAXM = 4096;  // list entries per query: 4 waves x (4096*8 + 128*28) B = 142 KiB of LDS at most
@@ -359,6 +363,11 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     int* si = ci + KS;
     const int KP = p.KP;
     const int k_eff = p.k + (p.exclude_self ? 1 : 0);
+    // the query's own row and norm first: their latency passes under the list phase
+    const int64_t qrow = p.row_map ? (int64_t)p.row_map[p.q_begin + q] : p.q_begin + q;
+    const int64_t qout = p.row_map ? qrow : q;   // output row (row_map: out_dist / out_ind / fail_list are indexed by matrix rows)
+    const T* qptr = reinterpret_cast<const T*>(p.qraw) + qrow * (int64_t)p.d;
+    const double qs = p.qsqn[qrow];
 
     const int64_t lrow = p.list_row0 + q;
     const int n_pieces = p.lay.pieces[kz_list_region(lrow, p.lay)];
@@ -503,11 +512,6 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         V = nsel;
     }
     kz_wave_sync();
-
-    const int64_t qrow = p.row_map ? (int64_t)p.row_map[p.q_begin + q] : p.q_begin + q;
-    const int64_t qout = p.row_map ? qrow : q;   // output row (row_map: out_dist / out_ind / fail_list are indexed by matrix rows)
-    const T* qptr = reinterpret_cast<const T*>(p.qraw) + qrow * (int64_t)p.d;
-    const double qs = p.qsqn[qrow];
 
     // Rounding bound of this query's approximate keys and the exact key of a candidate from its exact value.
     //   float32 / split-bf16 operands: |key~ - key| <= gamma (|y|max^2 / 2 + |q| |y|max), key = (|q|^2 - d^2) / 2 (euclidean
@@ -790,7 +794,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 // cache lines of one wave-interleaved block) measured 2x SLOWER than 4: finalize is latency-bound and wants many workgroups.
 constexpr int KZ_FIN_QPB = 4;
 #ifndef KZ_FIN_WAVES
-#define KZ_FIN_WAVES 7  // minimum waves per SIMD the finalize kernel is compiled for (see KZ_FIN_ROWS_N above; at 8 waves / 64 VGPRs it spills)
+#define KZ_FIN_WAVES 8  // minimum waves per SIMD the finalize kernel is compiled for (see KZ_FIN_ROWS_N above)
 #endif
 // FROWS / MINW: candidate rows gathered per group and the occupancy compiled for.  <1, KZ_FIN_WAVES> is the kernel of every
 // ordinary pass (a dozen to ~50 gathered rows per query: waves in flight beat rows in flight per wave); <8, 2> serves the long-k
@@ -800,7 +804,9 @@ template <typename T, int FROWS, int MINW>
 __global__ __launch_bounds__(256, MINW) void kz_knn_finalize_kernel(KnnFinParams p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // (wave number in a scalar register: the query number, its matrix row and everything loaded per query -- norm, image statistics
+    //  -- are then scalar loads issued at the top of the query, not vector loads of one address by 64 lanes)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* wbase = fsm + (size_t)wave * kz_fin_wave_bytes(p.max_m, p.KSEL > 0 ? p.KSEL : p.KP);
     for (int rep = 0; rep < KZ_FIN_QPB / 4; ++rep) {
         const int64_t q = p.q_first + (int64_t)blockIdx.x * KZ_FIN_QPB + rep * 4 + wave;
