@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "kz_common.h"
+#include "kz_floor.h"
 
 #include "kz_knn_device.h"
 
@@ -1196,27 +1197,7 @@ static int kz_floor_model(kz_ctx* ctx, const double* dist, const double* rowq, i
         kz_set_error("kz_knn: floor probe failed: %s", hipGetErrorString(e));
         return KZ_ERR_HIP;
     }
-    double sx = 0, sy = 0;
-    for (int i = 0; i < n_probe; ++i) {
-        sx += hp[2 * i];
-        sy += hp[2 * i + 1];
-    }
-    const double mx = sx / n_probe, my = sy / n_probe;
-    double sxx = 0, sxy = 0;
-    for (int i = 0; i < n_probe; ++i) {
-        sxx += (hp[2 * i] - mx) * (hp[2 * i] - mx);
-        sxy += (hp[2 * i] - mx) * (hp[2 * i + 1] - my);
-    }
-    const double beta = sxx > 0 ? sxy / sxx : 0.0, alpha = my - beta * mx;
-    double short_max = 0;
-    for (int i = 0; i < n_probe; ++i) {
-        const double r = alpha + beta * hp[2 * i] - hp[2 * i + 1];   // the model above the row's k-th key by r
-        if (r > short_max) short_max = r;
-    }
-    model[0] = alpha;
-    model[1] = beta;
-    model[2] = short_max * ctx->floor_margin;
-    *ok = (alpha - alpha == 0.0) && (beta - beta == 0.0) && (model[2] - model[2] == 0.0);
+    *ok = kz_floor_fit(hp.data(), n_probe, ctx->floor_margin, model);
     return KZ_OK;
 }
 
