@@ -18,6 +18,7 @@ struct kz_ctx {
     hipStream_t stream;
     bool own_stream;
     hipEvent_t ev[12];   // [0..7] work on `stream`, [8..11] the reverse direction of kz_knn_dual on `stream2`
+    int stream2_busy;    // kz_knn_dual: the reverse chain is (or is about to be) on stream2 -- nobody else may queue behind it
     hipStream_t stream2; // second stream: kz_knn_dual runs the reverse direction's event chain beside the forward direction's finalize
     double eps_scale;
     int qgroup;            // query tiles per group of the work table (0 = automatic: 24, an XCD's worth of workgroups for the fp16 kernel)

@@ -1037,32 +1037,60 @@ constexpr int KZ_EXACT_MAX_K = 4096;   // neighbours per query on the exact-only
 // The finalize launches of one pass: one per list region (the dynamic LDS follows the region's entry count: occupancy of
 // the gather).  fp.q_first / q_last / max_m are filled here.
 static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout& lay, int KP, int64_t q_count, int dtype) {
+    // the launches of this pass: [first query, last query), entries per query
+    struct Group { int64_t lo, hi; int max_m; } groups[KZ_MAX_REGIONS];
+    int n_groups = 0;
     for (int rg = 0; rg < lay.n_regions; ++rg) {
         const int64_t lo = (int64_t)(rg > 0 ? lay.qt_end[rg - 1] : 0) * KZ_TILE - fp.list_row0;
         // (neighbouring regions with the same number of ranges -- forced ranges: all of them -- go out as ONE launch)
         while (rg + 1 < lay.n_regions && lay.pieces[rg + 1] == lay.pieces[rg]) ++rg;
         const int64_t hi = (int64_t)lay.qt_end[rg] * KZ_TILE - fp.list_row0;
-        fp.q_first = lo < 0 ? 0 : lo;
-        fp.q_last = hi > q_count ? q_count : hi;
-        if (fp.q_last <= fp.q_first) continue;
-        fp.max_m = lay.pieces[rg] * lay.halves * KP;
-        fp.fast_div = ctx->fin_fast_div;
-        const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
-        const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, fp.KSEL > 0 ? fp.KSEL : KP);
-        const bool wide = (fp.KSEL > 0 ? fp.KSEL : KP) > 160;   // the long-k route
-        const void* fk = dtype == KZ_F32 ? (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>)
-                                         : (wide ? (const void*)kz_knn_finalize_kernel<double, 4, 2> : (const void*)kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>);
-        if (fin_lds > 65536) KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
-        if (dtype == KZ_F32 && wide)
-            hipLaunchKernelGGL((kz_knn_finalize_kernel<float, 8, 2>), dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
-        else if (dtype == KZ_F32)
-            hipLaunchKernelGGL((kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>), dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
-        else if (wide)
-            hipLaunchKernelGGL((kz_knn_finalize_kernel<double, 4, 2>), dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
-        else
-            hipLaunchKernelGGL((kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>), dim3(fin_blocks), dim3(256), fin_lds, ctx->stream, fp);
+        Group g = {lo < 0 ? 0 : lo, hi > q_count ? q_count : hi, lay.pieces[rg] * lay.halves * KP};
+        if (g.hi > g.lo) groups[n_groups++] = g;
+    }
+    // The SMALL launches -- the last query tiles of a pass, swept in many short ranges so that they fill the chip: a few hundred
+    // queries with hundreds of list entries each, all latency (100k x 100k: 117 us after the 284 us of the main launch) -- go to
+    // the context's second stream and run BESIDE the large one (fork / join by events), unless that stream is busy with the
+    // reverse chain of a shared sweep or is the stream this call runs on.
+    const hipStream_t main_stream = ctx->stream;
+    const bool fork = n_groups >= 2 && ctx->stream2 && ctx->stream2 != main_stream && !ctx->stream2_busy;
+    int big = 0;
+    for (int g = 1; g < n_groups; ++g)
+        if (groups[g].hi - groups[g].lo > groups[big].hi - groups[big].lo) big = g;
+    if (fork) {
+        KZ_HIP(hipEventRecord(ctx->ev[7], main_stream));
+        KZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev[7], 0));
+    }
+    for (int pass = 0; pass < 2; ++pass) {   // (fork: the small launches first, on the second stream; then the large one)
+        for (int g = 0; g < n_groups; ++g) {
+            const bool side = fork && g != big;
+            if (fork ? (side != (pass == 0)) : pass == 1) continue;
+            const hipStream_t st = side ? ctx->stream2 : main_stream;
+            fp.q_first = groups[g].lo;
+            fp.q_last = groups[g].hi;
+            fp.max_m = groups[g].max_m;
+            fp.fast_div = ctx->fin_fast_div;
+            const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
+            const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, fp.KSEL > 0 ? fp.KSEL : KP);
+            const bool wide = (fp.KSEL > 0 ? fp.KSEL : KP) > 160;   // the long-k route
+            const void* fk = dtype == KZ_F32 ? (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>)
+                                             : (wide ? (const void*)kz_knn_finalize_kernel<double, 4, 2> : (const void*)kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>);
+            if (fin_lds > 65536) KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
+            if (dtype == KZ_F32 && wide)
+                hipLaunchKernelGGL((kz_knn_finalize_kernel<float, 8, 2>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
+            else if (dtype == KZ_F32)
+                hipLaunchKernelGGL((kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
+            else if (wide)
+                hipLaunchKernelGGL((kz_knn_finalize_kernel<double, 4, 2>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
+            else
+                hipLaunchKernelGGL((kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
+        }
     }
     KZ_HIP(hipGetLastError());
+    if (fork) {
+        KZ_HIP(hipEventRecord(ctx->ev[11], ctx->stream2));
+        KZ_HIP(hipStreamWaitEvent(main_stream, ctx->ev[11], 0));
+    }
     return KZ_OK;
 }
 

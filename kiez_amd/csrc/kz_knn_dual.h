@@ -813,6 +813,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         dp.post_user = &rv;
     }
     kz_knn_stats st_ab;
+    ctx->stream2_busy = 1;   // (from here to the synchronisation below the second stream belongs to the reverse chain)
     rc = kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, -1, 0, d_dist_ab, d_ind_ab, &st_ab, &dp);
     if (rc == KZ_OK && !ctx->dual_overlap && !dp.broken) {   // ("dual_overlap" = 0: the same chain, behind the forward direction)
         dp.post_called = 1;
@@ -821,6 +822,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // whatever happened on the first stream: the second one is done with the buffers before anything is released
     {
         const hipError_t e2 = hipStreamSynchronize(ctx->stream2);
+        ctx->stream2_busy = 0;
         if (rc == KZ_OK && e2 != hipSuccess) {
             kz_set_error("kz_knn_dual: second stream failed: %s", hipGetErrorString(e2));
             rc = KZ_ERR_HIP;
