@@ -102,7 +102,8 @@ int kz_ctx_trim(kz_ctx* ctx);
  * events -- those are searched again; -1 = the safe k + 1; > 0 = that rank); "list_floor": 1 (default) = the candidate lists of a
  * large sweep start at a per-row floor modelled on a probe of the query rows ("floor_probe" rows of a in kz_knn_dual, default 1024;
  * the tier probe's rows in an ordinary search) instead of at -inf: keys at or below the floor never become list events, rows left
- * with fewer than k candidates are searched again ("floor_margin", default 1.3, scales the model's safety margin; 0 = none);
+ * with fewer than k candidates are searched again ("floor_margin", default 1.3, scales the model's safety margin; 0 = none;
+ * "probe_min_pairs", default 5e10: ordinary searches of fewer distance pairs take neither the tier probe nor a floor);
  * "fin_fast_div": 1 (default) = the cosine re-rank divides through one reciprocal per candidate row (bit-identical to the
  * division).  Every route gives identical results. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
