@@ -835,9 +835,79 @@ __global__ __launch_bounds__(256) void kz_exact_dist_kernel(const int* __restric
     if (lane == 0) vals[(int64_t)b * n_i + i] = v;
 }
 
+// First level of the exact selection on a long row: the k_eff smallest (value, index row) pairs of every CHUNK of KZ_EXACT_CHUNK
+// values (the smallest k_eff of the row are among the smallest k_eff of their chunks); kz_exact_select_kernel then picks from
+// n_chunks x k_eff survivors instead of passing k_eff times over the whole row with one workgroup (1 M index rows, k = 10: 2 ms
+// per query row before, the distance kernel's time now).  One workgroup per (chunk, query row); a thread holds 16 values.
+constexpr int KZ_EXACT_CHUNK = 4096;
+__global__ __launch_bounds__(256) void kz_exact_chunk_kernel(const double* __restrict__ vals, int64_t n_i, int k_eff, int n_chunks,
+                                                             double* __restrict__ cand_v, int* __restrict__ cand_i) {
+    __shared__ double s_v[4];
+    __shared__ int s_i[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x, b = blockIdx.y;
+    const double* v = vals + (int64_t)b * n_i;
+    const int64_t i0 = (int64_t)c * KZ_EXACT_CHUNK;
+    constexpr int PER = KZ_EXACT_CHUNK / 256;
+    double x[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = i0 + tid + 256 * u;
+        x[u] = i < n_i ? v[i] : INFINITY;
+    }
+    double* ov = cand_v + ((int64_t)b * n_chunks + c) * k_eff;
+    int* oi = cand_i + ((int64_t)b * n_chunks + c) * k_eff;
+    double pv = -1.0;  // values are >= 0
+    int pi = -1;
+    for (int r = 0; r < k_eff; ++r) {
+        double bv = INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int64_t i = i0 + tid + 256 * u;
+            const int id = i < n_i ? (int)i : 0x7fffffff;   // (places past the end of the row: (+inf, INT_MAX), after every real entry)
+            const bool after = (x[u] > pv) || (x[u] == pv && id > pi);
+            if (after && (x[u] < bv || (x[u] == bv && id < bi))) {
+                bv = x[u];
+                bi = id;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o_v = __shfl_xor(bv, off, 64);
+            const int o_i = __shfl_xor(bi, off, 64);
+            if (o_v < bv || (o_v == bv && o_i < bi)) {
+                bv = o_v;
+                bi = o_i;
+            }
+        }
+        if (lane == 0) {
+            s_v[wave] = bv;
+            s_i[wave] = bi;
+        }
+        __syncthreads();
+        bv = s_v[0];
+        bi = s_i[0];
+        for (int ww = 1; ww < 4; ++ww) {
+            if (s_v[ww] < bv || (s_v[ww] == bv && s_i[ww] < bi)) {
+                bv = s_v[ww];
+                bi = s_i[ww];
+            }
+        }
+        if (tid == 0) {
+            ov[r] = bv;
+            oi[r] = bi;
+        }
+        pv = bv;
+        pi = bi;
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restrict__ fail_list, int batch0, int64_t q_begin,
-                                                              const double* __restrict__ vals, int64_t n_i, int k,
+                                                              const double* __restrict__ vals, const int* __restrict__ cand_idx,
+                                                              int64_t n_entries, int64_t n_i, int k,
                                                               int exclude_self, const int64_t* __restrict__ self_ids,
                                                               int metric, double* __restrict__ out_dist,
                                                               int64_t* __restrict__ out_ind) {
@@ -847,7 +917,10 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int q = fail_list[batch0 + b];
-    const double* v = vals + (int64_t)b * n_i;
+    // the row's values: all n_i of them (cand_idx == nullptr: entry i is index row i), or the survivors of kz_exact_chunk_kernel
+    // (n_entries (value, index row) pairs; unused places hold (+inf, INT_MAX) and are never reached: k_eff <= n_i real entries exist)
+    const double* v = vals + (int64_t)b * n_entries;
+    const int* vid = cand_idx ? cand_idx + (int64_t)b * n_entries : nullptr;
     const int k_eff = (int)min((int64_t)(k + (exclude_self ? 1 : 0)), n_i);
     double* s_sv = reinterpret_cast<double*>(sel_sm);
     int* s_si = reinterpret_cast<int*>(s_sv + k_eff);
@@ -856,12 +929,13 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
     for (int r = 0; r < k_eff; ++r) {
         double bv = INFINITY;
         int bi = 0x7fffffff;
-        for (int64_t i = tid; i < n_i; i += 256) {
+        for (int64_t i = tid; i < n_entries; i += 256) {
             const double x = v[i];
-            const bool after = (x > pv) || (x == pv && (int)i > pi);
-            if (after && (x < bv || (x == bv && (int)i < bi))) {
+            const int id = vid ? vid[i] : (int)i;
+            const bool after = (x > pv) || (x == pv && id > pi);
+            if (after && (x < bv || (x == bv && id < bi))) {
                 bv = x;
-                bi = (int)i;
+                bi = id;
             }
         }
 #pragma unroll
@@ -1805,11 +1879,26 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 return rc;
             }
             const int dist_blocks = (int)((index->n + 3) / 4);
-            const size_t sel_lds = (size_t)(k_eff < index->n ? k_eff : (int)index->n) * 12 + 16;
+            const int k_sel = (int)(k_eff < index->n ? k_eff : index->n);
+            const size_t sel_lds = (size_t)k_sel * 12 + 16;
             if (sel_lds > 65536) {
                 kz_pool_free(ctx, fl, 0);
                 kz_set_error("kz_knn: k=%d is too large for the exact selection kernel", k_eff);
                 return KZ_ERR_UNSUPPORTED;
+            }
+            // rows of more than four chunks: the selection in two levels (kz_exact_chunk_kernel)
+            const int n_chunks = (int)((index->n + KZ_EXACT_CHUNK - 1) / KZ_EXACT_CHUNK);
+            const bool two_level = n_chunks > 4 && k_sel <= KZ_EXACT_CHUNK;
+            double* cand_v = nullptr;
+            int* cand_i = nullptr;
+            if (two_level) {
+                rc = kz_pool_alloc(ctx, (size_t)batch * n_chunks * k_sel * 8, (void**)&cand_v);
+                if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)batch * n_chunks * k_sel * 4, (void**)&cand_i);
+                if (rc != KZ_OK) {
+                    kz_pool_free(ctx, cand_v, 0);
+                    kz_pool_free(ctx, fl, 0);
+                    return rc;
+                }
             }
             for (int b0 = 0; b0 < n_fail; b0 += (int)batch) {
                 const int nb = (n_fail - b0 < batch) ? (n_fail - b0) : (int)batch;
@@ -1817,20 +1906,32 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                     hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
                                        cq_begin, (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn,
                                        index->n, (int)index->d, metric, (double*)vals);
+                    if (two_level)
+                        hipLaunchKernelGGL(kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0, ctx->stream, (const double*)vals, index->n, k_sel,
+                                           n_chunks, cand_v, cand_i);
                     hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
-                                       (const double*)vals, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, fp.out_dist, fp.out_ind);
+                                       two_level ? (const double*)cand_v : (const double*)vals, two_level ? (const int*)cand_i : (const int*)nullptr,
+                                       two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric,
+                                       fp.out_dist, fp.out_ind);
                 } else {
                     hipLaunchKernelGGL(kz_exact_dist_kernel<double>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
                                        cq_begin, (const double*)query->raw, (const double*)index->raw, query->sqn, index->sqn,
                                        index->n, (int)index->d, metric, (double*)vals);
+                    if (two_level)
+                        hipLaunchKernelGGL(kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0, ctx->stream, (const double*)vals, index->n, k_sel,
+                                           n_chunks, cand_v, cand_i);
                     hipLaunchKernelGGL(kz_exact_select_kernel<double>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
-                                       (const double*)vals, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, fp.out_dist, fp.out_ind);
+                                       two_level ? (const double*)cand_v : (const double*)vals, two_level ? (const int*)cand_i : (const int*)nullptr,
+                                       two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric,
+                                       fp.out_dist, fp.out_ind);
                 }
             }
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(ctx->ev[4], ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             kz_pool_free(ctx, fl, 0);
+            kz_pool_free(ctx, cand_v, 0);
+            kz_pool_free(ctx, cand_i, 0);
             if (e != hipSuccess) {
                 kz_set_error("kz_knn: exact fallback failed: %s", hipGetErrorString(e));
                 return KZ_ERR_HIP;
