@@ -303,7 +303,8 @@ constexpr int KZ_FIN_MAXM = 4096;  // list entries per query: 4 waves x (4096*8 
 // Rows a K' = 16 pass could not certify: few (the usual handful) -> more lists of 16, it is all latency; many (hard data) -> lists
 // of 64, which certify more of them in one go (400k x 400k, k = 10, clusters of very different density: 140 against 112 ms)
 constexpr int KZ_ESC_SHORT_MAX_ROWS = 2048;
-constexpr int KZ_MAX_PIECES = 64;  // index ranges per query tile (each range keeps its own K'-entry list per query)
+constexpr int KZ_MAX_PIECES = 128;  // index ranges per query tile (each range keeps its own K'-entry list per query).  Round 4: 64 -> 128
+                                    // (a search of 8 .. 700 rows against 1 M: 0.84 .. 0.92 -> 0.61 .. 0.74 ms; 256: the finalize kernel's selection eats the gain)
 static int kz_max_pieces(int KP, int halves) {
     const int m = KZ_FIN_MAXM / (halves * KP);
     return m < KZ_MAX_PIECES ? m : KZ_MAX_PIECES;
