@@ -31,7 +31,7 @@ static int region_of(const KzListLayout& L, int qt) {
 }
 
 static void check(int n_qtiles, int n_ytiles, int slots, int KP, int tpw, int force_splits, int min_splits) {
-    const int max_pieces = (4096 / KP) < 64 ? (4096 / KP) : 64;
+    const int max_pieces = (4096 / KP) < 128 ? (4096 / KP) : 128;   // (kz_max_pieces: KZ_MAX_PIECES = 128)
     KzPlan pl;
     kz_plan_pass(n_qtiles, n_ytiles, slots, max_pieces, KP, 1, 1, tpw, force_splits, min_splits, &pl);
     const KzListLayout& L = pl.lay;

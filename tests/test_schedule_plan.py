@@ -44,7 +44,7 @@ def test_rounds_cover_everything_and_balance(n_q, n_i, k_eff, slots):
     for n_qt, pieces, length in rounds:
         assert n_qt >= 1 and pieces >= 1
         assert (pieces - 1) * length < n_ytiles <= pieces * length          # the ranges tile the index exactly
-        assert pieces * kp <= 4096 and pieces <= 64                          # finalize's per-query list budget
+        assert pieces * kp <= 4096 and pieces <= 128                         # finalize's per-query list budget
         assert length >= min(8, n_ytiles) or pieces == 1                     # no confetti
     lengths = [r[2] for r in rounds]
     assert lengths == sorted(lengths, reverse=True)                          # long items first (LPT order)
