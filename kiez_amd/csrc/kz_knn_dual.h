@@ -413,9 +413,13 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // rank 11 -> 8: ns 108.7 -> 106.9 ms.  Option "dual_rank": 0 = automatic, -1 = k + 1, > 0 = that rank.
     const int rank_safe = k + 1 < KP ? k + 1 : KP;
     int rank = rank_safe;
+    // (small sweeps with lists of 16 keep the safe rank: the few hundred rows a lower rank sends to a re-search cost a fixed ~0.3 ms,
+    //  which the model of kz_dual_pick_rank does not know -- 100k x 100k, d 128, k 10 through the API: rank 8 / stride 6 6.01 ms,
+    //  rank 8 / stride 4 5.95 with 1 640 rows searched again, rank 11 / stride 4 5.72, two searches 6.10)
+    const bool small_sweep = KP == 16 && 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12 < 4.0;
     if (ctx->dual_rank > 0)
         rank = ctx->dual_rank < rank_safe ? ctx->dual_rank : rank_safe;
-    else if (ctx->dual_rank == 0 && ctx->dual_stride == 1)
+    else if (ctx->dual_rank == 0 && ctx->dual_stride == 1 && !small_sweep)
         rank = kz_dual_pick_rank(k, rank_safe, 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12, (double)a->n, (double)b->n);
     // list length of the REVERSE direction (the K' best events of a row): twice K' -- the events are there anyway
     // (~(k + 1) stride per row), the re-rank gathers only the candidates within 2 eps of the k-th key whatever the list length
@@ -432,7 +436,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         const double t_ms = 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12;
         // (0.10 ns per event: round 3, same box, 500k x 500k, k = 50: stride 4 / 5 / 6 / 7 / 8 -> 186.0 / 184.8 / 183.8 / 183.8 /
         //  186.8 ms per step -- every event also slows the sweep itself, 117.6 -> 126.4 ms; 250k x 1M, k = 10: flat from 16 to 28)
-        const double s_opt = sqrt(t_ms / ((double)b->n * rank * 0.10e-6));
+        const double s_opt = sqrt(t_ms / ((double)b->n * rank * (small_sweep ? 0.20e-6 : 0.10e-6)));   // (small sweeps: an event costs relatively more)
         stride = s_opt < 4.0 ? 4 : (s_opt > 32.0 ? 32 : (int)(s_opt + 0.5));
     }
     // (a row's event buffer -- k stride + 7 sqrt(k) stride entries -- is selected from LDS, 8 B per entry and four rows per
@@ -451,9 +455,15 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // and ~2 ms of fixed work (sort, permuted image, small kernels).  Measured: 1M x 250k, d 200, K' 16: 134 against 186 ms per
     // fit + kneighbors; 500k x 500k, K' 64: 207 against 249 ms; 100k x 100k, d 128: 11.0 against 6.8 ms -- the last one is what
     // the margin below keeps out.  "dual_force" (test knob) skips this gate.
+    // Round 4 (threshold at a lower sample rank, seeded lists, cheaper reverse chain), tools/dual_gate.py, two searches against the
+    // forced shared sweep, ms: 100k x 100k, d 128, k 10: 6.03 / 5.77; d 300: 12.1 / 9.3; 150k x 60k, d 128: 6.07 / 5.44; 200k x 50k, d 200:
+    // 8.80 / 6.44; 150k x 150k, d 128: 12.7 / 10.7; 100k x 100k, d 128, k 50: 12.6 / 10.6; 60k x 60k, d 200, k 50: 10.6 / 8.9 -- and on the
+    // losing side 100k x 100k, d 64: 4.39 / 4.89; 70k x 70k, d 128: 4.13 / 4.17; 40k x 200k, d 128: 5.93 / 7.52; 50k x 50k: 2.30 / 2.74.
+    // Fitted: the saving is ~0.7 T (twice that where the ordinary searches keep lists longer than 16) minus ~2 x the event term
+    // minus 0.3 ms.  (Through the API the gain is larger than between the bare calls: C2 6.49 -> 5.61 ms per fit + kneighbors.)
     const double t_sweep_ms = 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12;
     const double t_events_ms = (double)b->n * rank * stride * 0.15e-6;
-    const bool pays = ctx->dual_force || 0.5 * t_sweep_ms > t_events_ms + 2.0;
+    const bool pays = ctx->dual_force || 0.7 * t_sweep_ms * (KP > 16 ? 2.0 : 1.0) > 2.0 * t_events_ms + 0.3;
     const bool eligible = pays && stride >= 2 && ctx->precision == 0 && KP > 0 && n_slices >= 2 && n_slices <= 24 && a->kg == b->kg &&
                           s_rows >= (int64_t)8 * KP && b->n >= 1024 && b_tiles < (1 << 20);
     if (!eligible) return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
