@@ -689,7 +689,10 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // side of the probe (allocations, its work table, the waits for its counters) passes while the GPU works those off.
     double floor_model[3] = {0, 0, 0};
     bool have_floor = false;
-    if (ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe) {
+    // (the floor takes ~2 % off a sweep with one list of 16 per query, ~4.5 % with ten; its probe costs 0.4 - 1 ms: sweeps from
+    //  T ~ 25 model-ms on -- C2's shared sweep, T = 2.6: 5.94 ms per step with the floor, 5.58 without)
+    if (ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe &&
+        (ctx->dual_force || t_sweep_ms >= (main_pieces > 0 ? 12.0 : 25.0))) {   // ("dual_force", the test knob, skips this gate too)
         const int n_probe = ctx->floor_probe;
         const int64_t pstride = a->n / n_probe;
         int* plist = nullptr;
