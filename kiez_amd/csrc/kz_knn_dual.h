@@ -329,9 +329,12 @@ static void kz_dual_fill_stats(kz_knn_stats* st, const kz_knn_stats& v) {
 
 // Both directions by two ordinary searches (shapes or settings the dual pass does not cover)
 static int kz_knn_dual_separately(kz_ctx* ctx, kz_matrix* a, kz_matrix* b, int k, double* d_dist_ab, int64_t* d_ind_ab,
-                                  double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba) {
-    int rc = kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, -1, 0, d_dist_ab, d_ind_ab, stats_ab, nullptr);
-    if (rc == KZ_OK) rc = kz_knn_impl(ctx, b, 0, b->n, a, k, 0, nullptr, -1, 0, d_dist_ba, d_ind_ba, stats_ba, nullptr);
+                                  double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba,
+                                  int precision_override = -1) {
+    // (precision_override = 2: the caller's probe has found the data hard for fp16 -- both searches start at the split-bf16 tier
+    //  without probing again)
+    int rc = kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, precision_override, 0, d_dist_ab, d_ind_ab, stats_ab, nullptr);
+    if (rc == KZ_OK) rc = kz_knn_impl(ctx, b, 0, b->n, a, k, 0, nullptr, precision_override, 0, d_dist_ba, d_ind_ba, stats_ba, nullptr);
     return rc;
 }
 
@@ -583,6 +586,50 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         }                     \
     } while (0)
 
+    // ---- POPULATION FLOOR of the forward lists (kz_knn.hip "POPULATION FLOOR"): a strided probe of A's rows -- an escalation-style
+    // sub-search, exact float64 results written to their places -- gives the model.  It runs FIRST: it is this call's tier probe as well (below), and a call
+    // that is handed to two ordinary searches should not have enqueued a sample sweep.
+    double floor_model[3] = {0, 0, 0};
+    bool have_floor = false;
+    // (the floor takes ~2 % off a sweep with one list of 16 per query, ~4.5 % with ten; its probe costs 0.4 - 1 ms: sweeps from
+    //  T ~ 25 model-ms on -- C2's shared sweep, T = 2.6: 5.94 ms per step with the floor, 5.58 without)
+    const bool want_floor = ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe &&
+                            (ctx->dual_force || t_sweep_ms >= (KP > 16 ? 12.0 : 25.0));   // ("dual_force", the test knob, skips this gate too)
+    // The same probe is this call's TIER PROBE (kz_knn_impl): a shared sweep of a size at which an ordinary search would first
+    // look whether the data is hard for fp16 as a whole looks too -- more than half of the probe rows uncertified: two ordinary
+    // searches instead, each of which starts at the split-bf16 tier (bench.py "hard", 300k x 301k clustered rows: 127 ms per step
+    // that way, 201 ms through a shared fp16 sweep whose rows nearly all go down the tiers afterwards).
+    const bool want_tier = !ctx->dual_force && ctx->tier_probe > 0 && ctx->esc_bf && a->n >= (int64_t)16 * ctx->tier_probe &&
+                           (double)a->n * (double)b->n >= ctx->probe_min_pairs;
+    if (want_floor || want_tier) {
+        const int n_probe = want_floor ? ctx->floor_probe : (ctx->tier_probe < 1024 ? ctx->tier_probe : 1024);
+        const int64_t pstride = a->n / n_probe;
+        int* plist = nullptr;
+        rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);
+        if (rc == KZ_OK && want_floor) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&qfloor);
+        kz_knn_stats stp;
+        memset(&stp, 0, sizeof(stp));
+        float pms = 0;
+        if (rc == KZ_OK) {
+            hipLaunchKernelGGL(kz_strided_rows_kernel, dim3((unsigned)((n_probe + 255) / 256)), dim3(256), 0, ctx->stream, plist, n_probe, pstride);
+            rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, 0, d_dist_ab, d_ind_ab, &stp, &pms);
+        }
+        kz_pool_free(ctx, plist, 0);
+        if (rc == KZ_OK && want_tier && stp.n_escalated_rows * 2 > n_probe) {
+            release();
+            return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba, 2);
+        }
+        if (rc == KZ_OK && want_floor) rc = kz_floor_model(ctx, d_dist_ab, ia->rowq, n_probe, pstride, k, a->metric, floor_model, &have_floor);
+        if (rc != KZ_OK) {
+            release();
+            return rc;
+        }
+        if (!have_floor) {
+            kz_pool_free(ctx, qfloor, 0);
+            qfloor = nullptr;
+        }
+    }
+
     // ---- sample sweep's lists.  The threshold is the rank-th best sample key, and the rank-th best of ANY set of distinct sample
     // rows is a valid (lower) threshold.  The sweep therefore never needs lists of K' entries: the sample is cut into `pieces`
     // parts with a list of 16 (32) each, 2 rank entries in all.  A part holds rank / pieces +- sqrt(rank / pieces) of a row's rank
@@ -684,38 +731,6 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     KZ_DUAL_RC(kz_himage_pack_permuted(b, perm, p_packed, p_bias));
     KZ_DUAL_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     float sample_ms = 0;
-    // ---- POPULATION FLOOR of the forward lists (kz_knn.hip "POPULATION FLOOR"): a strided probe of A's rows -- an escalation-style
-    // sub-search, exact float64 results written to their places -- gives the model.  It runs HERE, behind the enqueued sample sweep and sorts: the host
-    // side of the probe (allocations, its work table, the waits for its counters) passes while the GPU works those off.
-    double floor_model[3] = {0, 0, 0};
-    bool have_floor = false;
-    // (the floor takes ~2 % off a sweep with one list of 16 per query, ~4.5 % with ten; its probe costs 0.4 - 1 ms: sweeps from
-    //  T ~ 25 model-ms on -- C2's shared sweep, T = 2.6: 5.94 ms per step with the floor, 5.58 without)
-    if (ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe &&
-        (ctx->dual_force || t_sweep_ms >= (main_pieces > 0 ? 12.0 : 25.0))) {   // ("dual_force", the test knob, skips this gate too)
-        const int n_probe = ctx->floor_probe;
-        const int64_t pstride = a->n / n_probe;
-        int* plist = nullptr;
-        rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);
-        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&qfloor);
-        kz_knn_stats stp;
-        float pms = 0;
-        if (rc == KZ_OK) {
-            hipLaunchKernelGGL(kz_strided_rows_kernel, dim3((unsigned)((n_probe + 255) / 256)), dim3(256), 0, ctx->stream, plist, n_probe, pstride);
-            rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, 0, d_dist_ab, d_ind_ab, &stp, &pms);
-        }
-        kz_pool_free(ctx, plist, 0);
-        if (rc == KZ_OK) rc = kz_floor_model(ctx, d_dist_ab, ia->rowq, n_probe, pstride, k, a->metric, floor_model, &have_floor);
-        if (rc != KZ_OK) {
-            release();
-            return rc;
-        }
-        if (!have_floor) {
-            kz_pool_free(ctx, qfloor, 0);
-            qfloor = nullptr;
-        }
-    }
-
     if (qfloor) {
         hipLaunchKernelGGL(kz_floor_rows_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, row_map, a->n, a_pad, ia->rowq,
                            ib->d_max, ib->center->d_scale, floor_model[0], floor_model[1], floor_model[2], ctx->eps_scale,

@@ -146,3 +146,35 @@ def test_tier_probe_starts_hard_data_at_the_split_bf16_tier():
                 assert s0["n_escalated_rows"] > n_q // 2
     finally:
         ctx.set_option("tier_probe", 4096)
+
+
+def test_shared_sweep_leaves_hard_data_to_two_searches():
+    """The shared sweep looks first, too (its floor probe is its tier probe): on data that is hard for fp16 as a whole it hands the
+    call to two ordinary searches, which start at the split-bf16 tier -- instead of sweeping in fp16 and sending nearly every row of
+    both directions down the tiers afterwards (bench.py "hard": 127 against 201 ms per step).  Easy data of the same size keeps the
+    shared sweep.  Identical results either way."""
+    from kiez_amd import _native as N
+    ctx = N.Context.get()
+    rng = np.random.RandomState(6)
+    d, n_a, n_b = 64, 300_000, 200_000
+    centres = rng.standard_normal((40, d)) * 3
+
+    def clustered(n):
+        sizes = rng.multinomial(n, np.ones(40) / 40)
+        return np.concatenate([centres[c] + 0.4 * rng.standard_normal((sizes[c], d)) for c in range(40)]).astype(np.float32)
+    try:
+        for kind, a, b in (("hard", clustered(n_a), clustered(n_b)), ("easy", rng.rand(n_a, d).astype(np.float32), rng.rand(n_b, d).astype(np.float32))):
+            am, bm = N.DeviceMatrix(ctx, a, "euclidean"), N.DeviceMatrix(ctx, b, "euclidean")
+            ctx.set_option("tier_probe", 4096)
+            (xd, xi, sa), (yd, yi, sb) = N.knn_dual(ctx, am, bm, 10)
+            assert sa["dual"] == (0 if kind == "hard" else 1), (kind, sa)
+            if kind == "hard":
+                assert sa["first_pass"] == 1 and sb["first_pass"] == 1           # both searches started at the split-bf16 tier
+            d_ab, i_ab, _ = N.knn(ctx, am, bm, 10)
+            d_ba, i_ba, _ = N.knn(ctx, bm, am, 10)
+            np.testing.assert_array_equal(xi.numpy(), i_ab.numpy())
+            np.testing.assert_array_equal(xd.numpy(), d_ab.numpy())
+            np.testing.assert_array_equal(yi.numpy(), i_ba.numpy())
+            np.testing.assert_array_equal(yd.numpy(), d_ba.numpy())
+    finally:
+        ctx.set_option("tier_probe", 4096)
