@@ -97,7 +97,7 @@ int kz_ctx_trim(kz_ctx* ctx);
  * "h_q64": the 64-queries-per-wave build of the fp16 kernel (K' = 16, 4 .. 13 slices): 2 (default) = where it pays (the shared
  * sweep from 9 slices on over >= 4 rounds of work items), 1 = wherever it is built, 0 = never; "tier_probe": rows of the strided sample a large ordinary search (>= 5e10
  * distance pairs) sends through the fp16 pass first -- more than half of them uncertified and the call starts at the split-bf16
- * operands instead of paying for a whole fp16 sweep (default 4096, 0 = off); "dual_rank": rank of the sample key that becomes a
+ * operands instead of paying for a whole fp16 sweep (default 1024, 0 = off); "dual_rank": rank of the sample key that becomes a
  * row's event threshold in kz_knn_dual (0 = automatic: the cheapest rank that leaves fewer than 1e-3 of the rows short of k
  * events -- those are searched again; -1 = the safe k + 1; > 0 = that rank); "list_floor": 1 (default) = the candidate lists of a
  * large sweep start at a per-row floor modelled on a probe of the query rows ("floor_probe" rows of a in kz_knn_dual, default 1024;

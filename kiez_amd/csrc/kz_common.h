@@ -52,7 +52,7 @@ struct kz_ctx {
     int floor_probe;  // ... rows of the probe behind it
     double floor_margin;  // ... the largest shortfall of the probe below the model, times this
     int dual_rank;    // kz_knn_dual: rank of the sample key that becomes a row's event threshold (0 = automatic, -1 = k + 1, > 0 = that rank; kz_knn_dual.h)
-    int tier_probe;   // rows of the strided sample a large ordinary search sends through the fp16 pass first (0 = off; default 4096): more than half uncertified -> the call starts at split-bf16
+    int tier_probe;   // rows of the strided sample a large ordinary search sends through the fp16 pass first (0 = off; default 1024): more than half uncertified -> the call starts at split-bf16
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)
     void* scratch;

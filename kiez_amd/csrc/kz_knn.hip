@@ -1531,11 +1531,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     }
     // TIER PROBE.  Data that is hard for fp16 as a whole (tight clusters far from the centre: nearly every row fails the first pass'
     // certification) used to pay for a complete fp16 sweep and its finalize before anything went down the tiers (bench.py "hard":
-    // 2 x 31.6 of 150 ms per step).  A large ordinary search therefore first sends a STRIDED sample of its query rows (4096 rows:
+    // 2 x 31.6 of 150 ms per step).  A large ordinary search therefore first sends a STRIDED sample of its query rows (1024 rows since the end of round 4, 4096 before:
     // representative whatever the row order) through the fp16 pass as an escalation-style sub-search; if more than half of them
     // cannot be certified, the call starts at the split-bf16 tier.  The sample's results are written to their places (the main
-    // pass writes the same values again).  Cost on data that is fine: ~1.4 % of a 300k-row sweep + ~0.3 ms; only top-level
-    // searches of >= 5e10 distance pairs and >= 64k query rows take it (C1 / C2 do not).  Option "tier_probe" = 0: off.
+    // pass writes the same values again).  Cost on data that is fine: ~0.35 % of a 300k-row sweep + ~0.3 ms (230k x 230k x 128: 13.5 -> 13.2 ms
+    // with 1024 instead of 4096 rows; 200k x 400k x 200, cosine, k = 50: 32.4 -> 31.8); only top-level searches of >= 5e10 distance pairs
+    // and >= 16 probe sizes of query rows take it (C1 / C2 do not).  Option "tier_probe" = 0: off.
     float* qfloor_ord = nullptr;   // seeded lists of an ordinary search (the context's buffer: nothing to release)
     if (tier == KZ_TIER_H && !dual && precision_override < 0 && kp_min == 0 && !exact_only && ctx->tier_probe > 0 && ctx->esc_bf &&
         q_count >= (int64_t)16 * ctx->tier_probe && (double)q_count * (double)index->n >= ctx->probe_min_pairs && ctx->chunk_rows == 0) {

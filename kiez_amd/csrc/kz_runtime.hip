@@ -64,7 +64,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
     c->lds_pad = 0;
     c->h_q64 = 2;
-    c->tier_probe = 4096;
+    c->tier_probe = 1024;
     c->dual_rank = 0;
     c->probe_min_pairs = 5e10;
     c->list_floor = 1;

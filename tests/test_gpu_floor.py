@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-_RESET = (("list_floor", 1), ("floor_probe", 1024), ("floor_margin", 1.3), ("dual_force", 0), ("tier_probe", 4096), ("h_q64", 2))
+_RESET = (("list_floor", 1), ("floor_probe", 1024), ("floor_margin", 1.3), ("dual_force", 0), ("tier_probe", 1024), ("h_q64", 2))
 
 
 @pytest.fixture()

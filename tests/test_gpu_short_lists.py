@@ -145,7 +145,7 @@ def test_tier_probe_starts_hard_data_at_the_split_bf16_tier():
             if kind == "hard":
                 assert s0["n_escalated_rows"] > n_q // 2
     finally:
-        ctx.set_option("tier_probe", 4096)
+        ctx.set_option("tier_probe", 1024)
 
 
 def test_shared_sweep_leaves_hard_data_to_two_searches():
@@ -177,4 +177,4 @@ def test_shared_sweep_leaves_hard_data_to_two_searches():
             np.testing.assert_array_equal(yi.numpy(), i_ba.numpy())
             np.testing.assert_array_equal(yd.numpy(), d_ba.numpy())
     finally:
-        ctx.set_option("tier_probe", 4096)
+        ctx.set_option("tier_probe", 1024)
