@@ -1831,7 +1831,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             int next_prec, next_kp;
             if (!widen) {   // fp16 with its longest lists, or fp16 altogether, has failed: better operands, this call's own list length
                 next_prec = (tier == KZ_TIER_H && ctx->esc_bf && (long_pieces == 0 || fp16_hard)) ? 2 : 1;
-                next_kp = 0;
+                // (the float32 operands are the LAST approximate tier and their a-priori bound is the loosest: with this call's own
+                //  list length -- 16 for k = 10 -- the K'-th key lies a handful of keys below the k-th and inside the bound wherever
+                //  the keys are dense; lists of 64 certify such rows instead of handing them to the exact kernels at ~60 us a row:
+                //  300k x 300k x 96, clusters of very different spread: 9 968 rows to the exact kernels and 726 ms per call before, none and
+                //  169 ms now; lists of 128 for every call: bench.py "hard", k = 50, 118 -> 225 ms -- its lists of 64 were long enough)
+                next_kp = (next_prec == 1 && KP_esc < 64) ? 64 : 0;
             } else if (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS) {
                 next_prec = 0;
                 next_kp = -1;   // a handful of rows of a K' = 16 pass: more lists of 16
