@@ -1554,6 +1554,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         probe_ms = pms;
         if (stp.n_escalated_rows * 2 > n_probe) {
             tier = KZ_TIER_BF;
+            // (data this hard for fp16 is hard for the split-bf16 operands, too, wherever the keys are dense: lists of 64 from the
+            //  start -- 300k x 300k x 96, k = 10, clusters of very different spread: rows searched again 135 k -> 51 k, call 170 -> 110 ms)
+            if (KSEL == 0 && KP < 64) KP = 64;
             if (short_ord) {   // (the other tiers' kernels keep one list of K' per query)
                 short_ord = false;
                 KP = KP_long;
@@ -1836,7 +1839,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 //  the keys are dense; lists of 64 certify such rows instead of handing them to the exact kernels at ~60 us a row:
                 //  300k x 300k x 96, clusters of very different spread: 9 968 rows to the exact kernels and 726 ms per call before, none and
                 //  169 ms now; lists of 128 for every call: bench.py "hard", k = 50, 118 -> 225 ms -- its lists of 64 were long enough)
-                next_kp = (next_prec == 1 && KP_esc < 64) ? 64 : 0;
+                next_kp = (next_prec == 1 && KP_class < 64) ? 64 : 0;
             } else if (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS) {
                 next_prec = 0;
                 next_kp = -1;   // a handful of rows of a K' = 16 pass: more lists of 16

@@ -332,9 +332,10 @@ static int kz_knn_dual_separately(kz_ctx* ctx, kz_matrix* a, kz_matrix* b, int k
                                   double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba,
                                   int precision_override = -1) {
     // (precision_override = 2: the caller's probe has found the data hard for fp16 -- both searches start at the split-bf16 tier
-    //  without probing again)
-    int rc = kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, precision_override, 0, d_dist_ab, d_ind_ab, stats_ab, nullptr);
-    if (rc == KZ_OK) rc = kz_knn_impl(ctx, b, 0, b->n, a, k, 0, nullptr, precision_override, 0, d_dist_ba, d_ind_ba, stats_ba, nullptr);
+    //  without probing again, with lists of at least 64 as an ordinary search's own probe would have chosen)
+    const int kp_min = precision_override == 2 ? 64 : 0;
+    int rc = kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, precision_override, kp_min, d_dist_ab, d_ind_ab, stats_ab, nullptr);
+    if (rc == KZ_OK) rc = kz_knn_impl(ctx, b, 0, b->n, a, k, 0, nullptr, precision_override, kp_min, d_dist_ba, d_ind_ba, stats_ba, nullptr);
     return rc;
 }
 
