@@ -72,17 +72,23 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
-def cpu_baseline(source, target, metric, K, k, hub, hub_kw, budget_flop=6e11):
+def cpu_baseline(source, target, metric, K, k, hub, hub_kw, budget_flop=6e11, n_s_total=None):
     """CPU leg on this host's cores: the reference's own CPU path = scikit-learn's brute-force kNN
     (what SklearnNN._kneighbors delegates to, kiez/neighbors/exact/sklearn_nearest_neighbors.py:98-101) for both distance
     passes + the oracle's restatement of the rescale / final sort (oracle/kiez_oracle.py), timed on a bounded ROW SAMPLE
     against the full index, one discarded warm-up, median of 3, and extrapolated linearly in rows (every stage is
-    row-independent given the fit state).  value = n_source / (t_fit + t_kneighbors)."""
+    row-independent given the fit state).  value = n_source / (t_fit + t_kneighbors).
+    N > 1 (rank 0, after the timed region): `source` = the source rows rank 0 holds on the host -- all shards gathered when the
+    workload has a reverse pass (its index is the WHOLE source), rank 0's own shard otherwise -- and `n_s_total` the job's rows:
+    the baseline is that of the whole job, as `value` is."""
     from oracle import kiez_oracle as O
-    n_s, d = source.shape
+    n_held, d = source.shape
+    n_s = int(n_s_total) if n_s_total else n_held
     n_t = target.shape[0]
-    rows_f = int(max(256, min(n_s, budget_flop / (2.0 * n_t * d))))   # forward sample: source rows vs ALL targets
-    rows_r = int(max(256, min(n_t, budget_flop / (2.0 * n_s * d))))   # reverse sample: target rows vs ALL source rows
+    rows_f = int(max(min(256, n_held), min(n_held, budget_flop / (2.0 * n_t * d))))   # forward sample: source rows vs ALL targets
+    rows_r = int(max(min(256, n_t), min(n_t, budget_flop / (2.0 * n_s * d))))          # reverse sample: target rows vs ALL source rows
+    if hub is not None and n_held != n_s:
+        raise ValueError("cpu_baseline: a reverse pass is timed against the whole source")
     out = {"unit": "queries/s", "cores": os.cpu_count(), "kind": "port"}
     metric_c = O.canonical_metric(metric)
     try:
@@ -153,56 +159,98 @@ def cpu_baseline(source, target, metric, K, k, hub, hub_kw, budget_flop=6e11):
     return out
 
 
-def sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, rows=1024):
-    """Result check that also works where the oracle cannot run the whole fit (1M-row reverse pass): a row sample of BOTH
-    kNN passes against the oracle's exact float64 search, then the oracle's rescale + final sort on the sampled source rows
-    fed with the (sample-verified) fit state of this run."""
+def strided_rows(n, rows):
+    """The row sample of every check: `rows` rows of n at a fixed stride (deterministic, spans the whole range)."""
+    return np.arange(0, n, max(1, n // max(rows, 1)))[:rows]
+
+
+def sample_check(res, sk, eng, comm, source_dev, target_h, K, k, metric, hub, hub_kw, rows=1024, rows_per_rank=128):
+    """Result check that also works where the oracle cannot run the whole fit (1M-row reverse pass) and on ANY number of ranks:
+    a row sample of BOTH kNN passes against the oracle's exact float64 search, then the oracle's rescale + final sort on the
+    sampled source rows fed with the (sample-verified) fit state of this run.
+
+    Collective (every rank calls it, OUTSIDE the timed region): each rank contributes `rows` sampled rows of its shard's result
+    (world 1) or `rows_per_rank` of them (world > 1), with the source rows they belong to and their global ids; where the fit has
+    a reverse pass the source shards are gathered so that rank 0 can check `rows` sampled TARGET rows of the fit state against
+    the whole source.  Rank 0 (the holder of `target_h`) runs the oracle and returns the record; the other ranks return None."""
     from oracle import kiez_oracle as O
+    torch_ = torch
     metric_c = O.canonical_metric(metric)
-    n_s, n_t = len(source_h), len(target_h)
-    rows = min(rows, n_s, n_t)
-    sel_s = np.arange(0, n_s, max(1, n_s // rows))[:rows]
-    s64 = source_h[sel_s].astype(np.float64) if metric_c == "cosine" else source_h[sel_s]
+    world, rank = comm.world, comm.rank
+    counts = list(sk.counts)
+    per_rank = rows if world == 1 else rows_per_rank
+    sel_counts = [len(strided_rows(c, min(per_rank, c))) for c in counts]
+    sel_local = strided_rows(counts[rank], min(per_rank, counts[rank]))
+    sel_t = torch_.from_numpy(sel_local).to(res[0].device)
+    g_d = comm.all_gather_rows(res[0][sel_t].contiguous(), sel_counts)
+    g_i = comm.all_gather_rows(res[1][sel_t].contiguous(), sel_counts)
+    g_src = comm.all_gather_rows(source_dev[sel_t].contiguous(), sel_counts)
+    src_full = comm.all_gather_rows(source_dev, counts) if hub is not None else None     # (the reverse pass' index: every shard)
+    if rank != 0:
+        return None
+    begins = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    gid = np.concatenate([begins[r] + strided_rows(counts[r], min(per_rank, counts[r])) for r in range(world)])
+    owner = np.repeat(np.arange(world), sel_counts)
+    got_d, got_i, s_rows = eng.to_numpy(g_d), eng.to_numpy(g_i), eng.to_numpy(g_src)
+    n_s, n_t = int(sum(counts)), len(target_h)
+    s64 = s_rows.astype(np.float64) if metric_c == "cosine" else s_rows
     t_all = target_h.astype(np.float64) if metric_c == "cosine" else target_h
-    dd, ii = res
-    got_d, got_i = dd.cpu().numpy()[sel_s], ii.cpu().numpy()[sel_s]
-    out = {"rows": int(rows)}
+    out = {"rows": int(len(gid)), "ranks": world, "rows_per_rank": [int(c) for c in sel_counts]}
+    h = hub.lower() if hub else None
+    empiric = h in ("mutualproximity", "mp") and hub_kw.get("method") in ("exact", "empiric")
     if hub is None:
         od, oi = O.knn_exact(s64, t_all, k, metric_c)
+        fi = oi
     else:
         fd, fi = O.knn_exact(s64, t_all, K, metric_c)
         st = sk.state
-        # verify the fit state on a sample of target rows
-        sel_t = np.arange(0, n_t, max(1, n_t // rows))[:rows]
-        s_all = source_h.astype(np.float64) if metric_c == "cosine" else source_h
-        rd, ri = O.knn_exact(t_all[sel_t], s_all, min(K, n_s), metric_c)
-        h = hub.lower()
+        # verify the fit state on a sample of target rows against ALL source rows (every shard)
+        sel_tg = strided_rows(n_t, min(rows, n_t))
+        s_all = eng.to_numpy(src_full)
+        if metric_c == "cosine":
+            s_all = s_all.astype(np.float64)
+        rd, ri = O.knn_exact(t_all[sel_tg], s_all, min(K, n_s), metric_c)
+        out["fit_state_rows"] = int(len(sel_tg))
+
+        def rel(got, want):
+            return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300)))
         if h == "csls":
-            r_t = st["r_t"].cpu().numpy()
-            out["fit_state_max_rel_err"] = float(np.max(np.abs(r_t[sel_t] - rd.mean(axis=1)) / np.abs(rd.mean(axis=1))))
-            r_s = fd.mean(axis=1)
-            hr = 2.0 * fd - r_s[:, None] - r_t[fi]
-        elif h in ("mutualproximity", "mp") and hub_kw.get("method") in ("exact", "empiric"):
-            d_t2s, i_t2s = st["dist_t2s"].cpu().numpy(), st["ind_t2s"].cpu().numpy()
-            out["fit_state_rows_identical"] = int((i_t2s[sel_t] == ri).all(axis=1).sum())
-            sub = min(rows, 256)
-            fd, fi, got_d, got_i, sel_s = fd[:sub], fi[:sub], got_d[:sub], got_i[:sub], sel_s[:sub]
-            out["rows"] = int(sub)
+            r_t = eng.to_numpy(st["r_t"])
+            out["fit_state_max_rel_err"] = rel(r_t[sel_tg], rd.mean(axis=1))
+            hr = 2.0 * fd - fd.mean(axis=1)[:, None] - r_t[fi]
+        elif h in ("localscaling", "ls"):
+            r_t = eng.to_numpy(st["r_t"])
+            nicdm = str(hub_kw.get("method", "standard")).lower() == "nicdm"
+            out["fit_state_max_rel_err"] = rel(r_t[sel_tg], rd.mean(axis=1) if nicdm else rd[:, -1])
+            hr = fd / np.sqrt(fd.mean(axis=1)[:, None] * r_t[fi]) if nicdm else 1.0 - np.exp(-1 * fd**2 / (fd[:, -1][:, None] * r_t[fi]))
+        elif empiric:
+            d_t2s, i_t2s = eng.to_numpy(st["dist_t2s"]), eng.to_numpy(st["ind_t2s"])
+            out["fit_state_rows_identical"] = int((i_t2s[sel_tg] == ri).all(axis=1).sum())
+            if world == 1:   # (the transform is the oracle's slow part: 256 rows of one shard; on > 1 rank every rank's 128)
+                sub = min(len(gid), 256)
+                fd, fi, got_d, got_i, gid, owner = fd[:sub], fi[:sub], got_d[:sub], got_i[:sub], gid[:sub], owner[:sub]
+                out["rows"] = int(sub)
             hr = O.mp_empiric_transform(fd, fi, d_t2s, i_t2s)
+        elif h in ("mutualproximity", "mp"):
+            mu_t, sd_t = eng.to_numpy(st["mu_t"]), eng.to_numpy(st["sd_t"])
+            out["fit_state_max_rel_err"] = max(rel(mu_t[sel_tg], np.nanmean(rd, axis=1)), rel(sd_t[sel_tg], np.nanstd(rd, axis=1)))
+            mu, sd = np.nanmean(fd, axis=1)[:, None], np.nanstd(fd, axis=1)[:, None]
+            hr = 1 - O._norm_sf(fd, mu, sd) * O._norm_sf(fd, mu_t[fi], sd_t[fi])
         else:
-            return None
+            return None     # DisSimLocal shifts by a minimum over the WHOLE result: no row sample decides it
         od, oi = O.sort_topk(hr, fi, k)
     same = (got_i == oi).all(axis=1)
-    if hub and hub.lower().startswith("mutual") and hub_kw.get("method") in ("exact", "empiric"):
+    if empiric:
         # MP-empiric values are multiples of 1/K; a row whose candidate list contains the query's own id is a knife edge
         # (DESIGN.md section 5: the reference compares a pair's forward and reverse BLAS value with a strict '>').  Those rows are
         # counted apart, never ORed into "identical": index_rows_identical counts the other rows only.
-        knife = (fi == sel_s[:, None]).any(axis=1)
+        knife = (fi == gid[:, None]).any(axis=1)
         out.update(knife_edge_rows=int(knife.sum()), knife_edge_rows_identical=int((same & knife).sum()),
                    rows_not_knife_edge=int((~knife).sum()))
         same &= ~knife
     plain = np.ones(len(got_d), dtype=bool) if "knife_edge_rows" not in out else ~knife     # (a knife-edge row may differ by one count, 1 / K)
     out.update(index_rows_identical=int(same.sum()),
+               index_rows_identical_per_rank=[int(same[owner == r].sum()) for r in range(world)],
                recall_at_k=float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got_i, oi)])),
                max_rel_dist_err=float(np.max(np.abs(got_d[plain] - od[plain]) / np.maximum(np.abs(od[plain]), 1e-12))) if plain.any() else 0.0)
     return out
@@ -228,18 +276,23 @@ def synth_rows(name, seed, rows, d):
     return out
 
 
-def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, scaling="weak", check_rows=1024):
-    """Generate the data, run warm-up + timed steps, return (summary dict, host arrays) on every rank.
-    scaling = "weak": every rank owns WORKLOADS[name][0] source rows; "strong": that many rows in total, split over the ranks."""
+def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, scaling="weak", check_rows=1024,
+                 target_upload="broadcast"):
+    """Generate the data, run warm-up + timed steps, return (summary dict, host arrays, result, source tensor) on every rank.
+    scaling = "weak": every rank owns WORKLOADS[name][0] source rows; "strong": that many rows in total, split over the ranks.
+    target_upload = "broadcast": the target lives on rank 0 and is RCCL-broadcast inside every fit (north_star's partitioning);
+    "local": every rank holds the target itself (generated from the same seed, uploaded over its own PCIe link before the timed
+    region; SURVEY 8e's alternative) -- `fit` then runs no broadcast."""
     from kiez_amd.distributed import ShardedKiez, row_slice
     n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[name]
     n_s_total = n_s * world if scaling == "weak" else n_s
     if scaling == "strong":
         n_s = row_slice(n_s_total, rank, world)[1]
     source_h = synth_rows(name, 0 if rank == 0 else 1000 + rank, n_s, d)
-    target_h = synth_rows(name, 77, n_t, d) if rank == 0 else None
+    local_target = target_upload == "local"
+    target_h = synth_rows(name, 77, n_t, d) if (rank == 0 or local_target) else None
     source = eng.to_engine(source_h)
-    target = eng.to_engine(target_h) if rank == 0 else None
+    target = eng.to_engine(target_h) if target_h is not None else None
     eng.sync()
     sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": metric}, hubness=hub, hubness_kwargs=hub_kw,
                      engine=eng, comm=comm)
@@ -271,7 +324,7 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
         eng.knn_dual = logged_dual
 
     def step():
-        sk.fit(source, target)
+        sk.fit(source, target, target_from_rank0=not local_target)
         return sk.kneighbors(k)
 
     def fence():
@@ -310,7 +363,7 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
     peak = PEAK_F32_MFMA_TFLOPS if tier == 0 else PEAK_BF16_MFMA_TFLOPS
     summary = {
         "name": name, "desc": desc, "n_s": n_s, "n_t": n_t, "d": d, "metric": metric, "K": K, "k": k, "hub": hub, "hub_kw": hub_kw,
-        "n_s_total": n_s_total, "scaling": scaling,
+        "n_s_total": n_s_total, "scaling": scaling, "shard_rows": [int(c) for c in sk.counts],
         "elapsed": elapsed, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "value": n_s_total * steps / elapsed,
         "tier": tier, "peak": peak, "achieved": achieved, "n_launch": n_launch, "kernel_s": kernel_s, "flops": flops,
         "fallback_rows": int(sum(st["n_fallback_rows"] for _, _, st in knn_log)),
@@ -328,11 +381,11 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
         # rows of the reverse direction searched again (an overflowing event buffer, fewer than k events, an uncertified list)
         "reverse_escalated_rows": int(sum(r.get("n_escalated_rows", 0) for r in rev_log)),
     }
-    chk = None
-    if check and rank == 0 and world == 1:
-        chk = sample_check(res, sk, eng, source_h, target_h, K, k, metric, hub, hub_kw, rows=check_rows)
-    summary["check"] = chk
-    return summary, (source_h, target_h), res
+    summary["target_upload"] = target_upload
+    # the oracle check is a collective of its own, outside the timed region: at any world size rank 0 verifies a sample of the
+    # fit state and sampled rows of EVERY rank's shard (None on the other ranks)
+    summary["check"] = sample_check(res, sk, eng, comm, source, target_h, K, k, metric, hub, hub_kw, rows=check_rows) if check else None
+    return summary, (source_h, target_h), res, source
 
 
 def pmc_traffic(workload, s):
@@ -340,11 +393,10 @@ def pmc_traffic(workload, s):
     tools/pmc_derive.py).  The counters are per KERNEL DISPATCH; a launch here (one kz_knn / kz_knn_dual call) sweeps its query
     rows in chunks of 524288, one dispatch each -- scaled by the ratio of the two durations so that `traffic` refers to the
     same launch as `achieved`.  (None, None) where no PMC pass was taken."""
-    pmc = ROOT / "profiles" / "pmc_traffic.json"
-    if not pmc.exists() or not s["n_launch"]:
+    rec = pmc_record(workload, s)
+    if not rec or not s["n_launch"]:
         return None, None
     try:
-        rec = json.loads(pmc.read_text()).get(workload + "_" + TIER_NAME[s["tier"]], {})
         per_dispatch = rec.get("hbm_bytes_per_launch")
         if per_dispatch is None:
             return None, None
@@ -355,15 +407,31 @@ def pmc_traffic(workload, s):
         return None, None
 
 
+def pmc_record(workload, s):
+    """This workload's record of the committed PMC passes (profiles/pmc_traffic.json), {} where none was taken."""
+    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    try:
+        return json.loads(pmc.read_text()).get(workload + "_" + TIER_NAME[s["tier"]], {}) if pmc.exists() else {}
+    except Exception:
+        return {}
+
+
 def roofline_of(workload, s):
     """The `roofline` object of one workload's dominant kernel (contract in the task statement)."""
     tier = s["tier"]
     traffic, dispatches = pmc_traffic(workload, s)
+    rec = pmc_record(workload, s)
+    clock, busy = rec.get("clock_ghz"), rec.get("mfma_pipe_busy")
     return {"bound": "mfma", "kernel": TIER_KERNEL[tier], "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s",
             "frac": s["achieved"] / s["peak"], "traffic": traffic, "traffic_kernel_dispatches_per_launch": dispatches,
             "launches": s["n_launch"], "avg_launch_ms": s["kernel_s"] / max(s["n_launch"], 1) * 1e3,
             "algorithmic_flop_per_launch": s["flops"] / max(s["n_launch"], 1), "mfma_products_per_mac": TIER_PRODUCTS[tier],
-            "shared_sweeps": s["shared_sweeps"]}
+            "shared_sweeps": s["shared_sweeps"],
+            # from the committed PMC pass of this workload's dominant kernel (profiles/pmc_traffic.json): the clock the chip held
+            # (GRBM_GUI_ACTIVE / 8 XCDs / duration) and the share of those cycles the matrix pipe was busy; their product over the
+            # nominal 2.4 GHz is the executed-MFMA fraction of peak -- frac = busy x clock / 2.4 x (d / d_pad)
+            "effective_clock_ghz": clock, "mfma_pipe_busy": busy,
+            "busy_x_clock_over_nominal": (busy * clock / 2.4) if (clock and busy) else None, "pmc_source": rec.get("source")}
 
 
 def short(summary):
@@ -440,6 +508,25 @@ def run_openea(args):
     return line
 
 
+def job_cpu_baseline(args, comm, eng, s, source_dev, source_h, target_h):
+    """`cpu_baseline` of the line at ANY world size: rank 0 times the reference's CPU path on a bounded sample of the WHOLE
+    job's workload after the timed region.  A collective when the workload has a reverse pass on more than one rank (its index is the
+    whole source: the shards are gathered to rank 0's host); returns the record on rank 0, None elsewhere."""
+    if args.no_cpu_baseline:
+        return None
+    n_s, n_t, d, metric, K, k, hub, hub_kw, _ = WORKLOADS[s["name"]]
+    held = source_h
+    if comm.world > 1 and hub is not None:
+        full = comm.all_gather_rows(source_dev, [row for row in s["shard_rows"]])
+        held = eng.to_numpy(full) if comm.rank == 0 else None
+        del full
+    if comm.rank != 0:
+        return None
+    out = cpu_baseline(held, target_h, metric, K, k, hub, hub_kw, n_s_total=s["n_s_total"])
+    out["workload_rows"] = {"n_source_total": s["n_s_total"], "n_target": n_t}
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -461,6 +548,10 @@ def parse_args(argv=None):
     ap.add_argument("--openea-hubness", default="CSLS")
     ap.add_argument("--openea-metric", default="euclidean")
     ap.add_argument("--openea-k", type=int, default=10)
+    ap.add_argument("--target-upload", default="broadcast", choices=("broadcast", "local"),
+                    help="N > 1: broadcast = the target lives on rank 0 and is RCCL-broadcast over xGMI inside every fit (default, "
+                         "north_star's partitioning); local = every rank uploads the target itself before the timed region and fit "
+                         "runs no broadcast (ShardedKiez.fit(target_from_rank0=False)) -- the A/B of the 0.8-1.2 GB transfer per step")
     ap.add_argument("--launch-check", action="store_true",
                     help="NOT a measurement: run the launch / rendezvous / sharding / collective / reporting path of this script on "
                          "the CPU test engine (tests/cpu_engine.py) over gloo with a tiny shape; `value` is null.  For machines "
@@ -516,14 +607,22 @@ def main():
         comm = Comm(time_collectives=True)
         WORKLOADS["launch-check"] = (2000 if args.scaling == "weak" else 4001, 1500, 16, "euclidean", 5, 5, "CSLS", {},
                                      "launch check (CPU test engine over gloo; NOT a measurement)")
-        s, _, _ = run_workload("launch-check", eng, comm, dist, rank, world, args.steps, args.warmup, check=False, scaling=args.scaling)
+        s, (src_h, tgt_h), _, src_dev = run_workload("launch-check", eng, comm, dist, rank, world, args.steps, args.warmup,
+                                                     check=not args.no_check, scaling=args.scaling, target_upload=args.target_upload)
+        cpu = job_cpu_baseline(args, comm, eng, s, src_dev, src_h, tgt_h)
         if rank == 0:
-            line = {"metric": METRIC, "value": None, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            line = {"metric": METRIC, "recall_at_k": (s["check"] or {}).get("recall_at_k"),
+                    "value": None, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                     "ms_per_step": s["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                     "dtype": None, "data": "synthetic", "launch_check": True,
                     "config": {"workload": s["desc"], "n_source_total": s["n_s_total"], "n_source_this_rank": s["n_s"], "n_target": s["n_t"],
+                               "target_upload": s["target_upload"],
                                "engine": "tests/cpu_engine.py over gloo -- launch path only, value deliberately null"},
                     "collective_ms_per_step": s["collective_ms_per_step"], "collective_traffic_per_step": s["collective_traffic_per_step"]}
+            if s["check"] is not None:
+                line["check"] = s["check"]
+            if cpu is not None:
+                line["cpu_baseline"] = cpu
             os.write(json_fd, (json.dumps(line) + "\n").encode())
         if dist.is_initialized():
             dist.barrier()
@@ -549,15 +648,17 @@ def main():
         name, val = o.split("=")
         eng.ctx.set_option(name, float(val))
 
-    main_s, (source_h, target_h), _ = run_workload(args.workload, eng, comm, dist, rank, world, args.steps, args.warmup,
-                                                   check=not args.no_check, scaling=args.scaling)
+    main_s, (source_h, target_h), _, source_dev = run_workload(args.workload, eng, comm, dist, rank, world, args.steps, args.warmup,
+                                                               check=not args.no_check, scaling=args.scaling,
+                                                               target_upload=args.target_upload)
+    cpu = job_cpu_baseline(args, comm, eng, main_s, source_dev, source_h, target_h)      # (collective: every rank calls it)
+    del source_dev
     n_s, n_t, d, metric, K, k, hub, hub_kw, desc = WORKLOADS[args.workload]
 
     line = None
     if rank == 0:
         s = main_s
         tier = s["tier"]
-        traffic, traffic_dispatches = pmc_traffic(args.workload, s)
         line = {
             "metric": METRIC,
             "recall_at_k": (s["check"] or {}).get("recall_at_k"),   # against the oracle on a row sample (None if not checked)
@@ -575,25 +676,22 @@ def main():
             "config": {"workload": desc, "n_source_total": s["n_s_total"], "n_source_per_gpu": s["n_s_total"] // world, "n_target": n_t, "d": d, "metric": metric,
                        "n_candidates": K, "k": k, "hubness": hub, "hubness_kwargs": hub_kw,
                        "inputs": "float32 rng.rand, resident in HBM; results left in HBM",
+                       "target_upload": s["target_upload"],
                        "parallelism": f"source row-sharded x{world}, target replicated"
-                                      + (" (per step: 1 RCCL broadcast of the target, 1 all-to-all of the per-shard reverse lists, 1 all-gather"
-                                         " of the per-target fit state; measured times and bytes: collective_ms_per_step, collective_traffic_per_step)"
+                                      + ((" (per step: " + ("1 RCCL broadcast of the target, " if s["target_upload"] == "broadcast" else
+                                                            "target uploaded by every rank before the timed region, no broadcast; ")
+                                          + "1 all-to-all of the per-shard reverse lists, 1 all-gather"
+                                          " of the per-target fit state; measured times and bytes: collective_ms_per_step, collective_traffic_per_step)")
                                          if world > 1 else " (single rank: no collective runs)")},
-            "roofline": {"bound": "mfma", "kernel": TIER_KERNEL[tier],
-                         "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s",
-                         "frac": s["achieved"] / s["peak"], "traffic": traffic, "traffic_kernel_dispatches_per_launch": traffic_dispatches,
-                         "launches": s["n_launch"], "avg_launch_ms": s["kernel_s"] / max(s["n_launch"], 1) * 1e3,
-                         "algorithmic_flop_per_launch": s["flops"] / max(s["n_launch"], 1),
-                         "mfma_products_per_mac": TIER_PRODUCTS[tier],
-                         "executed_mfma_frac": s["achieved"] * TIER_PRODUCTS[tier] / s["peak"],
-                         "vs_fp32_mfma_peak": s["achieved"] / PEAK_F32_MFMA_TFLOPS,
-                         "shared_sweeps": s["shared_sweeps"],
-                         # SURVEY.md section 8(d) prices a hubness-reduced step at TWO passes (4 n_s n_t d flop, what the reference
-                         # executes); that figure over the same kernel time, for comparison only -- `achieved` / `frac` above
-                         # count what this kernel executes
-                         "reference_work_tflops": (s["achieved"] * (1 + s["shared_sweeps"] / max(s["n_launch"], 1))),
-                         "note": ("algorithmic flop = 2 n_q n_i d per launch, counted ONCE for a launch that serves both search "
-                                  "directions (kz_knn_dual): the reference evaluates that distance matrix twice")},
+            "roofline": dict(roofline_of(args.workload, s),
+                             executed_mfma_frac=s["achieved"] * TIER_PRODUCTS[tier] / s["peak"],
+                             vs_fp32_mfma_peak=s["achieved"] / PEAK_F32_MFMA_TFLOPS,
+                             # SURVEY.md section 8(d) prices a hubness-reduced step at TWO passes (4 n_s n_t d flop, what the
+                             # reference executes); that figure over the same kernel time, for comparison only -- `achieved` /
+                             # `frac` count what this kernel executes
+                             reference_work_tflops=(s["achieved"] * (1 + s["shared_sweeps"] / max(s["n_launch"], 1))),
+                             note=("algorithmic flop = 2 n_q n_i d per launch, counted ONCE for a launch that serves both search "
+                                   "directions (kz_knn_dual): the reference evaluates that distance matrix twice")),
             "shared_sweep": {"launches": s["shared_sweeps"], "reverse_extra_ms_per_step": s["reverse_extra_ms_per_step"],
                              "reverse_events_per_row": s["reverse_events_per_row"], "reverse_escalated_rows": s["reverse_escalated_rows"]},
             "certification_fallback_rows": s["fallback_rows"],
@@ -621,8 +719,8 @@ def main():
             del kz
         line["host_api"] = {"value": n_s / t_host, "unit": "queries/s", "ms": t_host * 1e3,
                             "note": "Kiez(...).fit(numpy, numpy).kneighbors(k) -> numpy: includes H2D of both matrices and D2H of the result"}
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(source_h, target_h, metric, K, k, hub, hub_kw)
+    if rank == 0 and cpu is not None:
+        line["cpu_baseline"] = cpu
     del source_h, target_h
     if world == 1 and not args.no_others:
         others = {}
@@ -636,12 +734,21 @@ def main():
                 #  only turns this one's first releases into hipFree calls)
                 eng.ctx.trim()
                 o_steps, o_warm = (min(args.other_steps, 3), min(args.other_warmup, 1)) if name == "c4" else (args.other_steps, args.other_warmup)
-                osum, _, _ = run_workload(name, eng, comm, dist, rank, world, o_steps, o_warm, check=not args.no_check)
+                osum, _, _, _ = run_workload(name, eng, comm, dist, rank, world, o_steps, o_warm, check=not args.no_check)
                 others[name] = short(osum)
             except Exception as e:  # pragma: no cover  (a secondary workload must never cost the main line)
                 others[name] = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             line["other_workloads"] = others
+            # one short object for all workloads, moved to the front of the line below: [ms per step, main-kernel ms per launch,
+            # roofline fraction, M source queries/s, rows of the check identical / rows checked]
+            def brief(ms, r, value, chk):
+                return [round(ms, 3), round(r["avg_launch_ms"], 3), round(r["frac"], 4), round(value / 1e6, 3),
+                        f'{chk["index_rows_identical"]}/{chk.get("rows_not_knife_edge", chk["rows"])}' if chk else None]
+            summ = {args.workload: brief(line["ms_per_step"], line["roofline"], line["value"], line.get("check"))}
+            for name, o in others.items():
+                summ[name] = brief(o["ms_per_step"], o["roofline"], o["value"], o.get("check")) if "error" not in o else "error"
+            line["summary"] = {"columns": ["ms_per_step", "main_kernel_ms_per_launch", "roofline_frac", "M_queries_per_s", "check_rows_identical"], **summ}
             try:
                 # float64 near-ties: pairs of index rows 1/64 .. 16 ulps apart, the reference's own order on them as the golden
                 # (tests/near_ties.py; DESIGN.md section 5: how often the device's float64 order differs from sklearn's, by gap)
@@ -650,6 +757,8 @@ def main():
             except Exception as e:  # pragma: no cover
                 line["fp64_order_probe"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
+        if "summary" in line:    # first in the line: a truncated tail of the driver's record still shows every workload
+            line = {"metric": line["metric"], "summary": line.pop("summary"), **line}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

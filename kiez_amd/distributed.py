@@ -262,7 +262,8 @@ class Comm:
     def broadcast_begin(self, t, src=0):
         """Start the broadcast of `t` without making the current stream wait for it (RCCL runs it on its own stream); returns a
         token for `broadcast_end`.  What the caller enqueues in between -- work that does not touch `t` -- runs beside the
-        transfer.  The timer covers begin .. end on the caller's stream (what the step sees of the broadcast)."""
+        transfer.  Two timers: "broadcast" covers begin .. end on the caller's stream (the transfer INCLUDING whatever the caller
+        overlapped with it), "broadcast_exposed" only the wait inside `broadcast_end` (what the step pays for the exchange)."""
         if not (self.world > 1 or self.always):
             return None
         rec = self._bytes.setdefault("broadcast", [0, 0])
@@ -282,17 +283,24 @@ class Comm:
         if token is None:
             return
         work, start, t0, on_gpu = token
-        work.wait()   # (GPU: the current stream waits for RCCL's stream; the host does not block)
+        import time
         if not self.timed:
+            work.wait()   # (GPU: the current stream waits for RCCL's stream; the host does not block)
             return
         if on_gpu:
             torch = _torch()
-            end = torch.cuda.Event(enable_timing=True)
+            mid, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            mid.record()
+            work.wait()
             end.record()
             self._events.append(("broadcast", start, end))
+            self._events.append(("broadcast_exposed", mid, end))
         else:
-            import time
-            self._wall["broadcast"] = self._wall.get("broadcast", 0.0) + (time.perf_counter() - t0) * 1e3
+            t1 = time.perf_counter()
+            work.wait()
+            t2 = time.perf_counter()
+            self._wall["broadcast"] = self._wall.get("broadcast", 0.0) + (t2 - t0) * 1e3
+            self._wall["broadcast_exposed"] = self._wall.get("broadcast_exposed", 0.0) + (t2 - t1) * 1e3
 
     def all_gather_rows(self, t, counts):
         """Concatenate ragged row blocks [n_r, ...] of all ranks in rank order (padded all_gather)."""
@@ -455,6 +463,13 @@ class ShardedKiez:
         else:
             if bcast_target:
                 d, code = gathered[0][2], gathered[0][3]
+                # (shape and dtype are checked on the gathered sizes BEFORE the transfer starts: an error raised past
+                #  broadcast_begin would leave an RCCL work nobody waits for -- and every rank raises the same way)
+                if d != src.shape[1]:
+                    raise ValueError("Expected source and target to have the same number of features,"
+                                     f" but got source.shape: {tuple(src.shape)} and target.shape: {(n_t, d)}")
+                if (torch.float32 if code == 0 else torch.float64) != src.dtype:
+                    raise ValueError("source and target must have the same dtype")
                 tgt = tgt0 if comm.rank == 0 else eng.empty((n_t, d), torch.float32 if code == 0 else torch.float64)
                 # RCCL broadcast of the replicated target over xGMI, started here and awaited only where the target is first
                 # needed: the source shard's own preparation (norms of its rows) runs beside the transfer.  (The sweep itself
@@ -469,9 +484,11 @@ class ShardedKiez:
         self._keep = (src, src_full, tgt)  # the engine matrices borrow these tensors
         self.n_s, self.n_t = n_s, tgt.shape[0]
         S_own = None
-        if not need_full_source:
-            S_own = eng.matrix(src, self.metric)     # (beside the broadcast: touches the shard only)
-        comm.broadcast_end(bcast)
+        try:
+            if not need_full_source:
+                S_own = eng.matrix(src, self.metric)     # (beside the broadcast: touches the shard only)
+        finally:
+            comm.broadcast_end(bcast)                    # (also on an error: the transfer is always awaited)
         self.T = eng.matrix(tgt, self.metric)
         if need_full_source:
             self.S = self.T if self.single else eng.matrix(src_full, self.metric)

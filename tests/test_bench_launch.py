@@ -34,7 +34,27 @@ def test_bench_launches_its_own_ranks(gpus, scaling):
     # the exchange steps of the sharded path ran once per step on every rank
     traffic = line["collective_traffic_per_step"]
     assert traffic["broadcast"]["calls"] == 1 and traffic["all_to_all"]["calls"] == 1 and traffic["all_gather"]["calls"] == 1
-    assert set(line["collective_ms_per_step"]) == {"broadcast", "all_to_all", "all_gather"}
+    assert set(line["collective_ms_per_step"]) == {"broadcast", "broadcast_exposed", "all_to_all", "all_gather"}
+    # the line of an N > 1 run carries the evidence a measurement needs: an oracle check that covers the fit state and rows of
+    # EVERY rank's shard, recall@k, and the CPU baseline of the whole job (rank 0, after the timed region)
+    chk = line["check"]
+    assert chk["ranks"] == gpus and len(chk["index_rows_identical_per_rank"]) == gpus
+    assert chk["index_rows_identical_per_rank"] == chk["rows_per_rank"] and chk["index_rows_identical"] == chk["rows"]
+    assert chk["fit_state_rows"] >= 1000 and chk["fit_state_max_rel_err"] < 1e-12
+    assert line["recall_at_k"] == chk["recall_at_k"] == 1.0
+    cpu = line["cpu_baseline"]
+    assert cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["kind"] in ("reference", "port")
+    assert cpu["workload_rows"]["n_source_total"] == cfg["n_source_total"]
+
+
+def test_every_rank_can_upload_the_target_itself():
+    """`--target-upload local`: ShardedKiez.fit(target_from_rank0=False) -- no broadcast in the step, same results."""
+    r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--launch-check", "--target-upload", "local")
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert line["config"]["target_upload"] == "local"
+    assert "broadcast" not in line["collective_traffic_per_step"] and line["collective_traffic_per_step"]["all_to_all"]["calls"] == 1
+    assert line["check"]["index_rows_identical"] == line["check"]["rows"] and line["recall_at_k"] == 1.0
 
 
 def test_a_failing_rank_fails_the_launch():

@@ -79,3 +79,26 @@ print("SHARDED_RCCL_OK")
 def test_sharded_kiez_hip_engine_over_rccl_single_rank():
     r = subprocess.run([sys.executable, "-c", SCRIPT % str(ROOT)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "SHARDED_RCCL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
+
+
+def test_bench_line_of_a_launched_run_carries_check_and_cpu_baseline():
+    """`bench.py` as torch.distributed.run starts it (RANK / WORLD_SIZE / MASTER_* in the environment, RCCL process group), one
+    rank, every collective forced: the line of a launched run -- the code path of `--gpus 8` -- carries the oracle check
+    (fit state + rows of every rank's shard), recall@k and the CPU baseline, for both ways of getting the target onto the ranks."""
+    import json
+    import os
+    for upload, port in (("broadcast", "29631"), ("local", "29633")):
+        env = {**os.environ, "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port,
+               "KIEZ_AMD_FORCE_COLLECTIVES": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--workload", "c2", "--steps", "2", "--warmup", "1",
+                            "--no-others", "--target-upload", upload], capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+        assert r.returncode == 0, r.stderr[-6000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
+        chk = line["check"]
+        assert line["recall_at_k"] == chk["recall_at_k"] == 1.0
+        assert chk["index_rows_identical"] == chk["rows"] == 1024 and chk["index_rows_identical_per_rank"] == [1024]
+        assert chk["fit_state_rows"] == 1024 and chk["fit_state_max_rel_err"] < 1e-12
+        assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["workload_rows"]["n_source_total"] == 100_000
+        traffic = line["collective_traffic_per_step"]
+        assert ("broadcast" in traffic) == (upload == "broadcast") and traffic["all_to_all"]["calls"] == 1
+        assert line["config"]["target_upload"] == upload and line["value"] > 1e6
