@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 4
+#define KZ_ABI_VERSION 5
 /* candidates per query the rescaling / sort kernels take (kz_knn itself returns up to 4096 neighbours) */
 #define KZ_MAX_CANDIDATES 4096
 /* entries per row kz_merge_topk merges (segments x segment length) */
@@ -60,10 +60,14 @@ typedef struct kz_knn_stats {
     double max_err_ratio;    /* self-check: max over all re-ranked candidates of |approximate key - exact key| / eps,
                                 eps = the rounding bound the certification uses; must stay below 1          */
     int32_t dual;            /* kz_knn_dual: 1 = this direction came out of the shared sweep, 0 = ordinary search */
-    int32_t reserved_;
+    int32_t n_first_pass_fail; /* query rows the call's FIRST pass left uncertified, each counted once (n_escalated_rows is
+                                cumulative over the levels below: a row that went two levels down counts twice there)  */
     int64_t n_events;        /* kz_knn_dual, reverse direction: events filed for the rows of b                */
     int64_t n_overflow_rows; /* kz_knn_dual, reverse direction: rows of b whose event buffer overflowed (searched again) */
     int64_t n_logged_groups; /* kz_knn_dual, reverse direction: groups of four keys the sweep logged (>= n_events / 4)   */
+    int32_t wide_lists;      /* > 0: the call ran the fp16 tier's WIDE route -- that many lists of 16 per query (data whose keys
+                                are dense around the k-th neighbour: margin in ranks instead of better operands)           */
+    int32_t reserved_;
 } kz_knn_stats;
 
 /* ---- library / context -------------------------------------------------------------------------------- */

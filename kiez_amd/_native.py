@@ -32,7 +32,7 @@ MAX_FUSED_NEIGHBORS = 110   # neighbours per query ONE fused list keeps (list le
 MAX_NEIGHBORS = 4096
 MAX_HUBNESS_CANDIDATES = 4096  # n_candidates the device hubness kernels (transform, final sort) handle (KZ_MAX_CANDIDATES)
 MERGE_MAX_ENTRIES = 8192       # entries per row kz_merge_topk merges (KZ_MERGE_MAX_ENTRIES)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _ERR_TYPES = {1: ValueError, 2: RuntimeError, 3: NotImplementedError, 4: MemoryError, 5: ValueError}
 
@@ -50,10 +50,12 @@ class KnnStats(C.Structure):
         ("n_escalated_rows", C.c_int64),
         ("max_err_ratio", C.c_double),
         ("dual", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("n_first_pass_fail", C.c_int32),
         ("n_events", C.c_int64),
         ("n_overflow_rows", C.c_int64),
         ("n_logged_groups", C.c_int64),
+        ("wide_lists", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):

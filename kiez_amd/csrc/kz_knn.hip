@@ -1416,6 +1416,13 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // every re-search must differ from the pass that failed)
     const bool no_short = kp_min >= 1000;
     if (no_short) kp_min -= 1000;
+    // kp_min <= -2: the WIDE fp16 route with -kp_min lists of 16 per query (below, "WIDE ROUTE"): a caller's probe has found that
+    // this data needs more margin in ranks, not better operands
+    int forced_lists = 0;
+    if (kp_min <= -2) {
+        forced_lists = -kp_min;
+        kp_min = 0;
+    }
     const int k_eff = k + (exclude_self ? 1 : 0);
     KZ_REQUIRE((int64_t)k_eff <= index->n, "kz_knn: Expected n_neighbors %s n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld",
                exclude_self ? "<" : "<=", k, (long long)index->n);
@@ -1529,6 +1536,37 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             }   // (no memory for the second image: the long list)
         }
     }
+    // WIDE ROUTE (round 5): many lists of 16 -- "wide_lists" (32) of them over as many ranges of the row-dealt image, the finalize
+    // kernel selecting "wide_sel" (256) of their entries.  For data whose keys are DENSE around the k-th neighbour (tight clusters:
+    // hundreds of rows of a cluster lie within the rounding bound of the k-th key).  What such a row needs to be certified is margin
+    // in RANKS -- the bound on the rows outside the candidate set must fall 2 eps below the k-th key, i.e. the set must reach down
+    // to the ~250th key -- and that costs list events and re-ranked rows, not MFMA products: the fp16 kernel with one product per
+    // multiply-add stays, where the split-bf16 tier pays three (bench.py "hard": every row failed the fp16 pass with lists worth
+    // ~100 ranks; with 256 they are certified).  Taken when the tier probe says so (below) or a caller asks for it (forced_lists).
+    bool wide_route = false;
+    auto wide_geometry = [&](int P, int* sel_out) -> bool {
+        int sel = ctx->wide_sel < P * 16 ? ctx->wide_sel : P * 16;
+        if (sel < k_eff + 16) sel = k_eff + 16 < P * 16 ? k_eff + 16 : P * 16;
+        *sel_out = sel;
+        return !dual && tier == KZ_TIER_H && !exact_only && KP_long <= 128 && KSEL_long == 0 && P >= 2 && P <= 32 && P * 16 > KP_long &&
+               sel >= k_eff && (int64_t)index->n_tiles >= (int64_t)8 * P && 4 * kz_fin_wave_bytes(P * 16, sel) <= 160 * 1024;
+    };
+    auto take_wide = [&](int P) -> int {
+        int sel = 0;
+        if (!wide_geometry(P, &sel)) return KZ_ERR_UNSUPPORTED;
+        const int rc = kz_himage_dealt(index, P);
+        if (rc != KZ_OK) return rc;
+        short_ord = true;
+        wide_route = true;
+        KP = 16;
+        KSEL = sel;
+        long_pieces = P;
+        return KZ_OK;
+    };
+    if (forced_lists > 0) {
+        const int rc = take_wide(forced_lists);
+        if (rc != KZ_OK && rc != KZ_ERR_UNSUPPORTED && rc != KZ_ERR_NOMEM) return rc;   // (not available: this call's ordinary route)
+    }
     // TIER PROBE.  Data that is hard for fp16 as a whole (tight clusters far from the centre: nearly every row fails the first pass'
     // certification) used to pay for a complete fp16 sweep and its finalize before anything went down the tiers (bench.py "hard":
     // 2 x 31.6 of 150 ms per step).  A large ordinary search therefore first sends a STRIDED sample of its query rows (1024 rows since the end of round 4, 4096 before:
@@ -1538,7 +1576,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // with 1024 instead of 4096 rows; 200k x 400k x 200, cosine, k = 50: 32.4 -> 31.8); only top-level searches of >= 5e10 distance pairs
     // and >= 16 probe sizes of query rows take it (C1 / C2 do not).  Option "tier_probe" = 0: off.
     float* qfloor_ord = nullptr;   // seeded lists of an ordinary search (the context's buffer: nothing to release)
-    if (tier == KZ_TIER_H && !dual && precision_override < 0 && kp_min == 0 && !exact_only && ctx->tier_probe > 0 && ctx->esc_bf &&
+    if (tier == KZ_TIER_H && !dual && precision_override < 0 && kp_min == 0 && forced_lists == 0 && !exact_only && ctx->tier_probe > 0 && ctx->esc_bf &&
         q_count >= (int64_t)16 * ctx->tier_probe && (double)q_count * (double)index->n >= ctx->probe_min_pairs && ctx->chunk_rows == 0) {
         const int n_probe = ctx->tier_probe;
         int* plist = nullptr;
@@ -1549,10 +1587,34 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         kz_knn_stats stp;
         float pms = 0;
         rc = kz_escalate_rows(ctx, query, q_begin, plist, n_probe, index, k, exclude_self, d_self_ids, 0, 0, d_dist, d_ind, &stp, &pms);
-        kz_pool_free(ctx, plist, 0);
-        if (rc != KZ_OK) return rc;
+        int* plist_keep = plist;
+        if (rc != KZ_OK) {
+            kz_pool_free(ctx, plist, 0);
+            return rc;
+        }
         probe_ms = pms;
-        if (stp.n_escalated_rows * 2 > n_probe) {
+        // (the verdict counts the rows that left the probe's FIRST pass uncertified, once each -- not the cumulative count of the
+        //  levels below it, which counted a row that went two levels down twice)
+        bool hard = (int64_t)stp.n_first_pass_fail * 2 > n_probe;
+        if (hard && ctx->wide_lists >= 2) {
+            // LADDER: before better operands, more margin in ranks on the SAME operands -- the probe rows again through the wide
+            // route; at most a quarter of them uncertified and the whole call takes it
+            int sel = 0;
+            if (wide_geometry(ctx->wide_lists, &sel)) {
+                kz_knn_stats stw;
+                float wms = 0;
+                rc = kz_escalate_rows(ctx, query, q_begin, plist_keep, n_probe, index, k, exclude_self, d_self_ids, 0, -ctx->wide_lists, d_dist, d_ind,
+                                      &stw, &wms);
+                if (rc != KZ_OK) {
+                    kz_pool_free(ctx, plist_keep, 0);
+                    return rc;
+                }
+                probe_ms += wms;
+                if ((int64_t)stw.n_first_pass_fail * 4 <= n_probe && take_wide(ctx->wide_lists) == KZ_OK) hard = false;
+            }
+        }
+        kz_pool_free(ctx, plist_keep, 0);
+        if (hard) {
             tier = KZ_TIER_BF;
             // (data this hard for fp16 is hard for the split-bf16 operands, too, wherever the keys are dense: lists of 64 from the
             //  start -- 300k x 300k x 96, k = 10, clusters of very different spread: rows searched again 135 k -> 51 k, call 170 -> 110 ms)
@@ -1563,7 +1625,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 KSEL = KSEL_long;
                 long_pieces = pieces_long;
             }
-        } else if (ctx->list_floor) {
+        } else if (ctx->list_floor && !wide_route) {
             // POPULATION FLOOR (above kz_escalate_rows): the probe's results are the model's input
             double model[3];
             bool ok = false;
@@ -1618,7 +1680,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     const int KP_mem = KP_class > KP ? KP_class : KP;   // (short-list route: several lists of 16 -- the chunk of the replaced list length)
     const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (KP_mem <= 16 ? 4 : (KP_mem <= 32 ? 2 : 1));
     double main_ms = 0, fin_ms = 0, fb_ms = probe_ms;
-    int64_t n_fail_total = 0, n_escalated = 0;
+    int64_t n_fail_total = 0, n_escalated = 0, n_first_fail = 0;
     double max_err_ratio = 0.0;
     int last_splits = 1, last_blocks = 0, first_tier = tier;
     for (int64_t c0 = 0; c0 < q_count;) {
@@ -1792,6 +1854,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             unchecked[u]->checked = true;
         }
         const int n_fail = exact_only ? (int)cq_count : ctx->h_counters[8];
+        n_first_fail += n_fail;
         {
             double ratio;
             memcpy(&ratio, ctx->h_counters + 10, 8);
@@ -1820,7 +1883,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             // exact float64 kernels).  Results are scattered back.
             // (more than half of the chunk uncertified: the fp16 operands are the wrong tool for this data, longer lists of the
             //  same keys will not help most of them -- straight to the split-bf16 operands)
-            const bool fp16_hard = tier == KZ_TIER_H && ctx->esc_bf && (int64_t)n_fail * 2 > cq_count && (long_pieces == 0 || short_ord || (dual && dual->short_pieces > 0));
+            // (... and so are the rows the WIDE route leaves: it already is the fp16 tier's largest margin in ranks)
+            const bool fp16_hard = tier == KZ_TIER_H && ctx->esc_bf && (wide_route || ((int64_t)n_fail * 2 > cq_count && (long_pieces == 0 || short_ord || (dual && dual->short_pieces > 0))));
             const bool widen = tier == KZ_TIER_H && KP < 128 && !fp16_hard;
             // (short-list route: the rows it cannot certify are mostly the ones a list of K' could not certify either -- they go
             //  where that list's failures would have gone, lists four times K', not through a list of K' first)
@@ -1839,7 +1903,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 //  the keys are dense; lists of 64 certify such rows instead of handing them to the exact kernels at ~60 us a row:
                 //  300k x 300k x 96, clusters of very different spread: 9 968 rows to the exact kernels and 726 ms per call before, none and
                 //  169 ms now; lists of 128 for every call: bench.py "hard", k = 50, 118 -> 225 ms -- its lists of 64 were long enough)
-                next_kp = (next_prec == 1 && KP_class < 64) ? 64 : 0;
+                next_kp = ((next_prec == 1 || wide_route) && KP_class < 64) ? 64 : 0;
             } else if (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS) {
                 next_prec = 0;
                 next_kp = -1;   // a handful of rows of a K' = 16 pass: more lists of 16
@@ -1962,6 +2026,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         stats->first_pass = first_tier;
         stats->n_escalated_rows = n_escalated;
         stats->max_err_ratio = max_err_ratio;
+        stats->n_first_pass_fail = n_first_fail > 0x7fffffff ? 0x7fffffff : (int32_t)n_first_fail;
+        stats->wide_lists = wide_route ? long_pieces : 0;
     }
     return KZ_OK;
 }

@@ -330,10 +330,11 @@ static void kz_dual_fill_stats(kz_knn_stats* st, const kz_knn_stats& v) {
 // Both directions by two ordinary searches (shapes or settings the dual pass does not cover)
 static int kz_knn_dual_separately(kz_ctx* ctx, kz_matrix* a, kz_matrix* b, int k, double* d_dist_ab, int64_t* d_ind_ab,
                                   double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba,
-                                  int precision_override = -1) {
+                                  int precision_override = -1, int wide = 0) {
     // (precision_override = 2: the caller's probe has found the data hard for fp16 -- both searches start at the split-bf16 tier
-    //  without probing again, with lists of at least 64 as an ordinary search's own probe would have chosen)
-    const int kp_min = precision_override == 2 ? 64 : 0;
+    //  without probing again, with lists of at least 64 as an ordinary search's own probe would have chosen;
+    //  wide > 0: the probe has found that the fp16 tier's WIDE route certifies this data -- both searches take it, kz_knn_impl kp_min = -wide)
+    const int kp_min = wide > 0 ? -wide : (precision_override == 2 ? 64 : 0);
     int rc = kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, precision_override, kp_min, d_dist_ab, d_ind_ab, stats_ab, nullptr);
     if (rc == KZ_OK) rc = kz_knn_impl(ctx, b, 0, b->n, a, k, 0, nullptr, precision_override, kp_min, d_dist_ba, d_ind_ba, stats_ba, nullptr);
     return rc;
@@ -615,11 +616,24 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             hipLaunchKernelGGL(kz_strided_rows_kernel, dim3((unsigned)((n_probe + 255) / 256)), dim3(256), 0, ctx->stream, plist, n_probe, pstride);
             rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, 0, d_dist_ab, d_ind_ab, &stp, &pms);
         }
-        kz_pool_free(ctx, plist, 0);
-        if (rc == KZ_OK && want_tier && stp.n_escalated_rows * 2 > n_probe) {
+        // (the rows the probe's FIRST pass left uncertified, once each)
+        if (rc == KZ_OK && want_tier && (int64_t)stp.n_first_pass_fail * 2 > n_probe) {
+            // LADDER (kz_knn_impl "WIDE ROUTE"): the probe rows again with many lists of 16 on the same fp16 operands -- at most a
+            // quarter uncertified: two ordinary searches on that route; otherwise two that start at the split-bf16 tier
+            int wide = 0;
+            if (ctx->wide_lists >= 2) {
+                kz_knn_stats stw;
+                memset(&stw, 0, sizeof(stw));
+                float wms = 0;
+                rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, -ctx->wide_lists, d_dist_ab, d_ind_ab, &stw, &wms);
+                if (rc == KZ_OK && stw.wide_lists > 0 && (int64_t)stw.n_first_pass_fail * 4 <= n_probe) wide = ctx->wide_lists;
+            }
+            kz_pool_free(ctx, plist, 0);
             release();
-            return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba, 2);
+            if (rc != KZ_OK) return rc;
+            return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba, wide > 0 ? -1 : 2, wide);
         }
+        kz_pool_free(ctx, plist, 0);
         if (rc == KZ_OK && want_floor) rc = kz_floor_model(ctx, d_dist_ab, ia->rowq, n_probe, pstride, k, a->metric, floor_model, &have_floor);
         if (rc != KZ_OK) {
             release();

@@ -65,6 +65,8 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     c->lds_pad = 0;
     c->h_q64 = 2;
     c->tier_probe = 1024;
+    c->wide_lists = 32;
+    c->wide_sel = 256;
     c->dual_rank = 0;
     c->probe_min_pairs = 5e10;
     c->list_floor = 1;
@@ -222,6 +224,12 @@ int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     } else if (strcmp(name, "dual_rank") == 0) {
         KZ_REQUIRE(value >= -1 && value <= 128, "dual_rank must be -1 (k + 1), 0 (automatic) or in [1, 128]");
         c->dual_rank = (int)value;
+    } else if (strcmp(name, "wide_lists") == 0) {
+        KZ_REQUIRE(value == 0 || (value >= 2 && value <= 32), "wide_lists must be 0 or in [2, 32]");
+        c->wide_lists = (int)value;
+    } else if (strcmp(name, "wide_sel") == 0) {
+        KZ_REQUIRE(value >= 16 && value <= 512, "wide_sel must be in [16, 512]");
+        c->wide_sel = (int)value;
     } else if (strcmp(name, "tier_probe") == 0) {
         KZ_REQUIRE(value >= 0 && value <= 65536, "tier_probe must be in [0, 65536]");
         c->tier_probe = (int)value;

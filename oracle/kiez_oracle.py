@@ -70,7 +70,7 @@ def _topk_rows(val: np.ndarray, k: int):
 
 
 def knn_exact(query, index, k: int, metric: str = "euclidean", exclude_self: bool = False,
-              chunk_bytes: int = 1 << 28):
+              chunk_bytes: int = 1 << 28, threads: int = 0):
     """Exact k nearest index rows for every query row, sorted ascending.
 
     euclidean family — sklearn `EuclideanArgKmin`
@@ -82,6 +82,9 @@ def knn_exact(query, index, k: int, metric: str = "euclidean", exclude_self: boo
     index equals the row id (or the first entry when it is absent).
     Returns float64 distances and int64 indices.  For float32 query AND index with metric euclidean the
     float64 values are float32-representable (see the sqrt step below) — measured on sklearn 1.7.2.
+    threads > 1: the row chunks are worked on by that many Python threads (numpy's partition and BLAS release
+    the GIL; every chunk is computed exactly as in the serial loop, so the result does not depend on it) —
+    for the full-size checks of tests/ on a many-core host.
     """
     metric = canonical_metric(metric)
     both_f32 = np.asarray(query).dtype == np.float32 and np.asarray(index).dtype == np.float32
@@ -106,7 +109,7 @@ def knn_exact(query, index, k: int, metric: str = "euclidean", exclude_self: boo
     rows = max(1, int(chunk_bytes // (8 * max(n_i, 1))))
     dist = np.empty((n_q, kk), dtype=np.float64)
     ind = np.empty((n_q, kk), dtype=np.int64)
-    for s in range(0, n_q, rows):
+    def chunk(s):
         e = min(n_q, s + rows)
         g = q[s:e] @ y.T
         if metric == "cosine":
@@ -119,6 +122,15 @@ def knn_exact(query, index, k: int, metric: str = "euclidean", exclude_self: boo
             g += ysq[None, :]
             np.maximum(g, 0.0, out=g)
         dist[s:e], ind[s:e] = _topk_rows(g, kk)
+
+    starts = range(0, n_q, rows)
+    if threads > 1 and len(starts) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            list(pool.map(chunk, starts))
+    else:
+        for s in starts:
+            chunk(s)
     if metric == "euclidean":
         if both_f32:
             # ArgKmin32 orders in float64 but converts the surrogate with the float32 metric object:

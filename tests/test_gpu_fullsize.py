@@ -1,5 +1,8 @@
-"""BASELINE.json's full-size configuration (C1/C2: 100k x 100k, d=128, k=10) on the GPU: size-independent properties
-plus an oracle spot check on a row sample, and edge cases the domain has (exact duplicates, zero rows, tiny inputs)."""
+"""BASELINE.json's full-size configurations on the GPU.  C1 / C2 (100k x 100k, d=128, k=10): EVERY row of both kNN passes and of
+the final result against the oracle (2.56 Tflop of dgemm per pass: seconds on the GPU box's host cores) plus size-independent
+properties; C3 (500k x 500k): 1 024-row samples of both passes, 256 rows of the MP-empiric transform; edge cases the domain has
+(exact duplicates, zero rows, tiny inputs)."""
+import os
 import warnings
 
 import numpy as np
@@ -14,6 +17,9 @@ def c1_data():
     return rng.rand(100_000, 128).astype(np.float32), rng.rand(100_000, 128).astype(np.float32)
 
 
+THREADS = max(1, min(32, os.cpu_count() or 1))   # (oracle.knn_exact works on its row chunks with this many threads)
+
+
 def _props(dist, ind, n_index, k):
     assert dist.shape == ind.shape == (dist.shape[0], k)
     assert ind.dtype == np.int64 and dist.dtype == np.float64
@@ -23,7 +29,7 @@ def _props(dist, ind, n_index, k):
     assert np.isfinite(dist).all()
 
 
-def test_c1_full_size_properties_and_sample(c1_data):
+def test_c1_full_size_every_row_against_the_oracle(c1_data):
     from kiez_amd import Kiez
     from oracle import kiez_oracle as O
     s, t = c1_data
@@ -36,18 +42,17 @@ def test_c1_full_size_properties_and_sample(c1_data):
     assert (np.diff(d10, axis=1) >= 0).all(), "rows must be sorted ascending"
     np.testing.assert_array_equal(i5, i10[:, :5])          # k-prefix property
     np.testing.assert_array_equal(d5, d10[:, :5])
-    rows = np.random.RandomState(1).choice(len(s), 512, replace=False)
-    od, oi = O.knn_exact(s[rows], t, 10, "euclidean")
-    np.testing.assert_array_equal(i10[rows], oi)
-    np.testing.assert_array_equal(d10[rows], od)            # float32 inputs: bit-identical distances (sqrt rule)
+    od, oi = O.knn_exact(s, t, 10, "euclidean", threads=THREADS)      # ALL 100 000 rows
+    np.testing.assert_array_equal(i10, oi)
+    np.testing.assert_array_equal(d10, od)                  # float32 inputs: bit-identical distances (sqrt rule)
     # exact distance recomputed in float64 for a few entries
-    r = rows[:16]
+    r = np.random.RandomState(1).choice(len(s), 16, replace=False)
     ref = np.sqrt(((s[r, None, :].astype(np.float64) - t[i10[r]].astype(np.float64)) ** 2).sum(-1))
     np.testing.assert_allclose(d10[r], ref, rtol=2e-7)
     assert kz.algorithm.last_stats["n_fallback_rows"] < 100
 
 
-def test_c2_full_size_csls_sample(c1_data):
+def test_c2_full_size_csls_every_row_against_the_oracle(c1_data):
     from kiez_amd import Kiez
     from oracle import kiez_oracle as O
     s, t = c1_data
@@ -57,18 +62,13 @@ def test_c2_full_size_csls_sample(c1_data):
         d, i = kz.kneighbors(10)
     _props(d, i, len(t), 10)
     assert (np.diff(d, axis=1) >= 0).all()
-    # CSLS on a row sample: the fit state needs all rows of the reverse pass, so take it from the device
-    r_train = kz.hubness._r_train_dev.numpy()
-    rows = np.arange(0, 100_000, 997)
-    fd, fi = O.knn_exact(s[rows], t, 10, "euclidean")
-    tr = 2 * fd - fd.mean(axis=1).reshape(-1, 1) - r_train[fi]
-    od, oi = O.sort_topk(tr, fi, 10)
-    np.testing.assert_array_equal(i[rows], oi)
-    np.testing.assert_allclose(d[rows], od, rtol=1e-9, atol=1e-12)
-    # r_train itself against the oracle on a sample of target rows
-    trows = np.arange(0, 100_000, 1999)
-    rd, _ = O.knn_exact(t[trows], s, 10, "euclidean")
-    np.testing.assert_array_equal(r_train[trows], rd.mean(axis=1))
+    # the whole pipeline in the oracle, ALL rows: reverse pass (fit state), forward pass, CSLS, final sort
+    rd, _ = O.knn_exact(t, s, 10, "euclidean", threads=THREADS)
+    np.testing.assert_array_equal(kz.hubness._r_train_dev.numpy(), rd.mean(axis=1))       # csls.py:90, bit for bit
+    fd, fi = O.knn_exact(s, t, 10, "euclidean", threads=THREADS)
+    od, oi = O.sort_topk(O.csls_transform(fd, fi, rd), fi, 10)
+    np.testing.assert_array_equal(i, oi)
+    np.testing.assert_allclose(d, od, rtol=1e-9, atol=1e-12)
 
 
 def test_exact_duplicates_order_by_index():
@@ -177,8 +177,8 @@ def test_c3_full_size_mp_empiric_properties_and_oracle_sample():
     """BASELINE config 3 at FULL size through the drop-in API: 500k x 500k, d=200, cosine, k=50, MutualProximity empiric.
     The oracle cannot run this size (the reference's own loop is ~2.5e7 allocations of 4 MB), so:
       * size-independent properties of the full result;
-      * a 256-row sample of BOTH kNN passes against the oracle's exact float64 search;
-      * the oracle's MP-empiric transform + final sort on a row sample, fed with the (sample-verified) reverse lists."""
+      * a 1 024-row sample of BOTH kNN passes against the oracle's exact float64 search;
+      * the oracle's MP-empiric transform + final sort on 256 rows, fed with the (sample-verified) reverse lists."""
     from kiez_amd import Kiez
     from oracle import kiez_oracle as O
     from tests.golden_util import knife_edge_rows, knife_edge_topk_ok
@@ -202,20 +202,20 @@ def test_c3_full_size_mp_empiric_properties_and_oracle_sample():
     assert (srt[:, 1:] != srt[:, :-1]).all()                        # distinct neighbours per row
     # both passes on a row sample (float64 casts: the oracle's convention for cosine + float32)
     nn = kz.algorithm
-    rows = np.arange(0, n, n // 256)[:256]
+    rows = np.arange(0, n, n // 1024)[:1024]
     s64, t64 = s.astype(np.float64), None
     fd, fi = nn.kneighbors_device(k=K)
     fd, fi = fd.numpy(), fi.numpy()
     rd_dev, ri_dev = kz.hubness._dist_t2s_dev.numpy(), kz.hubness._ind_t2s_dev.numpy()
     t64 = t.astype(np.float64)
-    od, oi = O.knn_exact(s64[rows], t64, K, "cosine")
+    od, oi = O.knn_exact(s64[rows], t64, K, "cosine", threads=THREADS)
     np.testing.assert_array_equal(fi[rows], oi)
     np.testing.assert_allclose(fd[rows], od, rtol=1e-6, atol=1e-7)
-    od, oi = O.knn_exact(t64[rows], s64, K, "cosine")
+    od, oi = O.knn_exact(t64[rows], s64, K, "cosine", threads=THREADS)
     np.testing.assert_array_equal(ri_dev[rows], oi)
     np.testing.assert_allclose(rd_dev[rows], od, rtol=1e-6, atol=1e-7)
-    # transform + sort on a (smaller) sample: the oracle loop allocates n floats per candidate
-    sub = rows[:48]
+    # transform + sort on 256 of those rows (the oracle's per-row loop)
+    sub = rows[::4]
     hr = O.mp_empiric_transform(fd[sub], fi[sub], rd_dev, ri_dev)
     sd, si = O.sort_topk(hr, fi[sub], K)
     ke = (fi[sub] == sub[:, None]).any(axis=1)

@@ -38,6 +38,13 @@ def main():
         ctx.set_option("eps_scale", eps)
         q64 = int(rng.randint(0, 2))          # fp16 pass on the 64-queries-per-wave kernel where it is built (K' = 16, 4 .. 13 slices)
         ctx.set_option("h_q64", q64)
+        # tier probe + its ladder (default lists -> wide route -> split-bf16) on these small shapes: probe rows, lists and
+        # selected entries of the wide route drawn at random (with eps 30 the first rung fails and the ladder is climbed)
+        tp, wl, ws = int(rng.choice([0, 16, 64])), int(rng.choice([0, 2, 4, 8, 32])), int(rng.choice([64, 256]))
+        ctx.set_option("tier_probe", tp)
+        ctx.set_option("probe_min_pairs", 0.0 if tp else 5e10)
+        ctx.set_option("wide_lists", wl)
+        ctx.set_option("wide_sel", ws)
         res = {}
         for prec in (0, 2, 1):   # fp16 first pass (default), split-bf16, float32 operands only
             ctx.set_option("precision", prec)
@@ -51,6 +58,8 @@ def main():
         ctx.set_option("short_ord_min_tiles", 48)
         ctx.set_option("eps_scale", 1.0)
         ctx.set_option("h_q64", 2)
+        for name, v in (("tier_probe", 1024), ("probe_min_pairs", 5e10), ("wide_lists", 32), ("wide_sel", 256)):
+            ctx.set_option(name, v)
         ok = all(np.array_equal(res[0][1], res[p][1]) and np.array_equal(res[0][0], res[p][0]) for p in (1, 2))
         if len(s) * n_t <= 2_000_000:
             od, oi = O.knn_exact(s, t, k, O.canonical_metric(metric), exclude_self=single)
@@ -58,7 +67,7 @@ def main():
         tag = "ok " if ok else "BAD"
         bad += 0 if ok else 1
         print(tag, f"n_s={len(s)} n_t={n_t} d={d} {metric} {np.dtype(dtype).name} k={k} single={single}",
-              "tier", res[0][2]["first_pass"], "lists", res[0][2]["n_splits"], "x", res[0][2]["list_len"], f"min_tiles {min_tiles} eps {eps} q64 {q64}", "esc", res[0][2]["n_escalated_rows"], "fb", res[0][2]["n_fallback_rows"],
+              "tier", res[0][2]["first_pass"], "lists", res[0][2]["n_splits"], "x", res[0][2]["list_len"], f"min_tiles {min_tiles} eps {eps} q64 {q64} probe {tp} wide {wl}/{ws} -> {res[0][2]['wide_lists']}", "esc", res[0][2]["n_escalated_rows"], "fb", res[0][2]["n_fallback_rows"],
               "ratio %.3f" % res[0][2]["max_err_ratio"])
     print("cases", n_cases, "bad", bad)
     sys.exit(1 if bad else 0)
