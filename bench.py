@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: source queries/s over fit + kneighbors (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--workload ns|c1|c2|c3|c3s|c4s|c4|c1g|hard] [--no-others]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--workload ns|c1|c2|c3|c3s|c4s|c4|c1g|hard|gmm] [--no-others]
     python bench.py --openea EMB_DIR KG_DIR [--steps K] [--warmup W]      (real entity-alignment embeddings)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
@@ -55,6 +55,9 @@ WORKLOADS = {
     "hard": (300_000, 301_000, 64, "cosine", 50, 50, "MutualProximity", {"method": "empiric"},
              "data that is hard for the fp16 first pass (40 tight gaussian clusters far from the centre, rows stored cluster by "
              "cluster; tools/short_route_stress.py): 300k x 301k, d=64, cosine, k=50, MutualProximity empiric"),
+    "gmm": (200_000, 200_000, 300, "euclidean", 10, 10, "CSLS", {},
+            "entity-alignment-like embeddings (the reference's real workload, kiez/io/data_loading.py:75-99, has no synthetic stand-in): "
+            "L2-normalised gaussian mixture, 256 clusters shared by both sides, rows in random order: 200k x 200k, d=300, euclidean, k=10, CSLS"),
 }
 METRIC = "source queries/sec (fit+kneighbors) + recall@k vs reference, 1/2/4/8 GPU"   # BASELINE.json's metric
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
@@ -262,6 +265,15 @@ def synth_rows(name, seed, rows, d):
     the centre, stored cluster by cluster (tools/short_route_stress.py)."""
     rng = np.random.RandomState(seed)
     out = np.empty((rows, d), dtype=np.float32)
+    if name == "gmm":
+        # 256 cluster centres common to both embedding spaces (aligned KGs), within-cluster spread a third of the centres' own,
+        # every row L2-normalised, rows in random order
+        centres = np.random.RandomState(6).standard_normal((256, d)).astype(np.float32)
+        for b in range(0, rows, 100_000):
+            m = min(100_000, rows - b)
+            x = centres[rng.randint(0, 256, m)] + np.float32(0.35) * rng.standard_normal((m, d)).astype(np.float32)
+            out[b:b + m] = x / np.sqrt((x * x).sum(axis=1, keepdims=True))
+        return out
     if name == "hard":
         centres = np.random.RandomState(5).standard_normal((40, d)) * 3     # the same centres on both sides
         sizes = rng.multinomial(rows, np.ones(40) / 40)
@@ -371,6 +383,10 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
         "max_err_ratio": max((st.get("max_err_ratio", 0.0) for _, _, st in knn_log), default=0.0),
         "finalize_avg_ms": sum(st["finalize_ms"] for _, _, st in knn_log) / max(n_launch, 1),
         "fallback_total_ms": sum(st["fallback_ms"] for _, _, st in knn_log),
+        "probe_ms_per_step": sum(st.get("probe_ms", 0.0) for _, _, st in knn_log) / max(steps, 1),
+        # > 0: launches that ran the fp16 tier's WIDE route (that many lists of 16 per query: dense keys around the k-th neighbour)
+        "wide_lists": max((st.get("wide_lists", 0) for _, _, st in knn_log), default=0),
+        "first_pass_fail_rows": int(sum(st.get("n_first_pass_fail", 0) for _, _, st in knn_log)),
         "collective_ms_per_step": comm.timers_ms(steps),
         "collective_traffic_per_step": comm.traffic(steps),   # per kind: calls and payload bytes this rank handed over
         # shared sweeps (kz_knn_dual): how many of the launches served both directions, and what the reverse direction cost
@@ -441,7 +457,8 @@ def short(summary):
             "main_kernel_avg_ms": s["kernel_s"] / max(s["n_launch"], 1) * 1e3, "dtype": TIER_NAME[s["tier"]],
             "roofline_frac": s["achieved"] / s["peak"], "achieved_tflops": s["achieved"],
             "finalize_avg_ms": s["finalize_avg_ms"], "certification_fallback_rows": s["fallback_rows"],
-            "escalated_rows": s["escalated_rows"], "fallback_total_ms": s["fallback_total_ms"],
+            "escalated_rows": s["escalated_rows"], "fallback_total_ms": s["fallback_total_ms"], "probe_ms_per_step": s["probe_ms_per_step"],
+            "wide_lists": s["wide_lists"], "first_pass_fail_rows": s["first_pass_fail_rows"],
             "max_err_over_eps": s["max_err_ratio"], "steps": s["steps"], "shared_sweeps": s["shared_sweeps"],
             "reverse_extra_ms_per_step": s["reverse_extra_ms_per_step"], "reverse_escalated_rows": s["reverse_escalated_rows"], "check": s["check"]}
 
@@ -726,7 +743,7 @@ def main():
         others = {}
         # c4 = configuration 4 at its stated size on this one GPU (the N = 1 anchor of `--scaling strong`; ~1.3 s per step: fewer
         # steps); c1g / hard = the same kernels on gaussian and on clustered data (how often the tier chain runs is data dependent)
-        for name in ("c1", "c2", "c3", "c4s", "c4", "ns", "c1g", "hard"):
+        for name in ("c1", "c2", "c3", "c4s", "c4", "ns", "c1g", "hard", "gmm"):
             if name == args.workload:
                 continue
             try:

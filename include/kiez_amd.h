@@ -68,6 +68,8 @@ typedef struct kz_knn_stats {
     int32_t wide_lists;      /* > 0: the call ran the fp16 tier's WIDE route -- that many lists of 16 per query (data whose keys
                                 are dense around the k-th neighbour: margin in ranks instead of better operands)           */
     int32_t reserved_;
+    double probe_ms;         /* tier / floor probe of a large search (a strided sample of the query rows searched first), incl. the
+                                ladder's second rung; not part of fallback_ms                                                 */
 } kz_knn_stats;
 
 /* ---- library / context -------------------------------------------------------------------------------- */
@@ -82,34 +84,16 @@ int kz_ctx_sync(kz_ctx* ctx);
  * searches are kept for reuse -- up to 48 GiB -- so that a repeated fit() does not pay hipMalloc + hipFree; a process that
  * shares the GPU with another allocator, e.g. torch's, calls this after a large search).  Waits for the stream. */
 int kz_ctx_trim(kz_ctx* ctx);
-/* Options.  "precision": 0 (default) = fp16 first pass on centred operands (16 <= d_pad <= 384), uncertified rows go
- * down the tiers (longer lists -> float32 operands -> exact float64); 2 = split-bf16 first pass; 1 = float32 operands
- * only.  The neighbour order is the float64 one either way.  "dual_stride": kz_knn_dual samples every n-th tile of a
- * for its thresholds (default 1 = chosen from the shapes; 0 = always two ordinary searches).  Test/diagnostic knobs: "eps_scale" multiplies the
- * certification bound (huge value => every row takes the exact fallback); "force_splits" fixes the index split count
- * (0 = automatic); "min_splits", "chunk_rows", "h_wps", "h_wide", "lds_pad": scheduling / occupancy knobs;
- * "long_k": 1 (default) = 111 .. ~540 neighbours per query run on the fused kernels (lists over many index ranges), 0 = on the
- * exact float64 kernels like everything beyond; "dual_max_gb": transient footprint kz_knn_dual may claim (GiB; 0 = 32: beyond it, or beyond what the device has free, it
- * searches twice); "dual_overlap": 1 (default) = its reverse direction's chain runs on a second stream;
- * "dual_sample_short": 1 (default) = its sample sweep keeps lists of 16 (32) entries over several index ranges whatever k is;
- * "dual_short_main": 1 (default) = so does its main sweep for 13 .. 110 neighbours (k / "dual_short_div" lists of 16 per query, taken
- * when an index range has at least "dual_short_min_tiles" tiles; "dual_short_kp": 16 or 32); "esc_short": 1 (default) = rows a
- * K' = 16 pass could not certify are searched again with more lists of 16 instead of lists of 64; "qgroup": query tiles per group
- * of the work table (0 = automatic); "short_ord": 1 (default) = the ordinary search takes the short-list route too (13 .. 320
- * neighbours, a second row-dealt image of the index, ranges of at least "short_ord_min_tiles" tiles); "dual_rev_long": 1 (default) = reverse lists of twice the list length;
- * "esc_bf": 1 (default) = split-bf16 operands before the float32 ones for rows the fp16 tier cannot certify;
- * "h_q64": the 64-queries-per-wave build of the fp16 kernel (K' = 16, 4 .. 13 slices): 2 (default) = where it pays (the shared
- * sweep from 9 slices on over >= 4 rounds of work items), 1 = wherever it is built, 0 = never; "tier_probe": rows of the strided sample a large ordinary search (>= 5e10
- * distance pairs) sends through the fp16 pass first -- more than half of them uncertified and the call starts at the split-bf16
- * operands instead of paying for a whole fp16 sweep (default 1024, 0 = off); "dual_rank": rank of the sample key that becomes a
- * row's event threshold in kz_knn_dual (0 = automatic: the cheapest rank that leaves fewer than 1e-3 of the rows short of k
- * events -- those are searched again; -1 = the safe k + 1; > 0 = that rank); "list_floor": 1 (default) = the candidate lists of a
- * large sweep start at a per-row floor modelled on a probe of the query rows ("floor_probe" rows of a in kz_knn_dual, default 1024;
- * the tier probe's rows in an ordinary search) instead of at -inf: keys at or below the floor never become list events, rows left
- * with fewer than k candidates are searched again ("floor_margin", default 1.3, scales the model's safety margin; 0 = none;
- * "probe_min_pairs", default 5e10: ordinary searches of fewer distance pairs take neither the tier probe nor a floor);
- * "fin_fast_div": 1 (default) = the cosine re-rank divides through one reciprocal per candidate row (bit-identical to the
- * division).  Every route gives identical results. */
+/* Options (the public contract -- four names):
+ *   "precision"    0 (default) = fp16 first pass on centred operands (16 <= d_pad <= 384), rows it cannot certify go down the
+ *                  tiers (more / longer lists -> split-bf16 operands -> float32 operands -> exact float64); 2 = split-bf16 first
+ *                  pass; 1 = float32 operands only.  The neighbour order is the float64 one either way.
+ *   "dual_stride"  kz_knn_dual samples every n-th tile of a for its thresholds: 1 (default) = chosen from the shapes, 0 = always
+ *                  two ordinary searches, 2 .. 64 = that stride.
+ *   "dual_max_gb"  transient footprint kz_knn_dual may claim, GiB (0 = 32): beyond it, or beyond what is free, it searches twice.
+ *   "eps_scale"    multiplies the certification bound (test knob: a huge value sends every row to the exact float64 kernels).
+ * Every other name the call accepts is an internal tuning / diagnostic knob of this build (one table: kiez_amd/csrc/kz_options.h),
+ * outside this contract.  Options decide how fast a result arrives, never what it is.  Unknown name or value: KZ_ERR_INVALID. */
 int kz_ctx_set_option(kz_ctx* ctx, const char* name, double value);
 
 int kz_malloc(kz_ctx* ctx, size_t bytes, void** d_ptr);

@@ -56,6 +56,7 @@ class KnnStats(C.Structure):
         ("n_logged_groups", C.c_int64),
         ("wide_lists", C.c_int32),
         ("reserved_", C.c_int32),
+        ("probe_ms", C.c_double),
     ]
 
     def as_dict(self):

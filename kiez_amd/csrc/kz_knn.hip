@@ -1192,6 +1192,9 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
     const KzListLayout& lay = pl.lay;
     const int W = pl.W;
     const size_t list_elems = pl.list_elems;
+    // (the kernels address a launch's lists with 32-bit element offsets -- kz_knn_h16.h "off_u"; a K' = 16 chunk of 2 M rows over
+    //  KZ_MAX_PIECES = 128 ranges is exactly 2^32 elements: refused here instead of wrapping there)
+    KZ_REQUIRE(list_elems < ((size_t)1 << 32), "kz_knn: the candidate lists of one launch exceed 2^32 entries (%zu): fewer rows per chunk (option chunk_rows)", list_elems);
     const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
     const size_t fail_bytes = ((size_t)fail_rows * 4 + 255) & ~(size_t)255;
     const size_t work_bytes = ((size_t)W * sizeof(int4) + 255) & ~(size_t)255;
@@ -1678,8 +1681,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // times as many for shorter lists (1 M x 250 k, K' = 16: one launch instead of two -- one tail round, one read-back, one
     // re-search of the uncertified rows)
     const int KP_mem = KP_class > KP ? KP_class : KP;   // (short-list route: several lists of 16 -- the chunk of the replaced list length)
-    const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (KP_mem <= 16 ? 4 : (KP_mem <= 32 ? 2 : 1));
-    double main_ms = 0, fin_ms = 0, fb_ms = probe_ms;
+    // (the wide route keeps 32 lists of 16 per query -- 4 KiB: 524288 rows)
+    const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (wide_route ? 1 : (KP_mem <= 16 ? 4 : (KP_mem <= 32 ? 2 : 1)));
+    double main_ms = 0, fin_ms = 0, fb_ms = 0;   // (the tier probe's time is reported under its own field, kz_knn_stats.probe_ms)
     int64_t n_fail_total = 0, n_escalated = 0, n_first_fail = 0;
     double max_err_ratio = 0.0;
     int last_splits = 1, last_blocks = 0, first_tier = tier;
@@ -1711,7 +1715,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             // a SMALL launch on the short-list route (a re-search of a few hundred uncertified rows, a probe): P ranges per query
             // tile leave most of the chip idle (216 rows x 10 ranges: 20 workgroups sweeping 390 tiles each, 1.98 ms) -- every
             // range is cut further, s P lists of 16 per query (the finalize kernel selects from any number of lists), as long as
-            // a piece keeps at least 8 tiles and a query at most 64 lists
+            // a piece keeps at least 8 tiles and a query at most KZ_MAX_PIECES (128) lists
             const int units = (n_qtiles + tpw_h - 1) / tpw_h;
             int sub = slots / (units * force_pieces);
             if (sub > KZ_MAX_PIECES / force_pieces) sub = KZ_MAX_PIECES / force_pieces;
@@ -2019,6 +2023,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         stats->main_kernel_ms = main_ms;
         stats->finalize_ms = fin_ms;
         stats->fallback_ms = fb_ms;
+        stats->probe_ms = probe_ms;
         stats->n_fallback_rows = n_fail_total;
         stats->list_len = KP;
         stats->n_splits = last_splits;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
         }
     } else {
         // (uniform bases + a 32-bit per-lane element offset: no 64-bit per-lane pointers to keep alive; a launch's lists stay
-        //  far below 2^32 elements: <= 524288 rows x 64 ranges x K')
+        //  below 2^32 elements -- kz_prepare_pass refuses a launch whose lists reach that)
         st.list.kb = p.out_key;
         st.list.ib = p.out_idx;
         st.list.off = (unsigned)out_list_offset();

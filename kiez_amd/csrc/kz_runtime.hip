@@ -1,5 +1,6 @@
 // Context, memory and error plumbing of libkiez_amd.so.
 #include "kz_common.h"
+#include "kz_options.h"
 
 #include <cstdlib>
 
@@ -40,40 +41,7 @@ int kz_ctx_create(int device, void* stream, kz_ctx** out) {
     kz_ctx* c = new kz_ctx();
     memset(c, 0, sizeof(*c));
     c->device = device;
-    c->eps_scale = 1.0;
-    c->force_splits = 0;
-    c->h_wps = 0;
-    c->h_wide = 0;
-    c->long_k = 1;
-    c->min_splits = 1;
-    c->dual_stride = 1;
-    c->dual_deal = 1;
-    c->dual_overlap = 1;
-    c->dual_sample_short = 1;
-    c->dual_short_main = 1;
-    c->esc_short = 1;
-    c->short_ord = 1;
-    c->esc_bf = 1;
-    c->dual_short_kp = 16;
-    c->dual_short_extra = 48;   // (400k x 400k, k = 50, 40 clusters: rows searched again 27.9k at 16, 10.7k from 32 on; uniform data: no difference)
-    c->dual_rev_long = 1;
-    // (500k x nb, k = 50, uniform, tiles per range -> shared sweep without / with the route: 49: 33.7 / 39.9 ms, 65: 39.4 / 45.6,
-    //  78: 45.3 / 52.5, 98: 53.0 / 56.9, 133: 66.7 / 66.5, 195: 92.5 / 88.7, 390 (C3): -6 %)
-    c->dual_short_min_tiles = 128;
-    c->short_ord_min_tiles = 48;
-    c->dual_short_div = 5;   // (500k x 500k, k = 50, ms per step and rows searched again: 4: 171.5 / 14, 5: 165.7 / 206, 6: 166.9 / 905, 8: 169.5 / 8904)
-    c->lds_pad = 0;
-    c->h_q64 = 2;
-    c->tier_probe = 1024;
-    c->wide_lists = 32;
-    c->wide_sel = 256;
-    c->dual_rank = 0;
-    c->probe_min_pairs = 5e10;
-    c->list_floor = 1;
-    c->fin_fast_div = 1;
-    c->floor_probe = 1024;
-    c->floor_margin = 1.3;
-    c->precision = 0;
+    kz_options_defaults(c);   // (kz_options.h: the one table of options and their defaults)
     if (const char* pv = getenv("KZ_PRECISION"))  // A/B runs of the test-suite: fp32 | bf16 | fp16
         c->precision = (strcmp(pv, "fp32") == 0 || strcmp(pv, "1") == 0) ? 1 : ((strcmp(pv, "bf16") == 0 || strcmp(pv, "2") == 0) ? 2 : 0);
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -140,110 +108,27 @@ int kz_ctx_sync(kz_ctx* c) {
 
 int kz_ctx_set_option(kz_ctx* c, const char* name, double value) {
     KZ_REQUIRE(c && name, "kz_ctx_set_option: null argument");
-    if (strcmp(name, "eps_scale") == 0) {
-        KZ_REQUIRE(value > 0, "eps_scale must be > 0");
-        c->eps_scale = value;
-    } else if (strcmp(name, "force_splits") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 64, "force_splits must be in [0, 64]");
-        c->force_splits = (int)value;
-    } else if (strcmp(name, "dual_max_gb") == 0) {
-        KZ_REQUIRE(value >= 0, "dual_max_gb must be >= 0");
-        c->dual_max_gb = value;
-    } else if (strcmp(name, "dual_short_main") == 0) {
-        c->dual_short_main = value != 0 ? 1 : 0;
-    } else if (strcmp(name, "qgroup") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 4096, "kz_ctx_set_option: qgroup must be in [0, 4096]");
-        c->qgroup = (int)value;
-    } else if (strcmp(name, "short_ord") == 0) {
-        c->short_ord = value != 0 ? 1 : 0;
-    } else if (strcmp(name, "esc_bf") == 0) {
-        c->esc_bf = value != 0 ? 1 : 0;
-    } else if (strcmp(name, "esc_short") == 0) {
-        c->esc_short = value != 0 ? 1 : 0;
-    } else if (strcmp(name, "short_ord_min_tiles") == 0) {
-        KZ_REQUIRE(value >= 1, "kz_ctx_set_option: short_ord_min_tiles must be >= 1");
-        c->short_ord_min_tiles = (int)value;
-    } else if (strcmp(name, "dual_short_min_tiles") == 0) {
-        KZ_REQUIRE(value >= 1, "kz_ctx_set_option: dual_short_min_tiles must be >= 1");
-        c->dual_short_min_tiles = (int)value;
-    } else if (strcmp(name, "dual_rev_long") == 0) {
-        c->dual_rev_long = value != 0 ? 1 : 0;
-    } else if (strcmp(name, "dual_short_extra") == 0) {
-        KZ_REQUIRE(value >= 1 && value <= 200, "kz_ctx_set_option: dual_short_extra must be in [1, 200]");
-        c->dual_short_extra = (int)value;
-    } else if (strcmp(name, "dual_short_kp") == 0) {
-        KZ_REQUIRE(value == 16 || value == 32, "kz_ctx_set_option: dual_short_kp must be 16 or 32");
-        c->dual_short_kp = (int)value;
-    } else if (strcmp(name, "dual_short_div") == 0) {
-        KZ_REQUIRE(value >= 1 && value <= 16, "kz_ctx_set_option: dual_short_div must be in [1, 16]");
-        c->dual_short_div = (int)value;
-    } else if (strcmp(name, "dual_sample_short") == 0) {
-        c->dual_sample_short = value != 0 ? 1 : 0;
-    } else if (strcmp(name, "dual_overlap") == 0) {
-        c->dual_overlap = value != 0 ? 1 : 0;
-    } else if (strcmp(name, "long_k") == 0) {
-        c->long_k = value != 0 ? 1 : 0;
-    } else if (strcmp(name, "h_wide") == 0) {
-        KZ_REQUIRE(value == 0 || value == 1, "h_wide must be 0 or 1");
-        c->h_wide = (int)value;
-    } else if (strcmp(name, "h_wps") == 0) {
-        KZ_REQUIRE(value == 0 || value == 2 || value == 3, "h_wps must be 0 (automatic), 2 or 3");
-        c->h_wps = (int)value;
-    } else if (strcmp(name, "chunk_rows") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 1e9, "chunk_rows must be >= 0");
-        c->chunk_rows = (int)value;
-    } else if (strcmp(name, "precision") == 0) {
-        KZ_REQUIRE(value == 0 || value == 1 || value == 2,
-                   "precision must be 0 (fp16 first pass), 2 (split-bf16 first pass) or 1 (float32 operands only)");
-        c->precision = (int)value;
-    } else if (strcmp(name, "dual_stride") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 64, "dual_stride must be 0 (no dual pass), 1 (automatic) or in [2, 64]");
-        c->dual_stride = (int)value;
-    } else if (strcmp(name, "dual_deal") == 0) {
-        c->dual_deal = value != 0;
-    } else if (strcmp(name, "dual_force") == 0) {
-        c->dual_force = value != 0;
-    } else if (strcmp(name, "lds_pad") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 90000, "lds_pad must be in [0, 90000]");
-        c->lds_pad = (int)value;
-    } else if (strcmp(name, "fin_fast_div") == 0) {
-        KZ_REQUIRE(value == 0 || value == 1, "fin_fast_div must be 0 or 1");
-        c->fin_fast_div = (int)value;
-    } else if (strcmp(name, "probe_min_pairs") == 0) {
-        KZ_REQUIRE(value >= 0, "probe_min_pairs must be >= 0");
-        c->probe_min_pairs = value;
-    } else if (strcmp(name, "list_floor") == 0) {
-        KZ_REQUIRE(value == 0 || value == 1, "list_floor must be 0 or 1");
-        c->list_floor = (int)value;
-    } else if (strcmp(name, "floor_probe") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 65536, "floor_probe must be in [0, 65536]");
-        c->floor_probe = (int)value;
-    } else if (strcmp(name, "floor_margin") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 1e6, "floor_margin must be in [0, 1e6]");
-        c->floor_margin = value;
-    } else if (strcmp(name, "dual_rank") == 0) {
-        KZ_REQUIRE(value >= -1 && value <= 128, "dual_rank must be -1 (k + 1), 0 (automatic) or in [1, 128]");
-        c->dual_rank = (int)value;
-    } else if (strcmp(name, "wide_lists") == 0) {
-        KZ_REQUIRE(value == 0 || (value >= 2 && value <= 32), "wide_lists must be 0 or in [2, 32]");
-        c->wide_lists = (int)value;
-    } else if (strcmp(name, "wide_sel") == 0) {
-        KZ_REQUIRE(value >= 16 && value <= 512, "wide_sel must be in [16, 512]");
-        c->wide_sel = (int)value;
-    } else if (strcmp(name, "tier_probe") == 0) {
-        KZ_REQUIRE(value >= 0 && value <= 65536, "tier_probe must be in [0, 65536]");
-        c->tier_probe = (int)value;
-    } else if (strcmp(name, "h_q64") == 0) {
-        KZ_REQUIRE(value == 0 || value == 1 || value == 2, "h_q64 must be 0 (never), 1 (wherever built) or 2 (automatic)");
-        c->h_q64 = (int)value;
-    } else if (strcmp(name, "min_splits") == 0) {
-        KZ_REQUIRE(value >= 1 && value <= 32, "min_splits must be in [1, 32]");
-        c->min_splits = (int)value;
-    } else {
-        kz_set_error("kz_ctx_set_option: unknown option '%s'", name);
-        return KZ_ERR_INVALID;
+    for (int i = 0; i < KZ_N_OPTIONS; ++i) {
+        const KzOption& o = KZ_OPTIONS[i];
+        if (strcmp(name, o.name) != 0) continue;
+        bool ok = o.kind == KZ_OPT_BOOL || (value >= o.lo && value <= o.hi && value == value);
+        if (o.flags & KZ_OPT_SET) {
+            bool listed = false;
+            const int n = o.n_allowed < 0 ? -o.n_allowed : o.n_allowed;
+            for (int j = 0; j < n; ++j) listed = listed || value == o.allowed[j];
+            ok = o.n_allowed < 0 ? (ok || listed) : listed;    // (< 0: the listed values in addition to the range)
+        }
+        if (ok && o.kind == KZ_OPT_INT && value != (double)(long long)value) ok = false;
+        if (!ok) {
+            kz_set_error("kz_ctx_set_option: %s = %g is not allowed (range [%g, %g]%s)", name, value, o.lo, o.hi,
+                         (o.flags & KZ_OPT_SET) ? ", listed values" : "");
+            return KZ_ERR_INVALID;
+        }
+        kz_option_store(c, o, value);
+        return KZ_OK;
     }
-    return KZ_OK;
+    kz_set_error("kz_ctx_set_option: unknown option '%s'", name);
+    return KZ_ERR_INVALID;
 }
 
 int kz_malloc(kz_ctx* c, size_t bytes, void** d_ptr) {

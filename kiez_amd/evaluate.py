@@ -15,12 +15,19 @@ _NO_GOLD = np.iinfo(np.int64).min
 
 def _as_row_number(x):
     """x as an integer if the reference's `==` would match it against an integer row number / neighbour id (ints, and floats with an
-    integral value: 4.0 == 4 and hash(4.0) == hash(4), so `i in gold` and `gold[i] in nn_ind[i][:k]` both accept them), else None."""
+    integral value: 4.0 == 4 and hash(4.0) == hash(4), so `i in gold` and `gold[i] in nn_ind[i][:k]` both accept them), else None.
+    Values that no int64 row number or neighbour id can equal -- beyond [-2**63, 2**63), e.g. 1e20 -- are None as well (the
+    reference's `in` simply finds no hit for them; such pairs count in the denominator only).  bools stay what they are to
+    Python's `==` and `hash`: True is 1 and False is 0 -- `1 in {True: t}` holds in the reference, too."""
+    if isinstance(x, (bool, np.bool_)):
+        return int(bool(x))
     if isinstance(x, (int, np.integer)):
-        return int(x)
-    if isinstance(x, (float, np.floating)) and np.isfinite(x) and float(x) == int(x):
-        return int(x)
-    return None
+        v = int(x)
+    elif isinstance(x, (float, np.floating)) and np.isfinite(x) and float(x) == int(x):
+        v = int(x)
+    else:
+        return None
+    return v if -(1 << 63) <= v < (1 << 63) else None
 
 
 def _gold_vector(gold: Dict[Any, Any], n_rows: int) -> np.ndarray:

@@ -71,6 +71,10 @@ def test_hits_with_float_valued_gold():
     gold[7] = 3.5            # a fractional target never matches, but counts in len(gold)
     gold[9.5] = 1            # a fractional key is no row number
     gold["x"] = 2            # nor is a label
+    gold[11] = 1e20          # integral, but no int64 neighbour id can equal it: no hit, no OverflowError (round-4 advisor finding)
+    gold[13] = 2 ** 70
+    gold[float(2 ** 64)] = 4
+    gold[True] = int(nn_ind[1][0])    # True == 1 and hash(True) == hash(1): row 1's gold in the reference as well
     ref = _ref_hits(nn_ind, gold, [1, 5, 10])
     assert ref[10] > 0
     assert hits(nn_ind, gold) == pytest.approx(ref, abs=0)

@@ -26,6 +26,19 @@ def test_checker_sees_a_reader_without_a_write():
     assert check_m0.check(good) == (2, [])
     readers, violations = check_m0.check(bad)
     assert readers == 3 and len(violations) == 1 and violations[0][0] == "kern"
+    # a compiler-set M0, an inline-asm clobber, then a reader that is NOT glued to a write of its own (it would read the clobber's
+    # value): some M0 write does precede it in the block -- the round-4 rule passed this -- but not directly
+    stale = """
+0000000000002000 <kern2>:
+	s_mov_b32 m0, s4
+	s_mov_b32 m0, s8
+	s_nop 0
+	global_load_lds_dwordx4 v1, s[2:3]
+	v_add_u32 v2, v2, v3
+	ds_gws_barrier v0 gds
+"""
+    readers, violations = check_m0.check(stale)
+    assert readers == 2 and [v[1].split()[0] for v in violations] == ["ds_gws_barrier"]
 
 
 def test_no_m0_value_crosses_a_basic_block_in_the_built_kernels():

@@ -73,3 +73,17 @@ def test_context_and_error_reporting():
     with pytest.raises(NotImplementedError, match="maximum"):
         huge = N.DeviceMatrix(ctx, np.random.rand(5000, 4), "euclidean")
         N.knn(ctx, huge, huge, 4500)
+
+
+def test_public_options_are_the_four_the_header_documents():
+    """include/kiez_amd.h documents four options; kz_options.h (the one table behind kz_ctx_set_option) flags exactly those
+    KZ_OPT_PUBLIC.  Everything else is an internal knob outside the ABI's promise."""
+    import re
+    table = (ROOT / "kiez_amd" / "csrc" / "kz_options.h").read_text()
+    rows = re.findall(r'\{"(\w+)", KZ_OPT_(?:INT|BOOL|F64), KZ_O\(\w+\), [^,]+, [^,]+, [^,]+, (KZ_OPT_PUBLIC|KZ_OPT_SET|0)', table)
+    public = {n for n, f in rows if f == "KZ_OPT_PUBLIC"}
+    assert public == {"precision", "dual_stride", "dual_max_gb", "eps_scale"} and len(rows) >= 30
+    header = (ROOT / "include" / "kiez_amd.h").read_text()
+    block = header[header.index("/* Options (the public contract"):header.index("int kz_ctx_set_option")]
+    assert set(re.findall(r'^ \*   "(\w+)"', block, flags=re.M)) == public
+    assert block.count("\n") <= 12        # (round 4: 28 lines for 34 names)

@@ -2,9 +2,12 @@
 
 hipcc warns that a clobber of the reserved register m0 "may lead to undefined behaviour": it does not save and restore M0 around
 the asm statement.  That is harmless exactly when no compiler-managed M0 value is ever live ACROSS such a statement -- i.e. when
-every instruction that reads M0 takes it from an `s_mov_b32 m0, ...` in its own basic block.  This script checks that on the
+every instruction that reads M0 takes it from the `s_mov_b32 m0, ...` of ITS OWN asm statement.  This script checks that on the
 device code of the built objects: for every kernel, every M0 reader (LDS-DMA `global_load_lds_*` / `buffer_load ... lds`, `ds_gws_*`,
-`s_movrel*` / `v_movrel*`, `s_sendmsg*`, LDS-direct reads) must be preceded, with no label or branch in between, by a write of M0.
+`s_movrel*` / `v_movrel*`, `s_sendmsg*`, LDS-direct reads) must be the next instruction (`s_nop` apart) after a write of M0 -- the
+shape of kz_glds16_s / kz_glds4_s.  (Round 4's rule -- "some M0 write earlier in the basic block" -- would have passed a compiler-set
+M0, then an inline-asm clobber, then a compiler-issued reader of the OLD value: a reader that is not glued to its own write is a
+violation now, whoever issued it.)
 With that shown, the one diagnostic is switched off for the fp16 kernel units (Makefile: -Wno-inline-asm), so that any NEW warning
 is visible.     python3 tools/check_m0.py [objects...]     (default: the fp16 kernel objects of kiez_amd/csrc)"""
 import re
@@ -30,28 +33,33 @@ def device_disassembly(obj: Path) -> str:
         return subprocess.run([str(LLVM / "llvm-objdump"), "-d", "--no-show-raw-insn", str(dev)], check=True, capture_output=True, text=True).stdout
 
 
+NOP = re.compile(r"^\s*s_nop\b")
+
+
 def check(text: str):
-    """-> (readers, violations): every M0 reader needs an M0 write earlier in its basic block."""
+    """-> (readers, violations): every M0 reader must directly follow (s_nop apart) an M0 write of its own basic block."""
     readers, bad = 0, []
-    have_m0, kernel = False, "?"
+    fresh_m0, kernel = False, "?"     # fresh_m0: the last instruction that was not an s_nop wrote M0
     for line in text.splitlines():
         if LABEL.match(line):
             name = line.split("<", 1)[1].rsplit(">", 1)[0]
             if not name.startswith("L") and "BB" not in name:
                 kernel = name
-            have_m0 = False
+            fresh_m0 = False
             continue
         body = line.split("//")[0]
         if not body.strip():
             continue
         if WRITES_M0.match(body):
-            have_m0 = True
-        elif READS_M0.match(body):
-            readers += 1
-            if not have_m0:
-                bad.append((kernel, body.strip()))
-        if BRANCH.match(body):
-            have_m0 = False
+            fresh_m0 = True
+        elif NOP.match(body):
+            pass
+        else:
+            if READS_M0.match(body):
+                readers += 1
+                if not fresh_m0:
+                    bad.append((kernel, body.strip()))
+            fresh_m0 = False
     return readers, bad
 
 
@@ -62,7 +70,7 @@ def main(argv):
         readers, bad = check(device_disassembly(o))
         total += readers
         failures += [(o.name,) + b for b in bad]
-        print(f"{o.name}: {readers} M0 readers, {len(bad)} without an M0 write in their basic block")
+        print(f"{o.name}: {readers} M0 readers, {len(bad)} not directly behind their own M0 write")
     for f in failures[:20]:
         print("  VIOLATION", f)
     print("M0 readers checked:", total)
