@@ -53,6 +53,7 @@ struct kz_ctx {
     double floor_margin;  // ... the largest shortfall of the probe below the model, times this
     int dual_rank;    // kz_knn_dual: rank of the sample key that becomes a row's event threshold (0 = automatic, -1 = k + 1, > 0 = that rank; kz_knn_dual.h)
     int tier_probe;   // rows of the strided sample a large ordinary search sends through the fp16 pass first (0 = off; default 1024): more than half uncertified -> the call starts at split-bf16
+    int dual_nested;  // kz_knn_dual: 1 (default) = the sample is the first tiles of the dealt image and is swept ONLY by the sample sweep (kz_knn_dual.h "NESTED")
     int wide_lists;   // fp16 tier's WIDE route (kz_knn_impl): lists of 16 per query when the tier probe finds the keys dense around the k-th neighbour (default 32; 0 = off)
     int wide_sel;     // ... entries of those lists the finalize kernel selects (default 256)
     int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
@@ -145,6 +146,7 @@ int kz_matrix_image_f32(kz_matrix* m);
 int kz_matrix_image_bf(kz_matrix* m);
 int kz_himage_ensure(kz_matrix* query, kz_matrix* index);
 int kz_himage_pack_permuted(kz_matrix* m, const int* d_perm, unsigned short* packed, float* bias);
+int kz_himage_pack_rows(kz_matrix* m, const int* d_rows, int64_t n_rows, int64_t n_pad, unsigned short* packed, float* bias);
 int kz_himage_dealt(kz_matrix* m, int P);
 // stable sort of (float key, int value) pairs on the context's stream (kz_sort.hip)
 int kz_sort_pairs_f32_i32(kz_ctx* ctx, const float* keys_in, float* keys_out, const int* vals_in, int* vals_out, int n, int descending);

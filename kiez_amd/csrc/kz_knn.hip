@@ -1334,7 +1334,22 @@ struct KzDualPass {
     int (*post_sweep)(void* user);
     void* post_user;
     int post_called;
+    // NESTED sample sweep (kz_knn_dual.h "NESTED"): the pass is the sweep of b x sample(a) -- its index side is only the first
+    // n_ytiles tiles of `ypack` (the sorted sample image; `index` stays the whole matrix a), its forward lists are wanted RAW
+    // (thresholds are read off them by the caller's post_sweep hook: lists_* below are filled in before the hook runs) and are
+    // never finalized; at most max_entries list entries per query (the threshold kernel ranks <= 256).
+    int n_ytiles;
+    int raw_lists;
+    int max_entries;
+    const float* lists_key;
+    const int* lists_idx;
+    KzListLayout lists_lay;
+    int lists_KP;
 };
+// query rows one launch of the fused kernels takes (the candidate lists of a launch stay below ~1 GiB)
+static inline int64_t kz_rows_per_chunk(const kz_ctx* ctx, int KP_mem, bool wide_route) {
+    return ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (wide_route ? 1 : (KP_mem <= 16 ? 4 : (KP_mem <= 32 ? 2 : 1)));
+}
 static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q_count, kz_matrix* index, int k,
                        int exclude_self, const int64_t* d_self_ids, int precision_override, int kp_min, double* d_dist,
                        int64_t* d_ind, kz_knn_stats* stats, KzDualPass* dual);
@@ -1491,7 +1506,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     KZ_HIP(hipSetDevice(ctx->device));
 
     const int metric = index->metric;
-    const int n_ytiles = (int)index->n_tiles;
+    const int n_ytiles = (dual && dual->n_ytiles > 0) ? dual->n_ytiles : (int)index->n_tiles;
     const int n_slices = index->kg / 4;
     // rounding bound factors.  float32 operands: (d_pad + 16) 2^-24 covers the d+1 step fma chain, the float32 rounding of
     // the bias and (float64 inputs) of the operands; 1e-12 covers the float64 re-rank's own rounding.  fp16 operands: the
@@ -1682,7 +1697,11 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // re-search of the uncertified rows)
     const int KP_mem = KP_class > KP ? KP_class : KP;   // (short-list route: several lists of 16 -- the chunk of the replaced list length)
     // (the wide route keeps 32 lists of 16 per query -- 4 KiB: 524288 rows)
-    const int64_t max_rows_per_chunk = ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (wide_route ? 1 : (KP_mem <= 16 ? 4 : (KP_mem <= 32 ? 2 : 1)));
+    const int64_t max_rows_per_chunk = kz_rows_per_chunk(ctx, KP_mem, wide_route);
+    if (dual && dual->raw_lists && q_count > max_rows_per_chunk) {
+        kz_set_error("kz_knn: internal: a raw-list pass must be one launch");
+        return KZ_ERR_INVALID;
+    }
     double main_ms = 0, fin_ms = 0, fb_ms = 0;   // (the tier probe's time is reported under its own field, kz_knn_stats.probe_ms)
     int64_t n_fail_total = 0, n_escalated = 0, n_first_fail = 0;
     double max_err_ratio = 0.0;
@@ -1722,7 +1741,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             if (sub > n_ytiles / (8 * force_pieces)) sub = n_ytiles / (8 * force_pieces);
             if (sub > 1 && 4 * kz_fin_wave_bytes(force_pieces * sub * 16, KSEL) <= 160 * 1024) force_pieces *= sub;
         }
-        int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1), KP, tier, cq_count, &ps,
+        int max_pieces = kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1);
+        if (dual && dual->max_entries > 0 && max_pieces > dual->max_entries / KP) max_pieces = dual->max_entries / KP;
+        int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, max_pieces, KP, tier, cq_count, &ps,
                                  tier == KZ_TIER_H ? tpw_h : 1, force_pieces, min_pieces_call);
         if (rc != KZ_OK) return rc;
         const KzListLayout& lay = ps.lay;
@@ -1784,6 +1805,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (rc != KZ_OK) return rc;
         if (dual && tier != KZ_TIER_H) dual->broken = 1;   // this chunk's pairs were not scanned for events
         KZ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        if (dual) {
+            dual->lists_key = out_key;
+            dual->lists_idx = out_idx;
+            dual->lists_lay = lay;
+            dual->lists_KP = KP;
+        }
         if (dual && dual->post_sweep && !dual->broken && c0 + cq_count >= q_count) {
             dual->post_called = 1;
             rc = dual->post_sweep(dual->post_user);
@@ -1834,7 +1861,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fp.fail_count = fail_count;
         fp.fail_list = fail_list;
         fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
-        if (!exact_only) {
+        if (!exact_only && !(dual && dual->raw_lists)) {   // (raw lists: the caller's hook has read them; nothing is finalized)
             rc = kz_launch_finalize(ctx, fp, lay, KP, cq_count, index->dtype);
             if (rc != KZ_OK) return rc;
         }

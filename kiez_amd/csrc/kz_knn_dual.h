@@ -42,7 +42,13 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
                                                             KzListLayout lay, int KP, int rank, int64_t n_b, int64_t n_b_pad,
                                                             const float* __restrict__ bias_b, const double* __restrict__ a_hmax,
                                                             const double* __restrict__ b_hmax, const double* __restrict__ hscale,
-                                                            float* __restrict__ theta, float* __restrict__ floor_) {
+                                                            float* __restrict__ theta, float* __restrict__ floor_,
+                                                            const int* __restrict__ idx_to_row, int sev_cap, int* __restrict__ sev_cnt,
+                                                            uint2* __restrict__ sev) {
+    // NESTED sample (sev_cnt != nullptr; below "NESTED"): the lists ARE this row's events among the sample rows -- the main sweep no
+    // longer visits those.  Two changes: (1) the threshold is raised to the smallest key of any FULL list (a full list may have
+    // evicted rows: everything outside the lists then lies at or below the threshold, whatever rank it was taken at -- with rank <=
+    // K' that is already so); (2) the entries at or above it are written out as events (key, matrix row of the sample row).
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_b_pad) return;
@@ -82,6 +88,37 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
         if (valid[u] && rnk[u] == rank - 1) tau = x[u];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) tau = fmaxf(tau, __shfl_xor(tau, off, 64));
+    if (sev_cnt) {
+        for (int p0 = 0; p0 < M; p0 += KP) {   // (uniform; at most 256 / 16 lists)
+            int c = 0;
+            float mn = INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = lane + 64 * u;
+                const bool in = e >= p0 && e < p0 + KP && valid[u];
+                c += in ? 1 : 0;
+                mn = in ? fminf(mn, x[u]) : mn;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                c += __shfl_xor(c, off, 64);
+                mn = fminf(mn, __shfl_xor(mn, off, 64));
+            }
+            if (c == KP) tau = fmaxf(tau, mn);
+        }
+        int base = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool evt = valid[u] && x[u] >= tau && tau > -INFINITY;
+            const unsigned long long mask = __ballot(evt);
+            if (evt) {
+                const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (pos < sev_cap) sev[t * (int64_t)sev_cap + pos] = make_uint2(__float_as_uint(x[u]), (unsigned)idx_to_row[in_idx[l0 + lane + 64 * u]]);
+            }
+            base += (int)__popcll(mask);
+        }
+        if (lane == 0) sev_cnt[t] = base;
+    }
     if (lane == 0) {
         const double S2 = hscale[0] * hscale[0];
         const double margin = 4.76837158203125e-07 * S2 * (a_hmax[0] * b_hmax[0] + a_hmax[2] + b_hmax[2]);   // 2^-21 Mx
@@ -170,6 +207,30 @@ __global__ void kz_dual_deal_kernel(const int* __restrict__ sorted_rows, int64_t
 __global__ void kz_dual_natural_kernel(int64_t n, int64_t n_pad, int* __restrict__ row_map) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n_pad) row_map[p] = p < n ? (int)p : -1;
+}
+
+// NESTED sample: small kernels.  rows_of: out[i] = row_map[perm[i]] (sorted sample image row -> matrix row);
+// scatter_f32: out[map[j]] = in[j]; inject: the sample-row events of matrix row perm[t] become the first entries of sorted row
+// t's event buffer (the main sweep's scatter kernel appends behind them).
+__global__ void kz_dual_rows_of_kernel(const int* __restrict__ perm, const int* __restrict__ row_map, int64_t n, int* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = row_map[perm[i]];
+}
+__global__ void kz_dual_scatter_f32_kernel(const float* __restrict__ in, const int* __restrict__ map, int64_t n, float* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && map[j] >= 0) out[map[j]] = in[j];
+}
+__global__ void kz_dual_inject_kernel(const int* __restrict__ perm, int64_t n_b, const int* __restrict__ sev_cnt, const uint2* __restrict__ sev,
+                                      int sev_cap, int* __restrict__ ev_cnt, uint2* __restrict__ ev, int ev_cap) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_b) return;
+    const int64_t orig = perm[t];
+    if (orig < 0) return;
+    const int filed = sev_cnt[orig];
+    const int c = filed < sev_cap ? filed : sev_cap;
+    for (int i = 0; i < c && i < ev_cap; ++i) ev[t * (int64_t)ev_cap + i] = sev[orig * (int64_t)sev_cap + i];
+    // (more sample events than either buffer holds: the count says so, the select kernel sends the row to the ordinary search)
+    ev_cnt[t] = filed > sev_cap ? ev_cap + 1 : c;
 }
 
 // -bias of the query side (pad rows: +inf, never an event)
@@ -386,6 +447,102 @@ static inline int kz_dual_pick_rank(int k, int rank_safe, double t_sweep_ms, dou
     return best;
 }
 
+// The chain that turns a sweep's event log into results for the rows that OWN the events: scatter -> select -> ordinary finalize
+// with those rows as the query side.  Main sweep: the rows of b (events from the rows of a).  NESTED sample sweep: the sample rows of
+// a (events from the rows of b); their lists are kept under their position j in the dealt image (perm = sorted row -> j, fin_row_map =
+// j -> matrix row of a), the floor the finalize kernel reads goes by matrix row (floor_fin, filled from floor_sel through fin_row_map).
+struct KzRevChain {
+    kz_ctx* ctx;
+    kz_matrix *qm, *im;            // rows owning the events (query side of the finalize) / rows the events come from (index side)
+    const kz_himage *qi, *ii;
+    void *log_keys, *log_meta;
+    unsigned long long* d_cnt;
+    long long log_cap;
+    float *theta_s, *qnb, *p_bias, *col_key, *floor_sel, *floor_fin;
+    int *row_map, *ev_cnt, *perm, *col_idx, *fail_list, *fail_count;
+    const int* fin_row_map;
+    uint2* ev;
+    int ev_cap, KP, k;
+    int64_t n_rows, n_tiles;
+    double* d_dist;
+    int64_t* d_ind;
+    int timed, h_fail, h_cnt, second_stream;
+};
+static int kz_dual_enqueue_chain(KzRevChain& r) {
+    kz_ctx* ctx = r.ctx;
+    hipStream_t first = ctx->stream;
+    if (r.second_stream) {
+        // (the sweep was recorded as ev[1] of the first stream by kz_knn_impl just now)
+        KZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev[1], 0));
+        ctx->stream = ctx->stream2;   // every launch helper below enqueues on ctx->stream
+    }
+    auto body = [&]() -> int {
+        if (r.timed) KZ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
+        hipLaunchKernelGGL(kz_dual_scatter_kernel, dim3(ctx->n_cus * 8), dim3(256), 0, ctx->stream, (const f32x4e*)r.log_keys,
+                           (const i32x2e*)r.log_meta, r.d_cnt, r.log_cap, r.theta_s, r.qnb, r.p_bias, r.row_map, r.ev_cnt, r.ev, r.ev_cap);
+        const size_t sel_lds = (size_t)4 * 2 * r.ev_cap * 4;
+        if (sel_lds > 65536)
+            KZ_HIP(hipFuncSetAttribute((const void*)kz_dual_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+        hipLaunchKernelGGL(kz_dual_select_kernel, dim3((unsigned)((r.n_rows + 3) / 4)), dim3(256), sel_lds, ctx->stream, r.ev_cnt, r.ev, r.ev_cap,
+                           r.n_rows, r.perm, r.KP, r.col_key, r.col_idx, r.floor_sel, r.d_cnt + 16);
+        hipLaunchKernelGGL(kz_dual_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, r.d_cnt + 16, r.d_cnt + 1);
+        if (r.fin_row_map && r.floor_fin != r.floor_sel)
+            hipLaunchKernelGGL(kz_dual_scatter_f32_kernel, dim3((unsigned)((r.n_rows + 255) / 256)), dim3(256), 0, ctx->stream, r.floor_sel,
+                               r.fin_row_map, r.n_rows, r.floor_fin);
+        KZ_HIP(hipGetLastError());
+        if (r.timed) KZ_HIP(hipEventRecord(ctx->ev[9], ctx->stream));
+        KzListLayout lay;
+        memset(&lay, 0, sizeof(lay));
+        lay.n_regions = 1;
+        lay.qt_end[0] = (int)r.n_tiles;
+        lay.pieces[0] = 1;
+        lay.halves = 1;
+        lay.contig = 1;
+        KZ_HIP(hipMemsetAsync(r.fail_count, 0, 4 * sizeof(int), ctx->stream));
+        KnnFinParams fp;
+        memset(&fp, 0, sizeof(fp));
+        fp.in_key = r.col_key;
+        fp.in_idx = r.col_idx;
+        fp.lay = lay;
+        fp.KP = r.KP;
+        fp.list_row0 = 0;
+        fp.q_begin = 0;
+        fp.q_count = r.n_rows;
+        fp.row_map = r.fin_row_map;
+        fp.qraw = r.qm->raw;
+        fp.yraw = r.im->raw;
+        fp.qsqn = r.qm->sqn;
+        fp.ysqn = r.im->sqn;
+        fp.n_i = r.im->n;
+        fp.d = (int)r.im->d;
+        fp.metric = r.im->metric;
+        fp.k = r.k;
+        fp.ystats = r.im->d_stats;
+        fp.tier_h = 1;
+        fp.eps_mult = ctx->eps_scale;
+        fp.gamma_acc = 2.0 * (double)(r.im->kg * 4 + 16) * 5.9604644775390625e-08;
+        fp.q_rowq = r.qi->rowq;
+        fp.y_hmax = r.ii->d_max;
+        fp.hscale = r.ii->center->d_scale;
+        fp.excl_floor = r.floor_fin;
+        fp.dual_col = 1;
+        fp.out_dist = r.d_dist;
+        fp.out_ind = r.d_ind;
+        fp.fail_count = r.fail_count;
+        fp.fail_list = r.fail_list;
+        fp.err_ratio_bits = (unsigned long long*)(r.fail_count + 2);
+        const int rc2 = kz_launch_finalize(ctx, fp, lay, r.KP, r.n_rows, r.im->dtype);
+        if (rc2 != KZ_OK) return rc2;
+        if (r.timed) KZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
+        KZ_HIP(hipMemcpyAsync(ctx->h_counters + r.h_fail, r.fail_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        KZ_HIP(hipMemcpyAsync(ctx->h_counters + r.h_cnt, r.d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+        return KZ_OK;
+    };
+    const int rc2 = body();
+    ctx->stream = first;
+    return rc2;
+}
+
 extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b_c, int k, double* d_dist_ab, int64_t* d_ind_ab,
                            double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba) {
     kz_matrix* a = const_cast<kz_matrix*>(a_c);
@@ -509,7 +666,23 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     uint2* ev = nullptr;
     void *log_keys = nullptr, *log_meta = nullptr;
     unsigned long long* d_cnt = nullptr;   // [0] log counter, [1] events filed, [2] rows with an overflowing buffer, [16 ..] 32 spread pairs of [1], [2]
+    // buffers of the nested stages (released with everything else)
+    unsigned short *s3_packed = nullptr, *ss_packed = nullptr;
+    float *s3_bias = nullptr, *ss_bias = nullptr, *theta3 = nullptr, *theta3_s = nullptr, *theta3_min = nullptr, *floor3 = nullptr, *floor3m = nullptr,
+          *qnb_b = nullptr, *col3_key = nullptr;
+    int *iota3 = nullptr, *perm3 = nullptr, *rm3 = nullptr, *row_map_b = nullptr, *ev3_cnt = nullptr, *col3_idx = nullptr, *fail3 = nullptr, *sev_cnt = nullptr;
+    uint2 *ev3 = nullptr, *sev = nullptr;
+    void *log3_keys = nullptr, *log3_meta = nullptr;
+    unsigned long long* d_cnt3 = nullptr;
+    auto release_nested = [&]() {
+        void* bufs[] = {s3_packed, ss_packed, s3_bias, ss_bias, theta3, theta3_s, theta3_min, floor3, floor3m, qnb_b, col3_key, iota3, perm3, rm3,
+                        row_map_b, ev3_cnt, col3_idx, fail3, sev_cnt, ev3, sev, log3_keys, log3_meta, d_cnt3};
+        for (void* q : bufs) kz_pool_free(ctx, q, 0);
+        s3_packed = ss_packed = nullptr; s3_bias = ss_bias = theta3 = theta3_s = theta3_min = floor3 = floor3m = qnb_b = col3_key = nullptr;
+        iota3 = perm3 = rm3 = row_map_b = ev3_cnt = col3_idx = fail3 = sev_cnt = nullptr; ev3 = sev = nullptr; log3_keys = log3_meta = nullptr; d_cnt3 = nullptr;
+    };
     auto release = [&]() {
+        release_nested();
         kz_pool_free(ctx, s_packed, 0);
         kz_pool_free(ctx, s_bias, 0);
         kz_pool_free(ctx, p_packed, 0);
@@ -652,21 +825,23 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // would hold ALL the near rows of a query when the data is stored cluster by cluster, its list of 16 would overflow and the
     // threshold fall to the far rows).  The K' = 16 kernel keeps three workgroups per CU and short merges: 500k x 500k, k = 50:
     // reverse direction 51.0 -> 46.4 ms per step, same event counts.
-    int KPs = KP, force_s = 0;
-    if (ctx->dual_sample_short && KP > 16) {
-        KPs = rank > 96 ? 32 : 16;
-        const int need = (2 * rank + KPs - 1) / KPs, cap = 256 / KPs;
-        force_s = need < cap ? need : cap;
-        if ((int64_t)force_s * 4 > s_tiles || force_s * KPs < rank) {   // (a sample of a few tiles: one list of K')
-            KPs = KP;
-            force_s = 0;
+    auto sample_lists = [&](int rank_, int64_t tiles_, int* kps_out, int* force_out) {
+        int kps = KP, force = 0;
+        if (ctx->dual_sample_short && KP > 16) {
+            kps = rank_ > 96 ? 32 : 16;
+            const int need = (2 * rank_ + kps - 1) / kps, cap = 256 / kps;
+            force = need < cap ? need : cap;
+            if ((int64_t)force * 4 > tiles_ || force * kps < rank_) {   // (a sample of a few tiles: one list of K')
+                kps = KP;
+                force = 0;
+            }
         }
-    }
-    // ---- sample image: every stride-th tile of A's fp16 image (tiles are contiguous runs of n_slices x 4 KiB), dealt over the parts
+        *kps_out = kps;
+        *force_out = force;
+    };
+    int KPs = KP, force_s = 0;
+    sample_lists(rank, s_tiles, &KPs, &force_s);
     KZ_DUAL_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
-    hipLaunchKernelGGL(kz_dual_sample_kernel, dim3((unsigned)s_tiles), dim3(256), 0, ctx->stream, (const uint4*)ia->packed, ia->bias,
-                       n_slices, stride, (int)s_tiles, force_s > 0 ? force_s : 1, (uint4*)s_packed, s_bias);
-    KZ_DUAL_HIP(hipGetLastError());
     KZ_DUAL_HIP(hipMemsetAsync(ev_cnt, 0, (size_t)b_pad * 4, ctx->stream));
     KZ_DUAL_HIP(hipMemsetAsync(d_cnt, 0, 1024, ctx->stream));
     // ---- query side: rows dealt into tiles by |q_c|^2 (load balance), its image and its offsets in that order --------------
@@ -683,8 +858,205 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     KZ_DUAL_RC(kz_himage_pack_permuted(a, row_map, q_packed, q_bias));
     hipLaunchKernelGGL(kz_dual_negbias_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_bias, a->n, a_pad, qnb);
 
-    // ---- sample sweep: B x sample(A) with the ordinary kernel, lists of at most 256 entries per row -----------------------
-    {
+    // ---- NESTED sample (round 5).  The sample sweep b x sample(a) used to be work the main sweep repeated: the main sweep swept ALL
+    // of a, the sampled rows included.  Now the sample S is the FIRST s_tiles tiles of the DEALT image of a (a dealt tile is a
+    // stratified draw of a's rows -- sorted by |q_c|^2 and dealt round-robin -- whatever order the caller stored them in), the main
+    // sweep covers the other tiles only, and everything the sampled rows need comes out of the sample sweep, which is a shared
+    // sweep itself (b as its query side, S sorted by threshold as its index side):
+    //   * b's lists over S give tau(t) as before -- and ARE the events of t among the sample rows (kz_dual_theta_kernel, sev);
+    //   * the events of the rows of S (thresholds from a third, small sweep S x sample(b)) become their forward lists, certified
+    //     and re-ranked by the ordinary finalize kernel with S as the query side (KzRevChain), failures searched again.
+    // Saves 1 / stride of the main sweep (ns: stride 20, C3: 11) for a sample sweep that runs the dual build (+5 .. 10 %) and a
+    // 1 / stride^2 pre-sample.  Option "dual_nested" (1).
+    int rank3 = 0, stride3 = 0, KPs3 = KP, force_s3 = 0, ev_cap3 = 0;
+    int64_t s3_tiles = 0;
+    long long log_cap3 = 0;
+    const int64_t s_img_rows = s_tiles * KZ_TILE;   // rows of S: image rows [0, s_img_rows) of the dealt image
+    bool nested = ctx->dual_nested && ctx->dual_deal && s_tiles >= 8 && s_tiles < a->n / KZ_TILE && s_img_rows >= (int64_t)8 * KP &&
+                  b->n <= kz_rows_per_chunk(ctx, KP, false);
+    if (nested) {
+        const double t2_ms = 2.0 * (double)b->n * (double)s_img_rows * (double)(a->kg * 4) / 1e12;
+        const int rank3_safe = k + 1 < KP ? k + 1 : KP;
+        rank3 = rank3_safe;
+        if (ctx->dual_rank > 0)
+            rank3 = ctx->dual_rank < rank3_safe ? ctx->dual_rank : rank3_safe;
+        else if (ctx->dual_rank == 0 && t2_ms >= 4.0)
+            rank3 = kz_dual_pick_rank(k, rank3_safe, t2_ms, (double)b->n, (double)s_img_rows);
+        const double s_opt = sqrt(t2_ms / ((double)s_img_rows * rank3 * 0.20e-6));
+        stride3 = s_opt < 4.0 ? 4 : (s_opt > 32.0 ? 32 : (int)(s_opt + 0.5));
+        const int s_max = (int)(4096.0 / ((double)rank3 + 7.0 * sqrt((double)rank3) + 1.0));
+        if (stride3 > s_max) stride3 = s_max;
+        s3_tiles = (b_tiles + stride3 - 1) / stride3;
+        int64_t s3_rows = s3_tiles * KZ_TILE;
+        if ((b_tiles - 1) % stride3 == 0) s3_rows -= b_tiles * KZ_TILE - b->n;
+        if (s3_rows < (int64_t)8 * KP || s3_tiles < 2) nested = false;
+        sample_lists(rank3, s3_tiles, &KPs3, &force_s3);
+        ev_cap3 = (int)(((int64_t)rank3 * stride3 + (int64_t)(7.0 * sqrt((double)rank3) * stride3) + 63) & ~(int64_t)63);
+        log_cap3 = (long long)((double)s_img_rows * rank3 * stride3 * 1.5) + (1 << 20);
+    }
+    const int sev_cap = (force_s > 0 ? force_s : 256 / KPs) * KPs < 256 ? (force_s > 0 ? force_s : 256 / KPs) * KPs : 256;   // (every list entry can be an event)
+    if (nested) {
+        const int KPr3 = ctx->dual_rev_long ? (2 * KP < 128 ? 2 * KP : 128) : KP;
+        int rcn = kz_pool_alloc(ctx, (size_t)s3_tiles * tile_bytes + 32 * 4096, (void**)&s3_packed);
+        auto al = [&](size_t bytes, void** out) { if (rcn == KZ_OK) rcn = kz_pool_alloc(ctx, bytes, out); };
+        al((size_t)s3_tiles * KZ_TILE * 4, (void**)&s3_bias);
+        al((size_t)s_tiles * tile_bytes + 32 * 4096, (void**)&ss_packed);
+        al((size_t)s_img_rows * 4, (void**)&ss_bias);
+        al((size_t)s_img_rows * 4, (void**)&theta3);
+        al((size_t)s_img_rows * 4, (void**)&theta3_s);
+        al((size_t)s_img_rows * 4, (void**)&theta3_min);
+        al((size_t)s_img_rows * 4, (void**)&floor3);
+        al((size_t)a_pad * 4, (void**)&floor3m);
+        al((size_t)b_pad * 4, (void**)&qnb_b);
+        al((size_t)s_img_rows * KPr3 * 4, (void**)&col3_key);
+        al((size_t)s_img_rows * KPr3 * 4, (void**)&col3_idx);
+        al((size_t)s_img_rows * 4, (void**)&iota3);
+        al((size_t)s_img_rows * 4, (void**)&perm3);
+        al((size_t)s_img_rows * 4, (void**)&rm3);
+        al((size_t)b_pad * 4, (void**)&row_map_b);
+        al((size_t)s_img_rows * 4, (void**)&ev3_cnt);
+        al((size_t)s_img_rows * 4, (void**)&fail3);
+        al((size_t)b_pad * 4, (void**)&sev_cnt);
+        al((size_t)s_img_rows * ev_cap3 * 8, (void**)&ev3);
+        al((size_t)b->n * sev_cap * 8, (void**)&sev);
+        al((size_t)log_cap3 * 16, &log3_keys);
+        al((size_t)log_cap3 * 8, &log3_meta);
+        al(1024, (void**)&d_cnt3);
+        if (rcn != KZ_OK) {   // (no memory for the nested stages: the classic sample sweep)
+            release_nested();
+            nested = false;
+        }
+    }
+    KzRevChain rv3;
+    memset(&rv3, 0, sizeof(rv3));
+    KzDualPass dp2;
+    memset(&dp2, 0, sizeof(dp2));
+    struct Hook2 {
+        kz_ctx* ctx; KzDualPass* dp2; KzRevChain* rv3; int rank; int64_t b_n, b_pad; const kz_himage *ia, *ib;
+        float *theta, *floor_; const int* rm3; int sev_cap; int* sev_cnt; uint2* sev; int overlap;
+    } hk2 = {ctx, &dp2, &rv3, rank, b->n, b_pad, ia, ib, theta, floor_, nullptr, sev_cap, nullptr, nullptr, ctx->dual_overlap};
+    if (nested) {
+        // ---- third level: S x sample(b) with the ordinary kernel -> the event thresholds of the rows of S ----
+        hipLaunchKernelGGL(kz_dual_sample_kernel, dim3((unsigned)s3_tiles), dim3(256), 0, ctx->stream, (const uint4*)ib->packed, ib->bias,
+                           n_slices, stride3, (int)s3_tiles, force_s3 > 0 ? force_s3 : 1, (uint4*)s3_packed, s3_bias);
+        KZ_DUAL_HIP(hipGetLastError());
+        {
+            const int KP = KPs3;   // (KZ_DISPATCH_KP switches on `KP`)
+            int blocks_per_cu = 1, tpw = 1;
+            KZ_DISPATCH_KP(rc, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
+            if (rc != KZ_OK) {
+                release();
+                return rc;
+            }
+            KzPass ps;
+            rc = kz_prepare_pass(ctx, (int)s_tiles, (int)s3_tiles, blocks_per_cu * ctx->n_cus, 256 / KP, KP, KZ_TIER_H, 0, &ps, tpw, force_s3);
+            if (rc == KZ_OK) {
+                KnnCandParams cp;
+                memset(&cp, 0, sizeof(cp));
+                cp.qpack = (const float*)q_packed;     // S = the first s_tiles tiles of the dealt image of a
+                cp.ypack = (const float*)s3_packed;
+                cp.ybias = s3_bias;
+                cp.work = ps.d_work;
+                cp.qt0 = 0;
+                cp.n_ytiles = (int)s3_tiles;
+                cp.n_qtiles = (int)s_tiles;
+                cp.lay = ps.lay;
+                cp.kg = b->kg;
+                cp.out_key = ps.out_key;
+                cp.out_idx = ps.out_idx;
+                KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W, ctx->h_wps, ctx->h_wide));
+            }
+            if (rc != KZ_OK) {
+                release();
+                return rc;
+            }
+            // (the rows owning these thresholds are rows of S, position j of the dealt image: bias q_bias[j]; their events come from b)
+            hipLaunchKernelGGL(kz_dual_theta_kernel, dim3((unsigned)((s_img_rows + 3) / 4)), dim3(256), 0, ctx->stream, ps.out_key, ps.out_idx,
+                               ps.lay, KP, rank3, s_img_rows, s_img_rows, q_bias, ib->d_max, ia->d_max, ia->center->d_scale, theta3, floor3,
+                               (const int*)nullptr, 0, (int*)nullptr, (uint2*)nullptr);
+            KZ_DUAL_HIP(hipGetLastError());
+        }
+        // S sorted by descending threshold: perm3 (sorted row -> j), its image from the raw rows, per-tile minima
+        hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((s_img_rows + 255) / 256)), dim3(256), 0, ctx->stream, iota3, (int)s_img_rows);
+        KZ_DUAL_HIP(hipGetLastError());
+        rc = kz_sort_pairs_f32_i32(ctx, theta3, theta3_s, iota3, perm3, (int)s_img_rows, 1);
+        if (rc == KZ_OK) {
+            hipLaunchKernelGGL(kz_dual_rows_of_kernel, dim3((unsigned)((s_img_rows + 255) / 256)), dim3(256), 0, ctx->stream, perm3, row_map, s_img_rows, rm3);
+            hipLaunchKernelGGL(kz_dual_tilemin_kernel, dim3((unsigned)((s_img_rows + 255) / 256)), dim3(256), 0, ctx->stream, theta3_s, s_img_rows, s_img_rows, theta3_min);
+            hipLaunchKernelGGL(kz_dual_natural_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, b->n, b_pad, row_map_b);
+            hipLaunchKernelGGL(kz_dual_negbias_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, ib->bias, b->n, b_pad, qnb_b);
+            rc = kz_himage_pack_rows(a, rm3, s_img_rows, s_img_rows, ss_packed, ss_bias);
+        }
+        if (rc == KZ_OK && hipMemsetAsync(ev3_cnt, 0, (size_t)s_img_rows * 4, ctx->stream) != hipSuccess) rc = KZ_ERR_HIP;
+        if (rc == KZ_OK && hipMemsetAsync(d_cnt3, 0, 1024, ctx->stream) != hipSuccess) rc = KZ_ERR_HIP;
+        if (rc != KZ_OK) {
+            release();
+            return rc;
+        }
+        // ---- second level: b x S with the DUAL build.  Forward lists (raw) -> tau(t), theta(t) and the sample-row events of t;
+        // event log -> the forward results of the rows of S (chain rv3, second stream) ----
+        rv3.ctx = ctx; rv3.qm = a; rv3.im = b; rv3.qi = ia; rv3.ii = ib;
+        rv3.log_keys = log3_keys; rv3.log_meta = log3_meta; rv3.d_cnt = d_cnt3; rv3.log_cap = log_cap3;
+        rv3.theta_s = theta3_s; rv3.qnb = qnb_b; rv3.p_bias = ss_bias; rv3.col_key = col3_key; rv3.floor_sel = floor3; rv3.floor_fin = floor3m;
+        rv3.row_map = row_map_b; rv3.ev_cnt = ev3_cnt; rv3.perm = perm3; rv3.col_idx = col3_idx; rv3.fail_list = fail3;
+        rv3.fail_count = ctx->d_counters + 24; rv3.fin_row_map = row_map;
+        rv3.ev = ev3; rv3.ev_cap = ev_cap3; rv3.KP = ctx->dual_rev_long ? (2 * KP < 128 ? 2 * KP : 128) : KP; rv3.k = k;
+        rv3.n_rows = s_img_rows; rv3.n_tiles = s_tiles; rv3.d_dist = d_dist_ab; rv3.d_ind = d_ind_ab;
+        rv3.timed = 0; rv3.h_fail = 24; rv3.h_cnt = 28; rv3.second_stream = ctx->dual_overlap ? 1 : 0;
+        dp2.qpack = (const float*)ib->packed;
+        dp2.row_map = row_map_b;
+        dp2.ypack = (const float*)ss_packed;
+        dp2.ybias = ss_bias;
+        dp2.perm = rm3;
+        dp2.theta = theta3_min;
+        dp2.qnbias = qnb_b;
+        dp2.log_keys = log3_keys;
+        dp2.log_meta = log3_meta;
+        dp2.log_cnt = d_cnt3;
+        dp2.log_cap = log_cap3;
+        dp2.short_pieces = force_s;       // (lists of KPs over force_s parts of S, as the classic sample sweep keeps them)
+        dp2.short_kp = KPs;
+        dp2.short_ksel = k;
+        dp2.n_ytiles = (int)s_tiles;
+        dp2.raw_lists = 1;
+        dp2.max_entries = 256;
+        hk2.rm3 = rm3;
+        hk2.sev_cnt = sev_cnt;
+        hk2.sev = sev;
+        dp2.post_user = &hk2;
+        dp2.post_sweep = +[](void* user) -> int {
+            Hook2& h = *(Hook2*)user;
+            kz_ctx* ctx = h.ctx;
+            const KzDualPass& d2 = *h.dp2;
+            // thresholds of b's rows off the raw lists (first stream: the lists live in the scratch block until the next pass)
+            hipLaunchKernelGGL(kz_dual_theta_kernel, dim3((unsigned)((h.b_pad + 3) / 4)), dim3(256), 0, ctx->stream, d2.lists_key, d2.lists_idx,
+                               d2.lists_lay, d2.lists_KP, h.rank, h.b_n, h.b_pad, h.ib->bias, h.ia->d_max, h.ib->d_max, h.ib->center->d_scale,
+                               h.theta, h.floor_, h.rm3, h.sev_cap, h.sev_cnt, h.sev);
+            KZ_HIP(hipGetLastError());
+            return kz_dual_enqueue_chain(*h.rv3);   // the sample rows' own results, beside what follows on the first stream
+        };
+        kz_knn_stats st2;
+        ctx->stream2_busy = 1;
+        rc = kz_knn_impl(ctx, b, 0, b->n, a, k, 0, nullptr, -1, 0, d_dist_ba, d_ind_ba, &st2, &dp2);
+        if (rc == KZ_OK && (dp2.broken || !dp2.post_called)) {
+            // the sweep left the fp16 tier (cannot happen for a dual pass today) -- no thresholds: give the call to two ordinary searches
+            (void)hipStreamSynchronize(ctx->stream2);
+            ctx->stream2_busy = 0;
+            release();
+            return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
+        }
+        if (rc != KZ_OK) {
+            (void)hipStreamSynchronize(ctx->stream2);
+            ctx->stream2_busy = 0;
+            release();
+            return rc;
+        }
+    } else {
+        // ---- classic sample image: every stride-th tile of A's fp16 image (tiles are contiguous runs of n_slices x 4 KiB), dealt over the parts
+        hipLaunchKernelGGL(kz_dual_sample_kernel, dim3((unsigned)s_tiles), dim3(256), 0, ctx->stream, (const uint4*)ia->packed, ia->bias,
+                           n_slices, stride, (int)s_tiles, force_s > 0 ? force_s : 1, (uint4*)s_packed, s_bias);
+        KZ_DUAL_HIP(hipGetLastError());
+        // ---- sample sweep: B x sample(A) with the ordinary kernel, lists of at most 256 entries per row -----------------------
         const int KP = KPs;   // (KZ_DISPATCH_KP switches on `KP`)
         int blocks_per_cu = 1, tpw = 1;
         KZ_DISPATCH_KP(rc, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
@@ -713,7 +1085,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             return rc;
         }
         hipLaunchKernelGGL(kz_dual_theta_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, ctx->stream, ps.out_key, ps.out_idx,
-                           ps.lay, KP, rank, b->n, b_pad, ib->bias, ia->d_max, ib->d_max, ib->center->d_scale, theta, floor_);
+                           ps.lay, KP, rank, b->n, b_pad, ib->bias, ia->d_max, ib->d_max, ib->center->d_scale, theta, floor_,
+                           (const int*)nullptr, 0, (int*)nullptr, (uint2*)nullptr);
         KZ_DUAL_HIP(hipGetLastError());
     }
     // ---- B's rows in DESCENDING order of their threshold: permutation, sorted thresholds (+inf behind them), sorted image.
@@ -744,6 +1117,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     hipLaunchKernelGGL(kz_dual_tilemin_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, theta_s, b->n, b_pad, theta_min);
     KZ_DUAL_HIP(hipGetLastError());
     KZ_DUAL_RC(kz_himage_pack_permuted(b, perm, p_packed, p_bias));
+    if (nested) {
+        // the sample-row events of every row of b open its event buffer (the main sweep's scatter kernel appends behind them)
+        hipLaunchKernelGGL(kz_dual_inject_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, perm, b_pad, sev_cnt, sev, sev_cap,
+                           ev_cnt, ev, ev_cap);
+        KZ_DUAL_HIP(hipGetLastError());
+    }
     KZ_DUAL_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     float sample_ms = 0;
     if (qfloor) {
@@ -775,89 +1154,23 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // context's SECOND stream from inside kz_knn_impl, right behind the sweep (KzDualPass::post_sweep): it shares no buffer
     // with what the first stream does meanwhile (finalize of A's lists, fail-counter read-back, re-search of uncertified rows)
     int* fail_count_b = ctx->d_counters + 12;   // {fail counter, -, error-ratio bits x 2}: a set of its own beside the forward direction's
-    struct RevCtx {
-        kz_ctx* ctx; kz_matrix *a, *b; const kz_himage *ia, *ib;
-        void *log_keys, *log_meta; unsigned long long* d_cnt; long long log_cap;
-        float *theta_s, *qnb, *p_bias, *col_key, *floor_; int *row_map, *ev_cnt, *perm, *col_idx, *fail_list, *fail_count_b;
-        uint2* ev; int ev_cap, KP, k; int64_t b_tiles; double* d_dist_ba; int64_t* d_ind_ba;
-    } rv = {ctx, a, b, ia, ib, log_keys, log_meta, d_cnt, log_cap, theta_s, qnb, p_bias, col_key, floor_, row_map, ev_cnt, perm,
-            col_idx, fail_list, fail_count_b, ev, ev_cap, KPr, k, b_tiles, d_dist_ba, d_ind_ba};
-    auto enqueue_reverse = [](void* user) -> int {
-        RevCtx& r = *(RevCtx*)user;
-        kz_ctx* ctx = r.ctx;
-        hipStream_t first = ctx->stream;
-        // (the sweep was recorded as ev[1] of the first stream by kz_knn_impl just now)
-        KZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev[1], 0));
-        ctx->stream = ctx->stream2;   // every launch helper below enqueues on ctx->stream
-        auto body = [&]() -> int {
-            KZ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
-            hipLaunchKernelGGL(kz_dual_scatter_kernel, dim3(ctx->n_cus * 8), dim3(256), 0, ctx->stream, (const f32x4e*)r.log_keys,
-                               (const i32x2e*)r.log_meta, r.d_cnt, r.log_cap, r.theta_s, r.qnb, r.p_bias, r.row_map, r.ev_cnt, r.ev, r.ev_cap);
-            const size_t sel_lds = (size_t)4 * 2 * r.ev_cap * 4;
-            if (sel_lds > 65536)
-                KZ_HIP(hipFuncSetAttribute((const void*)kz_dual_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
-            hipLaunchKernelGGL(kz_dual_select_kernel, dim3((unsigned)((r.b->n + 3) / 4)), dim3(256), sel_lds, ctx->stream, r.ev_cnt, r.ev, r.ev_cap,
-                               r.b->n, r.perm, r.KP, r.col_key, r.col_idx, r.floor_, r.d_cnt + 16);
-            hipLaunchKernelGGL(kz_dual_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, r.d_cnt + 16, r.d_cnt + 1);
-            KZ_HIP(hipGetLastError());
-            KZ_HIP(hipEventRecord(ctx->ev[9], ctx->stream));
-            KzListLayout lay;
-            memset(&lay, 0, sizeof(lay));
-            lay.n_regions = 1;
-            lay.qt_end[0] = (int)r.b_tiles;
-            lay.pieces[0] = 1;
-            lay.halves = 1;
-            lay.contig = 1;
-            KZ_HIP(hipMemsetAsync(r.fail_count_b, 0, 4 * sizeof(int), ctx->stream));
-            KnnFinParams fp;
-            memset(&fp, 0, sizeof(fp));
-            fp.in_key = r.col_key;
-            fp.in_idx = r.col_idx;
-            fp.lay = lay;
-            fp.KP = r.KP;
-            fp.list_row0 = 0;
-            fp.q_begin = 0;
-            fp.q_count = r.b->n;
-            fp.qraw = r.b->raw;
-            fp.yraw = r.a->raw;
-            fp.qsqn = r.b->sqn;
-            fp.ysqn = r.a->sqn;
-            fp.n_i = r.a->n;
-            fp.d = (int)r.a->d;
-            fp.metric = r.a->metric;
-            fp.k = r.k;
-            fp.ystats = r.a->d_stats;
-            fp.tier_h = 1;
-            fp.eps_mult = ctx->eps_scale;
-            fp.gamma_acc = 2.0 * (double)(r.a->kg * 4 + 16) * 5.9604644775390625e-08;
-            fp.q_rowq = r.ib->rowq;
-            fp.y_hmax = r.ia->d_max;
-            fp.hscale = r.ia->center->d_scale;
-            fp.excl_floor = r.floor_;
-            fp.dual_col = 1;
-            fp.out_dist = r.d_dist_ba;
-            fp.out_ind = r.d_ind_ba;
-            fp.fail_count = r.fail_count_b;
-            fp.fail_list = r.fail_list;
-            fp.err_ratio_bits = (unsigned long long*)(r.fail_count_b + 2);
-            const int rc2 = kz_launch_finalize(ctx, fp, lay, r.KP, r.b->n, r.a->dtype);
-            if (rc2 != KZ_OK) return rc2;
-            KZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
-            KZ_HIP(hipMemcpyAsync(ctx->h_counters + 12, r.fail_count_b, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            KZ_HIP(hipMemcpyAsync(ctx->h_counters + 16, r.d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
-            return KZ_OK;
-        };
-        const int rc2 = body();
-        ctx->stream = first;
-        return rc2;
-    };
+    KzRevChain rv;
+    memset(&rv, 0, sizeof(rv));
+    rv.ctx = ctx; rv.qm = b; rv.im = a; rv.qi = ib; rv.ii = ia;
+    rv.log_keys = log_keys; rv.log_meta = log_meta; rv.d_cnt = d_cnt; rv.log_cap = log_cap;
+    rv.theta_s = theta_s; rv.qnb = qnb; rv.p_bias = p_bias; rv.col_key = col_key; rv.floor_sel = floor_; rv.floor_fin = floor_;
+    rv.row_map = row_map; rv.ev_cnt = ev_cnt; rv.perm = perm; rv.col_idx = col_idx; rv.fail_list = fail_list; rv.fail_count = fail_count_b;
+    rv.ev = ev; rv.ev_cap = ev_cap; rv.KP = KPr; rv.k = k; rv.n_rows = b->n; rv.n_tiles = b_tiles; rv.d_dist = d_dist_ba; rv.d_ind = d_ind_ba;
+    rv.timed = 1; rv.h_fail = 12; rv.h_cnt = 16; rv.second_stream = 1;
+    auto enqueue_reverse = [](void* user) -> int { return kz_dual_enqueue_chain(*(KzRevChain*)user); };
     if (ctx->dual_overlap) {
         dp.post_sweep = +enqueue_reverse;
         dp.post_user = &rv;
     }
     kz_knn_stats st_ab;
     ctx->stream2_busy = 1;   // (from here to the synchronisation below the second stream belongs to the reverse chain)
-    rc = kz_knn_impl(ctx, a, 0, a->n, b, k, 0, nullptr, -1, 0, d_dist_ab, d_ind_ab, &st_ab, &dp);
+    // (nested: the main sweep covers the image rows behind the sample -- in the dual pass a query range is a range of IMAGE rows)
+    rc = kz_knn_impl(ctx, a, nested ? s_img_rows : 0, nested ? a->n - s_img_rows : a->n, b, k, 0, nullptr, -1, 0, d_dist_ab, d_ind_ab, &st_ab, &dp);
     if (rc == KZ_OK && !ctx->dual_overlap && !dp.broken) {   // ("dual_overlap" = 0: the same chain, behind the forward direction)
         dp.post_called = 1;
         rc = enqueue_reverse(&rv);
@@ -878,6 +1191,33 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // (kz_knn_impl ends with a stream synchronisation: ev[5] and ev[6] around the sample sweep have completed)
     KZ_DUAL_HIP(hipEventElapsedTime(&sample_ms, ctx->ev[5], ctx->ev[6]));
     st_ab.dual = 1;
+    if (nested) {
+        // the sample rows' own chain (second stream, synchronised above): rows it could not certify -- or all of them when its
+        // event log overflowed -- are searched again the ordinary way, like the uncertified rows of the main sweep
+        int n_fail3 = ctx->h_counters[24];
+        unsigned long long hc3[4];
+        memcpy(hc3, ctx->h_counters + 28, 32);
+        const int* list3 = fail3;
+        if (hc3[0] > (unsigned long long)log_cap3) {
+            n_fail3 = (int)s_img_rows;
+            list3 = rm3;   // (the matrix rows of S)
+        }
+        if (n_fail3 > 0) {
+            const int kp_min3 = ((int64_t)n_fail3 * 8 > s_img_rows || KPr >= 128) ? 0 : (KPr == 16 && ctx->esc_short && n_fail3 <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
+            kz_knn_stats st3;
+            float ms3 = 0;
+            const int prec3 = ((int64_t)n_fail3 * 2 > s_img_rows && ctx->esc_bf) ? 2 : -1;
+            KZ_DUAL_RC(kz_escalate_rows(ctx, a, 0, list3, n_fail3, b, k, 0, nullptr, prec3, prec3 == 2 ? 0 : kp_min3, d_dist_ab, d_ind_ab, &st3, &ms3));
+            st_ab.fallback_ms += ms3;
+            st_ab.n_escalated_rows += n_fail3 + st3.n_escalated_rows;
+            st_ab.n_fallback_rows += st3.n_fallback_rows;
+            if (st3.max_err_ratio > st_ab.max_err_ratio) st_ab.max_err_ratio = st3.max_err_ratio;
+        }
+        double r3;
+        memcpy(&r3, ctx->h_counters + 26, 8);
+        if (r3 > st_ab.max_err_ratio) st_ab.max_err_ratio = r3;
+        st_ab.n_first_pass_fail += n_fail3;
+    }
     kz_dual_fill_stats(stats_ab, st_ab);
 
     kz_knn_stats st_ba;

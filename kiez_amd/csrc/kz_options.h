@@ -62,6 +62,7 @@ static const KzOption KZ_OPTIONS[] = {
     {"dual_force", KZ_OPT_BOOL, KZ_O(dual_force), 0, 1, 0, 0, {}, 0, "run the shared sweep also where its cost model says it does not pay (tests)"},
     {"dual_deal", KZ_OPT_BOOL, KZ_O(dual_deal), 0, 1, 1, 0, {}, 0, "query rows dealt into load-balanced tiles"},
     {"dual_overlap", KZ_OPT_BOOL, KZ_O(dual_overlap), 0, 1, 1, 0, {}, 0, "reverse direction's chain on the second stream"},
+    {"dual_nested", KZ_OPT_BOOL, KZ_O(dual_nested), 0, 1, 1, 0, {}, 0, "sampled rows are swept by the sample sweep only (itself a shared sweep)"},
     {"dual_rank", KZ_OPT_INT, KZ_O(dual_rank), -1, 128, 0, 0, {}, 0, "rank of the sample key that becomes a row's event threshold (0 automatic, -1 = k + 1)"},
     {"dual_rev_long", KZ_OPT_BOOL, KZ_O(dual_rev_long), 0, 1, 1, 0, {}, 0, "reverse lists of twice the list length"},
     {"dual_sample_short", KZ_OPT_BOOL, KZ_O(dual_sample_short), 0, 1, 1, 0, {}, 0, "sample sweep keeps lists of 16 (32) over several ranges"},

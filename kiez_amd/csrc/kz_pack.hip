@@ -521,6 +521,24 @@ int kz_himage_pack_permuted(kz_matrix* m, const int* d_perm, unsigned short* pac
     return KZ_OK;
 }
 
+// The same for ANY list of n_rows matrix rows (n_pad image rows, a multiple of 128; rows behind n_rows: zero image, bias -inf).
+int kz_himage_pack_rows(kz_matrix* m, const int* d_rows, int64_t n_rows, int64_t n_pad, unsigned short* packed, float* bias) {
+    kz_ctx* ctx = m->ctx;
+    KZ_REQUIRE(m->himg && n_pad % KZ_TILE == 0 && n_rows <= n_pad, "kz_himage_pack_rows: no fp16 image / bad row counts");
+    const kz_center* center = m->himg->center;
+    const int nsr = m->kg / 4;
+    if (m->dtype == KZ_F32)
+        hipLaunchKernelGGL(kz_pack_h_kernel<float>, dim3(kz_rowgroup_blocks(n_pad, 4)), dim3(256), 0, ctx->stream, (const float*)m->raw, m->sqn,
+                           n_rows, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, packed, bias, (double*)nullptr,
+                           (unsigned long long*)nullptr, d_rows);
+    else
+        hipLaunchKernelGGL(kz_pack_h_kernel<double>, dim3(kz_rowgroup_blocks(n_pad, 4)), dim3(256), 0, ctx->stream, (const double*)m->raw, m->sqn,
+                           n_rows, (int)m->d, m->metric, nsr, n_pad, center->d_mu, center->d_scale, packed, bias, (double*)nullptr,
+                           (unsigned long long*)nullptr, d_rows);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
 // A second fp16 image of m with its rows dealt over P index ranges (range p = rows p, p + P, p + 2 P, ...; kz_dealt_row): the
 // short-list route of the ordinary kernel keeps one list of 16 per query and RANGE, and the ranges must be alike -- in the
 // caller's row order the near rows of a query may all sit in one stretch of the matrix (data stored cluster by cluster).

@@ -399,3 +399,45 @@ def test_threshold_rank_below_k_plus_one(ctx, rank):
             assert s_ba["n_escalated_rows"] > 0      # rows short of events went down the ordinary way
     finally:
         ctx.set_option("dual_rank", 0)
+
+
+@pytest.mark.parametrize("kind,na,nb,d,k,metric,dtype", [
+    ("uniform", 60000, 9000, 48, 10, "euclidean", np.float32),        # one list of 16 per row
+    ("clustered", 50000, 30000, 64, 50, "cosine", np.float32),        # cluster-ordered rows, short lists in both sample levels
+    ("normal", 40000, 41000, 200, 26, "sqeuclidean", np.float64),     # 13 slices
+    ("duplicates", 30000, 8000, 32, 12, "euclidean", np.float32),     # exact ties among the sample rows and across the sample's edge
+])
+def test_nested_sample_rows_are_swept_once_and_come_out_the_same(ctx, kind, na, nb, d, k, metric, dtype):
+    """NESTED sample (kz_knn_dual.h, round 5): the sampled rows of a -- the first tiles of its dealt image -- are no longer rows of the
+    main sweep: their forward neighbours come out of the sample sweep (a shared sweep itself: events of the sample rows, thresholds
+    from a third, small sweep), and the sample-row events of every row of b are read off the sample sweep's lists.  Results with
+    the option on and off, and from two ordinary searches, must be identical; both directions also against the oracle."""
+    a, b = _data(kind, na, d, 31, dtype), _data(kind, nb, d, 32, dtype)
+    ctx.set_option("dual_nested", 0)
+    try:
+        sep, classic, s0_ab, s0_ba = _both_ways(ctx, a, b, k, metric)
+        ctx.set_option("dual_nested", 1)
+        _, nested, s_ab, s_ba = _both_ways(ctx, a, b, k, metric)
+    finally:
+        ctx.set_option("dual_nested", 1)
+    assert s_ab["dual"] == 1 and s_ba["dual"] == 1 and s0_ba["dual"] == 1
+    _assert_same(sep, classic)
+    _assert_same(sep, nested)
+    if kind != "duplicates":
+        _oracle_sample(a, b, k, metric, nested)
+    assert max(s_ab["max_err_ratio"], s_ba["max_err_ratio"]) < 1.0
+    # the main sweep no longer logs the sample rows' events: fewer logged groups than the classic sweep, same events filed in all
+    assert s_ba["n_logged_groups"] < s0_ba["n_logged_groups"]
+
+
+def test_nested_sample_with_a_tiny_event_threshold_rank(ctx):
+    """rank 1 leaves many rows of BOTH levels short of k events: the sample rows' own chain and the main chain send them to the
+    ordinary search; same results."""
+    ctx.set_option("dual_rank", 1)
+    try:
+        a, b = _data("uniform", 60000, 48, 41, np.float32), _data("uniform", 20000, 48, 42, np.float32)
+        sep, dual, s_ab, s_ba = _both_ways(ctx, a, b, 10, "euclidean")
+        _assert_same(sep, dual)
+        assert s_ab["n_escalated_rows"] > 0 and s_ba["n_escalated_rows"] > 0
+    finally:
+        ctx.set_option("dual_rank", 0)

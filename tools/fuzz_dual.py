@@ -43,6 +43,9 @@ for case in range(n_cases):
     if os.environ.get("KZ_FUZZ_Q64") is not None:
         q64 = int(os.environ["KZ_FUZZ_Q64"])
     fl = (int(rng.integers(0, 2)), int(rng.choice([64, 256, 2048])), float(rng.choice([0.3, 1.3, 1.3, 3.0])))   # seeded lists: on / probe rows / margin
+    nested = int(rng.integers(0, 3) > 0)      # nested sample (the sampled rows are swept by the sample sweep only): on in two cases of three
+    if os.environ.get("KZ_FUZZ_NESTED") is not None:
+        nested = int(os.environ["KZ_FUZZ_NESTED"])
     if os.environ.get("KZ_FUZZ_FLOOR") is not None:
         fl = (int(os.environ["KZ_FUZZ_FLOOR"]),) + fl[1:]
     if only >= 0 and not (only_first <= case <= only):
@@ -72,7 +75,9 @@ for case in range(n_cases):
     ctx.set_option("list_floor", fl[0])
     ctx.set_option("floor_probe", fl[1])
     ctx.set_option("floor_margin", fl[2])
+    ctx.set_option("dual_nested", nested)
     (xd, xi, sa), (yd, yi, sb) = N.knn_dual(ctx, am, bm, k)
+    ctx.set_option("dual_nested", 1)
     ctx.set_option("list_floor", 0)
     ctx.set_option("h_wide", 0)
     ctx.set_option("h_q64", 2)
@@ -102,7 +107,7 @@ for case in range(n_cases):
     if not ok or ratio >= 1.0:
         bad += 1
     print(("ok " if ok else "BAD"), f"na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} dual {sa['dual']}/{sb['dual']} "
-          f"q64 {q64} floor {fl} ev/row {sb['n_events'] / nb:.1f} esc {sa['n_escalated_rows']}/{sb['n_escalated_rows']} splits {sa['n_splits']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
+          f"q64 {q64} floor {fl} nested {nested} ev/row {sb['n_events'] / nb:.1f} esc {sa['n_escalated_rows']}/{sb['n_escalated_rows']} splits {sa['n_splits']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
 for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1), ("h_wide", 0), ("dual_overlap", 1),
                 ("dual_short_min_tiles", 128), ("short_ord_min_tiles", 48), ("dual_sample_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1), ("list_floor", 1), ("floor_probe", 1024), ("floor_margin", 1.3)):
     ctx.set_option(name, v)
