@@ -894,7 +894,9 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         ev_cap3 = (int)(((int64_t)rank3 * stride3 + (int64_t)(7.0 * sqrt((double)rank3) * stride3) + 63) & ~(int64_t)63);
         log_cap3 = (long long)((double)s_img_rows * rank3 * stride3 * 1.5) + (1 << 20);
     }
-    const int sev_cap = (force_s > 0 ? force_s : 256 / KPs) * KPs < 256 ? (force_s > 0 ? force_s : 256 / KPs) * KPs : 256;   // (every list entry can be an event)
+    // (events of a row among the sample rows: the entries at or above its rank-th best key -- `rank` of them but for ties; a row
+    //  with more than the buffer holds is flagged and searched again)
+    const int sev_cap = ((2 * rank + 16 + 15) & ~15) < 256 ? ((2 * rank + 16 + 15) & ~15) : 256;
     if (nested) {
         const int KPr3 = ctx->dual_rev_long ? (2 * KP < 128 ? 2 * KP : 128) : KP;
         int rcn = kz_pool_alloc(ctx, (size_t)s3_tiles * tile_bytes + 32 * 4096, (void**)&s3_packed);

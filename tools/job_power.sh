@@ -3,7 +3,7 @@
 #      centred fp16 image), ns-like shape and C1 -> <P>/r05_power_probe.log
 #   2. the same program under rocprofv3 --pmc (separate passes; program directly behind `--`): GRBM_GUI_ACTIVE (clock the chip held =
 #      GRBM / 8 XCDs / duration) and SQ_VALU_MFMA_BUSY_CYCLES (matrix-pipe busy) per dispatch of the fused kernel
-#      -> <P>/r05_power_probe.pmc.jsonl (one record per dispatch, in launch order: 3 operand kinds x 4 launches x 2 shapes)
+#      -> <P>/r05_power_probe.pmc.jsonl (one record per dispatch of the sweep, in launch order: 3 operand kinds x 3 launches x 2 shapes)
 #   3. tools/sweep_intercept.py (C1's start burst) -> <P>/r05_sweep_intercept.log
 #      gpurun -- 'bash tools/job_power.sh'
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -13,7 +13,7 @@ cat $P/r05_power_probe.log
 : > $P/r05_power_probe.pmc.jsonl
 for pass in "grbm GRBM_GUI_ACTIVE" "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA"; do
   set -- $pass; name=$1; shift
-  timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- python3 tools/power_probe.py > $O/$name.log 2>&1
+  timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- python3 tools/power_probe.py 3 > $O/$name.log 2>&1
   f=$(find $O/$name -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$name" >> $P/r05_power_probe.pmc.jsonl <<'PY'
 import csv, sys, json, collections
@@ -39,4 +39,4 @@ PY
   rm -rf $O/$name
 done
 wc -l $P/r05_power_probe.pmc.jsonl
-timeout 600 python3 tools/sweep_intercept.py > $P/r05_sweep_intercept.log 2>&1; cat $P/r05_sweep_intercept.log
+[ -n "${SKIP_INTERCEPT:-}" ] || { timeout 600 python3 tools/sweep_intercept.py > $P/r05_sweep_intercept.log 2>&1; cat $P/r05_sweep_intercept.log; }

@@ -9,8 +9,12 @@ from kiez_amd import _native as N
 
 ctx = N.Context.get()
 ctx.set_option("h_q64", 0)
+ctx.set_option("tier_probe", 0)     # (the probe would see that constant rows cannot be certified and start the call at the split-bf16 tier: the
+ctx.set_option("list_floor", 0)     #  point here is the SAME fp16 launch on three kinds of operand bits)
 rng = np.random.RandomState(0)
-for n_q, n_i, d in ((262_144, 250_000, 200), (100_000, 100_000, 128)):   # (constant rows tie everywhere: every row ends on the exact kernels -- the query side is kept small)
+LAUNCHES = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+# (constant rows tie everywhere: every row ends on the exact kernels, ~0.3 ms a row -- the query side is ONE full round of workgroups, 768 tiles)
+for n_q, n_i, d in ((98_304, 250_000, 200), (98_304, 100_000, 128)):
     v = rng.rand(1, d).astype(np.float32)
     sets = {"uniform random": (rng.rand(n_q, d).astype(np.float32), rng.rand(n_i, d).astype(np.float32)),
             "constant rows (fp16 image = zeros)": (np.repeat(v, n_q, 0), np.repeat(v, n_i, 0)),
@@ -18,7 +22,7 @@ for n_q, n_i, d in ((262_144, 250_000, 200), (100_000, 100_000, 128)):   # (cons
     for name, (a, b) in sets.items():
         q, y = N.DeviceMatrix(ctx, a, "euclidean"), N.DeviceMatrix(ctx, b, "euclidean")
         ms = []
-        for _ in range(4):
+        for _ in range(LAUNCHES):
             _, _, st = N.knn(ctx, q, y, 10)
             ms.append(st["main_kernel_ms"])
         print(f"{n_q} x {n_i} x {d}  {name:36s}: main kernel {min(ms[1:]):8.3f} ms   escalated {st['n_escalated_rows']} fallback {st['n_fallback_rows']}", flush=True)
