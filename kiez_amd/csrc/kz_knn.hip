@@ -12,6 +12,8 @@
 // Result: neighbour order == order of the float64 distances the reference computes; no approximation.
 #include <vector>
 
+#include <algorithm>
+
 #include "kz_common.h"
 #include "kz_floor.h"
 
@@ -422,7 +424,10 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     }
     // top-KS of the M entries by (key desc, idx asc)
     int V = 0;
-    if (M <= 512) {
+    // (rank counting is O(M^2 / 64) per lane: 512 entries = 4096 steps of 8 compares -- with KS = 256 selected entries, the wide
+    //  route, that selection alone was a quarter of a 55 ms finalize launch; from 257 entries on the radix select below,
+    //  O(32 M / 64 + KS^2 / 64), takes over when many entries are selected)
+    if (M <= 256 || (M <= 512 && KS <= 128)) {
         // E entries per lane: the rank of an entry among the valid entries is a count over uniform-lane broadcasts
         // (v_readlane), no cross-lane reduction chains; entries with rank < KS land in ck/ci already ordered
         if (M <= 64)
@@ -1173,6 +1178,7 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
 struct KzPass {
     KzListLayout lay;
     int W;            // workgroups
+    int W0;           // boot_first: the first W0 items of the table are the items of index range 0 (else 0)
     float* out_key;   // candidate lists (scratch)
     int* out_idx;
     int* fail_list;   // [fail_rows] (scratch)
@@ -1185,7 +1191,7 @@ struct KzPass {
 // query tiles -- one work item = one unit x one index range, w4.x = its first tile -- and converted back to tiles for the list
 // layout (a region ends on a unit boundary, the last one at the last tile).
 static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, int max_pieces, int KP, int tier, int64_t fail_rows,
-                           KzPass* out, int tpw = 1, int force_pieces = 0, int min_pieces = 0) {
+                           KzPass* out, int tpw = 1, int force_pieces = 0, int min_pieces = 0, bool boot_first = false) {
     KzPlan pl;
     kz_plan_pass(n_qtiles, n_ytiles, slots, max_pieces, (tier == KZ_TIER_H ? 1 : 2) * KP, tier == KZ_TIER_F32 ? 2 : 1,
                  tier == KZ_TIER_H ? 1 : 0, tpw, force_pieces > 0 ? force_pieces : ctx->force_splits, min_pieces > ctx->min_splits ? min_pieces : ctx->min_splits, &pl);
@@ -1230,6 +1236,13 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
         const int per_xcd = (slots + 7) / 8;
         const int qgroup = ctx->qgroup > 0 ? ctx->qgroup : (tier == KZ_TIER_H && 4 * per_xcd > KZ_QGROUP ? 4 * per_xcd : KZ_QGROUP);
         kz_plan_fill_work(pl, n_ytiles, tpw, (KzWorkItem*)hw, qgroup);
+        out->W0 = 0;
+        if (boot_first) {
+            // RANGE-0 BOOTSTRAP (kz_knn_impl): the items of index range 0 first -- they are launched on their own, the others
+            // behind them with a floor read off range 0's lists.  (Stable: both groups keep the XCD-aware order among themselves.)
+            KzWorkItem* w = (KzWorkItem*)hw;
+            out->W0 = (int)(std::stable_partition(w, w + W, [](const KzWorkItem& it) { return it.w == 0; }) - w);
+        }
         KZ_HIP(hipMemcpyAsync(out->d_work, hw, (size_t)W * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     }
     return KZ_OK;
@@ -1305,6 +1318,30 @@ static int kz_floor_model(kz_ctx* ctx, const double* dist, const double* rowq, i
     }
     *ok = kz_floor_fit(hp.data(), n_probe, ctx->floor_margin, model);
     return KZ_OK;
+}
+
+// RANGE-0 BOOTSTRAP of the short-list routes (round 5).  A query keeps one list of 16 per index RANGE of the row-dealt image, and
+// range 0 of a dealt image is a systematic 1 / P sample of the index: the smallest key of its full list -- the 16th best over the
+// sample, about rank 16 P over everything -- is a lower bound of the query's 16 P-th best key, known after 1 / P of the sweep.  The
+// other P - 1 ranges are swept behind it with their lists STARTING at that floor (KnnCandParams::qfloor, as the population floor of
+// the seeded lists does): keys at or below it never become events.  A list that starts empty takes 16 (1 + ln(n / (16 P)))
+// events; with the floor a range sees about the 16 P / P = 16 rows above it -- P = 32 lists on 300 k rows: ~3 800 events per query
+// without, ~700 with.  The finalize kernel counts the floor into its bound (KnnFinParams::list_floor) exactly as for seeded lists:
+// a floor can only make a row uncertified (searched again), never change a result.
+__global__ void kz_boot_floor_kernel(const float* __restrict__ in_key, const int* __restrict__ in_idx, KzListLayout lay, int KP, int64_t list_row0,
+                                     int64_t q_begin, int64_t q_count, const float* __restrict__ prev, float* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= q_count) return;
+    const int64_t l0 = kz_list_contig_off(list_row0 + q, lay, KP, 0);
+    float mn = INFINITY;
+    bool full = true;
+    for (int e = 0; e < KP; ++e) {
+        full = full && in_idx[l0 + e] >= 0;
+        mn = fminf(mn, in_key[l0 + e]);
+    }
+    float f = full ? mn : -INFINITY;
+    if (prev) f = fmaxf(f, prev[q_begin + q]);
+    out[q_begin + q] = f;
 }
 
 // Escalation of uncertified rows: gather rows cq_begin + fail_list[0 .. n_fail) of `query` into a dense block, search it
@@ -1743,8 +1780,10 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         }
         int max_pieces = kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1);
         if (dual && dual->max_entries > 0 && max_pieces > dual->max_entries / KP) max_pieces = dual->max_entries / KP;
+        // (range-0 bootstrap: the short-list routes of the ordinary 32-query kernel, from four ranges on)
+        const bool boot = tier == KZ_TIER_H && short_ord && !dual && !q64 && ctx->range_boot && force_pieces >= 4;
         int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, max_pieces, KP, tier, cq_count, &ps,
-                                 tier == KZ_TIER_H ? tpw_h : 1, force_pieces, min_pieces_call);
+                                 tier == KZ_TIER_H ? tpw_h : 1, force_pieces, min_pieces_call, boot);
         if (rc != KZ_OK) return rc;
         const KzListLayout& lay = ps.lay;
         const int W = ps.W;
@@ -1754,6 +1793,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         int4* d_work = ps.d_work;
         int* fail_count = ctx->d_counters + 8;
         KZ_HIP(hipMemsetAsync(fail_count, 0, 4 * sizeof(int), ctx->stream));  // fail counter, (unused), error-ratio bits
+        const float* boot_floor = nullptr;   // (this chunk's range-0 floor, if any: the finalize kernel must know it)
         KnnCandParams cp;
         memset(&cp, 0, sizeof(cp));
         if (tier == KZ_TIER_H) {
@@ -1796,7 +1836,23 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 KZ_DISPATCH_KP(rc, kz_hd_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
         } else if (tier == KZ_TIER_H && q64)
             rc = kz_h64_launch(n_slices, 0, ctx, cp, W);
-        else if (tier == KZ_TIER_H)
+        else if (tier == KZ_TIER_H && boot && ps.W0 > 0 && ps.W0 < W) {
+            // range 0 of every query tile, the floor off its lists, then the other ranges
+            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W0, ctx->h_wps, ctx->h_wide));
+            if (rc != KZ_OK) return rc;
+            float* bfloor = nullptr;
+            const int64_t n_pad = (int64_t)query->n_tiles * KZ_TILE;
+            rc = kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&bfloor);   // (a buffer of this chunk: escalated sub-searches boot too)
+            if (rc != KZ_OK) return rc;
+            hipLaunchKernelGGL(kz_boot_floor_kernel, dim3((unsigned)((cq_count + 255) / 256)), dim3(256), 0, ctx->stream, out_key, out_idx, lay, KP,
+                               cq_begin - (int64_t)qt0 * KZ_TILE, cq_begin, cq_count, cp.qfloor, bfloor);
+            KZ_HIP(hipGetLastError());
+            cp.qfloor = bfloor;
+            cp.work = d_work + ps.W0;
+            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W - ps.W0, ctx->h_wps, ctx->h_wide));
+            cp.work = d_work;
+            boot_floor = bfloor;
+        } else if (tier == KZ_TIER_H)
             KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
         else if (tier == KZ_TIER_BF)
             KZ_DISPATCH_KP(rc, kz_bf_launch, (n_slices, ctx, cp, W));
@@ -1850,7 +1906,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fp.out_dist = d_dist + c0 * (int64_t)k;
         fp.out_ind = d_ind + c0 * (int64_t)k;
         if (tier == KZ_TIER_H && short_ord) fp.idx_map = index->himg->dealt_perm;   // the lists hold rows of the dealt index image
-        if (tier == KZ_TIER_H && !dual) fp.list_floor = qfloor_ord;
+        if (tier == KZ_TIER_H && !dual) fp.list_floor = boot_floor ? boot_floor : qfloor_ord;
         if (tier == KZ_TIER_H && dual) {
             fp.idx_map = dual->perm;      // the lists hold rows of the sorted index image
             fp.row_map = dual->row_map;   // the chunk is a range of IMAGE rows: results and failures go by matrix row
@@ -1865,6 +1921,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             rc = kz_launch_finalize(ctx, fp, lay, KP, cq_count, index->dtype);
             if (rc != KZ_OK) return rc;
         }
+        if (boot_floor) kz_pool_free(ctx, const_cast<float*>(boot_floor), 0);   // (stream-ordered: the launches above have it)
         KZ_HIP(hipGetLastError());
         KZ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
         KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

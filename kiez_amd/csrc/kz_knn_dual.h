@@ -872,8 +872,10 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     int64_t s3_tiles = 0;
     long long log_cap3 = 0;
     const int64_t s_img_rows = s_tiles * KZ_TILE;   // rows of S: image rows [0, s_img_rows) of the dealt image
+    // (it saves t_sweep / stride and costs ~1 ms of extra launches, sorts and a host synchronisation: C2's shared sweep, 2.6 model-ms at
+    //  stride 4, went from 5.7 to 6.7 ms per step with it -- taken from 2 model-ms of saving on; "dual_force" keeps it for the tests)
     bool nested = ctx->dual_nested && ctx->dual_deal && s_tiles >= 8 && s_tiles < a->n / KZ_TILE && s_img_rows >= (int64_t)8 * KP &&
-                  b->n <= kz_rows_per_chunk(ctx, KP, false);
+                  b->n <= kz_rows_per_chunk(ctx, KP, false) && (ctx->dual_force || t_sweep_ms / stride >= 2.0);
     if (nested) {
         const double t2_ms = 2.0 * (double)b->n * (double)s_img_rows * (double)(a->kg * 4) / 1e12;
         const int rank3_safe = k + 1 < KP ? k + 1 : KP;
@@ -929,6 +931,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             nested = false;
         }
     }
+    double nested_sweep_ms = 0;   // the sample sweep b x S: part of the distance matrix the dominant kernel covers (reported with the main sweep)
     KzRevChain rv3;
     memset(&rv3, 0, sizeof(rv3));
     KzDualPass dp2;
@@ -1053,6 +1056,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             release();
             return rc;
         }
+        nested_sweep_ms = st2.main_kernel_ms;
     } else {
         // ---- classic sample image: every stride-th tile of A's fp16 image (tiles are contiguous runs of n_slices x 4 KiB), dealt over the parts
         hipLaunchKernelGGL(kz_dual_sample_kernel, dim3((unsigned)s_tiles), dim3(256), 0, ctx->stream, (const uint4*)ia->packed, ia->bias,
@@ -1193,6 +1197,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // (kz_knn_impl ends with a stream synchronisation: ev[5] and ev[6] around the sample sweep have completed)
     KZ_DUAL_HIP(hipEventElapsedTime(&sample_ms, ctx->ev[5], ctx->ev[6]));
     st_ab.dual = 1;
+    st_ab.main_kernel_ms += nested_sweep_ms;   // (nested: S x B is swept by the sample sweep, the rest of A x B by the main sweep)
     if (nested) {
         // the sample rows' own chain (second stream, synchronised above): rows it could not certify -- or all of them when its
         // event log overflowed -- are searched again the ordinary way, like the uncertified rows of the main sweep
@@ -1232,7 +1237,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         memcpy(&st_ba.max_err_ratio, ctx->h_counters + 14, 8);
         float ms = 0;
         KZ_DUAL_HIP(hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]));
-        st_ba.main_kernel_ms = sample_ms + ms;   // sample sweep + scatter + select: what this direction cost besides the shared sweep
+        st_ba.main_kernel_ms = sample_ms - (float)nested_sweep_ms + ms;   // sample stage (without the part of the matrix it covers for both directions) + scatter + select: what this direction cost besides the shared sweep
         KZ_DUAL_HIP(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]));
         st_ba.finalize_ms = ms;
         st_ba.list_len = KPr;
