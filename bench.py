@@ -773,6 +773,13 @@ def main():
                 line["fp64_order_probe"] = run_probe(eng.ctx)
             except Exception as e:  # pragma: no cover
                 line["fp64_order_probe"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                # cosine + float32 inputs: rows ordered as the REFERENCE RUN ON THE FLOAT32 INPUTS (sgemm) orders them, rows that
+                # differ only inside near-tie groups float32 cannot resolve, rows that differ otherwise (tests/cosine_f32.py)
+                from tests.cosine_f32 import run_probe as cosine_probe
+                line["cosine_f32_probe"] = cosine_probe(eng.ctx)
+            except Exception as e:  # pragma: no cover
+                line["cosine_f32_probe"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if "summary" in line:    # first in the line: a truncated tail of the driver's record still shows every workload
             line = {"metric": line["metric"], "summary": line.pop("summary"), **line}
