@@ -1125,7 +1125,9 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     KZ_DUAL_RC(kz_himage_pack_permuted(b, perm, p_packed, p_bias));
     if (nested) {
         // the sample-row events of every row of b open its event buffer (the main sweep's scatter kernel appends behind them)
-        hipLaunchKernelGGL(kz_dual_inject_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, perm, b_pad, sev_cnt, sev, sev_cap,
+        // (rows [0, b->n) of the sorted image: the permutation is only defined there without the dealt tiles, and they keep the
+        //  ragged last tile last)
+        hipLaunchKernelGGL(kz_dual_inject_kernel, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, ctx->stream, perm, b->n, sev_cnt, sev, sev_cap,
                            ev_cnt, ev, ev_cap);
         KZ_DUAL_HIP(hipGetLastError());
     }

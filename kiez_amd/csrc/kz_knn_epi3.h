@@ -191,6 +191,42 @@ __device__ __forceinline__ void kz_list_insert3(const KzListRef<IN_LDS>& L, KzBl
     tau = t;
 }
 
+// The four keys of a logged group against the list: LARGEST FIRST.  A group is logged blindly when its maximum beat the threshold
+// of its tile -- at merge time usually ONE of the four keys still beats the list's threshold, and which one differs from lane to
+// lane: four tests in row order made the wave execute the insert body (~45 instructions) up to four times per pool entry, once per
+// position some lane needed.  Largest first it runs once per entry for nearly every entry; the loop goes on only for the lanes whose
+// next-largest key beats the UPDATED threshold (the first tiles of a sweep).  Same set of rows kept (a top-K' set does not depend
+// on the order of insertion; equal keys compete for the last place as before: strictly greater wins).
+template <int KP, int IN_LDS>
+__device__ __forceinline__ void kz_insert_group3(const KzListRef<IN_LDS>& L, KzBlockMin3<KP>& bs,
+                                                 __attribute__((address_space(3))) f32x4e* entry,
+                                                 const __attribute__((address_space(3))) i32x2e* meta, const int half, float& tau) {
+    // (the largest key first -- and struck out of the pool entry; the four are then tested in row order against the UPDATED
+    //  threshold: bodies that run only in the first tiles of a sweep, when several keys of a group still beat it.  Keys and entry code
+    //  are re-read from LDS behind the first insert instead of being carried across it: at three workgroups per CU the kernel sits
+    //  exactly on its 168 registers, and anything more that lives across an insert is spilled)
+    auto row_of = [&]() {
+        const int code = meta->x;
+        return (code >> 4) * KZ_TILE + ((code >> 2) & 3) * 32 + (code & 3) * 8 + 4 * half;
+    };
+    {
+        const f32x4e kv = *entry;
+        const float m = fmaxf(fmaxf(kv.x, kv.y), fmaxf(kv.z, kv.w));
+        if (!(m > tau)) return;
+        const int slot = kv.x == m ? 0 : (kv.y == m ? 1 : (kv.z == m ? 2 : 3));
+        reinterpret_cast<__attribute__((address_space(3))) float*>(entry)[slot] = -INFINITY;
+        kz_list_insert3<KP, IN_LDS>(L, bs, m, row_of() + slot, tau);
+    }
+    const f32x4e kv = *entry;
+    if (fmaxf(fmaxf(kv.x, kv.y), fmaxf(kv.z, kv.w)) > tau) {
+        const int row0 = row_of();
+        if (kv.x > tau) kz_list_insert3<KP, IN_LDS>(L, bs, kv.x, row0, tau);
+        if (kv.y > tau) kz_list_insert3<KP, IN_LDS>(L, bs, kv.y, row0 + 1, tau);
+        if (kv.z > tau) kz_list_insert3<KP, IN_LDS>(L, bs, kv.z, row0 + 2, tau);
+        if (kv.w > tau) kz_list_insert3<KP, IN_LDS>(L, bs, kv.w, row0 + 3, tau);
+    }
+}
+
 // Merge: lane l < 32 walks its own chain, then its partner's (lane l + 32: the other half of the same query), inserting
 // every key that still beats the list's threshold.  code = 16 tile + 4 mt + g4; the keys of an entry are index rows
 // 128 tile + 32 mt + 8 g4 + 4 half + 0..3 (C layout of the 32x32 MFMA).
@@ -218,15 +254,24 @@ __device__ __forceinline__ void kz_merge_pool3(KzCandState3<IN_LDS>& st, KzWaveP
             int e = half ? other : st.head;
 #pragma unroll 1
             while (e >= 0) {
-                const f32x4e kv = pool.keys[e];
-                const i32x2e mt = pool.meta[e];
-                e = mt.y;
-                const int code = mt.x;
-                const int row0 = (code >> 4) * KZ_TILE + ((code >> 2) & 3) * 32 + (code & 3) * 8 + 4 * half;
-                if (kv.x > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.x, row0, st.tau);
-                if (kv.y > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.y, row0 + 1, st.tau);
-                if (kv.z > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.z, row0 + 2, st.tau);
-                if (kv.w > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.w, row0 + 3, st.tau);
+                if constexpr (RECOMP) {
+                    // (the dual build with 13 stationary slices at three workgroups per CU has no register to spare: the four tests
+                    //  in row order, as before -- largest-first spilled 2 .. 4 VGPRs there)
+                    const f32x4e kv = pool.keys[e];
+                    const i32x2e mt = pool.meta[e];
+                    e = mt.y;
+                    const int code = mt.x;
+                    const int row0 = (code >> 4) * KZ_TILE + ((code >> 2) & 3) * 32 + (code & 3) * 8 + 4 * half;
+                    if (kv.x > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.x, row0, st.tau);
+                    if (kv.y > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.y, row0 + 1, st.tau);
+                    if (kv.z > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.z, row0 + 2, st.tau);
+                    if (kv.w > st.tau) kz_list_insert3<KP, IN_LDS>(st.list, bs, kv.w, row0 + 3, st.tau);
+                } else {
+                    auto* entry = pool.keys + e;
+                    const auto* meta = pool.meta + e;
+                    e = meta->y;
+                    kz_insert_group3<KP, IN_LDS>(st.list, bs, entry, meta, half, st.tau);
+                }
             }
         }
     }

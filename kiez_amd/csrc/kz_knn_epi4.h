@@ -93,15 +93,10 @@ __device__ __forceinline__ void kz_merge_pool4(KzCandState4& st, KzWavePool& poo
                 int e = half ? other : own;
 #pragma unroll 1
                 while (e >= 0) {
-                    const f32x4e kv = pool.keys[e];
-                    const i32x2e mt = pool.meta[e];
-                    e = mt.y;
-                    const int code = mt.x;
-                    const int row0 = (code >> 4) * KZ_TILE + ((code >> 2) & 3) * 32 + (code & 3) * 8 + 4 * half;
-                    if (kv.x > tau) kz_list_insert3<KP, 1>(L, bs, kv.x, row0, tau);
-                    if (kv.y > tau) kz_list_insert3<KP, 1>(L, bs, kv.y, row0 + 1, tau);
-                    if (kv.z > tau) kz_list_insert3<KP, 1>(L, bs, kv.z, row0 + 2, tau);
-                    if (kv.w > tau) kz_list_insert3<KP, 1>(L, bs, kv.w, row0 + 3, tau);
+                    auto* entry = pool.keys + e;
+                    const auto* meta = pool.meta + e;
+                    e = meta->y;
+                    kz_insert_group3<KP, 1>(L, bs, entry, meta, half, tau);
                 }
             }
         }
