@@ -823,6 +823,8 @@ __global__ __launch_bounds__(256, MINW) void kz_knn_finalize_kernel(KnnFinParams
     }
 }
 
+#include "kz_knn_fin_wide.h"
+
 // ---------------------------------------------------------------------------------------------------
 // Stage 3: exact float64 brute force for uncertified rows (rare; correctness backstop)
 // ---------------------------------------------------------------------------------------------------
@@ -1153,10 +1155,14 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
             const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
             const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, fp.KSEL > 0 ? fp.KSEL : KP);
             const bool wide = (fp.KSEL > 0 ? fp.KSEL : KP) > 160;   // the long-k route
-            const void* fk = dtype == KZ_F32 ? (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>)
+            // (many selected candidates + float32 rows on the fp16 tier, ordinary direction: kz_knn_fin_wide.h -- option "fin_wide")
+            const bool wide2 = wide && dtype == KZ_F32 && fp.tier_h && !fp.excl_floor && ctx->fin_wide;
+            const void* fk = dtype == KZ_F32 ? (wide2 ? (const void*)kz_knn_finalize_wide_kernel<float, 3> : (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>))
                                              : (wide ? (const void*)kz_knn_finalize_kernel<double, 4, 2> : (const void*)kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>);
             if (fin_lds > 65536) KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
-            if (dtype == KZ_F32 && wide)
+            if (wide2)
+                hipLaunchKernelGGL((kz_knn_finalize_wide_kernel<float, 3>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
+            else if (dtype == KZ_F32 && wide)
                 hipLaunchKernelGGL((kz_knn_finalize_kernel<float, 8, 2>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
             else if (dtype == KZ_F32)
                 hipLaunchKernelGGL((kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);

@@ -89,7 +89,9 @@ def test_both_directions_identical_to_two_searches(ctx, kind, na, nb, d, k, metr
         assert s_ab["dual"] == 1                  #  call gives up on sharing; the forward direction otherwise always shares ...
     assert s_ab["max_err_ratio"] < 1.0 and s_ba["max_err_ratio"] < 1.0
     if s_ba["dual"] == 1:                         # ... the reverse one unless the log overflowed (tiny inputs: many events per tile)
-        assert s_ba["n_events"] >= k * nb
+        # (about rank x stride events per row, and the automatic rank sits near k / stride: ~k per row on average -- the rows that
+        #  get fewer than k are searched again, which the identity above has just checked)
+        assert s_ba["n_events"] >= 0.8 * k * nb
         assert s_ba["n_logged_groups"] * 4 >= s_ba["n_events"]
 
 
