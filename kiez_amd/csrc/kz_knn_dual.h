@@ -46,9 +46,12 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
                                                             const int* __restrict__ idx_to_row, int sev_cap, int* __restrict__ sev_cnt,
                                                             uint2* __restrict__ sev) {
     // NESTED sample (sev_cnt != nullptr; below "NESTED"): the lists ARE this row's events among the sample rows -- the main sweep no
-    // longer visits those.  Two changes: (1) the threshold is raised to the smallest key of any FULL list (a full list may have
-    // evicted rows: everything outside the lists then lies at or below the threshold, whatever rank it was taken at -- with rank <=
-    // K' that is already so); (2) the entries at or above it are written out as events (key, matrix row of the sample row).
+    // longer visits those.  Two changes: (1) the entries at or above the threshold are written out as events (key, matrix row of
+    // the sample row); (2) the BOUND on the rows that are not events (floor_, read by the certification) is raised to the smallest
+    // key of any FULL list: a full list may have evicted sample rows, and those lie at or below its smallest key -- which can
+    // exceed the threshold when a row's near sample rows crowd one range.  The event threshold itself (theta) stays at the rank-th
+    // best key: raising it too would only cost events (cluster-ordered rows, 12 k x 25 k, k = 50: 3 500 rows short of k events and
+    // searched again against 760).
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_b_pad) return;
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
         if (valid[u] && rnk[u] == rank - 1) tau = x[u];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) tau = fmaxf(tau, __shfl_xor(tau, off, 64));
+    float tau_bound = tau;
     if (sev_cnt) {
         for (int p0 = 0; p0 < M; p0 += KP) {   // (uniform; at most 256 / 16 lists)
             int c = 0;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
                 c += __shfl_xor(c, off, 64);
                 mn = fminf(mn, __shfl_xor(mn, off, 64));
             }
-            if (c == KP) tau = fmaxf(tau, mn);
+            if (c == KP) tau_bound = fmaxf(tau_bound, mn);
         }
         int base = 0;
 #pragma unroll
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
         float tf = (float)th;
         if ((double)tf > th) tf = nextafterf(tf, -INFINITY);
         theta[t] = tf;
-        floor_[t] = tau;
+        floor_[t] = tau_bound;
     }
 }
 
@@ -219,6 +223,20 @@ __global__ void kz_dual_rows_of_kernel(const int* __restrict__ perm, const int* 
 __global__ void kz_dual_scatter_f32_kernel(const float* __restrict__ in, const int* __restrict__ map, int64_t n, float* __restrict__ out) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n && map[j] >= 0) out[map[j]] = in[j];
+}
+// range number of every sorted sample row (as a float key for the stable radix sort) + its sorted position as the value
+__global__ void kz_dual_rangekey_kernel(const int* __restrict__ perm, int64_t n, int64_t range_rows, float* __restrict__ key, int* __restrict__ pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = (float)(perm[i] / range_rows);
+    pos[i] = (int)i;
+}
+__global__ void kz_dual_gather2_kernel(const int* __restrict__ order, const int* __restrict__ perm, const float* __restrict__ theta, int64_t n,
+                                       int* __restrict__ perm_out, float* __restrict__ theta_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    perm_out[i] = perm[order[i]];
+    theta_out[i] = theta[order[i]];
 }
 __global__ void kz_dual_inject_kernel(const int* __restrict__ perm, int64_t n_b, const int* __restrict__ sev_cnt, const uint2* __restrict__ sev,
                                       int sev_cap, int* __restrict__ ev_cnt, uint2* __restrict__ ev, int ev_cap) {
@@ -825,11 +843,11 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // would hold ALL the near rows of a query when the data is stored cluster by cluster, its list of 16 would overflow and the
     // threshold fall to the far rows).  The K' = 16 kernel keeps three workgroups per CU and short merges: 500k x 500k, k = 50:
     // reverse direction 51.0 -> 46.4 ms per step, same event counts.
-    auto sample_lists = [&](int rank_, int64_t tiles_, int* kps_out, int* force_out) {
+    auto sample_lists = [&](int rank_, int64_t tiles_, int* kps_out, int* force_out, int head = 2) {   // (entries per row = head x rank)
         int kps = KP, force = 0;
         if (ctx->dual_sample_short && KP > 16) {
             kps = rank_ > 96 ? 32 : 16;
-            const int need = (2 * rank_ + kps - 1) / kps, cap = 256 / kps;
+            const int need = (head * rank_ + kps - 1) / kps, cap = 256 / kps;
             force = need < cap ? need : cap;
             if ((int64_t)force * 4 > tiles_ || force * kps < rank_) {   // (a sample of a few tiles: one list of K')
                 kps = KP;
@@ -940,6 +958,17 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         kz_ctx* ctx; KzDualPass* dp2; KzRevChain* rv3; int rank; int64_t b_n, b_pad; const kz_himage *ia, *ib;
         float *theta, *floor_; const int* rm3; int sev_cap; int* sev_cnt; uint2* sev; int overlap;
     } hk2 = {ctx, &dp2, &rv3, rank, b->n, b_pad, ia, ib, theta, floor_, nullptr, sev_cap, nullptr, nullptr, ctx->dual_overlap};
+    // (the nested sample is STRATIFIED by |q_c|^2 -- which correlates with the keys at -0.75: rows near the centre are near
+    //  neighbours of everybody -- and the count of rows above the r-th best of a stratified sample is not negative binomial
+    //  (r, 1 / stride) but lower: sampled systematically along the key order, the r-th best sample row is the (stride (r - 1) + 1)-th
+    //  best overall, (stride - 1)(r - 1) other rows above it against (stride - 1) r at random.  Measured: 5 - 8 % fewer events per
+    //  row than the strided-tile sample at every rank, 100 x the rows short of k events on cluster-ordered data (758 against 6 of
+    //  12 000).  The threshold of the nested sample therefore sits one rank lower
+    //  ... two where a row keeps more than 16 neighbours: cluster-ordered data still came up 5 % short with one.)
+    if (nested) {
+        const int lower = KP > 16 ? 2 : 1, room = (force_s > 0 ? force_s : 1) * KPs;
+        hk2.rank = rank + lower <= room ? rank + lower : (rank + 1 <= room ? rank + 1 : rank);
+    }
     if (nested) {
         // ---- third level: S x sample(b) with the ordinary kernel -> the event thresholds of the rows of S ----
         hipLaunchKernelGGL(kz_dual_sample_kernel, dim3((unsigned)s3_tiles), dim3(256), 0, ctx->stream, (const uint4*)ib->packed, ib->bias,
@@ -985,6 +1014,28 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((s_img_rows + 255) / 256)), dim3(256), 0, ctx->stream, iota3, (int)s_img_rows);
         KZ_DUAL_HIP(hipGetLastError());
         rc = kz_sort_pairs_f32_i32(ctx, theta3, theta3_s, iota3, perm3, (int)s_img_rows, 1);
+        if (rc == KZ_OK && force_s > 1) {
+            // b's lists over S are kept per index RANGE of this image (force_s lists of 16), and the ranges must be ALIKE: a range
+            // that holds most of a row's near sample rows truncates them, the threshold is read too low and the row's event
+            // buffer overflows.  Dealing the sorted TILES over the ranges (as the main sweep does) is not enough here: the most
+            // central rows of a cluster have the highest thresholds AND are the nearest rows of everybody in it -- one tile, one
+            // range (cluster-ordered rows, 12 k x 25 k, k = 50: +53 % events, 1 217 overflowing buffers).  So range p = the S rows
+            // with dealt position j in [p L, (p + 1) L), L = the planner's range length -- a contiguous stretch of the DEALT image
+            // is a stratified draw of a -- sorted by threshold INSIDE the range: a stable sort by range number on top of the sort
+            // by threshold.  Tiles stay coherent in threshold (the per-tile test), ranges are fair.
+            const int64_t range_rows = ((s_tiles + force_s - 1) / force_s) * KZ_TILE;
+            hipLaunchKernelGGL(kz_dual_rangekey_kernel, dim3((unsigned)((s_img_rows + 255) / 256)), dim3(256), 0, ctx->stream, perm3, s_img_rows, range_rows,
+                               theta3, iota3);     // (theta3, iota3: free since the sort above) range number as the key, sorted position as the value
+            if (hipGetLastError() != hipSuccess) rc = KZ_ERR_HIP;
+            if (rc == KZ_OK) rc = kz_sort_pairs_f32_i32(ctx, theta3, floor3m, iota3, rm3, (int)s_img_rows, 0);   // (floor3m, rm3: scratch here, written later)
+            if (rc == KZ_OK) {
+                hipLaunchKernelGGL(kz_dual_gather2_kernel, dim3((unsigned)((s_img_rows + 255) / 256)), dim3(256), 0, ctx->stream, rm3, perm3, theta3_s,
+                                   s_img_rows, iota3, theta3);
+                if (hipGetLastError() != hipSuccess) rc = KZ_ERR_HIP;
+                int* ti = perm3; perm3 = iota3; iota3 = ti;
+                float* tf = theta3_s; theta3_s = theta3; theta3 = tf;
+            }
+        }
         if (rc == KZ_OK) {
             hipLaunchKernelGGL(kz_dual_rows_of_kernel, dim3((unsigned)((s_img_rows + 255) / 256)), dim3(256), 0, ctx->stream, perm3, row_map, s_img_rows, rm3);
             hipLaunchKernelGGL(kz_dual_tilemin_kernel, dim3((unsigned)((s_img_rows + 255) / 256)), dim3(256), 0, ctx->stream, theta3_s, s_img_rows, s_img_rows, theta3_min);

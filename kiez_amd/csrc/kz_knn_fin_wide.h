@@ -344,12 +344,14 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
         ns += (int)__popcll(mask);
     }
     kz_wave_sync();
-    if (ns > KS || ns > 256) {   // (hundreds of exact ties at the k-th place: the exact kernels order those)
+    if (ns > KS) {   // (more exact ties at the k-th place than the buffers hold: the exact kernels order those)
         fail();
         return;
     }
-    // rank sort of the ns (~k + 1) entries in place through registers: lane c holds entries c, c + 64, ...
-    {
+    const double* out_v = sv;
+    const int* out_i = si;
+    if (ns <= 256) {
+        // rank sort of the ns (~k + 1) entries in place through registers: lane c holds entries c, c + 64, ...
         double v[4];
         int id[4], rk[4];
 #pragma unroll
@@ -373,6 +375,22 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
                 si[rk[u]] = id[u];
             }
         }
+    } else {
+        // long k (more than 255 neighbours): out of place into cv / ci, which are spent
+        for (int c = lane; c < ns; c += 64) {
+            const double v = sv[c];
+            const int id = si[c];
+            int rk = 0;
+            for (int o = 0; o < ns; ++o) {
+                const double ov = sv[o];
+                const int oid = si[o];
+                rk += (ov < v || (ov == v && oid < id)) ? 1 : 0;
+            }
+            cv[rk] = v;
+            ci[rk] = id;
+        }
+        out_v = cv;
+        out_i = ci;
     }
     kz_wave_sync();
     // ---- certification (kz_finalize_query): rows outside the re-ranked set are the selected candidates left behind (<= left_max),
@@ -382,13 +400,13 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
     if (bound == -INFINITY)
         certified = (Vr >= min((int64_t)k_eff, p.n_i));
     else
-        certified = Vr >= k_eff && (double)bound * key_scale + eps_q < exact_key(sv[k_eff - 1]);
+        certified = Vr >= k_eff && (double)bound * key_scale + eps_q < exact_key(out_v[k_eff - 1]);
     if (bound_violated) certified = false;
     if (!certified) {
         fail();
         return;
     }
-    kz_emit_sorted<T>(sv, si, ns, p.k, p.exclude_self, p.self_ids ? p.self_ids[q] : qrow, p.metric,
+    kz_emit_sorted<T>(out_v, out_i, ns, p.k, p.exclude_self, p.self_ids ? p.self_ids[q] : qrow, p.metric,
                       p.out_dist + qout * (int64_t)p.k, p.out_ind + qout * (int64_t)p.k, lane);
 }
 
