@@ -132,13 +132,18 @@ def test_tier_probe_starts_hard_data_at_the_split_bf16_tier():
         for kind, q, y in (("hard", clustered(n_q), clustered(n_i)), ("easy", rng.rand(n_q, d).astype(np.float32), rng.rand(n_i, d).astype(np.float32))):
             qm, ym = N.DeviceMatrix(ctx, q, "euclidean"), N.DeviceMatrix(ctx, y, "euclidean")
             ctx.set_option("tier_probe", 4096)
+            ctx.set_option("wide_lists", 0)      # the ladder's second rung off: what the round-4 probe did
             d1, i1, s1 = N.knn(ctx, qm, ym, 10)
+            ctx.set_option("wide_lists", 32)     # round 5: before better operands, more margin in ranks on the same ones
+            d2, i2, s2 = N.knn(ctx, qm, ym, 10)
             ctx.set_option("tier_probe", 0)
             d0, i0, s0 = N.knn(ctx, qm, ym, 10)
             assert s0["first_pass"] == 2                                     # without the probe: always the fp16 pass first
             assert s1["first_pass"] == (1 if kind == "hard" else 2), (kind, s1)
-            np.testing.assert_array_equal(i1.numpy(), i0.numpy())
-            np.testing.assert_array_equal(d1.numpy(), d0.numpy())
+            assert s2["first_pass"] == 2 and s2["wide_lists"] == (32 if kind == "hard" else 0), (kind, s2)
+            for dd, ii in ((d1, i1), (d2, i2)):
+                np.testing.assert_array_equal(ii.numpy(), i0.numpy())
+                np.testing.assert_array_equal(dd.numpy(), d0.numpy())
             rows = np.arange(0, n_q, n_q // 300)[:300]
             od, oi = O.knn_exact(q[rows], y, 10, "euclidean")
             np.testing.assert_array_equal(i1.numpy()[rows], oi)
@@ -146,6 +151,7 @@ def test_tier_probe_starts_hard_data_at_the_split_bf16_tier():
                 assert s0["n_escalated_rows"] > n_q // 2
     finally:
         ctx.set_option("tier_probe", 1024)
+        ctx.set_option("wide_lists", 32)
 
 
 def test_shared_sweep_leaves_hard_data_to_two_searches():
@@ -178,3 +184,4 @@ def test_shared_sweep_leaves_hard_data_to_two_searches():
             np.testing.assert_array_equal(yd.numpy(), d_ba.numpy())
     finally:
         ctx.set_option("tier_probe", 1024)
+        ctx.set_option("wide_lists", 32)
