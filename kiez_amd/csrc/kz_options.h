@@ -52,7 +52,7 @@ static const KzOption KZ_OPTIONS[] = {
     {"esc_bf", KZ_OPT_BOOL, KZ_O(esc_bf), 0, 1, 1, 0, {}, 0, "split-bf16 operands before the float32 ones for rows the fp16 tier cannot certify"},
     {"tier_probe", KZ_OPT_INT, KZ_O(tier_probe), 0, 65536, 1024, 0, {}, 0, "rows of the strided sample a large search sends through the fp16 pass first (0 = off)"},
     {"probe_min_pairs", KZ_OPT_F64, KZ_O(probe_min_pairs), 0, 1e300, 5e10, 0, {}, 0, "searches of fewer distance pairs take neither the tier probe nor a floor"},
-    {"fin_wide", KZ_OPT_BOOL, KZ_O(fin_wide), 0, 1, 1, 0, {}, 0, "finalize of > 160 selected candidates without O(n^2) sorts, several rows per gather step"},
+    {"fin_wide", KZ_OPT_INT, KZ_O(fin_wide), 0, 2, 1, 0, {}, 0, "finalize of > 160 selected candidates without O(n^2) sorts, several rows per gather step"},
     {"range_boot", KZ_OPT_BOOL, KZ_O(range_boot), 0, 1, 1, 0, {}, 0, "short-list routes: index range 0 first, the other ranges' lists start at the floor read off it"},
     {"wide_lists", KZ_OPT_INT, KZ_O(wide_lists), 2, 32, 32, KZ_OPT_SET, {0}, -1, "fp16 tier's wide route: lists of 16 per query (0 = off)"},
     {"wide_sel", KZ_OPT_INT, KZ_O(wide_sel), 16, 512, 256, 0, {}, 0, "... entries of those lists the finalize kernel selects"},
