@@ -317,6 +317,58 @@ __host__ __device__ __forceinline__ int kz_fin_wave_bytes(int max_m, int KP) {
     return ((max_m * 8 + KP * 28) + 15) & ~15;
 }
 
+// k-th largest (rank = 1: the largest) of n float keys held as SORTABLE unsigned patterns in LDS; returns the pattern.
+// Wave-cooperative: 32 counting passes at most, fewer below the common prefix of the patterns.
+__device__ __forceinline__ unsigned kz_radix_kth_u32(const unsigned* u, int n, int rank, int lane) {
+    unsigned all_or = 0u, all_and = 0xffffffffu;
+    for (int e = lane; e < n; e += 64) {
+        all_or |= u[e];
+        all_and &= u[e];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        all_or |= __shfl_xor(all_or, off, 64);
+        all_and &= __shfl_xor(all_and, off, 64);
+    }
+    const unsigned differ = all_or ^ all_and;
+    const int top = differ ? 31 - __clz(differ) : -1;
+    unsigned thr = top >= 31 ? 0u : (top < 0 ? all_and : (all_and & ~((2u << top) - 1u)));
+    for (int bit = top; bit >= 0; --bit) {
+        const unsigned cand = thr | (1u << bit);
+        int c = 0;
+        for (int e0 = 0; e0 < n; e0 += 64) c += (int)__popcll(__ballot(e0 + lane < n && u[e0 + lane] >= cand));
+        if (c >= rank) thr = cand;
+    }
+    return thr;
+}
+// rank-th SMALLEST (rank = 1: the smallest) of n non-negative doubles in LDS (their bit patterns order like the values).
+__device__ __forceinline__ unsigned long long kz_radix_kth_small_f64(const double* v, int n, int rank, int lane) {
+    unsigned long long all_or = 0ull, all_and = ~0ull;
+    for (int e = lane; e < n; e += 64) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v[e]);
+        all_or |= b;
+        all_and &= b;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        all_or |= __shfl_xor(all_or, off, 64);
+        all_and &= __shfl_xor(all_and, off, 64);
+    }
+    const unsigned long long differ = all_or ^ all_and;
+    const int top = differ ? 63 - __clzll(differ) : -1;
+    // thr = the smallest value with at least `rank` entries <= it: build the largest prefix p such that fewer than `rank` entries are
+    // BELOW p, bit by bit from the top
+    unsigned long long thr = top >= 63 ? 0ull : (top < 0 ? all_and : (all_and & ~((2ull << top) - 1ull)));
+    for (int bit = top; bit >= 0; --bit) {
+        const unsigned long long cand = thr | (1ull << bit);
+        int c = 0;   // entries below cand
+        for (int e0 = 0; e0 < n; e0 += 64)
+            c += (int)__popcll(__ballot(e0 + lane < n && (unsigned long long)__double_as_longlong(v[e0 + lane]) < cand));
+        if (c < rank) thr = cand;
+    }
+    return thr;
+}
+
 // Rank-based selection of the KP best of M <= 64*E list entries (key descending, row ascending; entries with row < 0 are
 // empty).  Lane l holds entries l, l+64, ...; returns the number of entries written to ck/ci (ordered by rank).
 template <int E>
@@ -422,27 +474,17 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
             if (cnt == KP) piece_bound = fmaxf(piece_bound, mn);
         }
     }
-    // top-KS of the M entries by (key desc, idx asc)
+    // top-KS of the M entries by (key desc, idx asc).  Up to 64 entries: rank counting (ck / ci come out ordered).  More (round
+    // 5): rank counting is O(M^2 / 64) per lane -- 160 entries (ten lists of 16): ~3 500 of a query's ~8 000 instructions -- and
+    // NOTHING below needs the selected keys in order: the KS best by a radix select + compaction (unordered), further down the
+    // k-th best of them by a second radix select and the candidates within 2 eps of it by compaction.
     int V = 0;
-    // (rank counting is O(M^2 / 64) per lane: 512 entries = 4096 steps of 8 compares -- with KS = 256 selected entries, the wide
-    //  route, that selection alone was a quarter of a 55 ms finalize launch; from 257 entries on the radix select below,
-    //  O(32 M / 64 + KS^2 / 64), takes over when many entries are selected)
-    if (M <= 256 || (M <= 512 && KS <= 128)) {
-        // E entries per lane: the rank of an entry among the valid entries is a count over uniform-lane broadcasts
-        // (v_readlane), no cross-lane reduction chains; entries with rank < KS land in ck/ci already ordered
-        if (M <= 64)
-            V = kz_rank_select<1>(ekey, eidx, M, KS, ck, ci, lane);
-        else if (M <= 128)
-            V = kz_rank_select<2>(ekey, eidx, M, KS, ck, ci, lane);
-        else if (M <= 256)
-            V = kz_rank_select<4>(ekey, eidx, M, KS, ck, ci, lane);
-        else
-            V = kz_rank_select<8>(ekey, eidx, M, KS, ck, ci, lane);
+    bool unsorted = false;
+    float sel_min = INFINITY, left_max = -INFINITY;   // unsorted path: smallest selected key; largest selected key NOT re-ranked
+    if (M <= 64) {
+        V = kz_rank_select<1>(ekey, eidx, M, KS, ck, ci, lane);
     } else {
-        // More than 512 entries (long-k route): radix select of the KS-th largest key over the keys as sortable integers (32
-        // counting passes over the entries), the entries above it compacted, ties at it by ascending row, and the KS selected
-        // entries rank-sorted into ck / ci -- O(32 M + KS^2) / 64 steps per lane instead of the KS arg-max rounds over all M
-        // entries this branch used to run (k = 500, 21 lists of 128: 221 of the call's 282 ms were those rounds).
+        unsorted = true;
         unsigned* uk = reinterpret_cast<unsigned*>(ekey);   // (the keys are not needed as floats any more)
         auto key_of = [](unsigned u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); };
         int nv = 0;
@@ -456,36 +498,25 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) nv += __shfl_xor(nv, off, 64);
         kz_wave_sync();
-        float* tk = reinterpret_cast<float*>(cv);   // (cv / sv are written after the selection: KS doubles hold KS keys + KS rows)
-        int* ti = reinterpret_cast<int*>(tk + KS);
-        int nsel = 0;
-        unsigned thr = 0u;
         const bool all = nv <= KS;
-        if (!all) {
-            for (int bit = 31; bit >= 0; --bit) {
-                const unsigned cand = thr | (1u << bit);
-                int c = 0;
-                for (int e0 = 0; e0 < M; e0 += 64) {
-                    const int e = e0 + lane;
-                    c += (int)__popcll(__ballot(e < M && eidx[e] >= 0 && uk[e] >= cand));
-                }
-                if (c >= KS) thr = cand;
-            }
-        }
+        unsigned thr = 0u;
+        if (!all) thr = kz_radix_kth_u32(uk, M, KS, lane);   // (invalid entries carry the smallest pattern: they never reach rank KS)
         for (int e0 = 0; e0 < M; e0 += 64) {   // entries above the threshold (all valid entries when there are at most KS)
             const int e = e0 + lane;
             const bool sel = e < M && eidx[e] >= 0 && (all || uk[e] > thr);
             const unsigned long long mask = __ballot(sel);
             if (sel) {
-                const int pos = nsel + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                tk[pos] = key_of(uk[e]);
-                ti[pos] = eidx[e];
+                const int pos = V + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                const float kf = key_of(uk[e]);
+                ck[pos] = kf;
+                ci[pos] = eidx[e];
+                sel_min = fminf(sel_min, kf);
             }
-            nsel += (int)__popcll(mask);
+            V += (int)__popcll(mask);
         }
         if (!all) {   // the remaining places go to the entries AT the threshold with the smallest rows
             int last = -1;
-            while (nsel < KS) {
+            while (V < KS) {
                 int best = 0x7fffffff;
                 for (int e = lane; e < M; e += 64) {
                     const int xi = eidx[e];
@@ -495,28 +526,16 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                 for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
                 if (best == 0x7fffffff) break;   // (cannot happen: at least KS entries are >= thr)
                 if (lane == 0) {
-                    tk[nsel] = key_of(thr);
-                    ti[nsel] = best;
+                    ck[V] = key_of(thr);
+                    ci[V] = best;
                 }
                 last = best;
-                ++nsel;
+                ++V;
+                sel_min = fminf(sel_min, key_of(thr));
             }
         }
-        kz_wave_sync();
-        for (int c = lane; c < nsel; c += 64) {   // rank sort: (key descending, row ascending), as the rounds produced it
-            const float kc = tk[c];
-            const int ic = ti[c];
-            int r = 0;
-#pragma unroll 4
-            for (int o = 0; o < nsel; ++o) {
-                const float ko = tk[o];
-                const int io = ti[o];
-                r += (ko > kc || (ko == kc && io < ic)) ? 1 : 0;
-            }
-            ck[r] = kc;
-            ci[r] = ic;
-        }
-        V = nsel;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sel_min = fminf(sel_min, __shfl_xor(sel_min, off, 64));
     }
     kz_wave_sync();
 
@@ -566,7 +585,42 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
     // so it is out.  The list is ordered by approximate key: the re-rank covers a prefix of Vr >= k_eff candidates (K' = 64,
     // k = 50: ~52 gathered rows instead of 64).  The certification below re-checks the first pruned candidate.
     int Vr = V;
-    if (V > k_eff && eps_q < INFINITY) {
+    if (unsorted) {
+        if (V > k_eff && eps_q < INFINITY) {
+            // the k-th best selected key (radix select over the sortable patterns, scratch: sv is written after the re-rank), then
+            // the candidates within 2 eps of it to the front of ekey / eidx (the list copy is spent): the re-rank's set, unordered
+            unsigned* su = reinterpret_cast<unsigned*>(sv);
+            for (int c = lane; c < V; c += 64) {
+                unsigned b = __float_as_uint(ck[c]);
+                if (b == 0x80000000u) b = 0u;
+                su[c] = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+            }
+            kz_wave_sync();
+            const unsigned uk_k = kz_radix_kth_u32(su, V, k_eff, lane);
+            const float key_k = __uint_as_float(uk_k ^ ((uk_k >> 31) ? 0x80000000u : 0xffffffffu));
+            const double thr = (double)key_k * key_scale - 2.0 * eps_q;
+            int cnt = 0;
+            for (int c0 = 0; c0 < V; c0 += 64) {
+                const int c = c0 + lane;
+                const bool in = c < V && (double)ck[c] * key_scale >= thr;
+                const unsigned long long mask = __ballot(in);
+                if (in) {
+                    const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    ekey[pos] = ck[c];
+                    eidx[pos] = ci[c];
+                } else if (c < V) {
+                    left_max = fmaxf(left_max, ck[c]);
+                }
+                cnt += (int)__popcll(mask);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) left_max = fmaxf(left_max, __shfl_xor(left_max, off, 64));
+            Vr = cnt;       // (>= k_eff: the k_eff best keys are all >= key_k)
+            ck = ekey;
+            ci = eidx;
+            kz_wave_sync();
+        }
+    } else if (V > k_eff && eps_q < INFINITY) {
         const double thr = (double)ck[k_eff - 1] * key_scale - 2.0 * eps_q;
         int cnt = 0;
         for (int c = lane; c < V; c += 64) cnt += ((double)ck[c] * key_scale >= thr) ? 1 : 0;
@@ -768,21 +822,21 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         // dual pass: outside the list are events that lost the selection (key~ <= ck[KP-1], full lists only) and the rows
         // that never were events (key~ < floor)
         double bound = (double)p.excl_floor[qrow];
-        if (V == KP) bound = fmax(bound, (double)ck[KP - 1]);
+        if (V == KP) bound = fmax(bound, (double)(unsorted ? sel_min : ck[KP - 1]));
         certified = V >= k_eff && bound * key_scale + eps_q < exact_key(sv[k_eff - 1]);
     } else {
         // rows outside the selected set: behind the KS-th selected key (when the selection is full), or evicted from a full
         // list (long-k route: piece_bound; with KS = KP a full list implies a full selection whose KS-th key is at least as
         // large, so the first term alone is the round-1 rule).  Neither: no list ever evicted anything, the set is complete.
         float bound = piece_bound;
-        if (V == KS) bound = fmaxf(bound, ck[KS - 1]);
+        if (V == KS) bound = fmaxf(bound, unsorted ? sel_min : ck[KS - 1]);
         if (bound == -INFINITY)
             certified = (V >= min((int64_t)k_eff, p.n_i));
         else
             certified = V >= k_eff && (double)bound * key_scale + eps_q < exact_key(sv[k_eff - 1]);
     }
     // ... and the candidates that were not re-ranked are out by the same argument (implied by how Vr was chosen; re-checked)
-    if (Vr < V && !((double)ck[Vr] * key_scale + eps_q < exact_key(sv[k_eff - 1]))) certified = false;
+    if (Vr < V && !((double)(unsorted ? left_max : ck[Vr]) * key_scale + eps_q < exact_key(sv[k_eff - 1]))) certified = false;
     // An approximate key further than eps from its exact value contradicts the bound everything above rests on (a kernel
     // or hardware fault, not a property of the data): do not trust this row's candidate set, send it down a tier.
     if (bound_violated) certified = false;

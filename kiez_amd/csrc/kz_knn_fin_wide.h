@@ -12,58 +12,6 @@
 //     butterfly steps add without changing a bit; the steps inside the group are the same additions in the same order.
 #pragma once
 
-// k-th largest (rank = 1: the largest) of n float keys held as SORTABLE unsigned patterns in LDS; returns the pattern.
-// Wave-cooperative: 32 counting passes at most, fewer below the common prefix of the patterns.
-__device__ __forceinline__ unsigned kz_radix_kth_u32(const unsigned* u, int n, int rank, int lane) {
-    unsigned all_or = 0u, all_and = 0xffffffffu;
-    for (int e = lane; e < n; e += 64) {
-        all_or |= u[e];
-        all_and &= u[e];
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        all_or |= __shfl_xor(all_or, off, 64);
-        all_and &= __shfl_xor(all_and, off, 64);
-    }
-    const unsigned differ = all_or ^ all_and;
-    const int top = differ ? 31 - __clz(differ) : -1;
-    unsigned thr = top >= 31 ? 0u : (top < 0 ? all_and : (all_and & ~((2u << top) - 1u)));
-    for (int bit = top; bit >= 0; --bit) {
-        const unsigned cand = thr | (1u << bit);
-        int c = 0;
-        for (int e0 = 0; e0 < n; e0 += 64) c += (int)__popcll(__ballot(e0 + lane < n && u[e0 + lane] >= cand));
-        if (c >= rank) thr = cand;
-    }
-    return thr;
-}
-// rank-th SMALLEST (rank = 1: the smallest) of n non-negative doubles in LDS (their bit patterns order like the values).
-__device__ __forceinline__ unsigned long long kz_radix_kth_small_f64(const double* v, int n, int rank, int lane) {
-    unsigned long long all_or = 0ull, all_and = ~0ull;
-    for (int e = lane; e < n; e += 64) {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(v[e]);
-        all_or |= b;
-        all_and &= b;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        all_or |= __shfl_xor(all_or, off, 64);
-        all_and &= __shfl_xor(all_and, off, 64);
-    }
-    const unsigned long long differ = all_or ^ all_and;
-    const int top = differ ? 63 - __clzll(differ) : -1;
-    // thr = the smallest value with at least `rank` entries <= it: build the largest prefix p such that fewer than `rank` entries are
-    // BELOW p, bit by bit from the top
-    unsigned long long thr = top >= 63 ? 0ull : (top < 0 ? all_and : (all_and & ~((2ull << top) - 1ull)));
-    for (int bit = top; bit >= 0; --bit) {
-        const unsigned long long cand = thr | (1ull << bit);
-        int c = 0;   // entries below cand
-        for (int e0 = 0; e0 < n; e0 += 64)
-            c += (int)__popcll(__ballot(e0 + lane < n && (unsigned long long)__double_as_longlong(v[e0 + lane]) < cand));
-        if (c < rank) thr = cand;
-    }
-    return thr;
-}
-
 template <typename T>
 __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, const int64_t q, const int lane, char* wbase) {
     const int KS = p.KSEL;

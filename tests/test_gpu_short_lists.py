@@ -156,7 +156,8 @@ def test_tier_probe_starts_hard_data_at_the_split_bf16_tier():
 
 def test_shared_sweep_leaves_hard_data_to_two_searches():
     """The shared sweep looks first, too (its floor probe is its tier probe): on data that is hard for fp16 as a whole it hands the
-    call to two ordinary searches, which start at the split-bf16 tier -- instead of sweeping in fp16 and sending nearly every row of
+    call to two ordinary searches, which take the route the probe's ladder found (the fp16 tier's wide route, else the split-bf16
+    tier) -- instead of sweeping in fp16 and sending nearly every row of
     both directions down the tiers afterwards (bench.py "hard": 127 against 201 ms per step).  Easy data of the same size keeps the
     shared sweep.  Identical results either way."""
     from kiez_amd import _native as N
@@ -175,7 +176,10 @@ def test_shared_sweep_leaves_hard_data_to_two_searches():
             (xd, xi, sa), (yd, yi, sb) = N.knn_dual(ctx, am, bm, 10)
             assert sa["dual"] == (0 if kind == "hard" else 1), (kind, sa)
             if kind == "hard":
-                assert sa["first_pass"] == 1 and sb["first_pass"] == 1           # both searches started at the split-bf16 tier
+                # both searches took what the probe's ladder found: the fp16 tier's wide route (round 5) -- or, where its second
+                # rung fails too, the split-bf16 tier
+                assert (sa["first_pass"], sa["wide_lists"]) in ((2, 32), (1, 0)) and (sb["first_pass"], sb["wide_lists"]) in ((2, 32), (1, 0)), (sa, sb)
+                assert sa["wide_lists"] == 32                                     # (this set: the wide route)
             d_ab, i_ab, _ = N.knn(ctx, am, bm, 10)
             d_ba, i_ba, _ = N.knn(ctx, bm, am, 10)
             np.testing.assert_array_equal(xi.numpy(), i_ab.numpy())
