@@ -25,6 +25,12 @@
 // neighbour order in both directions, as from two separate kz_knn calls.
 #pragma once
 
+// Event counters of the rows owning events: ints per counter.  (Round 5, measured and left at 1: the event log is nearly sorted by
+// index tile, so the scatter kernel's threads that run together hit the counters of the same 128 rows -- but ONE counter per
+// 128-byte line, KZ_EVC = 32, changed nothing: C3 scatter 4.7 ms / select 5.2 ms either way.  The atomics are not what these two
+// kernels wait for.)
+constexpr int KZ_EVC = 1;
+
 // ---- thresholds from the sample sweep --------------------------------------------------------------------------------
 // One wave per row t of B.  The row's lists from the sample sweep hold pieces x K' <= 256 entries; tau = the `rank`-th best of
 // them (by key, ties by entry order; rank = k + 1: the sample rows are rows of A, so k rows above tau are there by
@@ -248,7 +254,7 @@ __global__ void kz_dual_inject_kernel(const int* __restrict__ perm, int64_t n_b,
     const int c = filed < sev_cap ? filed : sev_cap;
     for (int i = 0; i < c && i < ev_cap; ++i) ev[t * (int64_t)ev_cap + i] = sev[orig * (int64_t)sev_cap + i];
     // (more sample events than either buffer holds: the count says so, the select kernel sends the row to the ordinary search)
-    ev_cnt[t] = filed > sev_cap ? ev_cap + 1 : c;
+    ev_cnt[t * KZ_EVC] = filed > sev_cap ? ev_cap + 1 : c;
 }
 
 // -bias of the query side (pad rows: +inf, never an event)
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256) void kz_dual_scatter_kernel(const f32x4e* __re
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (kk[u] - tt[u] >= nb) {
-                const int slot = atomicAdd(ev_cnt + row0 + u, 1);
+                const int slot = atomicAdd(ev_cnt + (int64_t)(row0 + u) * KZ_EVC, 1);
                 // The event is filed as the reverse-direction key  key'(t, q) = acc - bias(t) + bias(q), evaluated in float64
                 // on the float32 values (exact) and rounded once to float32 (the list format), under the MATRIX row of the
                 // query (mt.y is a row of the dealt query image; -nb is its bias).
@@ -295,6 +301,8 @@ __global__ __launch_bounds__(256) void kz_dual_scatter_kernel(const f32x4e* __re
     }
 }
 
+constexpr int KZ_DUAL_SPREAD = 1024;                                   // counter pairs of the select kernel's statistics (a power of two)
+constexpr size_t KZ_DUAL_CNT_BYTES = 128 + (size_t)KZ_DUAL_SPREAD * 16;   // [0] log counter, [1] events, [2] overflowing rows, [16 ..] the pairs
 // ---- the K' best events of a row -> an ordinary candidate list ---------------------------------------------------------
 // One wave per row t of B.  Selection by (key' descending, q ascending) is a total order, so the list does not depend on
 // the order the atomics filed the events in.  K'-th key by radix select on the sortable bit pattern.
@@ -309,17 +317,30 @@ __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restri
     const int64_t orig = perm[t];                        // the matrix row: lists and floors are kept under it
     unsigned* su = reinterpret_cast<unsigned*>(ssm) + (size_t)wave * 2 * ev_cap;   // sortable key bits
     int* sq = reinterpret_cast<int*>(su + ev_cap);
-    const int filed = ev_cnt[t];
+    const int filed = ev_cnt[t * KZ_EVC];
     const int n = filed < ev_cap ? filed : ev_cap;
     if (lane == 0) {
-        // (statistics only: spread over 32 counter pairs -- one pair for all 250 k waves serialised the whole kernel on a
-        //  single L2 atomic: 3.1 ms of which 2 were this line)
-        unsigned long long* tot = totals + 2 * (blockIdx.x & 31);
+        // (statistics only: spread over KZ_DUAL_SPREAD counter pairs -- one pair for all 250 k waves serialised the whole kernel on
+        //  a single L2 atomic: 3.1 ms of which 2 were this line; 32 pairs still queued 15 000 atomics per address on C3's 500 k rows)
+        unsigned long long* tot = totals + 2 * (blockIdx.x & (KZ_DUAL_SPREAD - 1));
         atomicAdd(tot + 0, (unsigned long long)filed);
         if (filed > ev_cap) {
             floor_[orig] = INFINITY;   // incomplete events: the certification must fail, the row is searched again
             atomicAdd(tot + 1, 1ull);
         }
+    }
+    if (n <= KP) {
+        // the usual case where the list is longer than the events are many (reverse lists of 2 K'): every event is a list entry --
+        // straight from the buffer to the list, no LDS, no reductions
+        float* okd = out_key + orig * (int64_t)KP;
+        int* oid = out_idx + orig * (int64_t)KP;
+        for (int e = lane; e < KP; e += 64) {
+            uint2 v = make_uint2(0u, 0u);
+            if (e < n) v = ev[t * (int64_t)ev_cap + e];
+            okd[e] = e < n ? __uint_as_float(v.x) : -INFINITY;
+            oid[e] = e < n ? (int)v.y : -1;
+        }
+        return;
     }
     unsigned all_or = 0u, all_and = 0xffffffffu;
     for (int e = lane; e < n; e += 64) {
@@ -388,7 +409,11 @@ __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restri
 }
 
 __global__ void kz_dual_sum_kernel(const unsigned long long* __restrict__ spread, unsigned long long* __restrict__ out) {
-    unsigned long long a = threadIdx.x < 32 ? spread[2 * threadIdx.x] : 0ull, b = threadIdx.x < 32 ? spread[2 * threadIdx.x + 1] : 0ull;
+    unsigned long long a = 0ull, b = 0ull;
+    for (int i = threadIdx.x; i < KZ_DUAL_SPREAD; i += 64) {
+        a += spread[2 * i];
+        b += spread[2 * i + 1];
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         a += __shfl_xor(a, off, 64);
@@ -750,12 +775,12 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)a_pad * 4, (void**)&qnb);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * KPr * 4, (void**)&col_key);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * KPr * 4, (void**)&col_idx);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4, (void**)&ev_cnt);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * 4 * KZ_EVC, (void**)&ev_cnt);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b->n * 4, (void**)&fail_list);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)b_pad * ev_cap * 8, (void**)&ev);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 16, &log_keys);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 8, &log_meta);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, 1024, (void**)&d_cnt);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, KZ_DUAL_CNT_BYTES, (void**)&d_cnt);
     if (rc != KZ_OK) {
         release();
         // (not enough memory for the event buffers: the two ordinary searches need far less)
@@ -860,8 +885,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     int KPs = KP, force_s = 0;
     sample_lists(rank, s_tiles, &KPs, &force_s);
     KZ_DUAL_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
-    KZ_DUAL_HIP(hipMemsetAsync(ev_cnt, 0, (size_t)b_pad * 4, ctx->stream));
-    KZ_DUAL_HIP(hipMemsetAsync(d_cnt, 0, 1024, ctx->stream));
+    KZ_DUAL_HIP(hipMemsetAsync(ev_cnt, 0, (size_t)b_pad * 4 * KZ_EVC, ctx->stream));
+    KZ_DUAL_HIP(hipMemsetAsync(d_cnt, 0, KZ_DUAL_CNT_BYTES, ctx->stream));
     // ---- query side: rows dealt into tiles by |q_c|^2 (load balance), its image and its offsets in that order --------------
     hipLaunchKernelGGL(kz_dual_c2key_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, ctx->stream, ia->rowq, a->n, q_key);
     hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_iota, (int)a_pad);
@@ -936,14 +961,14 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         al((size_t)s_img_rows * 4, (void**)&perm3);
         al((size_t)s_img_rows * 4, (void**)&rm3);
         al((size_t)b_pad * 4, (void**)&row_map_b);
-        al((size_t)s_img_rows * 4, (void**)&ev3_cnt);
+        al((size_t)s_img_rows * 4 * KZ_EVC, (void**)&ev3_cnt);
         al((size_t)s_img_rows * 4, (void**)&fail3);
         al((size_t)b_pad * 4, (void**)&sev_cnt);
         al((size_t)s_img_rows * ev_cap3 * 8, (void**)&ev3);
         al((size_t)b->n * sev_cap * 8, (void**)&sev);
         al((size_t)log_cap3 * 16, &log3_keys);
         al((size_t)log_cap3 * 8, &log3_meta);
-        al(1024, (void**)&d_cnt3);
+        al(KZ_DUAL_CNT_BYTES, (void**)&d_cnt3);
         if (rcn != KZ_OK) {   // (no memory for the nested stages: the classic sample sweep)
             release_nested();
             nested = false;
@@ -1043,8 +1068,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             hipLaunchKernelGGL(kz_dual_negbias_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, ctx->stream, ib->bias, b->n, b_pad, qnb_b);
             rc = kz_himage_pack_rows(a, rm3, s_img_rows, s_img_rows, ss_packed, ss_bias);
         }
-        if (rc == KZ_OK && hipMemsetAsync(ev3_cnt, 0, (size_t)s_img_rows * 4, ctx->stream) != hipSuccess) rc = KZ_ERR_HIP;
-        if (rc == KZ_OK && hipMemsetAsync(d_cnt3, 0, 1024, ctx->stream) != hipSuccess) rc = KZ_ERR_HIP;
+        if (rc == KZ_OK && hipMemsetAsync(ev3_cnt, 0, (size_t)s_img_rows * 4 * KZ_EVC, ctx->stream) != hipSuccess) rc = KZ_ERR_HIP;
+        if (rc == KZ_OK && hipMemsetAsync(d_cnt3, 0, KZ_DUAL_CNT_BYTES, ctx->stream) != hipSuccess) rc = KZ_ERR_HIP;
         if (rc != KZ_OK) {
             release();
             return rc;
