@@ -1712,9 +1712,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         // (the verdict counts the rows that left the probe's FIRST pass uncertified, once each -- not the cumulative count of the
         //  levels below it, which counted a row that went two levels down twice)
         bool hard = (int64_t)stp.n_first_pass_fail * 2 > n_probe;
-        if (hard && ctx->wide_lists >= 2) {
+        if ((int64_t)stp.n_first_pass_fail * 8 > n_probe && ctx->wide_lists >= 2) {
             // LADDER: before better operands, more margin in ranks on the SAME operands -- the probe rows again through the wide
-            // route; at most a quarter of them uncertified and the whole call takes it
+            // route.  Tried from an eighth of the probe uncertified on: re-searching a quarter of the rows one by one costs more
+            // than the sweep itself (300 k x 300 k x 96, clusters of very different spread, k = 10: 24 % of the rows re-searched,
+            // 24 ms of sweep in a 93 ms call).  Taken when at most a quarter of the probe stays uncertified there AND that is less
+            // than half of what the ordinary lists left.
             int sel = 0;
             if (wide_geometry(ctx->wide_lists, &sel)) {
                 kz_knn_stats stw;
@@ -1726,7 +1729,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                     return rc;
                 }
                 probe_ms += wms;
-                if ((int64_t)stw.n_first_pass_fail * 4 <= n_probe && take_wide(ctx->wide_lists) == KZ_OK) hard = false;
+                if ((int64_t)stw.n_first_pass_fail * 4 <= n_probe && (int64_t)stw.n_first_pass_fail * 2 < stp.n_first_pass_fail &&
+                    take_wide(ctx->wide_lists) == KZ_OK)
+                    hard = false;
             }
         }
         kz_pool_free(ctx, plist_keep, 0);

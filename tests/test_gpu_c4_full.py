@@ -4,7 +4,7 @@ The per-GPU share (250k x 1M) is covered by tests/test_gpu_northstar.py; the ful
 touches: four query chunks of 524288 rows per sweep, event buffers / logs sized for 2M x 1M, the footprint gate of
 `kz_knn_dual`.  Reference path: kiez/hubness_reduction/base.py:33-50 (fit: reverse search), :89-105 (kneighbors), csls.py:85-96.
 
-  (a) `Kiez(hubness="CSLS").fit(source, target).kneighbors(10)` through the shared sweep: 512-row samples of BOTH raw kNN results
+  (a) `Kiez(hubness="CSLS").fit(source, target).kneighbors(10)` through the shared sweep: samples of BOTH raw kNN results (4 096 source rows, 2 048 target rows)
       array_equal to the oracle's exact float64 search, `r_train` bit-equal, the final (dist, ind) equal to the oracle's CSLS
       transform + `_sort` on the sampled rows;
   (b) ALL rows equal to the concatenation of EIGHT `ShardedKiez` ranks (the north-star partitioning: source row-sharded, target
@@ -63,13 +63,14 @@ def test_c4_full_size_against_the_oracle(c4_single):
     assert ind.min() >= 0 and ind.max() < D.N_TARGET
 
     # rows of every 524288-row chunk of the sweep and of every shard, plus both ends
-    rows = np.unique(np.concatenate([np.random.RandomState(1).choice(D.N_SOURCE, 504, replace=False),
+    threads = max(1, min(32, os.cpu_count() or 1))     # (oracle.knn_exact works on its row chunks with this many threads)
+    rows = np.unique(np.concatenate([np.random.RandomState(1).choice(D.N_SOURCE, 4088, replace=False),
                                      [0, 524287, 524288, 1048575, 1048576, 1572864, D.N_SOURCE - 1, D.SHARD_ROWS]]))
-    od, oi = O.knn_exact(s[rows], t, K, "euclidean")
+    od, oi = O.knn_exact(s[rows], t, K, "euclidean", threads=threads)
     np.testing.assert_array_equal(fi[rows], oi)
     np.testing.assert_array_equal(fd[rows], od)                # float32 inputs: bit-identical distances (sqrt rule)
-    trows = np.unique(np.concatenate([np.random.RandomState(2).choice(D.N_TARGET, 510, replace=False), [0, D.N_TARGET - 1]]))
-    ord_, ori = O.knn_exact(t[trows], s, K, "euclidean")
+    trows = np.unique(np.concatenate([np.random.RandomState(2).choice(D.N_TARGET, 2046, replace=False), [0, D.N_TARGET - 1]]))
+    ord_, ori = O.knn_exact(t[trows], s, K, "euclidean", threads=threads)
     np.testing.assert_array_equal(ri[trows], ori)
     np.testing.assert_array_equal(rd[trows], ord_)
     np.testing.assert_array_equal(r["r_train"][trows], ord_.mean(axis=1))          # csls.py:90
