@@ -114,11 +114,16 @@ struct kz_himage {
     float* bias;             // [n_tiles*128] accumulator init -S^2 |x_c|^2 / 2 (pad rows: -inf)
     double* rowq;            // [n][3] unscaled: |x_c|^2, |x_h|, |x_c - x_h|  (x_c = float32(x - mu), x_h = fp16 operand / S)
     double* d_max;           // device [3]: max |x_h|, max |x_c - x_h|, max |x_c|^2 over the rows
-    // a second image with the rows DEALT over dealt_P index ranges (kz_himage_dealt; short-list route of the ordinary kernel)
+    // a second image with the rows DEALT over dealt_P index ranges (kz_himage_dealt; short-list route of the ordinary kernel).
+    // dealt_* = the image kz_himage_dealt selected last; TWO are kept (slot): a search and the re-search of its uncertified rows
+    // deal the index over different numbers of ranges, and with one buffer every step re-packed the whole index twice (500 k x
+    // 200: 0.68 ms each)
     int dealt_P;
     unsigned short* dealt_packed;
     float* dealt_bias;
     int* dealt_perm;         // [n_tiles*128] matrix row of image row r (-1 behind the end)
+    struct { int P; unsigned short* packed; float* bias; int* perm; } slot[2];
+    int slot_cur;
 };
 
 struct kz_matrix {

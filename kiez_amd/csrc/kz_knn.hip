@@ -1630,6 +1630,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // 83k rows 11.3 -> 9.6, k = 26 on 60k rows 6.9 -> 6.5).  (The long lists' kernels stay for small indexes.)
     const int KP_long = KP, KSEL_long = KSEL, pieces_long = long_pieces;   // (the list geometry this call would use without the route)
     bool short_ord = false;
+    int route_P = 0;      // ranges the short-list route dealt the index over (kz_himage_dealt)
     float probe_ms = 0;   // (tier probe, below: reported with the fallback time)
     // (the long-k route up to 320 neighbours as well: k / 5 <= 64 lists of 16 instead of 4 .. 14 lists of 128 -- 50k x 500k x 200, main
     //  kernel: k = 128 32.4 -> 12.5 ms, k = 160 35.4 -> 13.3; beyond 32 lists the finalize kernel selects by repeated arg-max)
@@ -1647,6 +1648,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 KP = 16;
                 KSEL = sel;
                 long_pieces = P;
+                route_P = P;
             } else if (rc != KZ_ERR_NOMEM) {
                 return rc;
             }   // (no memory for the second image: the long list)
@@ -1818,6 +1820,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             int rc = kz_matrix_image_f32(query);
             if (rc == KZ_OK) rc = kz_matrix_image_f32(index);
             if (rc != KZ_OK) return rc;
+        }
+        if (tier == KZ_TIER_H && short_ord && long_pieces >= 2) {
+            // (a re-search of the previous chunk's uncertified rows may have selected -- or packed -- the index dealt over another
+            //  number of ranges: this route's own image again; cached, two are kept)
+            const int rcd = kz_himage_dealt(index, wide_route || forced_lists > 0 ? long_pieces : route_P);
+            if (rcd != KZ_OK && rcd != KZ_ERR_NOMEM) return rcd;
         }
         int slots = 0;
         {

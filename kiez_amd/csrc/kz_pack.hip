@@ -422,9 +422,11 @@ void kz_himage_free(kz_matrix* m) {
     kz_pool_free(m->ctx, im->bias, 0);
     kz_pool_free(m->ctx, im->rowq, 0);
     kz_pool_free(m->ctx, im->d_max, 0);
-    kz_pool_free(m->ctx, im->dealt_packed, 0);
-    kz_pool_free(m->ctx, im->dealt_bias, 0);
-    kz_pool_free(m->ctx, im->dealt_perm, 0);
+    for (int i = 0; i < 2; ++i) {
+        kz_pool_free(m->ctx, im->slot[i].packed, 0);
+        kz_pool_free(m->ctx, im->slot[i].bias, 0);
+        kz_pool_free(m->ctx, im->slot[i].perm, 0);
+    }
     kz_center_release(m->ctx, im->center);
     delete im;
     m->himg = nullptr;
@@ -552,29 +554,45 @@ int kz_himage_dealt(kz_matrix* m, int P) {
     kz_ctx* ctx = m->ctx;
     KZ_REQUIRE(m->himg && P >= 2 && (int64_t)P <= m->n, "kz_himage_dealt: no fp16 image / bad range count");
     kz_himage* im = m->himg;
-    if (im->dealt_P == P) return KZ_OK;
+    auto select = [&](int i) {
+        im->slot_cur = i;
+        im->dealt_P = im->slot[i].P;
+        im->dealt_packed = im->slot[i].packed;
+        im->dealt_bias = im->slot[i].bias;
+        im->dealt_perm = im->slot[i].perm;
+    };
+    for (int i = 0; i < 2; ++i)
+        if (im->slot[i].P == P && im->slot[i].packed) {
+            select(i);
+            return KZ_OK;
+        }
+    // not cached: an empty slot, else the one that was NOT selected last
+    int v = !im->slot[0].packed ? 0 : (!im->slot[1].packed ? 1 : 1 - im->slot_cur);
     const int nsr = m->kg / 4;
     const int64_t n_pad = m->n_tiles * KZ_TILE;
-    if (!im->dealt_packed) {
-        if (kz_pool_alloc(ctx, (size_t)n_pad * (size_t)nsr * 32 + 32 * 4096, (void**)&im->dealt_packed) != KZ_OK ||
-            kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&im->dealt_bias) != KZ_OK ||
-            kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&im->dealt_perm) != KZ_OK) {
-            kz_pool_free(ctx, im->dealt_packed, 0);
-            kz_pool_free(ctx, im->dealt_bias, 0);
-            kz_pool_free(ctx, im->dealt_perm, 0);
-            im->dealt_packed = nullptr;
-            im->dealt_bias = nullptr;
-            im->dealt_perm = nullptr;
-            im->dealt_P = 0;
-            return KZ_ERR_NOMEM;
+    if (!im->slot[v].packed) {
+        if (kz_pool_alloc(ctx, (size_t)n_pad * (size_t)nsr * 32 + 32 * 4096, (void**)&im->slot[v].packed) != KZ_OK ||
+            kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&im->slot[v].bias) != KZ_OK ||
+            kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&im->slot[v].perm) != KZ_OK) {
+            kz_pool_free(ctx, im->slot[v].packed, 0);
+            kz_pool_free(ctx, im->slot[v].bias, 0);
+            kz_pool_free(ctx, im->slot[v].perm, 0);
+            im->slot[v].packed = nullptr;
+            im->slot[v].bias = nullptr;
+            im->slot[v].perm = nullptr;
+            im->slot[v].P = 0;
+            // (no memory for a second image: the other slot is re-packed instead, if there is one)
+            v = 1 - v;
+            if (!im->slot[v].packed) return KZ_ERR_NOMEM;
         }
     }
-    im->dealt_P = 0;
-    hipLaunchKernelGGL(kz_dealt_perm_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, m->n, n_pad, P, im->dealt_perm);
+    im->slot[v].P = 0;
+    hipLaunchKernelGGL(kz_dealt_perm_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, m->n, n_pad, P, im->slot[v].perm);
     KZ_HIP(hipGetLastError());
-    const int rc = kz_himage_pack_permuted(m, im->dealt_perm, im->dealt_packed, im->dealt_bias);
+    const int rc = kz_himage_pack_permuted(m, im->slot[v].perm, im->slot[v].packed, im->slot[v].bias);
     if (rc != KZ_OK) return rc;
-    im->dealt_P = P;
+    im->slot[v].P = P;
+    select(v);
     return KZ_OK;
 }
 
