@@ -133,7 +133,7 @@ int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a, const kz_matrix* b, int k, doub
                 double* d_dist_ba, int64_t* d_ind_ba, kz_knn_stats* stats_ab, kz_knn_stats* stats_ba);
 
 /* Host-only (no GPU needed): the work schedule kz_knn builds for a launch with `slots` resident workgroups
- * (DESIGN.md section 3.1 "greedy rounds").  Round r covers round_qtiles[r] query tiles of 128 rows, each swept as
+ * (DESIGN.md section 3.0 "host schedule": greedy rounds).  Round r covers round_qtiles[r] query tiles of 128 rows, each swept as
  * round_pieces[r] index ranges of round_piece_tiles[r] tiles of 128 rows (the last range may be shorter).  Arrays
  * hold up to 8 rounds.  k_eff = neighbours kept per query (k + 1 in single-source mode).
  * Diagnostic ABI: it plans the CLASSIC route -- one candidate list of K' in {16, 32, 64, 128} per query and index range, one

@@ -23,7 +23,7 @@
 // NRES = number of leading 16-k slices whose QUERY fragments stay resident in registers for the whole sweep
 // (8 slices = d 128 = 64 VGPRs); slices beyond NRES are streamed from L2 with non-temporal loads.  Residency is opt-in
 // (force_nres): at the register budget of three waves per SIMD it spills and measured slower than streaming
-// (DESIGN.md section 7); NRES = 0 is what runs by default.
+// (HISTORY.md section 7); NRES = 0 is what runs by default.
 template <int KP, int NRES>
 __global__ __launch_bounds__(256, 3) void kz_knn_cand_kernel(KnnCandParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -1,4 +1,4 @@
-"""Host logic of kz_knn that needs no GPU: the work schedule (`kz_knn_plan`, DESIGN.md section 3.1 'greedy rounds')."""
+"""Host logic of kz_knn that needs no GPU: the work schedule (`kz_knn_plan`, DESIGN.md section 3.0 'host schedule': greedy rounds)."""
 import ctypes as C
 
 import pytest

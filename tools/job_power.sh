@@ -1,4 +1,4 @@
-# The raw evidence behind "the headline sweep sits on the chip's power limit" (VERDICT r4 item 7):
+# The raw evidence behind "the headline sweep sits on the chip's power limit" (HISTORY.md 7c):
 #   1. tools/power_probe.py: the SAME launch on three operand kinds (uniform random / small integers / constant rows = an all-zero
 #      centred fp16 image), ns-like shape and C1 -> <P>/r05_power_probe.log
 #   2. the same program under rocprofv3 --pmc (separate passes; program directly behind `--`): GRBM_GUI_ACTIVE (clock the chip held =
