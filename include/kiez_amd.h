@@ -38,8 +38,12 @@ extern "C" {
 enum { KZ_OK = 0, KZ_ERR_INVALID = 1, KZ_ERR_HIP = 2, KZ_ERR_UNSUPPORTED = 3, KZ_ERR_NOMEM = 4, KZ_ERR_NONFINITE = 5 };
 /* element types of an embedding matrix */
 enum { KZ_F32 = 0, KZ_F64 = 1 };
-/* metrics of the exact backend; minkowski(p=2) == euclidean (sklearn_nearest_neighbors.py:51-65) */
-enum { KZ_EUCLIDEAN = 0, KZ_SQEUCLIDEAN = 1, KZ_COSINE = 2 };
+/* metrics of the exact backend; minkowski(p=2) == euclidean (sklearn_nearest_neighbors.py:51-65).  0 .. 2 run the fused MFMA
+ * kernels; 3 .. 5 (the rest of the Minkowski family: manhattan = cityblock = l1, chebyshev, minkowski with any p >= 1 set by
+ * kz_matrix_set_minkowski_p) run entirely on the exact float64 kernels -- correct and slow, as scikit-learn's own generic
+ * DistanceMetric path is (sklearn/metrics/_dist_metrics.pyx.tp: |x_j - y_j| in the input dtype, float64 accumulation, result
+ * rounded to the input dtype) */
+enum { KZ_EUCLIDEAN = 0, KZ_SQEUCLIDEAN = 1, KZ_COSINE = 2, KZ_MANHATTAN = 3, KZ_CHEBYSHEV = 4, KZ_MINKOWSKI = 5 };
 
 typedef struct kz_ctx kz_ctx;       /* one GPU + one HIP stream + scratch                                   */
 typedef struct kz_matrix kz_matrix; /* an embedding matrix resident in HBM: raw rows, MFMA-packed tiles, norms */
@@ -111,6 +115,8 @@ int kz_memcpy_d2d(kz_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
  * the first kz_knn / kz_knn_dual that searches the matrix for device rows (this call then waits for nothing). */
 int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t n, int64_t d, int dtype,
                      int metric, kz_matrix** out);
+/* metric KZ_MINKOWSKI: the exponent p >= 1 (default 2; both matrices of a search must agree). */
+int kz_matrix_set_minkowski_p(kz_matrix* m, double p);
 int kz_matrix_destroy(kz_matrix* m);
 int kz_matrix_shape(const kz_matrix* m, int64_t* n, int64_t* d, int* dtype, int* metric);
 

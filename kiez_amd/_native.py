@@ -24,8 +24,16 @@ _lib = None
 _lock = threading.Lock()
 
 KZ_F32, KZ_F64 = 0, 1
-KZ_EUCLIDEAN, KZ_SQEUCLIDEAN, KZ_COSINE = 0, 1, 2
-METRIC_IDS = {"euclidean": KZ_EUCLIDEAN, "sqeuclidean": KZ_SQEUCLIDEAN, "cosine": KZ_COSINE}
+KZ_EUCLIDEAN, KZ_SQEUCLIDEAN, KZ_COSINE, KZ_MANHATTAN, KZ_CHEBYSHEV, KZ_MINKOWSKI = 0, 1, 2, 3, 4, 5
+METRIC_IDS = {"euclidean": KZ_EUCLIDEAN, "sqeuclidean": KZ_SQEUCLIDEAN, "cosine": KZ_COSINE, "manhattan": KZ_MANHATTAN,
+              "chebyshev": KZ_CHEBYSHEV, "minkowski": KZ_MINKOWSKI}
+
+
+def split_metric(metric: str):
+    """'minkowski[3.0]' -> ('minkowski', 3.0); any other canonical metric name -> (name, None)."""
+    if metric.startswith("minkowski[") and metric.endswith("]"):
+        return "minkowski", float(metric[len("minkowski["):-1])
+    return metric, None
 MAX_FUSED_NEIGHBORS = 110   # neighbours per query ONE fused list keeps (list length 128 minus the certification margin): the limit of
                             # the shared sweep and of the single-source split; kz_knn itself takes 111 .. ~540 on its long-k route
                             # (lists over many index ranges) and anything up to MAX_NEIGHBORS on the exact float64 kernels
@@ -82,6 +90,7 @@ SYMBOLS = [
     ("kz_memcpy_d2d", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("kz_matrix_create", C.c_int, [_P, _P, C.c_int, _I64, _I64, C.c_int, C.c_int, C.POINTER(_P)]),
     ("kz_matrix_destroy", C.c_int, [_P]),
+    ("kz_matrix_set_minkowski_p", C.c_int, [_P, C.c_double]),
     ("kz_matrix_shape", C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("kz_knn", C.c_int, [_P, _P, _I64, _I64, _P, C.c_int, C.c_int, _P, _P, C.POINTER(KnnStats)]),
     ("kz_knn_dual", C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(KnnStats), C.POINTER(KnnStats)]),
@@ -277,6 +286,7 @@ class DeviceMatrix:
         not be modified meanwhile (the reference holds its inputs the same way, neighbor_algorithm_base.py:95-96)."""
         self.ctx = ctx
         self.metric = metric
+        metric, mink_p = split_metric(metric)
         h = _P()
         if device_ptr is None:
             arr = np.ascontiguousarray(data)
@@ -300,6 +310,8 @@ class DeviceMatrix:
                                             KZ_F32 if self.dtype == np.float32 else KZ_F64, METRIC_IDS[metric], C.byref(h)),
                    "kz_matrix_create")
         self.handle = h
+        if mink_p is not None:
+            _check(ctx.lib.kz_matrix_set_minkowski_p(h, mink_p), "kz_matrix_set_minkowski_p")
 
     def __del__(self):
         h = getattr(self, "handle", None)

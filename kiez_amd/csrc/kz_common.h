@@ -130,6 +130,7 @@ struct kz_matrix {
     kz_ctx* ctx;
     int64_t n, d;
     int dtype, metric;
+    double mink_p;    // KZ_MINKOWSKI: the exponent (kz_matrix_set_minkowski_p; 2 by default)
     int64_t n_tiles;  // ceil(n / 128)
     int kg;           // d_pad / 4 (number of 4-wide k-groups), d_pad = round_up(d, 16)
     int kg_bf;        // same for the split-bf16 image (currently equal to kg)
@@ -267,8 +268,45 @@ __device__ __forceinline__ double kz_wave_dot_normalized(const T* __restrict__ a
 
 // The exact float64 value the search ranks an index row by (squared euclidean distance / cosine distance): the re-rank of
 // kz_knn_finalize_kernel, the exact fallback and kz_pair_values all evaluate THIS expression on the canonical dot product.
+// Minkowski family beyond p = 2 (KZ_MANHATTAN, KZ_CHEBYSHEV, KZ_MINKOWSKI): scikit-learn's generic DistanceMetric
+// (sklearn/metrics/_dist_metrics.pyx.tp: ManhattanDistance / ChebyshevDistance / MinkowskiDistance): the difference x_j - y_j in
+// the INPUT dtype, |.| (to the power p) accumulated in float64, the result -- the ranking value: sum |.|, max |.|, sum |.|^p --
+// rounded to the input dtype.  Same lane layout as kz_wave_dot (lane l owns elements 4l .. 4l+3 of every 256-element chunk), a
+// butterfly sum / max; scikit-learn accumulates in feature order, so float64 inputs agree to rounding (1e-15 relative), float32
+// inputs after the float32 rounding of the result almost always exactly.
 template <typename T>
-__device__ __forceinline__ double kz_exact_value(const T* q, const T* y, double qs, double ys, int d, int metric, int lane) {
+__device__ __forceinline__ double kz_wave_minkowski(const T* __restrict__ a, const T* __restrict__ b, int d, int metric, double p, int lane) {
+    const bool vec = kz_row_vec_ok(a, d) && kz_row_vec_ok(b, d);
+    double acc = 0.0;
+    for (int k0 = 4 * lane; k0 < d; k0 += 256) {
+        double x[4], y[4];
+        kz_row4(a, k0, d, vec, x);
+        kz_row4(b, k0, d, vec, y);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double df = sizeof(T) == 4 ? (double)fabsf((float)x[u] - (float)y[u]) : fabs(x[u] - y[u]);
+            if (metric == KZ_CHEBYSHEV)
+                acc = fmax(acc, df);
+            else if (metric == KZ_MANHATTAN)
+                acc += df;
+            else
+                acc += pow(df, p);
+        }
+    }
+    if (metric == KZ_CHEBYSHEV) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc = fmax(acc, __shfl_xor(acc, off, 64));
+    } else {
+        acc = kz_wave_sum(acc);
+    }
+    return sizeof(T) == 4 ? (double)(float)acc : acc;
+}
+
+// The exact float64 value the search ranks an index row by (squared euclidean distance / cosine distance / the Minkowski family's
+// reduced distance): the re-rank of kz_knn_finalize_kernel, the exact fallback and kz_pair_values all evaluate THIS expression.
+template <typename T>
+__device__ __forceinline__ double kz_exact_value(const T* q, const T* y, double qs, double ys, int d, int metric, int lane, double p = 2.0) {
+    if (metric >= KZ_MANHATTAN) return kz_wave_minkowski<T>(q, y, d, metric, p, lane);
     if (metric == KZ_COSINE) {
         const double sim = kz_wave_dot_normalized(q, qs, y, ys, d, lane);
         double v = 1.0 - sim;  // sklearn cosine_distances: S *= -1; S += 1; clip(0, 2)

@@ -247,7 +247,10 @@ struct KnnFinParams {
 
 // (kz_exact_value: kz_common.h -- shared with kz_pair_values, which must reproduce the re-rank's values bit for bit)
 template <typename T>
-__device__ __forceinline__ double kz_output_distance(double v, int metric) {
+__device__ __forceinline__ double kz_output_distance(double v, int metric, double p = 2.0) {
+    // (Minkowski family: the ranking value is the reduced distance; scikit-learn converts at the end,
+    //  MinkowskiDistance._rdist_to_dist: rdist ** (1 / p), rounded to the input dtype -- measured on scikit-learn 1.7.2)
+    if (metric == KZ_MINKOWSKI) return sizeof(T) == 4 ? (double)(float)pow(v, 1.0 / p) : pow(v, 1.0 / p);
     if (metric == KZ_EUCLIDEAN) {
         // ArgKmin32 converts the surrogate with the float32 metric object: (double)sqrtf((float)d2)
         // (_argkmin.pyx.tp:285-295 with INPUT_DTYPE_t = float32); ArgKmin64 uses sqrt in float64.
@@ -263,7 +266,7 @@ __device__ __forceinline__ double kz_output_distance(double v, int metric) {
 // query row; if it is absent drop the first one.
 template <typename T>
 __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* sidx, int n_sorted, int k, int exclude_self,
-                                               int64_t self_row, int metric, double* od, int64_t* oi, int lane) {
+                                               int64_t self_row, int metric, double* od, int64_t* oi, int lane, double p = 2.0) {
     int self_rank = -1;
     if (exclude_self) {
         self_rank = 0;
@@ -278,7 +281,7 @@ __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* si
         if (c == self_rank) continue;
         const int o = (self_rank >= 0 && c > self_rank) ? c - 1 : c;
         if (o < k) {
-            od[o] = kz_output_distance<T>(sval[c], metric);
+            od[o] = kz_output_distance<T>(sval[c], metric, p);
             oi[o] = (int64_t)sidx[c];
         }
     }
@@ -886,14 +889,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void kz_exact_dist_kernel(const int* __restrict__ fail_list, int batch0, int64_t q_begin,
                                                             const T* __restrict__ qraw, const T* __restrict__ yraw,
                                                             const double* __restrict__ qsqn, const double* __restrict__ ysqn,
-                                                            int64_t n_i, int d, int metric, double* __restrict__ vals) {
+                                                            int64_t n_i, int d, int metric, double p, double* __restrict__ vals) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     if (i >= n_i) return;
     const int b = blockIdx.y;
     const int64_t qrow = q_begin + fail_list[batch0 + b];
-    const double v = kz_exact_value<T>(qraw + qrow * (int64_t)d, yraw + i * (int64_t)d, qsqn[qrow], ysqn[i], d, metric, lane);
+    const double v = kz_exact_value<T>(qraw + qrow * (int64_t)d, yraw + i * (int64_t)d, qsqn[qrow], ysqn[i], d, metric, lane, p);
     if (lane == 0) vals[(int64_t)b * n_i + i] = v;
 }
 
@@ -971,7 +974,7 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
                                                               const double* __restrict__ vals, const int* __restrict__ cand_idx,
                                                               int64_t n_entries, int64_t n_i, int k,
                                                               int exclude_self, const int64_t* __restrict__ self_ids,
-                                                              int metric, double* __restrict__ out_dist,
+                                                              int metric, double p, double* __restrict__ out_dist,
                                                               int64_t* __restrict__ out_ind) {
     __shared__ double s_v[4];
     __shared__ int s_i[4];
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
     }
     if (wave == 0)
         kz_emit_sorted<T>(s_sv, s_si, k_eff, k, exclude_self, self_ids ? self_ids[q] : q_begin + q, metric,
-                          out_dist + (int64_t)q * k, out_ind + (int64_t)q * k, lane);
+                          out_dist + (int64_t)q * k, out_ind + (int64_t)q * k, lane, p);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1525,7 +1528,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     KZ_REQUIRE(query->d == index->d, "kz_knn: feature dimensions differ (%lld vs %lld)", (long long)query->d,
                (long long)index->d);
     KZ_REQUIRE(query->dtype == index->dtype, "kz_knn: query and index must have the same dtype");
-    KZ_REQUIRE(query->metric == index->metric, "kz_knn: query and index were packed for different metrics");
+    KZ_REQUIRE(query->metric == index->metric && query->mink_p == index->mink_p, "kz_knn: query and index were packed for different metrics");
     KZ_REQUIRE(q_begin >= 0 && q_count >= 0 && q_begin + q_count <= query->n, "kz_knn: query row range out of bounds");
     KZ_REQUIRE(k >= 1, "kz_knn: Expected k > 0. Got %d", k);
     // kp_min >= 1000: lists of kp_min - 1000, and NOT the short-list route (the re-search of rows that route could not certify:
@@ -1552,9 +1555,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // ranges of >= 4 tiles) the call runs entirely on the exact float64 kernels (k selection rounds over the full distance row
     // per query: correct for any k <= n, and slow -- the reference's scikit-learn path has no such limit either,
     // sklearn_nearest_neighbors.py:51-65; INTEGRATION.md "Deviations").
-    int KP = kz_pick_list_len(k_eff);
+    // The Minkowski family beyond p = 2 (KZ_MANHATTAN, KZ_CHEBYSHEV, KZ_MINKOWSKI) has no inner-product form: no MFMA kernel, the
+    // call runs entirely on the exact float64 kernels (scikit-learn's own generic DatasetsPair path is the slow one there too).
+    const bool no_gemm_form = index->metric >= KZ_MANHATTAN;
+    int KP = no_gemm_form ? 0 : kz_pick_list_len(k_eff);
     int KSEL = 0, long_pieces = 0;
-    if (KP == 0 && !dual && ctx->long_k) {
+    if (KP == 0 && !dual && ctx->long_k && !no_gemm_form) {
         const int S = k_eff / 24 + 1 > 4 ? k_eff / 24 + 1 : 4;
         const int sel = k_eff + (k_eff / 8 > 16 ? k_eff / 8 : 16);
         // (finalize: 4 waves x (S 128 entries x 8 B + KSEL x 28 B) of LDS per workgroup)
@@ -2141,24 +2147,24 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 if (index->dtype == KZ_F32) {
                     hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
                                        cq_begin, (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn,
-                                       index->n, (int)index->d, metric, (double*)vals);
+                                       index->n, (int)index->d, metric, index->mink_p, (double*)vals);
                     if (two_level)
                         hipLaunchKernelGGL(kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0, ctx->stream, (const double*)vals, index->n, k_sel,
                                            n_chunks, cand_v, cand_i);
                     hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
                                        two_level ? (const double*)cand_v : (const double*)vals, two_level ? (const int*)cand_i : (const int*)nullptr,
-                                       two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric,
+                                       two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p,
                                        fp.out_dist, fp.out_ind);
                 } else {
                     hipLaunchKernelGGL(kz_exact_dist_kernel<double>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
                                        cq_begin, (const double*)query->raw, (const double*)index->raw, query->sqn, index->sqn,
-                                       index->n, (int)index->d, metric, (double*)vals);
+                                       index->n, (int)index->d, metric, index->mink_p, (double*)vals);
                     if (two_level)
                         hipLaunchKernelGGL(kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0, ctx->stream, (const double*)vals, index->n, k_sel,
                                            n_chunks, cand_v, cand_i);
                     hipLaunchKernelGGL(kz_exact_select_kernel<double>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
                                        two_level ? (const double*)cand_v : (const double*)vals, two_level ? (const int*)cand_i : (const int*)nullptr,
-                                       two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric,
+                                       two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p,
                                        fp.out_dist, fp.out_ind);
                 }
             }

@@ -669,7 +669,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     const double t_sweep_ms = 2.0 * (double)a->n * (double)b->n * (double)(a->kg * 4) / 1e12;
     const double t_events_ms = (double)b->n * rank * stride * 0.15e-6;
     const bool pays = ctx->dual_force || 0.7 * t_sweep_ms * (KP > 16 ? 2.0 : 1.0) > 2.0 * t_events_ms + 0.3;
-    const bool eligible = pays && stride >= 2 && ctx->precision == 0 && KP > 0 && n_slices >= 2 && n_slices <= 24 && a->kg == b->kg &&
+    const bool eligible = pays && stride >= 2 && ctx->precision == 0 && KP > 0 && a->metric < KZ_MANHATTAN && n_slices >= 2 && n_slices <= 24 && a->kg == b->kg &&
                           s_rows >= (int64_t)8 * KP && b->n >= 1024 && b_tiles < (1 << 20);
     if (!eligible) return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba);
     {

@@ -14,7 +14,7 @@
 template <typename T>
 __global__ __launch_bounds__(256) void kz_pair_values_kernel(const T* __restrict__ qraw, const double* __restrict__ qsqn,
                                                              int64_t q_begin, int64_t q_count, const T* __restrict__ yraw,
-                                                             const double* __restrict__ ysqn, int64_t n_i, int d, int metric,
+                                                             const double* __restrict__ ysqn, int64_t n_i, int d, int metric, double p,
                                                              const int64_t* __restrict__ ind, int K, double* __restrict__ val) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void kz_pair_values_kernel(const T* __restrict
     for (int c = 0; c < K; ++c) {
         const int64_t yi = ind[r * (int64_t)K + c];   // wave-uniform
         double v = INFINITY;
-        if (yi >= 0 && yi < n_i) v = kz_exact_value<T>(q, yraw + yi * (int64_t)d, qs, ysqn[yi], d, metric, lane);
+        if (yi >= 0 && yi < n_i) v = kz_exact_value<T>(q, yraw + yi * (int64_t)d, qs, ysqn[yi], d, metric, lane, p);
         if (lane == 0) val[r * (int64_t)K + c] = v;
     }
 }
@@ -91,7 +91,7 @@ int kz_pair_values(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t
                    const int64_t* d_ind, int k, double* d_val) {
     KZ_REQUIRE(ctx && query && index && d_ind && d_val, "kz_pair_values: null argument");
     KZ_REQUIRE(query && index && !query->raw_only && !index->raw_only, "kz_pair_values: null or rows-only matrix");
-    KZ_REQUIRE(query->d == index->d && query->dtype == index->dtype && query->metric == index->metric,
+    KZ_REQUIRE(query->d == index->d && query->dtype == index->dtype && query->metric == index->metric && query->mink_p == index->mink_p,
                "kz_pair_values: query/index mismatch (d %lld vs %lld)", (long long)query->d, (long long)index->d);
     KZ_REQUIRE(q_begin >= 0 && q_count >= 0 && q_begin + q_count <= query->n && k >= 1, "kz_pair_values: bad row range");
     KZ_HIP(hipSetDevice(ctx->device));
@@ -99,10 +99,10 @@ int kz_pair_values(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t
     const dim3 grid((unsigned)((q_count + 3) / 4));
     if (query->dtype == KZ_F32)
         hipLaunchKernelGGL(kz_pair_values_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)query->raw, query->sqn, q_begin,
-                           q_count, (const float*)index->raw, index->sqn, index->n, (int)query->d, query->metric, d_ind, k, d_val);
+                           q_count, (const float*)index->raw, index->sqn, index->n, (int)query->d, query->metric, query->mink_p, d_ind, k, d_val);
     else
         hipLaunchKernelGGL(kz_pair_values_kernel<double>, grid, dim3(256), 0, ctx->stream, (const double*)query->raw, query->sqn, q_begin,
-                           q_count, (const double*)index->raw, index->sqn, index->n, (int)query->d, query->metric, d_ind, k, d_val);
+                           q_count, (const double*)index->raw, index->sqn, index->n, (int)query->d, query->metric, query->mink_p, d_ind, k, d_val);
     KZ_HIP(hipGetLastError());
     return KZ_OK;
 }

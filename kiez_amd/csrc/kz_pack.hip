@@ -646,8 +646,7 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     KZ_REQUIRE(d <= 65536, "kz_matrix_create: d=%lld too large", (long long)d);
     KZ_REQUIRE(n < ((int64_t)1 << 31) - 256, "kz_matrix_create: n=%lld exceeds the int32 row-id range", (long long)n);
     KZ_REQUIRE(dtype == KZ_F32 || dtype == KZ_F64, "kz_matrix_create: dtype must be KZ_F32 or KZ_F64");
-    KZ_REQUIRE(metric == KZ_EUCLIDEAN || metric == KZ_SQEUCLIDEAN || metric == KZ_COSINE,
-               "kz_matrix_create: unknown metric %d", metric);
+    KZ_REQUIRE(metric >= KZ_EUCLIDEAN && metric <= KZ_MINKOWSKI, "kz_matrix_create: unknown metric %d", metric);
     KZ_REQUIRE(rows_on_device >= 0 && rows_on_device <= 3, "kz_matrix_create: rows_on_device must be 0, 1, 2 or 3");
     KZ_HIP(hipSetDevice(ctx->device));
     kz_matrix* m = new kz_matrix();
@@ -657,6 +656,7 @@ int kz_matrix_create(kz_ctx* ctx, const void* rows, int rows_on_device, int64_t 
     m->d = d;
     m->dtype = dtype;
     m->metric = metric;
+    m->mink_p = 2.0;
     m->n_tiles = (n + KZ_TILE - 1) / KZ_TILE;
     const int64_t d_pad = ((d + KZ_KSLICE - 1) / KZ_KSLICE) * KZ_KSLICE;
     m->kg = (int)(d_pad / 4);
@@ -736,6 +736,14 @@ int kz_matrix_destroy(kz_matrix* m) {
         kz_pool_free(m->ctx, m->d_stats, 0);
     }
     delete m;
+    return KZ_OK;
+}
+
+int kz_matrix_set_minkowski_p(kz_matrix* m, double p) {
+    KZ_REQUIRE(m != nullptr, "kz_matrix_set_minkowski_p: null matrix");
+    KZ_REQUIRE(m->metric == KZ_MINKOWSKI, "kz_matrix_set_minkowski_p: the matrix was not created for KZ_MINKOWSKI");
+    KZ_REQUIRE(p >= 1.0 && p < 1e6, "kz_matrix_set_minkowski_p: p must be >= 1 (got %g)", p);
+    m->mink_p = p;
     return KZ_OK;
 }
 

@@ -407,8 +407,8 @@ class ShardedKiez:
             if self.method not in ("exact", "empiric", "normal", "gaussi"):
                 raise ValueError(f'Mutual proximity method "{self.method}" not recognized. Try "normal" or "empiric".')
             self.method = "empiric" if self.method in ("exact", "empiric") else "normal"
-        if self.hub == "dsl" and self.metric == "cosine":
-            raise ValueError("DisSimLocal only supports squared Euclidean distances, not metric=cosine.")
+        if self.hub == "dsl" and self.metric not in ("euclidean", "sqeuclidean"):
+            raise ValueError(f"DisSimLocal only supports squared Euclidean distances, not metric={akw.get('metric')}.")
         self.engine = engine if engine is not None else HipEngine()
         self.comm = comm if comm is not None else Comm()
         self.state: Dict[str, Any] = {}
@@ -515,7 +515,7 @@ class ShardedKiez:
                     # ranked by (euclidean: sqrt, for float32 inputs through float32) -- the exact ordering values too: merging
                     # by rounded distances would break ties differently from one GPU.  ONE all-to-all either way.
                     gids = (i_rev + self.s_begin).contiguous()
-                    lossless = self.metric in ("sqeuclidean", "cosine")     # the returned distance IS the ordering value
+                    lossless = self.metric in ("sqeuclidean", "cosine", "manhattan", "chebyshev")   # the returned distance IS the ordering value
                     planes = [d_rev, gids.view(torch.float64)] if lossless else \
                         [eng.pair_values(self.T, 0, self.n_t, self.S, i_rev), d_rev, gids.view(torch.float64)]
                     parts = comm.all_to_all_rows(torch.stack(planes, dim=1), t_counts)          # [W, t_count, 2 or 3, K]

@@ -153,15 +153,26 @@ def _is_tensor(x) -> bool:
 
 
 def canonical_metric(metric: str, p=2) -> str:
-    """Map the reference's metric spelling to one the HIP kernels implement; anything else fails loudly."""
+    """Map the reference's metric spelling to one the HIP kernels implement; anything else fails loudly.
+
+    scikit-learn's own aliases (sklearn/metrics/_dist_metrics.pyx.tp, DistanceMetric.get_metric): minkowski with p = 1 / 2 / inf IS
+    manhattan / euclidean / chebyshev; `p` is ignored for every other metric name.  Euclidean, squared euclidean and cosine run the
+    fused MFMA kernels; manhattan, chebyshev and minkowski(p) have no inner-product form and run on the exact float64 kernels."""
     if metric == "minkowski":
-        if p != 2:
-            raise ValueError(
-                f"metric='minkowski' with p={p} is not implemented by the MI355X exact backend (only p=2, i.e. euclidean)")
-        return "euclidean"
+        if not isinstance(p, (int, float, np.integer, np.floating)) or isinstance(p, bool) or not p >= 1:
+            raise ValueError(f"metric='minkowski' needs p >= 1 on the MI355X exact backend (got p={p!r})")
+        if p == 2:
+            return "euclidean"
+        if p == 1:
+            return "manhattan"
+        if np.isinf(p):
+            return "chebyshev"
+        return f"minkowski[{float(p)!r}]"
     if metric in ("l2", "euclidean"):
         return "euclidean"
-    if metric in ("sqeuclidean", "cosine"):
+    if metric in ("manhattan", "cityblock", "l1"):
+        return "manhattan"
+    if metric in ("sqeuclidean", "cosine", "chebyshev"):
         return metric
     raise ValueError(
         f"metric='{metric}' is not implemented by the MI355X exact backend; valid metrics: {SklearnNN.valid_metrics}")
@@ -176,7 +187,7 @@ class SklearnNN(NNAlgorithm):
     distance + top-k pass on the GPU.
     """
 
-    valid_metrics = ["cosine", "euclidean", "l2", "minkowski", "sqeuclidean"]
+    valid_metrics = ["chebyshev", "cityblock", "cosine", "euclidean", "l1", "l2", "manhattan", "minkowski", "sqeuclidean"]
     # numpy arrays as in the reference; additionally arrays already resident in HBM (zero-copy fit)
     _ALLOWED_INPUT_TYPES = (np.ndarray, N.DeviceArray)
 
@@ -189,6 +200,8 @@ class SklearnNN(NNAlgorithm):
         self.metric_params = metric_params
         self.device = device
         self._metric_c = canonical_metric(metric, p)
+        if metric_params:
+            raise NotImplementedError(f"metric_params={metric_params!r} is not implemented by the MI355X exact backend")
         if isinstance(n_candidates, (int, np.integer)) and n_candidates > N.MAX_NEIGHBORS - 1:
             raise NotImplementedError(f"n_candidates={n_candidates} exceeds the {N.MAX_NEIGHBORS - 1} neighbours per query the "
                                       "MI355X exact backend supports")

@@ -23,20 +23,55 @@ from __future__ import annotations
 import numpy as np
 from scipy import special
 
-METRICS = ("euclidean", "sqeuclidean", "cosine")
+METRICS = ("euclidean", "sqeuclidean", "cosine", "manhattan", "chebyshev")
 
 
 def canonical_metric(metric: str, p: float = 2) -> str:
-    """minkowski(p=2) == euclidean.  kiez/neighbors/exact/sklearn_nearest_neighbors.py:51-65 (defaults)."""
+    """One name per distinct metric.  minkowski(p=2) == euclidean: kiez/neighbors/exact/sklearn_nearest_neighbors.py:51-65
+    (defaults); scikit-learn's aliases: `sklearn/metrics/_dist_metrics.pyx.tp` (METRIC_MAPPING: l2 = euclidean, l1 = cityblock =
+    manhattan; DistanceMetric.get_metric: minkowski with p = 1 / 2 / inf -> Manhattan / Euclidean / Chebyshev).  Any other
+    minkowski exponent p >= 1 is written 'minkowski[p]'."""
+    if metric.startswith("minkowski["):
+        return metric
     if metric == "minkowski":
-        if p != 2:
-            raise ValueError("only p=2 is supported")
-        return "euclidean"
+        if not p >= 1:
+            raise ValueError("minkowski needs p >= 1")
+        if p == 2:
+            return "euclidean"
+        if p == 1:
+            return "manhattan"
+        if np.isinf(p):
+            return "chebyshev"
+        return f"minkowski[{float(p)!r}]"
     if metric in ("l2",):
         return "euclidean"
+    if metric in ("l1", "cityblock"):
+        return "manhattan"
     if metric not in METRICS:
         raise ValueError(f"unsupported metric {metric}")
     return metric
+
+
+def minkowski_family_rdist(q: np.ndarray, y: np.ndarray, metric: str) -> np.ndarray:
+    """Reduced distances [len(q), len(y)] of manhattan / chebyshev / 'minkowski[p]' as scikit-learn's generic DistanceMetric
+    computes them for the brute-force search (`sklearn/metrics/_dist_metrics.pyx.tp`: ManhattanDistance.dist,
+    ChebyshevDistance.dist, MinkowskiDistance.rdist; DistanceMetric32 for float32 inputs): the difference x_j - y_j in the INPUT
+    dtype, |.| (to the power p) accumulated in float64 in feature order, the result rounded to the input dtype.
+    q and y must have the same dtype (float32 or float64)."""
+    assert q.dtype == y.dtype and q.dtype in (np.float32, np.float64)
+    p = float(metric[len("minkowski["):-1]) if metric.startswith("minkowski[") else None
+    acc = np.zeros((q.shape[0], y.shape[0]), dtype=np.float64)
+    for j in range(q.shape[1]):
+        df = np.abs(q[:, j, None] - y[None, :, j]).astype(np.float64)      # (the subtraction in the input dtype)
+        if metric == "chebyshev":
+            np.maximum(acc, df, out=acc)
+        elif metric == "manhattan":
+            acc += df
+        else:
+            acc += df ** p
+    if q.dtype == np.float32:
+        acc = acc.astype(np.float32).astype(np.float64)
+    return acc
 
 
 # --------------------------------------------------------------------------------------------
@@ -78,6 +113,8 @@ def knn_exact(query, index, k: int, metric: str = "euclidean", exclude_self: boo
     d2 = |x|^2 - 2 x.y + |y|^2, clamp at 0, sqrt at the end (skipped for sqeuclidean).
     cosine — `sklearn/metrics/pairwise.py:1166-1175,1728-1736`: normalise rows, S = Xn Yn^T,
     1 - S, clip to [0, 2]; then the k smallest (`sklearn/neighbors/_base.py:749-753`).
+    manhattan / chebyshev / minkowski[p] — the generic `ArgKmin` over a DatasetsPair of the metric object
+    (`_argkmin.pyx.tp:170-310` with `minkowski_family_rdist` above), ranked by the reduced distance.
     exclude_self — `sklearn/neighbors/_base.py:828-834,937-965`: ask for k+1, drop the entry whose
     index equals the row id (or the first entry when it is absent).
     Returns float64 distances and int64 indices.  For float32 query AND index with metric euclidean the
@@ -88,6 +125,12 @@ def knn_exact(query, index, k: int, metric: str = "euclidean", exclude_self: boo
     """
     metric = canonical_metric(metric)
     both_f32 = np.asarray(query).dtype == np.float32 and np.asarray(index).dtype == np.float32
+    family = metric in ("manhattan", "chebyshev") or metric.startswith("minkowski[")
+    if family:
+        # (no float64 cast of float32 inputs here: DistanceMetric32 subtracts in float32)
+        dt = np.float32 if both_f32 else np.float64
+        q_in = np.ascontiguousarray(query, dtype=dt)
+        y_in = np.ascontiguousarray(index, dtype=dt)
     q = np.ascontiguousarray(query, dtype=np.float64)
     y = np.ascontiguousarray(index, dtype=np.float64)
     n_q, n_i = q.shape[0], y.shape[0]
@@ -103,7 +146,7 @@ def knn_exact(query, index, k: int, metric: str = "euclidean", exclude_self: boo
         yn[yn == 0.0] = 1.0
         q = q / qn[:, None]
         y = y / yn[:, None]
-    else:
+    elif not family:
         qsq = _row_sqnorms(q)
         ysq = _row_sqnorms(y)
     rows = max(1, int(chunk_bytes // (8 * max(n_i, 1))))
@@ -111,6 +154,9 @@ def knn_exact(query, index, k: int, metric: str = "euclidean", exclude_self: boo
     ind = np.empty((n_q, kk), dtype=np.int64)
     def chunk(s):
         e = min(n_q, s + rows)
+        if family:
+            dist[s:e], ind[s:e] = _topk_rows(minkowski_family_rdist(q_in[s:e], y_in, metric), kk)
+            return
         g = q[s:e] @ y.T
         if metric == "cosine":
             g *= -1.0
@@ -139,6 +185,12 @@ def knn_exact(query, index, k: int, metric: str = "euclidean", exclude_self: boo
             dist = np.sqrt(dist.astype(np.float32)).astype(np.float64)
         else:
             np.sqrt(dist, out=dist)
+    elif metric.startswith("minkowski["):
+        # MinkowskiDistance._rdist_to_dist: rdist ** (1 / p), in the input dtype's metric object: float32 inputs give
+        # float32-representable distances (measured on scikit-learn 1.7.2: (float32) pow((double) rdist, 1 / p) reproduces all)
+        dist = dist ** (1.0 / float(metric[len("minkowski["):-1]))
+        if both_f32:
+            dist = dist.astype(np.float32).astype(np.float64)
     if exclude_self:
         rows_id = np.arange(n_q)[:, None]
         mask = ind != rows_id
@@ -315,7 +367,7 @@ def kiez_pipeline(source, target=None, n_candidates=10, k=None, metric="euclidea
         else:
             raise ValueError(f'Mutual proximity method "{method}" not recognized.')
     elif hub in ("dissimlocal", "dsl"):
-        if metric_c == "cosine":
+        if metric_c not in ("euclidean", "sqeuclidean"):                      # dis_sim.py:47-61 (minkowski only with p = 2)
             raise ValueError("DisSimLocal only supports squared Euclidean distances")
         squared = metric_c == "sqeuclidean"                                  # dis_sim.py:47-56
         s64 = np.asarray(source, dtype=np.float64)

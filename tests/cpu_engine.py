@@ -115,6 +115,11 @@ class OracleEngine:
     def pair_values(self, qm, q_begin, q_count, im, ind):
         """Exact float64 ordering value of (query row, index row) pairs, the expression of O.knn_exact."""
         i = ind.numpy()
+        mc = O.canonical_metric(im.metric)
+        if mc in ("manhattan", "chebyshev") or mc.startswith("minkowski["):
+            qr = qm.rows[q_begin:q_begin + q_count]
+            v = np.stack([O.minkowski_family_rdist(qr[r:r + 1], im.rows[i[r]], mc)[0] for r in range(len(qr))])
+            return torch.from_numpy(v)
         q = qm.rows[q_begin:q_begin + q_count].astype(np.float64)
         y = im.rows.astype(np.float64)
         if O.canonical_metric(im.metric) == "cosine":

@@ -18,6 +18,7 @@ HUB = {
 PIPELINE_CASES = [
     "conftest_two_source", "conftest_single_source", "c0_two_source", "c0_single_source",
     "f32_euclidean", "f32_sqeuclidean", "f32_gauss_single", "cosine_k50", "cosine_single",
+    "f64_manhattan", "f32_chebyshev_single", "f32_minkowski_p3", "f64_minkowski_p1_5_single", "f32_cityblock",
 ]
 
 
@@ -27,7 +28,7 @@ def load_case(name):
     g["_name"] = name
     g["_K"] = int(g["K"])
     g["_metric"] = str(g["metric"])
-    g["_p"] = int(g["p"])
+    g["_p"] = int(g["p"]) if float(g["p"]) == int(g["p"]) else float(g["p"])
     g["_ks"] = [None if k < 0 else int(k) for k in g["ks"]]
     g["_target"] = g.get("target")
     g["_tags"] = sorted({k.split("__")[0] for k in g if "__" in k and not k.endswith("__raises")})

@@ -23,6 +23,16 @@ CASES = [
     ("dsl_single", "DisSimLocal", {}, "euclidean", True),
 ]
 SEVEN = [c for c in CASES if not c[4]]
+# the rest of the Minkowski family (a metric given as (name, p) carries the exponent): float32 rows, so that the merge across
+# shards must go by the exact ordering values where the returned distance is a rounded function of them (minkowski[p])
+FAMILY = [
+    ("none", None, {}, "manhattan", False),
+    ("csls", "CSLS", {}, "cityblock", False),
+    ("mp_empiric", "MutualProximity", {"method": "empiric"}, ("minkowski", 3), False),
+    ("nicdm", "LocalScaling", {"method": "nicdm"}, "chebyshev", False),
+    ("mp_normal", "MutualProximity", {"method": "normal"}, ("minkowski", 1.5), False),
+    ("ls_single", "LocalScaling", {"method": "standard"}, ("minkowski", 1), True),
+]
 
 
 def _free_port():
@@ -36,6 +46,8 @@ def _scenario(name):
     rng = np.random.RandomState(17)
     if name == "base":          # uneven shards (203 rows), 157 targets: neither divides by 2, 3 or 8
         return rng.rand(203, 12), rng.rand(157, 12), 7, 4, CASES, {}, None
+    if name == "family":
+        return rng.rand(150, 9).astype(np.float32), rng.rand(113, 9).astype(np.float32), 7, 4, FAMILY, {}, None
     if name == "k50":           # the C3 candidate count: world x K = 100 ... 400 entries per merged row
         return rng.rand(431, 10), rng.rand(333, 10), 50, 50, SEVEN, {}, None
     if name == "ties":          # integer data: all arithmetic exact, MANY exact distance ties across the shards
@@ -75,10 +87,12 @@ def _worker(rank, world, port, scenario, q):
             for a, v in attrs.items():
                 setattr(eng, a, v)
             comm = Comm()
-            sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": metric}, hubness=hub, hubness_kwargs=kw, engine=eng, comm=comm)
+            metric, p = (metric, 2) if isinstance(metric, str) else metric
+            sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": metric, "p": p}, hubness=hub, hubness_kwargs=kw, engine=eng, comm=comm)
             sk.fit(source[b:b + c], None if single else (target if rank == 0 else None), single_source=single)
             d, i = sk.kneighbors(k)
-            od, oi = O.kiez_pipeline(source, None if single else target, K, k, metric, 2, hub, kw)
+            od, oi = O.kiez_pipeline(source, None if single else target, K, k, metric, p, hub, kw)
+            metric = O.canonical_metric(metric, p)
             want = (hub is not None and not single) if expect_shared is None else (expect_shared and hub is not None)
             assert bool(getattr(sk, "shared", False)) == want, (name, sk.shared, want)
             tr = comm.traffic()
@@ -133,6 +147,11 @@ def _run(world, scenario):
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_pipeline_gloo_every_kind(world):
     _run(world, "base")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pipeline_gloo_minkowski_family(world):
+    _run(world, "family")
 
 
 @pytest.mark.parametrize("world", [2, 8])

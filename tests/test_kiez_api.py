@@ -45,17 +45,32 @@ def test_n_candidates_wrong_type():
 def test_dis_sim_local_wrong():
     with pytest.raises(ValueError, match="only supports"):
         Kiez(algorithm=SklearnNN(p=2, metric="cosine"), hubness="DisSimLocal")
-    nn = SklearnNN()
-    nn.p = 1   # the reference checks nn_algo.p (dis_sim.py:51-55); the GPU backend itself rejects p != 2 earlier
+    with pytest.raises(ValueError, match="only supports"):   # the reference's own case (tests/hubness_reduction/test_dis_sim.py)
+        DisSimLocal(nn_algo=SklearnNN(p=1))
     with pytest.raises(ValueError, match="only supports"):
-        DisSimLocal(nn_algo=nn)
+        Kiez(algorithm=SklearnNN(metric="manhattan"), hubness="DisSimLocal")
 
 
 def test_unsupported_metric_fails_loudly():
     with pytest.raises(ValueError, match="not implemented"):
-        SklearnNN(p=1)
-    with pytest.raises(ValueError, match="not implemented"):
-        SklearnNN(metric="manhattan")
+        SklearnNN(metric="canberra")
+    with pytest.raises(ValueError, match="p >= 1"):
+        SklearnNN(p=0.5)
+    with pytest.raises(NotImplementedError, match="metric_params"):
+        SklearnNN(p=3, metric_params={"w": [1.0, 2.0]})
+
+
+def test_metric_aliases_follow_scikit_learn():
+    """DistanceMetric.get_metric: minkowski with p = 1 / 2 / inf IS manhattan / euclidean / chebyshev; l1 = cityblock = manhattan;
+    `p` is ignored for every other metric name."""
+    from kiez_amd.neighbors import canonical_metric
+    assert canonical_metric("minkowski", 2) == canonical_metric("l2") == canonical_metric("euclidean", 7) == "euclidean"
+    assert canonical_metric("minkowski", 1) == canonical_metric("l1") == canonical_metric("cityblock") == "manhattan"
+    assert canonical_metric("minkowski", float("inf")) == canonical_metric("chebyshev") == "chebyshev"
+    assert canonical_metric("minkowski", 3) == "minkowski[3.0]" and canonical_metric("minkowski", 1.5) == "minkowski[1.5]"
+    from kiez_amd._native import split_metric
+    assert split_metric("minkowski[1.5]") == ("minkowski", 1.5) and split_metric("cosine") == ("cosine", None)
+    assert set(SklearnNN.valid_metrics) >= {"manhattan", "chebyshev", "minkowski", "cosine", "euclidean", "sqeuclidean"}
 
 
 def test_dis_sim_local_squaring():

@@ -46,10 +46,15 @@ CLS = {None: R.NoHubnessReduction, "CSLS": R.CSLS, "MutualProximity": R.MutualPr
        "LocalScaling": R.LocalScaling, "DisSimLocal": R.DisSimLocal}
 
 
+ONLY = [a for a in os.environ.get("KZ_GOLDEN_ONLY", "").split(",") if a]   # (regenerate only the cases whose name starts so)
+
+
 def run_case(name, source, target, K, ks, metric, p=2, hubs=None, sk_algorithm="auto"):
     """Run the reference for every hubness setting; save one npz."""
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
     out = {"source": source, "K": np.int64(K), "ks": np.array([(-1 if k is None else k) for k in ks]),
-           "metric": np.array(metric), "p": np.int64(p)}
+           "metric": np.array(metric), "p": np.int64(p) if p == int(p) else np.float64(p)}
     if target is not None:
         out["target"] = target
     for tag, hname, kw in HUBNESS:
@@ -109,6 +114,20 @@ def main():
              sk_algorithm="brute")
     run_case("cosine_single", s32.astype(np.float64), None, 12, [12, 5], "cosine",
              hubs={"none", "csls", "mp_empiric"}, sk_algorithm="brute")
+    # 5b. the rest of the Minkowski family (SklearnNN.valid_metrics, sklearn_nearest_neighbors.py:49): scikit-learn's generic
+    #     DistanceMetric path -- manhattan (and its aliases), chebyshev, minkowski with p = 3 / 1.5; DisSimLocal raises
+    rng = np.random.RandomState(21)
+    s, t = rng.rand(120, 20), rng.rand(90, 20)
+    run_case("f64_manhattan", s, t, 10, [10, 3], "manhattan", sk_algorithm="brute")
+    s32, t32 = rng.randn(150, 24).astype(np.float32), rng.randn(131, 24).astype(np.float32)
+    run_case("f32_chebyshev_single", s32, None, 8, [8, 2], "chebyshev", hubs={"none", "csls", "ls"}, sk_algorithm="brute")
+    run_case("f32_minkowski_p3", s32, t32, 10, [10, 4], "minkowski", p=3, hubs={"none", "csls", "mp_empiric", "nicdm", "dsl"},
+             sk_algorithm="brute")
+    run_case("f64_minkowski_p1_5_single", s, None, 6, [6, 1], "minkowski", p=1.5, hubs={"none", "mp_normal"},
+             sk_algorithm="brute")
+    run_case("f32_cityblock", s32, t32, 5, [5], "cityblock", hubs={"none", "csls"})
+    if ONLY:
+        return
     # 6. HubnessReduction._sort (kiez/hubness_reduction/base.py:72-87): the reference's own test input
     #    (tests/hubness_reduction/test_hubness_base.py:17-21) plus tie-heavy rows
     rng = np.random.default_rng(42)
