@@ -40,9 +40,9 @@ enum { KZ_OK = 0, KZ_ERR_INVALID = 1, KZ_ERR_HIP = 2, KZ_ERR_UNSUPPORTED = 3, KZ
 enum { KZ_F32 = 0, KZ_F64 = 1 };
 /* metrics of the exact backend; minkowski(p=2) == euclidean (sklearn_nearest_neighbors.py:51-65).  0 .. 2 run the fused MFMA
  * kernels; 3 .. 5 (the rest of the Minkowski family: manhattan = cityblock = l1, chebyshev, minkowski with any p >= 1 set by
- * kz_matrix_set_minkowski_p) run entirely on the exact float64 kernels -- correct and slow, as scikit-learn's own generic
- * DistanceMetric path is (sklearn/metrics/_dist_metrics.pyx.tp: |x_j - y_j| in the input dtype, float64 accumulation, result
- * rounded to the input dtype) */
+ * kz_matrix_set_minkowski_p) have no inner-product form: a register-tiled VALU kernel computes scikit-learn's generic
+ * DistanceMetric expression (sklearn/metrics/_dist_metrics.pyx.tp: |x_j - y_j| in the input dtype, float64 accumulation in
+ * feature order, result rounded to the input dtype), the exact float64 selection kernels pick the neighbours */
 enum { KZ_EUCLIDEAN = 0, KZ_SQEUCLIDEAN = 1, KZ_COSINE = 2, KZ_MANHATTAN = 3, KZ_CHEBYSHEV = 4, KZ_MINKOWSKI = 5 };
 
 typedef struct kz_ctx kz_ctx;       /* one GPU + one HIP stream + scratch                                   */

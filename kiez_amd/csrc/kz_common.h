@@ -270,43 +270,51 @@ __device__ __forceinline__ double kz_wave_dot_normalized(const T* __restrict__ a
 // kz_knn_finalize_kernel, the exact fallback and kz_pair_values all evaluate THIS expression on the canonical dot product.
 // Minkowski family beyond p = 2 (KZ_MANHATTAN, KZ_CHEBYSHEV, KZ_MINKOWSKI): scikit-learn's generic DistanceMetric
 // (sklearn/metrics/_dist_metrics.pyx.tp: ManhattanDistance / ChebyshevDistance / MinkowskiDistance): the difference x_j - y_j in
-// the INPUT dtype, |.| (to the power p) accumulated in float64, the result -- the ranking value: sum |.|, max |.|, sum |.|^p --
-// rounded to the input dtype.  Same lane layout as kz_wave_dot (lane l owns elements 4l .. 4l+3 of every 256-element chunk), a
-// butterfly sum / max; scikit-learn accumulates in feature order, so float64 inputs agree to rounding (1e-15 relative), float32
-// inputs after the float32 rounding of the result almost always exactly.
-template <typename T>
-__device__ __forceinline__ double kz_wave_minkowski(const T* __restrict__ a, const T* __restrict__ b, int d, int metric, double p, int lane) {
-    const bool vec = kz_row_vec_ok(a, d) && kz_row_vec_ok(b, d);
+// the INPUT dtype, |.| (to the power p) accumulated in float64 IN FEATURE ORDER, the result -- the ranking value: sum |.|, max |.|,
+// sum |.|^p -- rounded to the input dtype.  Every kernel that evaluates the family (the tiled distance kernel of kz_knn.hip,
+// kz_pair_values) adds the terms of a pair in this order, one thread per pair: manhattan and chebyshev values are scikit-learn's
+// bit for bit, minkowski's to the last bit of pow().
+// One term.  p_int > 0: p is a small integer, the power is a product chain (float32 inputs, p <= 4: one rounding, as a
+// correctly rounded pow); else pow().
+template <typename T, int METRIC, bool CHAIN_ONLY = false>
+__device__ __forceinline__ double kz_family_term(T x, T y, double p, int p_int) {
+    const T df = x - y;
+    const double a = fabs((double)df);
+    if (METRIC != KZ_MINKOWSKI) return a;
+    if (CHAIN_ONLY || p_int > 0) {
+        double r = a;
+        for (int i = 1; i < p_int; ++i) r *= a;
+        return r;
+    }
+    return pow(a, p);
+}
+template <int METRIC>
+__device__ __forceinline__ double kz_family_add(double acc, double term) {
+    return METRIC == KZ_CHEBYSHEV ? fmax(acc, term) : acc + term;
+}
+__host__ __device__ __forceinline__ int kz_family_p_int(int metric, double p) {
+    return (metric == KZ_MINKOWSKI && p >= 2.0 && p <= 8.0 && p == (double)(int)p) ? (int)p : 0;
+}
+template <typename T, int METRIC>
+__device__ __forceinline__ double kz_family_value_seq_m(const T* __restrict__ a, const T* __restrict__ b, int d, double p, int p_int) {
     double acc = 0.0;
-    for (int k0 = 4 * lane; k0 < d; k0 += 256) {
-        double x[4], y[4];
-        kz_row4(a, k0, d, vec, x);
-        kz_row4(b, k0, d, vec, y);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double df = sizeof(T) == 4 ? (double)fabsf((float)x[u] - (float)y[u]) : fabs(x[u] - y[u]);
-            if (metric == KZ_CHEBYSHEV)
-                acc = fmax(acc, df);
-            else if (metric == KZ_MANHATTAN)
-                acc += df;
-            else
-                acc += pow(df, p);
-        }
-    }
-    if (metric == KZ_CHEBYSHEV) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc = fmax(acc, __shfl_xor(acc, off, 64));
-    } else {
-        acc = kz_wave_sum(acc);
-    }
+    for (int j = 0; j < d; ++j) acc = kz_family_add<METRIC>(acc, kz_family_term<T, METRIC>(a[j], b[j], p, p_int));
     return sizeof(T) == 4 ? (double)(float)acc : acc;
+}
+// (one thread, one pair)
+template <typename T>
+__device__ __forceinline__ double kz_family_value_seq(const T* __restrict__ a, const T* __restrict__ b, int d, int metric, double p) {
+    const int p_int = kz_family_p_int(metric, p);
+    if (metric == KZ_MANHATTAN) return kz_family_value_seq_m<T, KZ_MANHATTAN>(a, b, d, p, p_int);
+    if (metric == KZ_CHEBYSHEV) return kz_family_value_seq_m<T, KZ_CHEBYSHEV>(a, b, d, p, p_int);
+    return kz_family_value_seq_m<T, KZ_MINKOWSKI>(a, b, d, p, p_int);
 }
 
 // The exact float64 value the search ranks an index row by (squared euclidean distance / cosine distance / the Minkowski family's
 // reduced distance): the re-rank of kz_knn_finalize_kernel, the exact fallback and kz_pair_values all evaluate THIS expression.
 template <typename T>
 __device__ __forceinline__ double kz_exact_value(const T* q, const T* y, double qs, double ys, int d, int metric, int lane, double p = 2.0) {
-    if (metric >= KZ_MANHATTAN) return kz_wave_minkowski<T>(q, y, d, metric, p, lane);
+    if (metric >= KZ_MANHATTAN) return kz_family_value_seq<T>(q, y, d, metric, p);   // (every lane the whole pair: no fused kernel ranks by this metric)
     if (metric == KZ_COSINE) {
         const double sim = kz_wave_dot_normalized(q, qs, y, ys, d, lane);
         double v = 1.0 - sim;  // sklearn cosine_distances: S *= -1; S += 1; clip(0, 2)

@@ -900,6 +900,92 @@ __global__ __launch_bounds__(256) void kz_exact_dist_kernel(const int* __restric
     if (lane == 0) vals[(int64_t)b * n_i + i] = v;
 }
 
+// The Minkowski family beyond p = 2 (KZ_MANHATTAN, KZ_CHEBYSHEV, KZ_MINKOWSKI): no inner-product form, hence no MFMA -- a
+// register-tiled VALU kernel.  A workgroup of 256 threads owns 64 queries x 64 index rows, a thread 4 x 4 pairs; the rows are
+// staged through LDS DK features at a time, transposed ([feature][row]: a thread reads its four query values and its four index
+// values of a feature as one 16- / 32-byte LDS read each).  Per pair and feature: subtract in the input dtype, |.| into float64
+// (the conversion carries the abs modifier), add -- three VALU operations; every thread adds the terms of its pairs in feature
+// order (kz_common.h: kz_family_term / kz_family_add), which is scikit-learn's order.  VALU-bound: 15 k x 15 k x 300 float32,
+// manhattan: see DESIGN section 9.  Output: the same [batch][n_i] float64 value matrix kz_exact_dist_kernel writes.
+template <typename T, int METRIC, int DK, bool CHAIN_ONLY>
+__global__ __launch_bounds__(256) void kz_family_dist_kernel(const int* __restrict__ fail_list, int batch0, int nb, int64_t q_begin,
+                                                             const T* __restrict__ qraw, const T* __restrict__ yraw, int64_t n_i, int d,
+                                                             double p, int p_int, double* __restrict__ vals) {
+    __shared__ __attribute__((aligned(32))) T sQ[DK][64];
+    __shared__ __attribute__((aligned(32))) T sY[DK][64];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int64_t y0 = (int64_t)blockIdx.x * 64;
+    const int b0 = blockIdx.y * 64;
+    // staging: thread t copies DK / 4 consecutive features of row (t & 63) of both tiles (rows past the end: the last row again)
+    const int lrow = t & 63, lseg = (t >> 6) * (DK / 4);
+    const int bq = b0 + lrow < nb ? b0 + lrow : nb - 1;
+    const T* __restrict__ qp = qraw + (q_begin + fail_list[batch0 + bq]) * (int64_t)d;
+    const T* __restrict__ yp = yraw + (y0 + lrow < n_i ? y0 + lrow : n_i - 1) * (int64_t)d;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
+    for (int k0 = 0; k0 < d; k0 += DK) {
+        T rq[DK / 4], ry[DK / 4];
+#pragma unroll
+        for (int u = 0; u < DK / 4; ++u) {
+            const int k = k0 + lseg + u;
+            rq[u] = k < d ? qp[k] : (T)0;
+            ry[u] = k < d ? yp[k] : (T)0;   // (|0 - 0| = 0 changes no sum and no maximum)
+        }
+        __syncthreads();   // (the previous chunk has been read)
+#pragma unroll
+        for (int u = 0; u < DK / 4; ++u) {
+            sQ[lseg + u][lrow] = rq[u];
+            sY[lseg + u][lrow] = ry[u];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < DK; ++j) {
+            T q4[4], y4[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                q4[a] = sQ[j][ty * 4 + a];
+                y4[a] = sY[j][tx * 4 + a];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = kz_family_add<METRIC>(acc[a][c], kz_family_term<T, METRIC, CHAIN_ONLY>(q4[a], y4[c], p, p_int));
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int b = b0 + ty * 4 + a;
+        if (b >= nb) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t i = y0 + tx * 4 + c;
+            if (i < n_i) vals[(int64_t)b * n_i + i] = sizeof(T) == 4 ? (double)(float)acc[a][c] : acc[a][c];
+        }
+    }
+}
+template <typename T>
+static void kz_launch_family_dist(kz_ctx* ctx, const int* fl, int b0, int nb, int64_t cq_begin, const kz_matrix* query, const kz_matrix* index,
+                                  double* vals) {
+    constexpr int DK = sizeof(T) == 4 ? 32 : 16;
+    const dim3 grid((unsigned)((index->n + 63) / 64), (unsigned)((nb + 63) / 64));
+    const int p_int = kz_family_p_int(index->metric, index->mink_p);
+#define KZ_FAMILY_LAUNCH(M, C)                                                                                                          \
+    hipLaunchKernelGGL((kz_family_dist_kernel<T, M, DK, C>), grid, dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin, (const T*)query->raw, \
+                       (const T*)index->raw, index->n, (int)index->d, index->mink_p, p_int, vals)
+    if (index->metric == KZ_MANHATTAN)
+        KZ_FAMILY_LAUNCH(KZ_MANHATTAN, false);
+    else if (index->metric == KZ_CHEBYSHEV)
+        KZ_FAMILY_LAUNCH(KZ_CHEBYSHEV, false);
+    else if (p_int > 0)
+        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, true);    // (integer exponent 2 .. 8: a product chain, no pow() in the kernel)
+    else
+        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, false);
+#undef KZ_FAMILY_LAUNCH
+}
+
 // First level of the exact selection on a long row: the k_eff smallest (value, index row) pairs of every CHUNK of KZ_EXACT_CHUNK
 // values (the smallest k_eff of the row are among the smallest k_eff of their chunks); kz_exact_select_kernel then picks from
 // n_chunks x k_eff survivors instead of passing k_eff times over the whole row with one workgroup (1 M index rows, k = 10: 2 ms
@@ -2145,9 +2231,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             for (int b0 = 0; b0 < n_fail; b0 += (int)batch) {
                 const int nb = (n_fail - b0 < batch) ? (n_fail - b0) : (int)batch;
                 if (index->dtype == KZ_F32) {
-                    hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
-                                       cq_begin, (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn,
-                                       index->n, (int)index->d, metric, index->mink_p, (double*)vals);
+                    if (no_gemm_form)
+                        kz_launch_family_dist<float>(ctx, fl, b0, nb, cq_begin, query, index, (double*)vals);
+                    else
+                        hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
+                                           cq_begin, (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn,
+                                           index->n, (int)index->d, metric, index->mink_p, (double*)vals);
                     if (two_level)
                         hipLaunchKernelGGL(kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0, ctx->stream, (const double*)vals, index->n, k_sel,
                                            n_chunks, cand_v, cand_i);
@@ -2156,9 +2245,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                                        two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p,
                                        fp.out_dist, fp.out_ind);
                 } else {
-                    hipLaunchKernelGGL(kz_exact_dist_kernel<double>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
-                                       cq_begin, (const double*)query->raw, (const double*)index->raw, query->sqn, index->sqn,
-                                       index->n, (int)index->d, metric, index->mink_p, (double*)vals);
+                    if (no_gemm_form)
+                        kz_launch_family_dist<double>(ctx, fl, b0, nb, cq_begin, query, index, (double*)vals);
+                    else
+                        hipLaunchKernelGGL(kz_exact_dist_kernel<double>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
+                                           cq_begin, (const double*)query->raw, (const double*)index->raw, query->sqn, index->sqn,
+                                           index->n, (int)index->d, metric, index->mink_p, (double*)vals);
                     if (two_level)
                         hipLaunchKernelGGL(kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0, ctx->stream, (const double*)vals, index->n, k_sel,
                                            n_chunks, cand_v, cand_i);

@@ -22,6 +22,15 @@ __global__ __launch_bounds__(256) void kz_pair_values_kernel(const T* __restrict
     const int64_t qrow = q_begin + r;
     const T* q = qraw + qrow * (int64_t)d;
     const double qs = qsqn[qrow];
+    if (metric >= KZ_MANHATTAN) {
+        // the Minkowski family: one lane per pair, terms in feature order (kz_common.h: kz_family_value_seq) -- the order of the
+        // tiled distance kernel the search ranked by, so that the values that travel between GPUs ARE the search's values
+        for (int c = threadIdx.x & 63; c < K; c += 64) {
+            const int64_t yi = ind[r * (int64_t)K + c];
+            val[r * (int64_t)K + c] = (yi >= 0 && yi < n_i) ? kz_family_value_seq<T>(q, yraw + yi * (int64_t)d, d, metric, p) : INFINITY;
+        }
+        return;
+    }
     for (int c = 0; c < K; ++c) {
         const int64_t yi = ind[r * (int64_t)K + c];   // wave-uniform
         double v = INFINITY;

@@ -157,7 +157,7 @@ def canonical_metric(metric: str, p=2) -> str:
 
     scikit-learn's own aliases (sklearn/metrics/_dist_metrics.pyx.tp, DistanceMetric.get_metric): minkowski with p = 1 / 2 / inf IS
     manhattan / euclidean / chebyshev; `p` is ignored for every other metric name.  Euclidean, squared euclidean and cosine run the
-    fused MFMA kernels; manhattan, chebyshev and minkowski(p) have no inner-product form and run on the exact float64 kernels."""
+    fused MFMA kernels; manhattan, chebyshev and minkowski(p) have no inner-product form and run on a register-tiled VALU kernel + the exact selection."""
     if metric == "minkowski":
         if not isinstance(p, (int, float, np.integer, np.floating)) or isinstance(p, bool) or not p >= 1:
             raise ValueError(f"metric='minkowski' needs p >= 1 on the MI355X exact backend (got p={p!r})")

@@ -1,6 +1,6 @@
 """The rest of SklearnNN.valid_metrics' Minkowski family (kiez/neighbors/exact/sklearn_nearest_neighbors.py:49 -> scikit-learn's
-VALID_METRICS): manhattan = cityblock = l1, chebyshev, minkowski with any p >= 1.  No inner-product form, so the call runs on the
-exact float64 kernels (kz_knn.hip: kz_exact_dist_kernel / kz_exact_select_kernel) -- against the oracle's restatement of
+VALID_METRICS): manhattan = cityblock = l1, chebyshev, minkowski with any p >= 1.  No inner-product form, so the call runs on a
+register-tiled VALU kernel and the exact float64 selection (kz_knn.hip: kz_family_dist_kernel / kz_exact_select_kernel) -- against the oracle's restatement of
 scikit-learn's DistanceMetric32 / 64 (pinned by tests/golden/f64_manhattan.npz ... f32_cityblock.npz, generated from the real
 reference): indices bit-exact, distances to rounding.  `pytest -m gpu`."""
 import warnings
@@ -10,8 +10,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-# float64: the device sums a row's terms lane-parallel + butterfly, scikit-learn in feature order: 1e-13 relative is rounding;
-# float32 inputs: the ranking value is ROUNDED to float32 (DistanceMetric32), which hides that almost always
+# manhattan / chebyshev: the device adds a pair's terms in feature order like scikit-learn -- the same values; minkowski[p]: pow()
+# (or a product chain for integer p) against libm's: last-bit differences of the float64 sum, 1e-13 relative is generous;
+# float32 inputs: the ranking value is ROUNDED to float32 (DistanceMetric32), a last-bit difference can move it by one float32 ulp
 RTOL64, RTOL32 = 1e-13, 2e-7
 
 
@@ -54,6 +55,9 @@ def test_knn_against_the_oracle(metric, p, dtype):
         assert _rank_tolerant_equal(od, oi, dd.numpy(), ii.numpy(), rtol), (metric, p, dtype, d)
         assert (ii.numpy() == oi).mean() > 0.999
         np.testing.assert_allclose(dd.numpy(), od, rtol=rtol, atol=0)
+        if mc in ("manhattan", "chebyshev"):     # same terms, same order of additions as scikit-learn: bit for bit
+            np.testing.assert_array_equal(ii.numpy(), oi)
+            np.testing.assert_array_equal(dd.numpy(), od)
 
 
 @pytest.mark.parametrize("metric,p", [("manhattan", 2), ("minkowski", 3), ("chebyshev", 2)])
