@@ -32,3 +32,10 @@ def test_tiers_agree_on_random_shapes(seed):
 def test_shared_sweep_equals_two_searches_on_random_shapes(seed):
     out = _run("fuzz_dual.py", 20, seed)
     assert "cases 20 bad 0" in out
+
+
+def test_minkowski_family_on_random_shapes():
+    """tools/fuzz_family.py: manhattan / chebyshev / minkowski[p] (the register-tiled VALU kernel + exact selection) against the
+    oracle's restatement of scikit-learn's DistanceMetric32 / 64 -- ragged sizes, ties, self queries."""
+    out = _run("fuzz_family.py", 60, 505)
+    assert "cases 60 bad 0" in out
