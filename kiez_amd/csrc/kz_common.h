@@ -12,6 +12,7 @@
 #define KZ_TILE 128   // rows per packed tile (= MFMA block tile edge)
 #define KZ_KSLICE 16  // k elements staged per LDS slice (4 k-groups of 4)
 #define KZ_LIVE_MAX 1024
+#define KZ_POOL_SLOTS 256   // cached released buffers (a shared-sweep fit + kneighbors releases ~90: 64 slots evicted ~28 a step -- hipFree, a device-wide sync each)
 
 struct kz_ctx {
     int device;
@@ -72,7 +73,7 @@ struct kz_ctx {
     int h_stage_flip; // which half of h_stage the last pass used (kz_prepare_pass)
     // stream-ordered free list: buffers released by kz_free / kz_matrix_destroy are reused by later allocations of a
     // similar size instead of going through hipFree (device-wide sync) + hipMalloc on every fit()
-    struct { void* ptr; size_t bytes; } pool[64];
+    struct { void* ptr; size_t bytes; } pool[KZ_POOL_SLOTS];
     int pool_n;
     size_t pool_bytes;
     void* live_ptr[KZ_LIVE_MAX];   // capacity of every buffer handed out (so kz_free needs no size)

@@ -248,7 +248,7 @@ void kz_pool_free(kz_ctx* c, void* ptr, size_t /*bytes*/) {
         // entries go -- a cache that refuses new buffers once stale ones fill it turns every call into hipMalloc + hipFree of
         // gigabytes (seen: 260 ms per fit after other workloads had run in the same process)
         bool synced = false;
-        while (c->pool_n > 0 && (c->pool_n >= 64 || c->pool_bytes + cap > KZ_POOL_MAX_BYTES)) {
+        while (c->pool_n > 0 && (c->pool_n >= KZ_POOL_SLOTS || c->pool_bytes + cap > KZ_POOL_MAX_BYTES)) {
             if (!synced) kz_sync_streams(c);
             synced = true;
             (void)hipFree(c->pool[0].ptr);
