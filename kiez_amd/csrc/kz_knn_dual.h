@@ -449,6 +449,20 @@ static int kz_knn_dual_separately(kz_ctx* ctx, kz_matrix* a, kz_matrix* b, int k
 // the slower sweep) + P_fail |B| c_row (rows with fewer than k events, searched again; c_row = three times a row's share of a
 // sweep: small batches run well below the sweep's rate); P_fail = P(Gamma(r) < (k - r + 1) / (s - 1)) -- the lower tail of the
 // negative binomial count of non-sample rows above the r-th best of an s-fold sample.  Ranks with P_fail > 1e-3 are out.
+// P(a row gets fewer than k events) at threshold rank r of an st-fold sample: P(Gamma(r) < (k - r + 1) / (st - 1))
+static inline double kz_dual_p_fail(int k, int r, double st) {
+    if (r >= k + 1) return 0.0;
+    const double x = (double)(k - r + 1) / (st - 1.0);   // Gamma(r, 1) must reach this
+    // P(Gamma(r) < x) = e^-x sum_{j >= r} x^j / j!
+    double term = exp(-x);
+    for (int j = 1; j <= r; ++j) term *= x / j;
+    double sum = 0.0;
+    for (int j = r; j < r + 200 && term > 1e-300; ++j) {
+        sum += term;
+        term *= x / (j + 1);
+    }
+    return sum < 1.0 ? sum : 1.0;
+}
 static inline int kz_dual_pick_rank(int k, int rank_safe, double t_sweep_ms, double a_n, double b_n) {
     const double c_ev = 0.10e-6;   // ms per event (kz_knn_dual's stride model)
     auto stride_of = [&](int r) {
@@ -457,19 +471,7 @@ static inline int kz_dual_pick_rank(int k, int rank_safe, double t_sweep_ms, dou
         const double s_max = floor(4096.0 / ((double)r + 7.0 * sqrt((double)r) + 1.0));
         return st > s_max ? s_max : st;
     };
-    auto p_fail = [&](int r, double st) {
-        if (r >= k + 1) return 0.0;
-        const double x = (double)(k - r + 1) / (st - 1.0);   // Gamma(r, 1) must reach this
-        // P(Gamma(r) < x) = e^-x sum_{j >= r} x^j / j!
-        double term = exp(-x);
-        for (int j = 1; j <= r; ++j) term *= x / j;
-        double sum = 0.0;
-        for (int j = r; j < r + 200 && term > 1e-300; ++j) {
-            sum += term;
-            term *= x / (j + 1);
-        }
-        return sum < 1.0 ? sum : 1.0;
-    };
+    auto p_fail = [&](int r, double st) { return kz_dual_p_fail(k, r, st); };
     const double c_row = 3.0 * t_sweep_ms / a_n;
     int best = rank_safe;
     double best_cost = 1e300;
@@ -643,6 +645,18 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         //  186.8 ms per step -- every event also slows the sweep itself, 117.6 -> 126.4 ms; 250k x 1M, k = 10: flat from 16 to 28)
         const double s_opt = sqrt(t_ms / ((double)b->n * rank * (small_sweep ? 0.20e-6 : 0.10e-6)));   // (small sweeps: an event costs relatively more)
         stride = s_opt < 4.0 ? 4 : (s_opt > 32.0 ? 32 : (int)(s_opt + 0.5));
+        // With the NESTED sample (below; round 5) the sample rows are no longer swept twice: the sample sweep costs little more than
+        // it saves the main sweep, while an event costs what it did -- the balance moves to HALF the stride (twice the sample, half
+        // the events), as long as the rank's share of rows that end up short of k events stays below 1e-3 (kz_dual_p_fail).
+        // Same box, rank 8, ms per step: ns stride 9 / 10 / 11 / 12 / 13 / 14 / 16 / 18 / 23 (the old choice) -> 98.5 / 98.4 / 98.0 /
+        // 97.5 / 98.1 / 97.8 / 98.6 / 99.6 / 99.8; C4's share 10 / 12 / 14 / 16 / 28 -> 147.3 / 146.1 / 148.2 / 147.5 / 149.7; gmm
+        // (200k x 200k x 300) 6 / 8 / 10 / 12 -> 34.0 / 34.7 / 34.9 / 35.7; C3 (rank 12) 8 / 10 / 13 / 16 -> 127.7 / 124.9 / 125.8 / 126.8.
+        if (ctx->dual_nested && ctx->dual_deal && !small_sweep && b->n <= kz_rows_per_chunk(ctx, KP, false) && t_ms / stride >= 2.0) {
+            int half = (int)(0.5 * (s_opt > 32.0 ? 32.0 : s_opt) + 0.5);
+            if (half < 4) half = 4;
+            while (half < stride && kz_dual_p_fail(k, rank, (double)half) > 1e-3) ++half;
+            if (half < stride) stride = half;
+        }
     }
     // (a row's event buffer -- k stride + 7 sqrt(k) stride entries -- is selected from LDS, 8 B per entry and four rows per
     //  workgroup: at most 4096 entries)
