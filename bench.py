@@ -711,7 +711,11 @@ def main():
                              # `frac` count what this kernel executes
                              reference_work_tflops=(s["achieved"] * (1 + s["shared_sweeps"] / max(s["n_launch"], 1))),
                              note=("algorithmic flop = 2 n_q n_i d per launch, counted ONCE for a launch that serves both search "
-                                   "directions (kz_knn_dual): the reference evaluates that distance matrix twice")),
+                                   "directions (kz_knn_dual): the reference evaluates that distance matrix twice; with the nested sample "
+                                   "(large shared sweeps) a launch is TWO dispatches that together visit every pair once -- the sample "
+                                   "sweep (kz_knn_cand_h_kernel<..,true,..>, 1 / stride of the query rows) and the main sweep "
+                                   "(kz_knn_cand_h64_kernel or kz_knn_cand_h_kernel, the other rows): avg_launch_ms is the sum of their "
+                                   "rocprof averages; traffic / clock / pipe-busy are the main sweep's")),
             "shared_sweep": {"launches": s["shared_sweeps"], "reverse_extra_ms_per_step": s["reverse_extra_ms_per_step"],
                              "reverse_events_per_row": s["reverse_events_per_row"], "reverse_escalated_rows": s["reverse_escalated_rows"]},
             "certification_fallback_rows": s["fallback_rows"],

@@ -17,4 +17,11 @@ for w in ${PMC_WL:-ns c3 c4s c1 c2 hard}; do
   cp $O/pmc_$w/summary.jsonl $P/${R}_${w}_pmc.jsonl
   echo "pmc $w: $(wc -l < $P/${R}_${w}_pmc.jsonl) records"
 done
+# the step's kernels in start order + idle gaps (tools/gaps.py), the Minkowski-family timing beside scikit-learn
+for w in ${SEQ_WL:-ns c3}; do
+  timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/kt_$w -- python3 bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-others --no-check > /dev/null 2> $O/kt_$w.err
+  f=$(find $O/kt_$w -name "*kernel_trace.csv" | head -1)
+  python3 tools/gaps.py "$f" 15 $P/${R}_${w}_step_sequence.txt > $P/${R}_${w}_step_gaps.txt; tail -1 $P/${R}_${w}_step_gaps.txt; rm -rf $O/kt_$w
+done
+timeout 900 python3 tools/minkowski_time.py 15000 300 2>&1 | grep -v amdgpu.ids > $P/${R}_minkowski_time.log; head -3 $P/${R}_minkowski_time.log
 ls -la $P
