@@ -31,11 +31,11 @@ def test_library_exports_every_declared_symbol():
 def test_code_object_is_gfx950_only():
     import re
     so = (ROOT / "kiez_amd" / "libkiez_amd.so").read_bytes()
-    # the offload bundle's entry ids name the targets of the embedded code objects (plain arch names also occur as strings
-    # of rocPRIM's host-side tuning tables, which say nothing about what was compiled)
+    # the offload bundle's entry ids name the targets of the embedded code objects
     targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", so))
     assert targets == {b"gfx950"}, targets
     assert b"sm_90" not in so and b"nvptx" not in so
+    assert b"rocprim" not in so.lower() and b"hipcub" not in so.lower()     # every device kernel of the library is its own
 
 
 def test_no_gpu_means_loud_failure(have_gpu):
