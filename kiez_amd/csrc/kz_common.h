@@ -277,12 +277,15 @@ __device__ __forceinline__ double kz_wave_dot_normalized(const T* __restrict__ a
 // bit for bit, minkowski's to the last bit of pow().
 // One term.  p_int > 0: p is a small integer, the power is a product chain (float32 inputs, p <= 4: one rounding, as a
 // correctly rounded pow); else pow().
-template <typename T, int METRIC, bool CHAIN_ONLY = false>
+// CHAIN: -1 = decide at run time (p_int > 0: chain, else pow); 0 = a chain of run-time length p_int; 3 / 4 = that chain, unrolled
+template <typename T, int METRIC, int CHAIN = -1>
 __device__ __forceinline__ double kz_family_term(T x, T y, double p, int p_int) {
     const T df = x - y;
     const double a = fabs((double)df);
     if (METRIC != KZ_MINKOWSKI) return a;
-    if (CHAIN_ONLY || p_int > 0) {
+    if (CHAIN == 3) return (a * a) * a;            // (the order of the run-time chain: ((a a) a) a ...)
+    if (CHAIN == 4) return ((a * a) * a) * a;
+    if (CHAIN == 0 || p_int > 0) {
         double r = a;
         for (int i = 1; i < p_int; ++i) r *= a;
         return r;

@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void kz_exact_dist_kernel(const int* __restric
 // (the conversion carries the abs modifier), add -- three VALU operations; every thread adds the terms of its pairs in feature
 // order (kz_common.h: kz_family_term / kz_family_add), which is scikit-learn's order.  VALU-bound: 15 k x 15 k x 300 float32,
 // manhattan: see DESIGN section 9.  Output: the same [batch][n_i] float64 value matrix kz_exact_dist_kernel writes.
-template <typename T, int METRIC, int DK, bool CHAIN_ONLY>
+template <typename T, int METRIC, int DK, int CHAIN>
 __global__ __launch_bounds__(256) void kz_family_dist_kernel(const int* __restrict__ fail_list, int batch0, int nb, int64_t q_begin,
                                                              const T* __restrict__ qraw, const T* __restrict__ yraw, int64_t n_i, int d,
                                                              double p, int p_int, double* __restrict__ vals) {
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) void kz_family_dist_kernel(const int* __restri
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[a][c] = kz_family_add<METRIC>(acc[a][c], kz_family_term<T, METRIC, CHAIN_ONLY>(q4[a], y4[c], p, p_int));
+                for (int c = 0; c < 4; ++c) acc[a][c] = kz_family_add<METRIC>(acc[a][c], kz_family_term<T, METRIC, CHAIN>(q4[a], y4[c], p, p_int));
         }
     }
 #pragma unroll
@@ -976,13 +976,17 @@ static void kz_launch_family_dist(kz_ctx* ctx, const int* fl, int b0, int nb, in
     hipLaunchKernelGGL((kz_family_dist_kernel<T, M, DK, C>), grid, dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin, (const T*)query->raw, \
                        (const T*)index->raw, index->n, (int)index->d, index->mink_p, p_int, vals)
     if (index->metric == KZ_MANHATTAN)
-        KZ_FAMILY_LAUNCH(KZ_MANHATTAN, false);
+        KZ_FAMILY_LAUNCH(KZ_MANHATTAN, -1);
     else if (index->metric == KZ_CHEBYSHEV)
-        KZ_FAMILY_LAUNCH(KZ_CHEBYSHEV, false);
+        KZ_FAMILY_LAUNCH(KZ_CHEBYSHEV, -1);
+    else if (p_int == 3)
+        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, 3);     // (integer exponent 2 .. 8: a product chain, no pow() in the kernel; 3 and 4 unrolled)
+    else if (p_int == 4)
+        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, 4);
     else if (p_int > 0)
-        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, true);    // (integer exponent 2 .. 8: a product chain, no pow() in the kernel)
+        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, 0);
     else
-        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, false);
+        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, -1);
 #undef KZ_FAMILY_LAUNCH
 }
 

@@ -1,4 +1,4 @@
-"""Time of the Minkowski-family metrics (exact float64 kernels) beside scikit-learn on the host cores.   python tools/minkowski_time.py [n] [d]"""
+"""Time of the Minkowski-family metrics (exact float64 kernels) beside scikit-learn on the host cores.   python tools/minkowski_time.py [n] [d] [nosk]"""
 import sys
 import time
 
@@ -9,6 +9,7 @@ from kiez_amd import _native as N  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 15000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+with_sklearn = not (len(sys.argv) > 3 and sys.argv[3] == "nosk")     # (third argument "nosk": GPU times only)
 ctx = N.Context.get()
 rng = np.random.default_rng(0)
 for dtype in (np.float32, np.float64):
@@ -22,7 +23,7 @@ for dtype in (np.float32, np.float64):
         ctx.sync()
         ms = (time.perf_counter() - t0) * 1e3
         line = f"{dtype.__name__} {mc}: {ms:.1f} ms  ({n * n * d / ms / 1e6:.1f} G element-pairs/s)"
-        if mc != "euclidean" and dtype == np.float32:
+        if mc != "euclidean" and dtype == np.float32 and with_sklearn:
             from sklearn.neighbors import NearestNeighbors
             name, p = ("minkowski", float(mc[10:-1])) if mc.startswith("minkowski") else (mc, 2)
             nn = NearestNeighbors(n_neighbors=10, metric=name, p=p, algorithm="brute", n_jobs=-1).fit(t)
