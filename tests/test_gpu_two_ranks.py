@@ -95,6 +95,32 @@ for name, hub, kw, metric in CASES:
     assert np.array_equal(i[keep], oi[keep]), name
     assert np.allclose(d[keep], od[keep], rtol=1e-5, atol=1e-6), name
     print(rank, name, "ok", flush=True)
+# the rest of the Minkowski family (exact tiled kernel; the shards' reverse lists merge by kz_pair_values' ordering values where the
+# returned distance is a rounded function of them): smaller matrices, the oracle's feature loop is slow
+fs, ft = source[:3001], target[:2503]
+fb, fc = row_slice(len(fs), rank, world)
+for name, hub, kw, metric, p in [("fam_manhattan_csls", "CSLS", {}, "manhattan", 2), ("fam_mink3_empiric", "MutualProximity", {"method": "empiric"}, "minkowski", 3),
+                                 ("fam_chebyshev_nicdm", "LocalScaling", {"method": "nicdm"}, "chebyshev", 2), ("fam_mink15_none", None, {}, "minkowski", 1.5)]:
+    comm = _StagedComm()
+    sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": metric, "p": p}, hubness=hub, hubness_kwargs=kw, engine=eng, comm=comm)
+    sk.fit(fs[fb:fb + fc], ft if rank == 0 else None)
+    d, i = sk.kneighbors(k)
+    d, i = d.cpu().numpy(), i.cpu().numpy()
+    od, oi = O.kiez_pipeline(fs, ft, K, k, metric, p, hub, kw)
+    od, oi = od[fb:fb + fc], oi[fb:fb + fc]
+    if hub is not None:
+        assert sk.shared and comm.traffic()["all_to_all"]["calls"] == 1, (name, comm.traffic())
+    keep = np.ones(len(i), dtype=bool)
+    if "empiric" in name:
+        mc = O.canonical_metric(metric, p)
+        ri = O.knn_exact(ft, fs, K, mc)[1]
+        assert np.array_equal(sk.state["ind_t2s"].cpu().numpy(), ri), name + ": merged reverse indices differ from the single-GPU search"
+        keep = ~knife_edge_rows(O.knn_exact(fs, ft, K, mc)[1])[fb:fb + fc]
+        for r in np.flatnonzero(~keep):
+            assert knife_edge_topk_ok(od[r], oi[r], d[r], i[r], fb + r, K, ri), (name, fb + r)
+    assert np.array_equal(i[keep], oi[keep]), name
+    assert np.allclose(d[keep], od[keep], rtol=1e-5, atol=1e-6), name
+    print(rank, name, "ok", flush=True)
 dist.barrier()
 dist.destroy_process_group()
 print("TWO_RANKS_OK", rank)
