@@ -56,6 +56,7 @@ struct kz_ctx {
     int tier_probe;   // rows of the strided sample a large ordinary search sends through the fp16 pass first (0 = off; default 1024): more than half uncertified -> the call starts at split-bf16
     int dual_nested;  // kz_knn_dual: 1 (default) = the sample is the first tiles of the dealt image and is swept ONLY by the sample sweep (kz_knn_dual.h "NESTED")
     int fin_wide;     // 1 (default): finalize launches with more than 160 selected candidates run kz_knn_fin_wide.h (no O(n^2) sorts, several rows per gather step)
+    int exact_direct_rows;   // a split-bf16 pass that leaves at most this many rows (default 32) hands them to the exact kernels directly (kz_knn_impl)
     int range_boot;   // 1 (default): short-list routes of the ordinary kernel sweep index range 0 first and start the other ranges' lists at the floor read off it (kz_knn.hip "RANGE-0 BOOTSTRAP")
     int wide_lists;   // fp16 tier's WIDE route (kz_knn_impl): lists of 16 per query when the tier probe finds the keys dense around the k-th neighbour (default 32; 0 = off)
     int wide_sel;     // ... entries of those lists the finalize kernel selects (default 256)
@@ -147,12 +148,15 @@ struct kz_matrix {
     bool checked;     // the norm kernel's verdict (finite input, max_norm) has been read back (kz_matrix_check)
     double* d_stats;  // device [4]: max |y_j| (as max_norm), max |operand element| (normalised rows for cosine)
     kz_himage* himg;  // fp16 image (NULL until a kz_knn call builds it)
+    double* norm64;   // cosine, float32 rows: [n][d] float64 rows x / |x| -- the values the re-rank's per-element divisions produce
+                      // (NULL until kz_matrix_norm64: built for finalize launches with many candidates per query, kz_knn_fin_wide.h)
     size_t raw_bytes, packed_bytes, bias_bytes, sqn_bytes;
 };
 
 // operand images are built on first use (kz_pack.hip); all enqueue on the context's stream
 int kz_matrix_image_f32(kz_matrix* m);
 int kz_matrix_image_bf(kz_matrix* m);
+int kz_matrix_norm64(kz_matrix* m);   // KZ_OK also when the image is not built (wrong metric / dtype / shape, or too large): m->norm64 stays NULL
 int kz_himage_ensure(kz_matrix* query, kz_matrix* index);
 int kz_himage_pack_permuted(kz_matrix* m, const int* d_perm, unsigned short* packed, float* bias);
 int kz_himage_pack_rows(kz_matrix* m, const int* d_rows, int64_t n_rows, int64_t n_pad, unsigned short* packed, float* bias);

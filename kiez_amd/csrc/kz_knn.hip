@@ -211,6 +211,7 @@ struct KnnFinParams {
     int64_t q_count;
     const void* qraw;     // raw query rows (global row indexing)
     const void* yraw;     // raw index rows
+    const double* ynorm64; // cosine, float32 rows: the index rows normalised in float64 (kz_matrix_norm64), or NULL
     const double* qsqn;
     const double* ysqn;
     int64_t n_i;
@@ -321,8 +322,71 @@ __host__ __device__ __forceinline__ int kz_fin_wave_bytes(int max_m, int KP) {
 }
 
 // k-th largest (rank = 1: the largest) of n float keys held as SORTABLE unsigned patterns in LDS; returns the pattern.
-// Wave-cooperative: 32 counting passes at most, fewer below the common prefix of the patterns.
+// Wave-cooperative: 32 counting passes at most, fewer below the common prefix of the patterns.  The entries are read ONCE into
+// registers (E per lane, n <= 64 E): a counting pass is then E compares and E ballots, no LDS round trip in the dependent chain
+// bit -> count -> next bit (round 5: the finalize kernel for many candidates runs three such selections per query at three waves
+// per SIMD -- the chains, not the instruction count, were what it waited for).
+// Largest "smallest key of a FULL list" over a query's lists of KP = 16 or 32 entries, the entries held E per lane (entry e = lane +
+// 64 i): a list's entries sit in KP consecutive lanes of one i, so every list is reduced inside its lane group -- all lists of an
+// i at once, no loop over the lists (32 lists: 8 x 4 shuffle steps instead of 32 dependent rounds of 5).  -inf: no full list.
+template <int E>
+__device__ __forceinline__ float kz_full_lists_bound(const float (&key)[E], const bool (&ok)[E], int M, int KP, int lane) {
+    float bound = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        if (64 * i >= M) break;   // (uniform)
+        int c = ok[i] ? 1 : 0;
+        float mn = ok[i] ? key[i] : INFINITY;
+        for (int off = KP >> 1; off >= 1; off >>= 1) {   // (uniform trip count: 4 or 5)
+            c += __shfl_xor(c, off, 64);
+            mn = fminf(mn, __shfl_xor(mn, off, 64));
+        }
+        if (c == KP && lane + 64 * i < M) bound = fmaxf(bound, mn);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bound = fmaxf(bound, __shfl_xor(bound, off, 64));
+    return bound;
+}
+
+// (core: the lane's E patterns in registers; pattern 0 = no entry)
+template <int E>
+__device__ __forceinline__ unsigned kz_radix_kth_u32_regs(const unsigned (&x)[E], unsigned all_or, unsigned all_and, int rank) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        all_or |= __shfl_xor(all_or, off, 64);
+        all_and &= __shfl_xor(all_and, off, 64);
+    }
+    const unsigned differ = all_or ^ all_and;
+    const int top = differ ? 31 - __clz(differ) : -1;
+    unsigned thr = top >= 31 ? 0u : (top < 0 ? all_and : (all_and & ~((2u << top) - 1u)));
+    for (int bit = top; bit >= 0; --bit) {
+        const unsigned cand = thr | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) c += (int)__popcll(__ballot(x[i] >= cand));
+        if (c >= rank) thr = cand;
+    }
+    return thr;
+}
+template <int E>
+__device__ __forceinline__ unsigned kz_radix_kth_u32_e(const unsigned* u, int n, int rank, int lane) {
+    unsigned x[E];
+    unsigned all_or = 0u, all_and = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int e = lane + 64 * i;
+        const bool in = e < n;
+        x[i] = in ? u[e] : 0u;   // (pattern 0 is below every candidate threshold, which has at least one bit set)
+        all_or |= x[i];
+        all_and &= in ? x[i] : 0xffffffffu;
+    }
+    return kz_radix_kth_u32_regs<E>(x, all_or, all_and, rank);
+}
+// (the generic finalize kernel is compiled for 64 VGPRs: it keeps the LDS loops)
+template <bool REGS = false>
 __device__ __forceinline__ unsigned kz_radix_kth_u32(const unsigned* u, int n, int rank, int lane) {
+    if (REGS && n <= 256) return kz_radix_kth_u32_e<4>(u, n, rank, lane);
+    if (REGS && n <= 512) return kz_radix_kth_u32_e<8>(u, n, rank, lane);
     unsigned all_or = 0u, all_and = 0xffffffffu;
     for (int e = lane; e < n; e += 64) {
         all_or |= u[e];
@@ -345,7 +409,38 @@ __device__ __forceinline__ unsigned kz_radix_kth_u32(const unsigned* u, int n, i
     return thr;
 }
 // rank-th SMALLEST (rank = 1: the smallest) of n non-negative doubles in LDS (their bit patterns order like the values).
+template <int E>
+__device__ __forceinline__ unsigned long long kz_radix_kth_small_f64_e(const double* v, int n, int rank, int lane) {
+    unsigned long long x[E];
+    unsigned long long all_or = 0ull, all_and = ~0ull;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int e = lane + 64 * i;
+        const bool in = e < n;
+        x[i] = in ? (unsigned long long)__double_as_longlong(v[e]) : ~0ull;   // (the largest pattern: never BELOW a candidate)
+        all_or |= in ? x[i] : 0ull;
+        all_and &= x[i];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        all_or |= __shfl_xor(all_or, off, 64);
+        all_and &= __shfl_xor(all_and, off, 64);
+    }
+    const unsigned long long differ = all_or ^ all_and;
+    const int top = differ ? 63 - __clzll(differ) : -1;
+    unsigned long long thr = top >= 63 ? 0ull : (top < 0 ? all_and : (all_and & ~((2ull << top) - 1ull)));
+    for (int bit = top; bit >= 0; --bit) {
+        const unsigned long long cand = thr | (1ull << bit);
+        int c = 0;   // entries below cand
+#pragma unroll
+        for (int i = 0; i < E; ++i) c += (int)__popcll(__ballot(x[i] < cand));
+        if (c < rank) thr = cand;
+    }
+    return thr;
+}
+template <bool REGS = false>
 __device__ __forceinline__ unsigned long long kz_radix_kth_small_f64(const double* v, int n, int rank, int lane) {
+    if (REGS && n <= 256) return kz_radix_kth_small_f64_e<4>(v, n, rank, lane);
     unsigned long long all_or = 0ull, all_and = ~0ull;
     for (int e = lane; e < n; e += 64) {
         const unsigned long long b = (unsigned long long)__double_as_longlong(v[e]);
@@ -2087,6 +2182,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fp.fail_count = fail_count;
         fp.fail_list = fail_list;
         fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
+        if (fp.tier_h && metric == KZ_COSINE && (fp.KSEL > 0 ? fp.KSEL : KP) > 160 && ctx->fin_wide && !(dual && dual->raw_lists)) {
+            // (hundreds of re-ranked candidates per query: the normalised float64 rows of the index, built once -- kz_pack.hip)
+            rc = kz_matrix_norm64(index);
+            if (rc != KZ_OK) return rc;
+            fp.ynorm64 = index->norm64;
+        }
         if (!exact_only && !(dual && dual->raw_lists)) {   // (raw lists: the caller's hook has read them; nothing is finalized)
             rc = kz_launch_finalize(ctx, fp, lay, KP, cq_count, index->dtype);
             if (rc != KZ_OK) return rc;
@@ -2133,7 +2234,11 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         int tier_next = tier;
         if (!dual && tier != KZ_TIER_F32 && (int64_t)n_fail * 4 > cq_count)
             tier_next = (tier == KZ_TIER_H && ctx->esc_bf && long_pieces == 0) ? KZ_TIER_BF : KZ_TIER_F32;
-        if (tier != KZ_TIER_F32 && n_fail > 0) {
+        // A HANDFUL of rows left by the split-bf16 operands skips the float32-operand kernel: that kernel sweeps the whole index for
+        // one query tile in at most eight pieces -- 2.2 ms on 300 k rows of d = 64 whatever the row count -- while the exact kernels
+        // cost ~35 us a row there (both scale with n d): bench.py "hard", ~20 rows per direction and step: 60.6 -> see r05_notes.
+        const bool exact_direct = tier == KZ_TIER_BF && !dual && n_fail > 0 && n_fail <= ctx->exact_direct_rows;
+        if (tier != KZ_TIER_F32 && n_fail > 0 && !exact_direct) {
             // Escalate only the uncertified rows: gather them into a dense query block and search it again -- fp16 tier
             // with lists shorter than 128: same operands, lists four times as long (no new image of the index: 14 rows
             // of a 1M-row index cost 0.4 ms this way against 7 ms for packing its float32 image); otherwise the split-bf16

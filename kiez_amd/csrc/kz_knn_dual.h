@@ -68,53 +68,53 @@ __global__ __launch_bounds__(256) void kz_dual_theta_kernel(const float* __restr
     const int M = lay.pieces[kz_list_region(t, lay)] * KP;
     const int64_t l0 = kz_list_contig_off(t, lay, KP, 0);
     float x[4];
-    int valid[4], rnk[4];
+    int valid[4];
+    unsigned ux[4];   // sortable patterns (0 = no entry)
+    unsigned all_or = 0u, all_and = 0xffffffffu;
+    int nv = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int e = lane + 64 * u;
         x[u] = e < M ? in_key[l0 + e] : -INFINITY;
         valid[u] = e < M && in_idx[l0 + e] >= 0;
-        rnk[u] = 0;
+        const unsigned b = __float_as_uint(x[u]);
+        ux[u] = valid[u] ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
+        all_or |= ux[u];
+        all_and &= valid[u] ? ux[u] : 0xffffffffu;
+        nv += valid[u] ? 1 : 0;
     }
-    // rank of every entry = the number of valid entries in front of it: entry oe is broadcast from its lane through a scalar
-    // register (v_readlane: jj is uniform) -- not through the LDS crossbar -- and only the 64-entry blocks that exist are ranked
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int lim = min(64, M - 64 * v);
-        for (int jj = 0; jj < lim; ++jj) {
-            const float ox = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x[v]), jj));
-            const int ov = __builtin_amdgcn_readlane(valid[v], jj);
-            if (!ov) continue;   // (uniform)
-            const int oe = jj + 64 * v;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (64 * u < M) rnk[u] += (ox > x[u] || (ox == x[u] && oe < lane + 64 * u)) ? 1 : 0;
-        }
-    }
+    for (int off = 32; off >= 1; off >>= 1) nv += __shfl_xor(nv, off, 64);
+    // tau = the rank-th best valid key (its VALUE: ties do not matter) -- a radix selection on the entries in registers (round 5;
+    // rounds 3 - 4 ranked all M entries against each other through v_readlane: M^2 / 64 compares per lane, 0.6 ms on ns's 250 k rows)
     float tau = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (valid[u] && rnk[u] == rank - 1) tau = x[u];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) tau = fmaxf(tau, __shfl_xor(tau, off, 64));
+    if (nv >= rank) {   // (uniform)
+        const unsigned thr = kz_radix_kth_u32_regs<4>(ux, all_or, all_and, rank);
+        tau = __uint_as_float(thr ^ ((thr >> 31) ? 0x80000000u : 0xffffffffu));
+    }
     float tau_bound = tau;
     if (sev_cnt) {
-        for (int p0 = 0; p0 < M; p0 += KP) {   // (uniform; at most 256 / 16 lists)
-            int c = 0;
-            float mn = INFINITY;
+        if (KP <= 32) {
+            const bool okv[4] = {valid[0] != 0, valid[1] != 0, valid[2] != 0, valid[3] != 0};
+            tau_bound = fmaxf(tau_bound, kz_full_lists_bound<4>(x, okv, M, KP, lane));
+        } else {
+            for (int p0 = 0; p0 < M; p0 += KP) {   // (uniform; at most 256 / 64 lists)
+                int c = 0;
+                float mn = INFINITY;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = lane + 64 * u;
-                const bool in = e >= p0 && e < p0 + KP && valid[u];
-                c += in ? 1 : 0;
-                mn = in ? fminf(mn, x[u]) : mn;
-            }
+                for (int u = 0; u < 4; ++u) {
+                    const int e = lane + 64 * u;
+                    const bool in = e >= p0 && e < p0 + KP && valid[u];
+                    c += in ? 1 : 0;
+                    mn = in ? fminf(mn, x[u]) : mn;
+                }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                c += __shfl_xor(c, off, 64);
-                mn = fminf(mn, __shfl_xor(mn, off, 64));
+                for (int off = 32; off >= 1; off >>= 1) {
+                    c += __shfl_xor(c, off, 64);
+                    mn = fminf(mn, __shfl_xor(mn, off, 64));
+                }
+                if (c == KP) tau_bound = fmaxf(tau_bound, mn);
             }
-            if (c == KP) tau_bound = fmaxf(tau_bound, mn);
         }
         int base = 0;
 #pragma unroll
@@ -368,18 +368,12 @@ __global__ __launch_bounds__(256) void kz_dual_select_kernel(const int* __restri
         }
         return;
     }
-    // thr = the largest value with at least K' entries >= it
-    // (the keys of a row share their leading bits -- same sign, same exponent range: the radix select starts below the common
-    //  prefix instead of at bit 31)
-    const unsigned differ = all_or ^ all_and;
-    const int top = differ ? 31 - __clz(differ) : -1;
-    unsigned thr = top >= 31 ? 0u : (top < 0 ? all_and : (all_and & ~((2u << top) - 1u)));   // top = -1: every key equal, thr = that key
-    for (int bit = top; bit >= 0; --bit) {
-        const unsigned cand = thr | (1u << bit);
-        int c = 0;
-        for (int e0 = 0; e0 < n; e0 += 64) c += (int)__popcll(__ballot(e0 + lane < n && su[e0 + lane] >= cand));
-        if (c >= KP) thr = cand;
-    }
+    // thr = the largest value with at least K' entries >= it: the K'-th largest key (kz_radix_kth_u32: below the common prefix of
+    // the keys, and -- round 5 -- on the row's entries held in REGISTERS when there are at most 512: the counting passes of the
+    // LDS version each waited for their LDS reads, bit after bit; C3's 500 k rows: 3.3 -> see profiles/r05_notes.md section 10)
+    (void)all_or;
+    (void)all_and;
+    const unsigned thr = kz_radix_kth_u32<true>(su, n, KP, lane);
     int base = 0;
     for (int e0 = 0; e0 < n; e0 += 64) {
         const int e = e0 + lane;

@@ -54,30 +54,43 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
     kz_wave_sync();
     // a FULL list may have evicted rows (at or below its smallest key); the lists' own floor
     float piece_bound = p.list_floor ? p.list_floor[p.q_begin + q] : -INFINITY;
-    for (int l0 = 0; l0 < M; l0 += KP) {
-        float mn = INFINITY;
-        int cnt = 0;
-        for (int e = lane; e < KP; e += 64) {
-            const bool ok = eidx[l0 + e] >= 0;
-            cnt += ok ? 1 : 0;
-            mn = ok ? fminf(mn, ekey[l0 + e]) : mn;
-        }
-        if (KP >= 64) {
+    if (KP <= 32 && M <= 512) {
+        // (all lists of a 64-entry block at once, inside their lane groups: kz_full_lists_bound)
+        float kk[8];
+        bool okv[8];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                cnt += __shfl_xor(cnt, off, 64);
-                mn = fminf(mn, __shfl_xor(mn, off, 64));
-            }
-        } else {   // (lists of 16 / 32: the entries sit in the first lanes)
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) {
-                cnt += __shfl_xor(cnt, off, 64);
-                mn = fminf(mn, __shfl_xor(mn, off, 64));
-            }
-            cnt = __builtin_amdgcn_readfirstlane(cnt);
-            mn = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mn)));
+        for (int i = 0; i < 8; ++i) {
+            const int e = lane + 64 * i;
+            okv[i] = e < M && eidx[e] >= 0;
+            kk[i] = e < M ? ekey[e] : INFINITY;
         }
-        if (cnt == KP) piece_bound = fmaxf(piece_bound, mn);
+        piece_bound = fmaxf(piece_bound, kz_full_lists_bound<8>(kk, okv, M, KP, lane));
+    } else {
+        for (int l0 = 0; l0 < M; l0 += KP) {
+            float mn = INFINITY;
+            int cnt = 0;
+            for (int e = lane; e < KP; e += 64) {
+                const bool ok = eidx[l0 + e] >= 0;
+                cnt += ok ? 1 : 0;
+                mn = ok ? fminf(mn, ekey[l0 + e]) : mn;
+            }
+            if (KP >= 64) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    cnt += __shfl_xor(cnt, off, 64);
+                    mn = fminf(mn, __shfl_xor(mn, off, 64));
+                }
+            } else {   // (lists of 16 / 32: the entries sit in the first lanes)
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    cnt += __shfl_xor(cnt, off, 64);
+                    mn = fminf(mn, __shfl_xor(mn, off, 64));
+                }
+                cnt = __builtin_amdgcn_readfirstlane(cnt);
+                mn = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mn)));
+            }
+            if (cnt == KP) piece_bound = fmaxf(piece_bound, mn);
+        }
     }
     // ---- the KS best approximate keys, unordered, into ck / ci; sel_bound = the largest key left behind -----------------
     unsigned* uk = reinterpret_cast<unsigned*>(ekey);
@@ -98,7 +111,7 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
     {
         const bool all = nv <= KS;
         unsigned thr = 0u;
-        if (!all) thr = kz_radix_kth_u32(uk, M, KS, lane);   // (invalid entries carry the smallest pattern: they never reach rank KS)
+        if (!all) thr = kz_radix_kth_u32<true>(uk, M, KS, lane);   // (invalid entries carry the smallest pattern: they never reach rank KS)
         for (int e0 = 0; e0 < M; e0 += 64) {
             const int e = e0 + lane;
             const bool sel = e < M && eidx[e] >= 0 && (all || uk[e] > thr);
@@ -155,7 +168,7 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
         su[c] = (b == 0x80000000u ? 0u : b) ^ (((b == 0x80000000u ? 0u : b) >> 31) ? 0xffffffffu : 0x80000000u);
     }
     kz_wave_sync();
-    const float key_k = key_of(kz_radix_kth_u32(su, V, k_eff, lane));
+    const float key_k = key_of(kz_radix_kth_u32<true>(su, V, k_eff, lane));
     const double thr2 = (double)key_k * key_scale - 2.0 * eps_q;
     int Vr = 0;
     float left_max = -INFINITY;
@@ -176,8 +189,9 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
     for (int off = 32; off >= 1; off >>= 1) left_max = fmaxf(left_max, __shfl_xor(left_max, off, 64));
     kz_wave_sync();
     // ---- exact float64 values of the Vr candidates: G rows per wave step ---------------------------------------------------
-    auto rerank = [&](auto lpr_c) {
+    auto rerank = [&](auto lpr_c, auto norm_c) {
         constexpr int LPR = decltype(lpr_c)::value;   // lanes per row
+        constexpr bool NORM = decltype(norm_c)::value;   // cosine: the index rows come normalised in float64 (kz_matrix_norm64)
         constexpr int G = 64 / LPR;
         const int grp = lane / LPR, sl = lane & (LPR - 1);
         const int k0 = 4 * sl;
@@ -192,16 +206,34 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
             }
         }
         const int steps = (Vr + G - 1) / G;
-        auto issue = [&](int st, float4& buf, double& ysb) {
+        struct Buf {
+            float4 f;        // raw row elements               (!NORM)
+            double ys;       // the row's norm / squared norm  (!NORM)
+            double2 n0, n1;  // normalised row elements        (NORM)
+        };
+        auto issue = [&](int st, Buf& b) {
             // (no load under a condition: steps and candidates past the end repeat the last candidate, see kz_finalize_query)
             const int yi = eidx[min(min(st, steps - 1) * G + grp, Vr - 1)];
-            ysb = p.ysqn[yi];
-            buf = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(yraw) + (int64_t)yi * p.d + k0r);
+            if (NORM) {
+                const double* row = p.ynorm64 + (int64_t)yi * p.d + k0r;
+                b.n0 = *reinterpret_cast<const double2*>(row);
+                b.n1 = *reinterpret_cast<const double2*>(row + 2);
+            } else {
+                b.ys = p.ysqn[yi];
+                b.f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(yraw) + (int64_t)yi * p.d + k0r);
+            }
         };
-        auto reduce = [&](int st, const float4& buf, const double ysb) {
-            const double yk[4] = {(double)buf.x, (double)buf.y, (double)buf.z, (double)buf.w};
+        auto reduce = [&](int st, const Buf& b) {
             double a = 0.0;
-            if (act) {
+            if (NORM) {
+                if (act) {
+                    const double yn[4] = {b.n0.x, b.n0.y, b.n1.x, b.n1.y};   // = y_e / |y|: the quotients of the branch below
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = fma(qk[e], yn[e], a);
+                }
+            } else if (act) {
+                const double yk[4] = {(double)b.f.x, (double)b.f.y, (double)b.f.z, (double)b.f.w};
+                const double ysb = b.ys;
                 if (p.metric == KZ_COSINE) {
                     bool done = false;
                     if (p.fast_div) {
@@ -228,36 +260,42 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
             if (p.metric == KZ_COSINE)
                 v = fmin(fmax(1.0 - a, 0.0), 2.0);
             else
-                v = fmax((qs + ysb) - 2.0 * a, 0.0);
+                v = fmax((qs + (NORM ? 0.0 : b.ys)) - 2.0 * a, 0.0);
             const int c = st * G + grp;
             if (sl == 0 && c < Vr) cv[c] = v;
         };
-        float4 b0, b1, b2;
-        double y0, y1, y2;
-        issue(0, b0, y0);
-        issue(1, b1, y1);
+        Buf b0, b1, b2;
+        issue(0, b0);
+        issue(1, b1);
         for (int st = 0;;) {   // (all conditions wave-uniform; three steps in flight)
-            issue(st + 2, b2, y2);
-            reduce(st, b0, y0);
+            issue(st + 2, b2);
+            reduce(st, b0);
             if (++st >= steps) break;
-            issue(st + 2, b0, y0);
-            reduce(st, b1, y1);
+            issue(st + 2, b0);
+            reduce(st, b1);
             if (++st >= steps) break;
-            issue(st + 2, b1, y1);
-            reduce(st, b2, y2);
+            issue(st + 2, b1);
+            reduce(st, b2);
             if (++st >= steps) break;
         }
     };
     {
         const int lanes_needed = (p.d + 3) >> 2;   // (wave-uniform)
+        const bool norm = p.metric == KZ_COSINE && p.ynorm64 != nullptr;
+        auto go = [&](auto lpr_c) {
+            if (norm)
+                rerank(lpr_c, std::true_type{});
+            else
+                rerank(lpr_c, std::false_type{});
+        };
         if (lanes_needed <= 8)
-            rerank(std::integral_constant<int, 8>{});
+            go(std::integral_constant<int, 8>{});
         else if (lanes_needed <= 16)
-            rerank(std::integral_constant<int, 16>{});
+            go(std::integral_constant<int, 16>{});
         else if (lanes_needed <= 32)
-            rerank(std::integral_constant<int, 32>{});
+            go(std::integral_constant<int, 32>{});
         else
-            rerank(std::integral_constant<int, 64>{});
+            go(std::integral_constant<int, 64>{});
     }
     kz_wave_sync();
     // ---- self-check of the rounding bound on every re-ranked candidate -------------------------------------------------------
@@ -278,7 +316,7 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
     }
     // ---- the (k_eff + 1) smallest exact values, sorted by (value, row): everything the output and the certification read ------
     const int need = Vr < k_eff + 1 ? Vr : k_eff + 1;
-    const unsigned long long tbits = kz_radix_kth_small_f64(cv, Vr, need, lane);
+    const unsigned long long tbits = kz_radix_kth_small_f64<true>(cv, Vr, need, lane);
     int ns = 0;
     for (int c0 = 0; c0 < Vr; c0 += 64) {
         const int c = c0 + lane;

@@ -54,6 +54,7 @@ static const KzOption KZ_OPTIONS[] = {
     {"probe_min_pairs", KZ_OPT_F64, KZ_O(probe_min_pairs), 0, 1e300, 5e10, 0, {}, 0, "searches of fewer distance pairs take neither the tier probe nor a floor"},
     {"fin_wide", KZ_OPT_INT, KZ_O(fin_wide), 0, 2, 1, 0, {}, 0, "finalize of > 160 selected candidates without O(n^2) sorts, several rows per gather step"},
     {"range_boot", KZ_OPT_BOOL, KZ_O(range_boot), 0, 1, 1, 0, {}, 0, "short-list routes: index range 0 first, the other ranges' lists start at the floor read off it"},
+    {"exact_direct_rows", KZ_OPT_INT, KZ_O(exact_direct_rows), 0, 4096, 32, 0, {}, 0, "at most this many rows left by the split-bf16 tier skip the float32-operand kernel and go to the exact kernels"},
     {"wide_lists", KZ_OPT_INT, KZ_O(wide_lists), 2, 32, 32, KZ_OPT_SET, {0}, -1, "fp16 tier's wide route: lists of 16 per query (0 = off)"},
     {"wide_sel", KZ_OPT_INT, KZ_O(wide_sel), 16, 512, 256, 0, {}, 0, "... entries of those lists the finalize kernel selects"},
     {"list_floor", KZ_OPT_INT, KZ_O(list_floor), 0, 1, 1, 0, {}, 0, "seeded candidate lists (population floor from a probe)"},

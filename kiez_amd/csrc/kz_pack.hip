@@ -392,6 +392,30 @@ int kz_matrix_image_f32(kz_matrix* m) {
     return KZ_OK;
 }
 
+// Normalised float64 rows of a cosine matrix: x_e / |x| by the IEEE division -- bit for bit what the re-rank's kz_div_shared (and
+// the plain division it stands for) gives per element, computed once per row instead of once per (query, candidate) pair.  Only
+// where a finalize launch re-ranks HUNDREDS of candidates per query (the wide route on clustered data, long k: kz_knn_fin_wide.h):
+// there the kernel is bound by instructions, and the divisions are 40 % of them (bench.py "hard": 12.5 -> see DESIGN section 3.2).
+__global__ void kz_norm64_kernel(const float* __restrict__ raw, const double* __restrict__ nrm, int64_t n_elems, int d, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_elems) out[i] = (double)raw[i] / nrm[i / d];
+}
+int kz_matrix_norm64(kz_matrix* m) {
+    if (m->norm64 || m->metric != KZ_COSINE || m->dtype != KZ_F32 || m->raw_only || (m->d & 3) != 0 || m->d > 256) return KZ_OK;
+    const size_t bytes = (size_t)m->n * (size_t)m->d * 8;
+    if (bytes > ((size_t)8 << 30)) return KZ_OK;   // (of 288 GB; beyond, the per-pair divisions stay)
+    kz_ctx* ctx = m->ctx;
+    if (kz_pool_alloc(ctx, bytes, (void**)&m->norm64) != KZ_OK) {
+        m->norm64 = nullptr;
+        return KZ_OK;   // (an optimisation only)
+    }
+    const int64_t n_elems = m->n * m->d;
+    hipLaunchKernelGGL(kz_norm64_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)m->raw, m->sqn, n_elems,
+                       (int)m->d, m->norm64);
+    KZ_HIP(hipGetLastError());
+    return KZ_OK;
+}
+
 int kz_matrix_image_bf(kz_matrix* m) {
     if (m->packed_bf) return KZ_OK;
     kz_ctx* ctx = m->ctx;
@@ -731,6 +755,7 @@ int kz_matrix_destroy(kz_matrix* m) {
         if (!m->raw_borrowed) kz_pool_free(m->ctx, m->raw, 0);
         kz_pool_free(m->ctx, m->packed, 0);
         kz_pool_free(m->ctx, m->packed_bf, 0);
+        kz_pool_free(m->ctx, m->norm64, 0);
         kz_pool_free(m->ctx, m->bias, 0);
         kz_pool_free(m->ctx, m->sqn, 0);
         kz_pool_free(m->ctx, m->d_stats, 0);
