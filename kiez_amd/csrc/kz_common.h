@@ -49,6 +49,7 @@ struct kz_ctx {
     int h_q64;        // 64-queries-per-wave kernel (kz_knn_h64.h) for K' = 16 sweeps of 4 .. 13 slices: 2 (default) = where it pays (kz_knn_impl), 1 = always, 0 = never
     int fin_fast_div; // finalize kernel, cosine: shared-reciprocal division (kz_div_shared)
     double probe_min_pairs;  // ordinary searches below this many distance pairs take neither the tier probe nor a floor (5e10)
+    double probe_min_ms;     // ... unless the sweep is this long (2 n_q n_i d / 1e12 model-ms; 12): a probe is ~0.45 ms
     int list_floor;   // kz_knn_dual: 1 = the forward lists of the shared sweep start at a population floor (kz_knn_dual.h "POPULATION FLOOR")
     int floor_probe;  // ... rows of the probe behind it
     double floor_margin;  // ... the largest shortfall of the probe below the model, times this

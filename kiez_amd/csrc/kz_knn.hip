@@ -1886,7 +1886,9 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // and >= 16 probe sizes of query rows take it (C1 / C2 do not).  Option "tier_probe" = 0: off.
     float* qfloor_ord = nullptr;   // seeded lists of an ordinary search (the context's buffer: nothing to release)
     if (tier == KZ_TIER_H && !dual && precision_override < 0 && kp_min == 0 && forced_lists == 0 && !exact_only && ctx->tier_probe > 0 && ctx->esc_bf &&
-        q_count >= (int64_t)16 * ctx->tier_probe && (double)q_count * (double)index->n >= ctx->probe_min_pairs && ctx->chunk_rows == 0) {
+        q_count >= (int64_t)16 * ctx->tier_probe && ctx->chunk_rows == 0 &&
+        ((double)q_count * (double)index->n >= ctx->probe_min_pairs ||
+         2.0 * (double)q_count * (double)index->n * (double)(index->kg * 4) / 1e12 >= ctx->probe_min_ms)) {
         const int n_probe = ctx->tier_probe;
         int* plist = nullptr;
         int rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);

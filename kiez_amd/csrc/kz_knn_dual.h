@@ -826,7 +826,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // searches instead, each of which starts at the split-bf16 tier (bench.py "hard", 300k x 301k clustered rows: 127 ms per step
     // that way, 201 ms through a shared fp16 sweep whose rows nearly all go down the tiers afterwards).
     const bool want_tier = !ctx->dual_force && ctx->tier_probe > 0 && ctx->esc_bf && a->n >= (int64_t)16 * ctx->tier_probe &&
-                           (double)a->n * (double)b->n >= ctx->probe_min_pairs;
+                           ((double)a->n * (double)b->n >= ctx->probe_min_pairs || t_sweep_ms >= ctx->probe_min_ms);
     if (want_floor || want_tier) {
         const int n_probe = want_floor ? ctx->floor_probe : (ctx->tier_probe < 1024 ? ctx->tier_probe : 1024);
         const int64_t pstride = a->n / n_probe;
@@ -841,21 +841,29 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, 0, d_dist_ab, d_ind_ab, &stp, &pms);
         }
         // (the rows the probe's FIRST pass left uncertified, once each)
-        if (rc == KZ_OK && want_tier && (int64_t)stp.n_first_pass_fail * 2 > n_probe) {
-            // LADDER (kz_knn_impl "WIDE ROUTE"): the probe rows again with many lists of 16 on the same fp16 operands -- at most a
-            // quarter uncertified: two ordinary searches on that route; otherwise two that start at the split-bf16 tier
+        if (rc == KZ_OK && want_tier && (int64_t)stp.n_first_pass_fail * 8 > n_probe) {
+            // LADDER (kz_knn_impl "WIDE ROUTE"), from an EIGHTH of the probe uncertified on, as an ordinary search's: re-searching
+            // a quarter of the rows costs more than the sweep (round 5, tools/cliff_probe.py: 300k x 301k x 64, cosine, k = 50, 40
+            // tight clusters in random row order -- 44 % of the probe uncertified, below the old "more than half": shared sweep with
+            // 314 k rows searched again, 153 ms; wide route 50 ms).  The probe rows again with many lists of 16 on the same fp16
+            // operands: at most a quarter uncertified and less than half of what the ordinary lists left -- two ordinary searches on
+            // that route; else, with more than half uncertified, two that start at the split-bf16 tier; else the shared sweep.
             int wide = 0;
             if (ctx->wide_lists >= 2) {
                 kz_knn_stats stw;
                 memset(&stw, 0, sizeof(stw));
                 float wms = 0;
                 rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, -ctx->wide_lists, d_dist_ab, d_ind_ab, &stw, &wms);
-                if (rc == KZ_OK && stw.wide_lists > 0 && (int64_t)stw.n_first_pass_fail * 4 <= n_probe) wide = ctx->wide_lists;
+                if (rc == KZ_OK && stw.wide_lists > 0 && (int64_t)stw.n_first_pass_fail * 4 <= n_probe &&
+                    (int64_t)stw.n_first_pass_fail * 2 < stp.n_first_pass_fail)
+                    wide = ctx->wide_lists;
             }
-            kz_pool_free(ctx, plist, 0);
-            release();
-            if (rc != KZ_OK) return rc;
-            return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba, wide > 0 ? -1 : 2, wide);
+            if (rc != KZ_OK || wide > 0 || (int64_t)stp.n_first_pass_fail * 2 > n_probe) {
+                kz_pool_free(ctx, plist, 0);
+                release();
+                if (rc != KZ_OK) return rc;
+                return kz_knn_dual_separately(ctx, a, b, k, d_dist_ab, d_ind_ab, d_dist_ba, d_ind_ba, stats_ab, stats_ba, wide > 0 ? -1 : 2, wide);
+            }
         }
         kz_pool_free(ctx, plist, 0);
         if (rc == KZ_OK && want_floor) rc = kz_floor_model(ctx, d_dist_ab, ia->rowq, n_probe, pstride, k, a->metric, floor_model, &have_floor);

@@ -52,6 +52,7 @@ static const KzOption KZ_OPTIONS[] = {
     {"esc_bf", KZ_OPT_BOOL, KZ_O(esc_bf), 0, 1, 1, 0, {}, 0, "split-bf16 operands before the float32 ones for rows the fp16 tier cannot certify"},
     {"tier_probe", KZ_OPT_INT, KZ_O(tier_probe), 0, 65536, 1024, 0, {}, 0, "rows of the strided sample a large search sends through the fp16 pass first (0 = off)"},
     {"probe_min_pairs", KZ_OPT_F64, KZ_O(probe_min_pairs), 0, 1e300, 5e10, 0, {}, 0, "searches of fewer distance pairs take neither the tier probe nor a floor"},
+    {"probe_min_ms", KZ_OPT_F64, KZ_O(probe_min_ms), 0, 1e300, 12.0, 0, {}, 0, "... unless the sweep is at least this many model-ms (2 n_q n_i d / 1e12) long"},
     {"fin_wide", KZ_OPT_INT, KZ_O(fin_wide), 0, 2, 1, 0, {}, 0, "finalize of > 160 selected candidates without O(n^2) sorts, several rows per gather step"},
     {"range_boot", KZ_OPT_BOOL, KZ_O(range_boot), 0, 1, 1, 0, {}, 0, "short-list routes: index range 0 first, the other ranges' lists start at the floor read off it"},
     {"exact_direct_rows", KZ_OPT_INT, KZ_O(exact_direct_rows), 0, 4096, 32, 0, {}, 0, "at most this many rows left by the split-bf16 tier skip the float32-operand kernel and go to the exact kernels"},
