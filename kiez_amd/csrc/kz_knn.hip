@@ -995,6 +995,142 @@ __global__ __launch_bounds__(256) void kz_exact_dist_kernel(const int* __restric
     if (lane == 0) vals[(int64_t)b * n_i + i] = v;
 }
 
+// The same values for float32 rows of d <= 256 (d a multiple of 4), many pairs per wave step (round 5).  kz_exact_dist_kernel spends
+// a wave on ONE pair -- at d = 64 a quarter of its lanes, re-reading the query row and, for cosine, dividing every element twice:
+// 2.9 G pairs/s, 125 us per query row against 301 k index rows; on data with clusters three orders of magnitude tighter than the
+// data's extent a tenth of the rows end there, and a 300 k x 300 k call took 8 s (tools/cliff_probe.py).  Here a wave keeps Q = 4
+// query rows in registers and walks CONSECUTIVE index rows, G = 64 / LPR of them per step (a row needs LPR = d / 4 lanes rounded up
+// to a power of two): one coalesced load serves G x Q pairs.  The arithmetic of a pair is kz_wave_dot's, operation for operation
+// -- the lane's four fma in element order, then the butterfly inside the lane group (the steps of the full-wave butterfly that it
+// skips add the exact zeros of lanes past the row) -- as in the finalize kernel for many candidates (kz_knn_fin_wide.h), so the
+// values are bit for bit those of kz_exact_value, kz_pair_values and the re-rank.  Cosine: the index rows normalised once in
+// float64 (kz_matrix_norm64) where that image exists, else the shared-reciprocal division.
+template <int LPR, bool NORM>
+__global__ __launch_bounds__(256) void kz_exact_dist_rows_kernel(const int* __restrict__ fail_list, int batch0, int nb, int64_t q_begin,
+                                                                 const float* __restrict__ qraw, const float* __restrict__ yraw,
+                                                                 const double* __restrict__ ynorm64, const double* __restrict__ qsqn,
+                                                                 const double* __restrict__ ysqn, int64_t n_i, int d, int metric,
+                                                                 int rows_per_wave, double* __restrict__ vals) {
+    constexpr int G = 64 / LPR, Q = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPR, sl = lane & (LPR - 1);
+    const int k0 = 4 * sl;
+    const bool act = k0 < d;
+    const int k0r = act ? k0 : 0;
+    const int b0 = blockIdx.y * Q;
+    double qk[Q][4], qs[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const int bq = b0 + j < nb ? b0 + j : nb - 1;
+        const int64_t qrow = q_begin + fail_list[batch0 + bq];
+        qs[j] = qsqn[qrow];
+        qk[j][0] = qk[j][1] = qk[j][2] = qk[j][3] = 0.0;
+        if (act) {
+            kz_row4(qraw + qrow * (int64_t)d, k0, d, true, qk[j]);
+            if (metric == KZ_COSINE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qk[j][e] = qk[j][e] / qs[j];
+            }
+        }
+    }
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+    const int64_t i1 = i0 + rows_per_wave < n_i ? i0 + rows_per_wave : n_i;
+    if (i0 >= i1) return;
+    struct Buf {
+        float4 f;
+        double ys;
+        double2 n0, n1;
+    };
+    auto issue = [&](int64_t i, Buf& b) {   // (rows past the end: the last row again, nothing is written for them)
+        const int64_t yi = i + grp < i1 ? i + grp : i1 - 1;
+        if (NORM) {
+            const double* row = ynorm64 + yi * (int64_t)d + k0r;
+            b.n0 = *reinterpret_cast<const double2*>(row);
+            b.n1 = *reinterpret_cast<const double2*>(row + 2);
+        } else {
+            b.ys = ysqn[yi];
+            b.f = *reinterpret_cast<const float4*>(yraw + yi * (int64_t)d + k0r);
+        }
+    };
+    auto reduce = [&](int64_t i, const Buf& b) {
+        double yv[4] = {0.0, 0.0, 0.0, 0.0};
+        if (act) {
+            if (NORM) {
+                yv[0] = b.n0.x, yv[1] = b.n0.y, yv[2] = b.n1.x, yv[3] = b.n1.y;
+            } else {
+                const double yk[4] = {(double)b.f.x, (double)b.f.y, (double)b.f.z, (double)b.f.w};
+                if (metric == KZ_COSINE) {
+                    const double rcp = 1.0 / b.ys;
+                    const bool fin = (((unsigned long long)__double_as_longlong(rcp) >> 52) & 0x7ff) != 0x7ff;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yv[e] = fin ? kz_div_shared(yk[e], b.ys, rcp) : yk[e] / b.ys;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yv[e] = yk[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            double a = 0.0;
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a = fma(qk[j][e], yv[e], a);
+            }
+#pragma unroll
+            for (int off = LPR >> 1; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+            double v;
+            if (metric == KZ_COSINE)
+                v = fmin(fmax(1.0 - a, 0.0), 2.0);
+            else
+                v = fmax((qs[j] + b.ys) - 2.0 * a, 0.0);
+            if (sl == 0 && i + grp < i1 && b0 + j < nb) vals[(int64_t)(b0 + j) * n_i + i + grp] = v;
+        }
+    };
+    Buf ba, bb;
+    issue(i0, ba);
+    for (int64_t i = i0; i < i1;) {   // (two steps in flight; the conditions are wave-uniform)
+        issue(i + G, bb);
+        reduce(i, ba);
+        i += G;
+        if (i >= i1) break;
+        issue(i + G, ba);
+        reduce(i, bb);
+        i += G;
+    }
+}
+// -> true when the kernel above took the batch
+static bool kz_launch_exact_rows(kz_ctx* ctx, const int* fl, int b0, int nb, int64_t cq_begin, const kz_matrix* query, const kz_matrix* index,
+                                 int metric, double* vals) {
+    const int d = (int)index->d;
+    if (index->dtype != KZ_F32 || (d & 3) != 0 || d > 256 || metric > KZ_COSINE) return false;
+    const bool norm = metric == KZ_COSINE && index->norm64 != nullptr;
+    const int rows_per_wave = 256;
+    const dim3 grid((unsigned)((index->n + 4 * rows_per_wave - 1) / (4 * rows_per_wave)), (unsigned)((nb + 3) / 4));
+    const int lanes = (d + 3) >> 2;
+#define KZ_EXACT_ROWS(L)                                                                                                                \
+    do {                                                                                                                                \
+        if (norm)                                                                                                                       \
+            hipLaunchKernelGGL((kz_exact_dist_rows_kernel<L, true>), grid, dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin,          \
+                               (const float*)query->raw, (const float*)index->raw, index->norm64, query->sqn, index->sqn, index->n, d, \
+                               metric, rows_per_wave, vals);                                                                            \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((kz_exact_dist_rows_kernel<L, false>), grid, dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin,         \
+                               (const float*)query->raw, (const float*)index->raw, (const double*)nullptr, query->sqn, index->sqn,      \
+                               index->n, d, metric, rows_per_wave, vals);                                                               \
+    } while (0)
+    if (lanes <= 8)
+        KZ_EXACT_ROWS(8);
+    else if (lanes <= 16)
+        KZ_EXACT_ROWS(16);
+    else if (lanes <= 32)
+        KZ_EXACT_ROWS(32);
+    else
+        KZ_EXACT_ROWS(64);
+#undef KZ_EXACT_ROWS
+    return true;
+}
+
 // The Minkowski family beyond p = 2 (KZ_MANHATTAN, KZ_CHEBYSHEV, KZ_MINKOWSKI): no inner-product form, hence no MFMA -- a
 // register-tiled VALU kernel.  A workgroup of 256 threads owns 64 queries x 64 index rows, a thread 4 x 4 pairs; the rows are
 // staged through LDS DK features at a time, transposed ([feature][row]: a thread reads its four query values and its four index
@@ -2307,6 +2443,10 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&fl);  // stream-ordered pool: no device sync
             if (rc != KZ_OK) return rc;
             KZ_HIP(hipMemcpyAsync(fl, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+            if (metric == KZ_COSINE && n_fail >= 64 && ctx->exact_rows) {   // (many rows: the normalised float64 index rows, once)
+                rc = kz_matrix_norm64(index);
+                if (rc != KZ_OK) return rc;
+            }
             int64_t batch = ((int64_t)256 << 20) / (index->n * 8);
             if (batch < 1) batch = 1;
             if (batch > n_fail) batch = n_fail;
@@ -2344,7 +2484,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 if (index->dtype == KZ_F32) {
                     if (no_gemm_form)
                         kz_launch_family_dist<float>(ctx, fl, b0, nb, cq_begin, query, index, (double*)vals);
-                    else
+                    else if (ctx->exact_rows && kz_launch_exact_rows(ctx, fl, b0, nb, cq_begin, query, index, metric, (double*)vals)) {
+                    } else
                         hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3(dist_blocks, nb), dim3(256), 0, ctx->stream, fl, b0,
                                            cq_begin, (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn,
                                            index->n, (int)index->d, metric, index->mink_p, (double*)vals);

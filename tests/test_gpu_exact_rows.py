@@ -1,0 +1,60 @@
+"""The exact float64 distance kernel that takes many pairs per wave step (kz_exact_dist_rows_kernel: four query rows in registers,
+64 / LPR consecutive index rows per step) against the one-pair-per-wave kernel it replaces for float32 rows of d <= 256: the same
+values bit for bit (both reproduce kz_wave_dot's order of operations), on every metric, ragged sizes, with and without the
+normalised float64 rows of a cosine index.  The exact kernels are the backstop below every approximate tier (the reference has no
+tiers: scikit-learn's brute force, sklearn_nearest_neighbors.py:96-101).  `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx():
+    from kiez_amd import _native as N
+    c = N.Context.get()
+    yield c
+    c.set_option("eps_scale", 1.0)
+    c.set_option("exact_rows", 1)
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "sqeuclidean", "cosine"])
+@pytest.mark.parametrize("d", [4, 20, 32, 64, 100, 128, 200, 256])
+def test_same_bits_as_the_one_pair_kernel(ctx, metric, d):
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.default_rng(d)
+    n_q, n_i, k = (70, 3001, 7) if d != 64 else (301, 9000, 50)      # (d = 64, 301 rows: the batch that builds the float64 rows too)
+    q = rng.standard_normal((n_q, d)).astype(np.float32)
+    y = rng.standard_normal((n_i, d)).astype(np.float32)
+    y[5] = y[17]              # exact duplicates
+    y[100] = 0.0              # a zero row (cosine: norm 0 -> 1)
+    qm, ym = N.DeviceMatrix(ctx, q, metric), N.DeviceMatrix(ctx, y, metric)
+    ctx.set_option("eps_scale", 1e30)      # every row fails every certification: the exact kernels answer
+    out = {}
+    for rows in (0, 1):
+        ctx.set_option("exact_rows", rows)
+        dd, ii, st = N.knn(ctx, qm, ym, k)
+        assert st["n_fallback_rows"] == n_q, st
+        out[rows] = (dd.numpy(), ii.numpy())
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    q64, y64 = (q.astype(np.float64), y.astype(np.float64)) if metric == "cosine" else (q, y)
+    od, oi = O.knn_exact(q64, y64, k, metric)
+    np.testing.assert_array_equal(out[1][1], oi)
+
+
+def test_values_are_those_of_kz_pair_values(ctx):
+    """... and bit for bit the values kz_pair_values gives for the same pairs (the ordering values that travel between GPUs)."""
+    from kiez_amd import _native as N
+    rng = np.random.default_rng(1)
+    q = rng.standard_normal((200, 96)).astype(np.float32)
+    y = rng.standard_normal((5000, 96)).astype(np.float32)
+    for metric in ("sqeuclidean", "cosine"):
+        qm, ym = N.DeviceMatrix(ctx, q, metric), N.DeviceMatrix(ctx, y, metric)
+        ctx.set_option("eps_scale", 1e30)
+        dd, ii, st = N.knn(ctx, qm, ym, 9)
+        ctx.set_option("eps_scale", 1.0)
+        val = ctx.empty((200, 9), np.float64)
+        N._check(ctx.lib.kz_pair_values(ctx.handle, qm.handle, 0, 200, ym.handle, ii.ptr, 9, val.ptr), "kz_pair_values")
+        np.testing.assert_array_equal(val.numpy(), dd.numpy())       # (sqeuclidean / cosine + float64 output: the distance IS the value)
