@@ -1734,6 +1734,7 @@ __global__ void kz_boot_floor_kernel(const float* __restrict__ in_key, const int
 // and scatter the results into out_dist / out_ind at the rows' positions.  Ends with a stream synchronisation.
 // Dual pass (kz_knn_dual.h): what the main sweep needs to report the events of the index rows besides its own lists.
 struct KzDualPass {
+    int probed;                    // the caller's tier probe has looked at this data (and chose the shared fp16 sweep): no ladder after the fact
     const float* qpack;            // fp16 image of the query rows in a load-balanced order (kz_knn_dual.h "stratified deal") ...
     const int* row_map;            // ... and [query tiles * 128] the matrix row of each of its rows
     const float* ypack;            // fp16 image of the index rows SORTED by their event threshold (kz_himage_pack_permuted) ...
@@ -1840,6 +1841,55 @@ static int kz_escalate_rows(kz_ctx* ctx, kz_matrix* query, int64_t cq_begin, con
 // kp_min: smallest list length to use (escalated subsets of the fp16 tier are first re-done with LONGER lists on the same
 // operand images: the certification compares the K'-th approximate key with the k-th exact one, so more margin in ranks
 // is usually all a failed row needs, and unlike the float32 tier it costs no new image of the index).
+// LADDER AFTER THE FACT (round 5).  A pass that leaves MORE THAN HALF of its rows uncertified without a tier probe having looked at
+// the data first (searches below the probe's size gates; tools/cliff_probe.py: 100k x 101k x 128, tight clusters, 60 - 100 ms
+// against 5.6 on uniform rows) used to hand all of them to the split-bf16 operands, where rows of a tight cluster fail again --
+// what they lack is margin in ranks.  Now a strided sample of the failed rows goes through the fp16 tier's WIDE route first (their
+// results are final either way); at most a quarter of the sample uncertified there: every failed row takes that route, else the
+// caller's choice (prec, kp_min).  Fewer than 4096 failed rows: the caller's choice at once.
+__global__ void kz_strided_pick_kernel(const int* __restrict__ in, int n_out, int64_t stride, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_out) out[i] = in[(int64_t)i * stride];
+}
+static int kz_escalate_ladder(kz_ctx* ctx, kz_matrix* query, int64_t cq_begin, const int* fail_list, int n_fail, kz_matrix* index, int k,
+                              int exclude_self, const int64_t* d_self_ids, int prec, int kp_min, double* out_dist, int64_t* out_ind,
+                              kz_knn_stats* st, float* ms_out) {
+    float ms_probe = 0;
+    // (the wide route wants at least 8 index tiles per list: a small index gets fewer lists, down to 8 -- 128 entries per query)
+    int P = ctx->wide_lists;
+    if ((int64_t)index->n_tiles < (int64_t)8 * P) P = (int)(index->n_tiles / 8);
+    int* keep = nullptr;   // (the caller's list lives in the pass's scratch block, which the probe's own search reuses: a private copy)
+    if (P >= 8 && ctx->esc_ladder && n_fail >= 4096) {
+        const int n_probe = 1024;
+        int* plist = nullptr;
+        int rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);
+        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&keep);
+        if (rc != KZ_OK) {
+            kz_pool_free(ctx, plist, 0);
+            return rc;
+        }
+        KZ_HIP(hipMemcpyAsync(keep, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(kz_strided_pick_kernel, dim3((n_probe + 255) / 256), dim3(256), 0, ctx->stream, keep, n_probe, (int64_t)(n_fail / n_probe), plist);
+        kz_knn_stats stw;
+        memset(&stw, 0, sizeof(stw));
+        rc = kz_escalate_rows(ctx, query, cq_begin, plist, n_probe, index, k, exclude_self, d_self_ids, 0, -P, out_dist, out_ind, &stw, &ms_probe);
+        kz_pool_free(ctx, plist, 0);
+        if (rc != KZ_OK) {
+            kz_pool_free(ctx, keep, 0);
+            return rc;
+        }
+        if (stw.wide_lists > 0 && (int64_t)stw.n_first_pass_fail * 4 <= n_probe) {
+            prec = 0;
+            kp_min = -P;
+        }
+        fail_list = keep;
+    }
+    const int rc = kz_escalate_rows(ctx, query, cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids, prec, kp_min, out_dist, out_ind, st, ms_out);
+    kz_pool_free(ctx, keep, 0);
+    if (ms_out) *ms_out += ms_probe;
+    return rc;
+}
+
 static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q_count, kz_matrix* index, int k,
                        int exclude_self, const int64_t* d_self_ids, int precision_override, int kp_min, double* d_dist,
                        int64_t* d_ind, kz_knn_stats* stats, KzDualPass* dual) {
@@ -2021,6 +2071,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // with 1024 instead of 4096 rows; 200k x 400k x 200, cosine, k = 50: 32.4 -> 31.8); only top-level searches of >= 5e10 distance pairs
     // and >= 16 probe sizes of query rows take it (C1 / C2 do not).  Option "tier_probe" = 0: off.
     float* qfloor_ord = nullptr;   // seeded lists of an ordinary search (the context's buffer: nothing to release)
+    bool probed = false;           // the tier probe below has run: its verdict stands (no ladder after the fact)
     if (tier == KZ_TIER_H && !dual && precision_override < 0 && kp_min == 0 && forced_lists == 0 && !exact_only && ctx->tier_probe > 0 && ctx->esc_bf &&
         q_count >= (int64_t)16 * ctx->tier_probe && ctx->chunk_rows == 0 &&
         ((double)q_count * (double)index->n >= ctx->probe_min_pairs ||
@@ -2040,6 +2091,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             return rc;
         }
         probe_ms = pms;
+        probed = true;
         // (the verdict counts the rows that left the probe's FIRST pass uncertified, once each -- not the cumulative count of the
         //  levels below it, which counted a row that went two levels down twice)
         bool hard = (int64_t)stp.n_first_pass_fail * 2 > n_probe;
@@ -2416,8 +2468,15 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 next_kp = (long_only ? 1000 : 0) + len;
             }
             kz_knn_stats st2;
-            rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids, next_prec,
-                                  next_kp, fp.out_dist, fp.out_ind, &st2, &ms);
+            // (fp16 found hard after the fact, no probe beforehand: the ladder on the failed rows -- top-level calls only)
+            const bool ladder = fp16_hard && !wide_route && next_prec == 2 && !probed && kp_min == 0 && forced_lists == 0 && precision_override < 0 &&
+                                !(dual && dual->probed);
+            if (ladder)
+                rc = kz_escalate_ladder(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids, next_prec,
+                                        next_kp, fp.out_dist, fp.out_ind, &st2, &ms);
+            else
+                rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids, next_prec,
+                                      next_kp, fp.out_dist, fp.out_ind, &st2, &ms);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;
             n_escalated += n_fail + st2.n_escalated_rows;

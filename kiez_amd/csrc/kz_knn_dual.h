@@ -817,6 +817,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // that is handed to two ordinary searches should not have enqueued a sample sweep.
     double floor_model[3] = {0, 0, 0};
     bool have_floor = false;
+    bool tier_probed = false;   // the tier probe below has looked at the data
     // (the floor takes ~2 % off a sweep with one list of 16 per query, ~4.5 % with ten; its probe costs 0.4 - 1 ms: sweeps from
     //  T ~ 25 model-ms on -- C2's shared sweep, T = 2.6: 5.94 ms per step with the floor, 5.58 without)
     const bool want_floor = ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe &&
@@ -840,6 +841,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             hipLaunchKernelGGL(kz_strided_rows_kernel, dim3((unsigned)((n_probe + 255) / 256)), dim3(256), 0, ctx->stream, plist, n_probe, pstride);
             rc = kz_escalate_rows(ctx, a, 0, plist, n_probe, b, k, 0, nullptr, 0, 0, d_dist_ab, d_ind_ab, &stp, &pms);
         }
+        if (rc == KZ_OK && want_tier) tier_probed = true;
         // (the rows the probe's FIRST pass left uncertified, once each)
         if (rc == KZ_OK && want_tier && (int64_t)stp.n_first_pass_fail * 8 > n_probe) {
             // LADDER (kz_knn_impl "WIDE ROUTE"), from an EIGHTH of the probe uncertified on, as an ordinary search's: re-searching
@@ -995,6 +997,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     memset(&rv3, 0, sizeof(rv3));
     KzDualPass dp2;
     memset(&dp2, 0, sizeof(dp2));
+    dp2.probed = 1;   // (the nested sample sweep: its failures are a sample's, the main sweep decides)
     struct Hook2 {
         kz_ctx* ctx; KzDualPass* dp2; KzRevChain* rv3; int rank; int64_t b_n, b_pad; const kz_himage *ia, *ib;
         float *theta, *floor_; const int* rm3; int sev_cap; int* sev_cnt; uint2* sev; int overlap;
@@ -1235,6 +1238,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // ---- main sweep: A x B, lists of A's rows + event log of B's rows ---------------------------------------------------------
     KzDualPass dp;
     memset(&dp, 0, sizeof(dp));
+    dp.probed = tier_probed ? 1 : 0;
     dp.qpack = (const float*)q_packed;
     dp.row_map = row_map;
     dp.ypack = (const float*)p_packed;
@@ -1350,7 +1354,10 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             kz_knn_stats st2;
             // (more than half of B's rows: fp16 is the wrong tier for this data -- the split-bf16 operands at once)
             const int prec = ((int64_t)n_fail * 2 > b->n && ctx->esc_bf) ? 2 : -1;
-            KZ_DUAL_RC(kz_escalate_rows(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, prec, prec == 2 ? 0 : kp_min, d_dist_ba, d_ind_ba, &st2, &ms));
+            if (prec == 2 && !tier_probed)   // (no probe has looked at this data: the ladder on the failed rows, kz_knn.hip "LADDER AFTER THE FACT")
+                KZ_DUAL_RC(kz_escalate_ladder(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, prec, 0, d_dist_ba, d_ind_ba, &st2, &ms));
+            else
+                KZ_DUAL_RC(kz_escalate_rows(ctx, b, 0, fail_list, n_fail, a, k, 0, nullptr, prec, prec == 2 ? 0 : kp_min, d_dist_ba, d_ind_ba, &st2, &ms));
             st_ba.fallback_ms = ms;
             st_ba.n_escalated_rows = n_fail + st2.n_escalated_rows;
             st_ba.n_fallback_rows = st2.n_fallback_rows;

@@ -8,7 +8,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-OPTS = (("tier_probe", 1024), ("probe_min_pairs", 5e10), ("wide_lists", 32), ("wide_sel", 256), ("dual_force", 0), ("eps_scale", 1.0))
+OPTS = (("tier_probe", 1024), ("probe_min_pairs", 5e10), ("wide_lists", 32), ("wide_sel", 256), ("dual_force", 0), ("eps_scale", 1.0), ("esc_ladder", 1),
+        ("probe_min_ms", 12.0))
 
 
 @pytest.fixture()
@@ -86,3 +87,39 @@ def test_shared_sweep_hands_hard_data_to_two_wide_searches(ctx):
     np.testing.assert_array_equal(d_ab.numpy(), d0.numpy())
     np.testing.assert_array_equal(i_ba.numpy(), i1.numpy())
     np.testing.assert_array_equal(d_ba.numpy(), d1.numpy())
+
+
+@pytest.mark.parametrize("metric,k,n_q,n_i,shared", [("euclidean", 10, 30_000, 40_000, False), ("cosine", 50, 30_000, 31_000, True),
+                                                     ("euclidean", 10, 9_000, 12_000, False)])
+def test_ladder_after_the_fact_on_searches_too_small_for_a_probe(ctx, metric, k, n_q, n_i, shared):
+    """Below the probe's size gates a pass finds out AFTERWARDS that fp16 with ordinary lists certifies next to nothing on this
+    data; the failed rows then try the wide route on a sample of themselves before the split-bf16 tier (kz_knn.hip "LADDER AFTER
+    THE FACT").  Results with and without that ladder are identical and the oracle's; with it the call is several times faster
+    (tools/cliff_probe.py) -- here only: not slower by more than measurement noise."""
+    import time
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    q, y = clustered(n_q, 64, 3, clusters=20, shuffle=True), clustered(n_i, 64, 4, clusters=20, shuffle=True)
+    qm, ym = N.DeviceMatrix(ctx, q, metric), N.DeviceMatrix(ctx, y, metric)
+    out, ms = {}, {}
+    for ladder in (0, 1, 0, 1):
+        ctx.set_option("esc_ladder", ladder)
+        ctx.sync()
+        t0 = time.perf_counter()
+        if shared:
+            (d, i, st), (e, j, st2) = N.knn_dual(ctx, qm, ym, k)
+            res = (d.numpy(), i.numpy(), e.numpy(), j.numpy())
+        else:
+            d, i, st = N.knn(ctx, qm, ym, k)
+            res = (d.numpy(), i.numpy())
+        ctx.sync()
+        ms[ladder] = (time.perf_counter() - t0) * 1e3
+        assert st["n_escalated_rows"] >= 4096, st      # (the situation this test is about: most rows left the first pass uncertified)
+        out[ladder] = res
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+    rows = np.arange(0, n_q, max(n_q // 300, 1))
+    q64, y64 = (q.astype(np.float64), y.astype(np.float64)) if metric == "cosine" else (q, y)
+    od, oi = O.knn_exact(q64[rows], y64, k, metric)
+    np.testing.assert_array_equal(out[1][1][rows], oi)
+    assert ms[1] <= 1.25 * ms[0] + 1.0, ms

@@ -1,7 +1,7 @@
 """GPU box: how much slower is the search on data that is NOT uniform?  kz_knn_dual (both directions of a hubness-reduced fit +
 kneighbors) on six kinds of data at a few shapes -- time, ratio to uniform rows of the same shape, and the route the call took
 (first-pass tier, wide lists, rows re-searched, rows on the exact kernels).  Round 4's verdict: clustered data must not fall off a
-cliff (hard: 5 x uniform then).      python3 tools/cliff_probe.py"""
+cliff (hard: 5 x uniform then).      python3 tools/cliff_probe.py [n d k metric]"""
 import sys
 import time
 
@@ -38,7 +38,10 @@ def gen(kind, n, d, rng):
 
 KINDS = ["uniform", "normal", "40 tight clusters, stored cluster by cluster", "40 tight clusters, shuffled", "clusters of very different density",
          "256-component mixture, L2-normalised"]
-for n, d, k, metric in ((300_000, 64, 50, "cosine"), (300_000, 96, 10, "euclidean"), (200_000, 200, 10, "euclidean")):
+SHAPES = ((300_000, 64, 50, "cosine"), (300_000, 96, 10, "euclidean"), (200_000, 200, 10, "euclidean"))
+if len(sys.argv) > 4:      # one shape from the command line: n d k metric
+    SHAPES = ((int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]),)
+for n, d, k, metric in SHAPES:
     base = None
     for kind in KINDS:
         rng = np.random.default_rng(11)
