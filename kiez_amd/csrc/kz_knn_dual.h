@@ -820,14 +820,16 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     bool tier_probed = false;   // the tier probe below has looked at the data
     // (the floor takes ~2 % off a sweep with one list of 16 per query, ~4.5 % with ten; its probe costs 0.4 - 1 ms: sweeps from
     //  T ~ 25 model-ms on -- C2's shared sweep, T = 2.6: 5.94 ms per step with the floor, 5.58 without)
-    const bool want_floor = ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe &&
-                            (ctx->dual_force || t_sweep_ms >= (KP > 16 ? 12.0 : 25.0));   // ("dual_force", the test knob, skips this gate too)
+    bool want_floor = ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe &&
+                      (ctx->dual_force || t_sweep_ms >= (KP > 16 ? 12.0 : 25.0));   // ("dual_force", the test knob, skips this gate too)
     // The same probe is this call's TIER PROBE (kz_knn_impl): a shared sweep of a size at which an ordinary search would first
     // look whether the data is hard for fp16 as a whole looks too -- more than half of the probe rows uncertified: two ordinary
     // searches instead, each of which starts at the split-bf16 tier (bench.py "hard", 300k x 301k clustered rows: 127 ms per step
     // that way, 201 ms through a shared fp16 sweep whose rows nearly all go down the tiers afterwards).
     const bool want_tier = !ctx->dual_force && ctx->tier_probe > 0 && ctx->esc_bf && a->n >= (int64_t)16 * ctx->tier_probe &&
                            ((double)a->n * (double)b->n >= ctx->probe_min_pairs || t_sweep_ms >= ctx->probe_min_ms);
+    // (a tier probe that runs anyway gives the floor for nothing: sweeps of 12 .. 25 model-ms with lists of 16)
+    if (want_tier && ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe) want_floor = true;
     if (want_floor || want_tier) {
         const int n_probe = want_floor ? ctx->floor_probe : (ctx->tier_probe < 1024 ? ctx->tier_probe : 1024);
         const int64_t pstride = a->n / n_probe;
