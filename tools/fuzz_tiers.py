@@ -45,6 +45,11 @@ def main():
         ctx.set_option("probe_min_pairs", 0.0 if tp else 5e10)
         ctx.set_option("wide_lists", wl)
         ctx.set_option("wide_sel", ws)
+        # the bottom of the ladder: the exact kernels' two distance kernels, the shortcut to them, the ladder after the fact
+        er, ed, el = int(rng.randint(0, 2)), int(rng.choice([0, 32, 4096])), int(rng.randint(0, 2))
+        ctx.set_option("exact_rows", er)
+        ctx.set_option("exact_direct_rows", ed)
+        ctx.set_option("esc_ladder", el)
         res = {}
         for prec in (0, 2, 1):   # fp16 first pass (default), split-bf16, float32 operands only
             ctx.set_option("precision", prec)
@@ -58,7 +63,8 @@ def main():
         ctx.set_option("short_ord_min_tiles", 48)
         ctx.set_option("eps_scale", 1.0)
         ctx.set_option("h_q64", 2)
-        for name, v in (("tier_probe", 1024), ("probe_min_pairs", 5e10), ("wide_lists", 32), ("wide_sel", 256)):
+        for name, v in (("tier_probe", 1024), ("probe_min_pairs", 5e10), ("wide_lists", 32), ("wide_sel", 256), ("exact_rows", 1), ("exact_direct_rows", 32),
+                        ("esc_ladder", 1)):
             ctx.set_option(name, v)
         ok = all(np.array_equal(res[0][1], res[p][1]) and np.array_equal(res[0][0], res[p][0]) for p in (1, 2))
         if len(s) * n_t <= 2_000_000:
@@ -67,7 +73,7 @@ def main():
         tag = "ok " if ok else "BAD"
         bad += 0 if ok else 1
         print(tag, f"n_s={len(s)} n_t={n_t} d={d} {metric} {np.dtype(dtype).name} k={k} single={single}",
-              "tier", res[0][2]["first_pass"], "lists", res[0][2]["n_splits"], "x", res[0][2]["list_len"], f"min_tiles {min_tiles} eps {eps} q64 {q64} probe {tp} wide {wl}/{ws} -> {res[0][2]['wide_lists']}", "esc", res[0][2]["n_escalated_rows"], "fb", res[0][2]["n_fallback_rows"],
+              "tier", res[0][2]["first_pass"], "lists", res[0][2]["n_splits"], "x", res[0][2]["list_len"], f"min_tiles {min_tiles} eps {eps} q64 {q64} probe {tp} wide {wl}/{ws} -> {res[0][2]['wide_lists']} exact {er}/{ed} ladder {el}", "esc", res[0][2]["n_escalated_rows"], "fb", res[0][2]["n_fallback_rows"],
               "ratio %.3f" % res[0][2]["max_err_ratio"])
     print("cases", n_cases, "bad", bad)
     sys.exit(1 if bad else 0)
