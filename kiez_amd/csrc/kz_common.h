@@ -57,6 +57,7 @@ struct kz_ctx {
     int tier_probe;   // rows of the strided sample a large ordinary search sends through the fp16 pass first (0 = off; default 1024): more than half uncertified -> the call starts at split-bf16
     int dual_nested;  // kz_knn_dual: 1 (default) = the sample is the first tiles of the dealt image and is swept ONLY by the sample sweep (kz_knn_dual.h "NESTED")
     int fin_wide;     // 1 (default): finalize launches with more than 160 selected candidates run kz_knn_fin_wide.h (no O(n^2) sorts, several rows per gather step)
+    double nested_min_ms;   // kz_knn_dual: the nested sample is taken from this saving on (model-ms of sweep / stride; 2)
     int esc_ladder;   // 1 (default): kz_knn.hip "LADDER AFTER THE FACT"
     int exact_rows;   // 1 (default): the exact distance kernel that keeps four query rows in registers and takes 64 / LPR index rows per step
     int exact_direct_rows;   // a split-bf16 pass that leaves at most this many rows (default 32) hands them to the exact kernels directly (kz_knn_impl)

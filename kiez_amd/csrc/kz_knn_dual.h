@@ -645,7 +645,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         // Same box, rank 8, ms per step: ns stride 9 / 10 / 11 / 12 / 13 / 14 / 16 / 18 / 23 (the old choice) -> 98.5 / 98.4 / 98.0 /
         // 97.5 / 98.1 / 97.8 / 98.6 / 99.6 / 99.8; C4's share 10 / 12 / 14 / 16 / 28 -> 147.3 / 146.1 / 148.2 / 147.5 / 149.7; gmm
         // (200k x 200k x 300) 6 / 8 / 10 / 12 -> 34.0 / 34.7 / 34.9 / 35.7; C3 (rank 12) 8 / 10 / 13 / 16 -> 127.7 / 124.9 / 125.8 / 126.8.
-        if (ctx->dual_nested && ctx->dual_deal && !small_sweep && b->n <= kz_rows_per_chunk(ctx, KP, false) && t_ms / stride >= 2.0) {
+        if (ctx->dual_nested && ctx->dual_deal && !small_sweep && b->n <= kz_rows_per_chunk(ctx, KP, false) && t_ms / stride >= ctx->nested_min_ms) {
             int half = (int)(0.5 * (s_opt > 32.0 ? 32.0 : s_opt) + 0.5);
             if (half < 4) half = 4;
             while (half < stride && kz_dual_p_fail(k, rank, (double)half) > 1e-3) ++half;
@@ -938,7 +938,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     // (it saves t_sweep / stride and costs ~1 ms of extra launches, sorts and a host synchronisation: C2's shared sweep, 2.6 model-ms at
     //  stride 4, went from 5.7 to 6.7 ms per step with it -- taken from 2 model-ms of saving on; "dual_force" keeps it for the tests)
     bool nested = ctx->dual_nested && ctx->dual_deal && s_tiles >= 8 && s_tiles < a->n / KZ_TILE && s_img_rows >= (int64_t)8 * KP &&
-                  b->n <= kz_rows_per_chunk(ctx, KP, false) && (ctx->dual_force || t_sweep_ms / stride >= 2.0);
+                  b->n <= kz_rows_per_chunk(ctx, KP, false) && (ctx->dual_force || t_sweep_ms / stride >= ctx->nested_min_ms);
     if (nested) {
         const double t2_ms = 2.0 * (double)b->n * (double)s_img_rows * (double)(a->kg * 4) / 1e12;
         const int rank3_safe = k + 1 < KP ? k + 1 : KP;

@@ -55,6 +55,7 @@ static const KzOption KZ_OPTIONS[] = {
     {"probe_min_ms", KZ_OPT_F64, KZ_O(probe_min_ms), 0, 1e300, 12.0, 0, {}, 0, "... unless the sweep is at least this many model-ms (2 n_q n_i d / 1e12) long"},
     {"fin_wide", KZ_OPT_INT, KZ_O(fin_wide), 0, 2, 1, 0, {}, 0, "finalize of > 160 selected candidates without O(n^2) sorts, several rows per gather step"},
     {"range_boot", KZ_OPT_BOOL, KZ_O(range_boot), 0, 1, 1, 0, {}, 0, "short-list routes: index range 0 first, the other ranges' lists start at the floor read off it"},
+    {"nested_min_ms", KZ_OPT_F64, KZ_O(nested_min_ms), 0, 1e300, 2.0, 0, {}, 0, "the nested sample of the shared sweep is taken when it saves at least this many model-ms (sweep / stride)"},
     {"esc_ladder", KZ_OPT_BOOL, KZ_O(esc_ladder), 0, 1, 1, 0, {}, 0, "a pass without a probe that leaves more than half of its rows uncertified tries the wide route on a sample of them before the split-bf16 tier"},
     {"exact_rows", KZ_OPT_BOOL, KZ_O(exact_rows), 0, 1, 1, 0, {}, 0, "exact float64 kernels: many pairs per wave step for float32 rows of d <= 256 (kz_exact_dist_rows_kernel)"},
     {"exact_direct_rows", KZ_OPT_INT, KZ_O(exact_direct_rows), 0, 4096, 32, 0, {}, 0, "at most this many rows left by the split-bf16 tier skip the float32-operand kernel and go to the exact kernels"},
