@@ -297,7 +297,9 @@ __device__ __forceinline__ void kz_emit_sorted(const double* sval, const int* si
 // Round 4 (the loads of the loop issued without branches, so that the prefetch overlaps at all; the per-query values in scalar
 // registers: 71 -> 59 VGPRs), finalize time over 4 steps of C3 + 4 of ns, reverse chain not overlapped: rows 1 depth 2 at 8 waves
 // 69.2 ms; rows 2 depth 2 at 7 (70 VGPRs) 69.1; rows 1 depth 3 at 7 69.5; **rows 1 depth 3 at 8 (64 VGPRs, no spill) 67.4**; rows 2
-// depth 3 at 6 72.9.
+// depth 3 at 6 72.9.  Round 5: the selection paths added since (unsorted path, radix selections) brought the 8-wave build to 8
+// spilled VGPRs; 7 waves (72 VGPRs, none spilled), same box, two runs each: ns 98.14 / 98.04 -> 97.56 / 97.16 ms per step, C3
+// 122.43 / 122.34 -> 122.19 / 121.87.
 #ifndef KZ_FIN_ROWS_N
 #define KZ_FIN_ROWS_N 1
 #endif
@@ -953,7 +955,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 // cache lines of one wave-interleaved block) measured 2x SLOWER than 4: finalize is latency-bound and wants many workgroups.
 constexpr int KZ_FIN_QPB = 4;
 #ifndef KZ_FIN_WAVES
-#define KZ_FIN_WAVES 8  // minimum waves per SIMD the finalize kernel is compiled for (see KZ_FIN_ROWS_N above)
+#define KZ_FIN_WAVES 7  // minimum waves per SIMD the finalize kernel is compiled for (see KZ_FIN_ROWS_N above)
 #endif
 // FROWS / MINW: candidate rows gathered per group and the occupancy compiled for.  <1, KZ_FIN_WAVES> is the kernel of every
 // ordinary pass (a dozen to ~50 gathered rows per query: waves in flight beat rows in flight per wave); <8, 2> serves the long-k
