@@ -1537,7 +1537,8 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
             const bool wide = (fp.KSEL > 0 ? fp.KSEL : KP) > 160;   // the long-k route
             // (many selected candidates + float32 rows on the fp16 tier, ordinary direction: kz_knn_fin_wide.h -- option "fin_wide")
             // ("fin_wide" = 2: every launch that selects from several lists, KSEL > 0 -- the short-list routes -- takes it too)
-            const bool wide2 = (wide || (ctx->fin_wide >= 2 && fp.KSEL > 0)) && dtype == KZ_F32 && fp.tier_h && !fp.excl_floor && ctx->fin_wide;
+            const bool rows_vec = fp.d <= 256 && (fp.d & 3) == 0 && (((uintptr_t)fp.qraw | (uintptr_t)fp.yraw) & 15u) == 0;
+            const bool wide2 = (wide || (ctx->fin_wide >= 2 && fp.KSEL > 0)) && dtype == KZ_F32 && fp.tier_h && !fp.excl_floor && ctx->fin_wide && rows_vec;
             const void* fk = dtype == KZ_F32 ? (wide2 ? (const void*)kz_knn_finalize_wide_kernel<float, 3> : (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>))
                                              : (wide ? (const void*)kz_knn_finalize_kernel<double, 4, 2> : (const void*)kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>);
             if (fin_lds > 65536) KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));

@@ -18,11 +18,9 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
     const int64_t qrow = p.row_map ? (int64_t)p.row_map[p.q_begin + q] : p.q_begin + q;
     const T* qptr = reinterpret_cast<const T*>(p.qraw) + qrow * (int64_t)p.d;
     const T* yraw = reinterpret_cast<const T*>(p.yraw);
-    // what this path is built for; everything else: the generic path
-    if (sizeof(T) != 4 || !p.tier_h || p.excl_floor || p.d > 256 || !(kz_row_vec_ok(qptr, p.d) && kz_row_vec_ok(yraw, p.d))) {
-        kz_finalize_query<T, 8>(p, q, lane, wbase);
-        return;
-    }
+    // what this path is built for is decided per LAUNCH on the host (kz_launch_finalize: float32 rows on the fp16 tier, ordinary
+    // direction, d <= 256, 16-byte aligned rows); the generic path used to be inlined here as a per-query fallback and cost the
+    // kernel 57 spilled VGPRs at its three waves per SIMD
     double* cv = reinterpret_cast<double*>(wbase);
     double* sv = cv + KS;
     float* ekey = reinterpret_cast<float*>(sv + KS);
