@@ -322,6 +322,10 @@ static int kz_max_pieces(int KP, int halves) {
 __host__ __device__ __forceinline__ int kz_fin_wave_bytes(int max_m, int KP) {
     return ((max_m * 8 + KP * 28) + 15) & ~15;
 }
+// (the finalize kernel for many candidates shares bytes between arrays that are never live together: kz_knn_fin_wide.h)
+__host__ __device__ __forceinline__ int kz_fin_wide_wave_bytes(int max_m, int KS) {
+    return ((max_m * 8 + KS * 20) + 15) & ~15;
+}
 
 // k-th largest (rank = 1: the largest) of n float keys held as SORTABLE unsigned patterns in LDS; returns the pattern.
 // Wave-cooperative: 32 counting passes at most, fewer below the common prefix of the patterns.  The entries are read ONCE into
@@ -1533,17 +1537,18 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
             fp.max_m = groups[g].max_m;
             fp.fast_div = ctx->fin_fast_div;
             const int fin_blocks = (int)((fp.q_last - fp.q_first + KZ_FIN_QPB - 1) / KZ_FIN_QPB);
-            const size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, fp.KSEL > 0 ? fp.KSEL : KP);
+            size_t fin_lds = (size_t)4 * kz_fin_wave_bytes(fp.max_m, fp.KSEL > 0 ? fp.KSEL : KP);
             const bool wide = (fp.KSEL > 0 ? fp.KSEL : KP) > 160;   // the long-k route
             // (many selected candidates + float32 rows on the fp16 tier, ordinary direction: kz_knn_fin_wide.h -- option "fin_wide")
             // ("fin_wide" = 2: every launch that selects from several lists, KSEL > 0 -- the short-list routes -- takes it too)
             const bool rows_vec = fp.d <= 256 && (fp.d & 3) == 0 && (((uintptr_t)fp.qraw | (uintptr_t)fp.yraw) & 15u) == 0;
             const bool wide2 = (wide || (ctx->fin_wide >= 2 && fp.KSEL > 0)) && dtype == KZ_F32 && fp.tier_h && !fp.excl_floor && ctx->fin_wide && rows_vec;
-            const void* fk = dtype == KZ_F32 ? (wide2 ? (const void*)kz_knn_finalize_wide_kernel<float, 3> : (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>))
+            const void* fk = dtype == KZ_F32 ? (wide2 ? (const void*)kz_knn_finalize_wide_kernel<float, 4> : (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>))
                                              : (wide ? (const void*)kz_knn_finalize_kernel<double, 4, 2> : (const void*)kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>);
+            if (wide2) fin_lds = (size_t)4 * kz_fin_wide_wave_bytes(fp.max_m, fp.KSEL);
             if (fin_lds > 65536) KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
             if (wide2)
-                hipLaunchKernelGGL((kz_knn_finalize_wide_kernel<float, 3>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
+                hipLaunchKernelGGL((kz_knn_finalize_wide_kernel<float, 4>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
             else if (dtype == KZ_F32 && wide)
                 hipLaunchKernelGGL((kz_knn_finalize_kernel<float, 8, 2>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
             else if (dtype == KZ_F32)

@@ -21,12 +21,20 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
     // what this path is built for is decided per LAUNCH on the host (kz_launch_finalize: float32 rows on the fp16 tier, ordinary
     // direction, d <= 256, 16-byte aligned rows); the generic path used to be inlined here as a per-query fallback and cost the
     // kernel 57 spilled VGPRs at its three waves per SIMD
+    // LDS of a wave (kz_fin_wide_wave_bytes: 8 max_m + 20 KS bytes -- 9 KiB at 512 entries / 256 selected: FOUR workgroups per CU;
+    // with every array on its own, 11.3 KiB, it was three, and the kernel is bound by latency; five -- si in the free half of eidx --
+    // measured no faster):
+    //   cv   [KS] float64   exact values of the re-ranked candidates; before the re-rank: scratch for sortable key patterns (su)
+    //   ekey / eidx [max_m] the list copy; after the selection: the candidates within 2 eps of the k-th key; eidx later the ids of
+    //                       the long-k sort's output
+    //   ck / ci [KS]        the KS selected keys and rows -- dead after the 2-eps compaction, then sv [KS] float64: the k + 1 smallest values
+    //   si   [KS]           their rows
     double* cv = reinterpret_cast<double*>(wbase);
-    double* sv = cv + KS;
-    float* ekey = reinterpret_cast<float*>(sv + KS);
+    float* ekey = reinterpret_cast<float*>(cv + KS);
     int* eidx = reinterpret_cast<int*>(ekey + p.max_m);
     float* ck = reinterpret_cast<float*>(eidx + p.max_m);
     int* ci = reinterpret_cast<int*>(ck + KS);
+    double* sv = reinterpret_cast<double*>(ck);
     int* si = ci + KS;
     const int KP = p.KP;
     const int k_eff = p.k + (p.exclude_self ? 1 : 0);
@@ -160,7 +168,7 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
     const double key_scale = p.hscale[1];
     auto exact_key = [&](double v) { return 0.5 * (qc2 - (p.metric == KZ_COSINE ? 2.0 * v : v)); };
     // ---- the k-th best approximate key; candidates within 2 eps of it go to the front (ekey / eidx: the list copy is spent) ----
-    unsigned* su = reinterpret_cast<unsigned*>(sv);   // (scratch: sv is written after the re-rank)
+    unsigned* su = reinterpret_cast<unsigned*>(cv);   // (scratch: cv is written by the re-rank)
     for (int c = lane; c < V; c += 64) {
         const unsigned b = __float_as_uint(ck[c]);
         su[c] = (b == 0x80000000u ? 0u : b) ^ (((b == 0x80000000u ? 0u : b) >> 31) ? 0xffffffffu : 0x80000000u);
@@ -360,7 +368,7 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
             }
         }
     } else {
-        // long k (more than 255 neighbours): out of place into cv / ci, which are spent
+        // long k (more than 255 neighbours): out of place into cv / eidx, which are spent (ci shares its bytes with sv)
         for (int c = lane; c < ns; c += 64) {
             const double v = sv[c];
             const int id = si[c];
@@ -371,10 +379,10 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
                 rk += (ov < v || (ov == v && oid < id)) ? 1 : 0;
             }
             cv[rk] = v;
-            ci[rk] = id;
+            eidx[rk] = id;
         }
         out_v = cv;
-        out_i = ci;
+        out_i = eidx;
     }
     kz_wave_sync();
     // ---- certification (kz_finalize_query): rows outside the re-ranked set are the selected candidates left behind (<= left_max),
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256, MINW) void kz_knn_finalize_wide_kernel(KnnFinP
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char* wbase = fsm + (size_t)wave * kz_fin_wave_bytes(p.max_m, p.KSEL);
+    char* wbase = fsm + (size_t)wave * kz_fin_wide_wave_bytes(p.max_m, p.KSEL);
     const int64_t q = p.q_first + (int64_t)blockIdx.x * 4 + wave;
     if (q >= p.q_last) return;
     kz_finalize_query_wide<T>(p, q, lane, wbase);
