@@ -1296,6 +1296,131 @@ __global__ __launch_bounds__(256) void kz_exact_chunk_kernel(const double* __res
     }
 }
 
+// The same first level for MANY neighbours (k_eff >= 24): the k_eff-th smallest value of the chunk by a workgroup-wide radix
+// selection on the float64 bit patterns (non-negative doubles order like their patterns; a thread holds 16 of them, a counting pass
+// is 16 compares, a wave sum and one exchange through LDS -- ~55 passes below the common prefix whatever k is, against k_eff rounds
+// of a workgroup-wide arg-min: k = 50: 0.96 -> see r05_notes), then everything below it and, of the entries equal to it, those with
+// the smallest index rows.  The survivors come out in no particular order: kz_exact_select_kernel orders by (value, index row).
+__global__ __launch_bounds__(256) void kz_exact_chunk_radix_kernel(const double* __restrict__ vals, int64_t n_i, int k_eff, int n_chunks,
+                                                                   double* __restrict__ cand_v, int* __restrict__ cand_i) {
+    __shared__ unsigned long long s_or[4], s_and[4];
+    __shared__ int s_cnt[4];
+    __shared__ int s_pos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x, b = blockIdx.y;
+    const double* v = vals + (int64_t)b * n_i;
+    const int64_t i0 = (int64_t)c * KZ_EXACT_CHUNK;
+    constexpr int PER = KZ_EXACT_CHUNK / 256;
+    const int nvalid = (int)(n_i - i0 < KZ_EXACT_CHUNK ? n_i - i0 : KZ_EXACT_CHUNK);
+    double* ov = cand_v + ((int64_t)b * n_chunks + c) * k_eff;
+    int* oi = cand_i + ((int64_t)b * n_chunks + c) * k_eff;
+    unsigned long long x[PER];
+    unsigned long long all_or = 0ull, all_and = ~0ull;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + 256 * u;
+        const bool in = e < nvalid;
+        x[u] = in ? (unsigned long long)__double_as_longlong(v[i0 + e]) : ~0ull;   // (places past the end: above every value)
+        all_or |= in ? x[u] : 0ull;
+        all_and &= x[u];
+    }
+    if (nvalid <= k_eff) {   // (a short last chunk: every entry survives; the unused places hold (+inf, INT_MAX))
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 256 * u;
+            if (e < nvalid) {
+                ov[e] = __longlong_as_double((long long)x[u]);
+                oi[e] = (int)(i0 + e);
+            }
+        }
+        for (int e = nvalid + tid; e < k_eff; e += 256) {
+            ov[e] = INFINITY;
+            oi[e] = 0x7fffffff;
+        }
+        return;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        all_or |= __shfl_xor(all_or, off, 64);
+        all_and &= __shfl_xor(all_and, off, 64);
+    }
+    if (lane == 0) {
+        s_or[wave] = all_or;
+        s_and[wave] = all_and;
+    }
+    if (tid == 0) s_pos = 0;
+    __syncthreads();
+    all_or = s_or[0] | s_or[1] | s_or[2] | s_or[3];
+    all_and = s_and[0] & s_and[1] & s_and[2] & s_and[3];
+    auto block_sum = [&](int cnt) {   // (every thread gets the workgroup's total)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        __syncthreads();   // (the previous round's readers are done with s_cnt)
+        if (lane == 0) s_cnt[wave] = cnt;
+        __syncthreads();
+        return s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    };
+    const unsigned long long differ = all_or ^ all_and;
+    const int top = differ ? 63 - __clzll(differ) : -1;
+    // thr = the k_eff-th smallest pattern: the largest prefix with fewer than k_eff entries below it, bit by bit
+    unsigned long long thr = top >= 63 ? 0ull : (top < 0 ? all_and : (all_and & ~((2ull << top) - 1ull)));
+    for (int bit = top; bit >= 0; --bit) {
+        const unsigned long long cand = thr | (1ull << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) cnt += x[u] < cand ? 1 : 0;
+        if (block_sum(cnt) < k_eff) thr = cand;
+    }
+    // everything below thr
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (x[u] < thr) {
+            const int pos = atomicAdd(&s_pos, 1);
+            ov[pos] = __longlong_as_double((long long)x[u]);
+            oi[pos] = (int)(i0 + tid + 256 * u);
+        }
+    }
+    int ties = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) ties += x[u] == thr ? 1 : 0;
+    const int T = block_sum(ties);   // (its barriers also publish s_pos)
+    const int L = s_pos;
+    const int m = k_eff - L;         // places left for entries equal to thr: 1 <= m <= T
+    if (T == m) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (x[u] == thr) {
+                const int pos = atomicAdd(&s_pos, 1);
+                ov[pos] = __longlong_as_double((long long)thr);
+                oi[pos] = (int)(i0 + tid + 256 * u);
+            }
+        }
+        return;
+    }
+    // more ties at the k_eff-th place than places: those with the smallest index rows, one per round
+    int last = -1;
+    for (int r = 0; r < m; ++r) {
+        int best = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = (int)(i0 + tid + 256 * u);
+            if (x[u] == thr && id > last && id < best) best = id;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+        __syncthreads();
+        if (lane == 0) s_cnt[wave] = best;
+        __syncthreads();
+        best = min(min(s_cnt[0], s_cnt[1]), min(s_cnt[2], s_cnt[3]));
+        if (tid == 0) {
+            ov[L + r] = __longlong_as_double((long long)thr);
+            oi[L + r] = best;
+        }
+        last = best;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restrict__ fail_list, int batch0, int64_t q_begin,
                                                               const double* __restrict__ vals, const int* __restrict__ cand_idx,
@@ -2557,8 +2682,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                                            cq_begin, (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn,
                                            index->n, (int)index->d, metric, index->mink_p, (double*)vals);
                     if (two_level)
-                        hipLaunchKernelGGL(kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0, ctx->stream, (const double*)vals, index->n, k_sel,
-                                           n_chunks, cand_v, cand_i);
+                        hipLaunchKernelGGL(k_sel >= 24 && ctx->exact_rows ? kz_exact_chunk_radix_kernel : kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0,
+                                           ctx->stream, (const double*)vals, index->n, k_sel, n_chunks, cand_v, cand_i);
                     hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
                                        two_level ? (const double*)cand_v : (const double*)vals, two_level ? (const int*)cand_i : (const int*)nullptr,
                                        two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p,
@@ -2571,8 +2696,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                                            cq_begin, (const double*)query->raw, (const double*)index->raw, query->sqn, index->sqn,
                                            index->n, (int)index->d, metric, index->mink_p, (double*)vals);
                     if (two_level)
-                        hipLaunchKernelGGL(kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0, ctx->stream, (const double*)vals, index->n, k_sel,
-                                           n_chunks, cand_v, cand_i);
+                        hipLaunchKernelGGL(k_sel >= 24 && ctx->exact_rows ? kz_exact_chunk_radix_kernel : kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0,
+                                           ctx->stream, (const double*)vals, index->n, k_sel, n_chunks, cand_v, cand_i);
                     hipLaunchKernelGGL(kz_exact_select_kernel<double>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
                                        two_level ? (const double*)cand_v : (const double*)vals, two_level ? (const int*)cand_i : (const int*)nullptr,
                                        two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p,

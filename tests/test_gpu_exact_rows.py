@@ -58,3 +58,27 @@ def test_values_are_those_of_kz_pair_values(ctx):
         val = ctx.empty((200, 9), np.float64)
         N._check(ctx.lib.kz_pair_values(ctx.handle, qm.handle, 0, 200, ym.handle, ii.ptr, 9, val.ptr), "kz_pair_values")
         np.testing.assert_array_equal(val.numpy(), dd.numpy())       # (sqeuclidean / cosine + float64 output: the distance IS the value)
+
+
+@pytest.mark.parametrize("k", [30, 64])
+def test_many_exact_ties_at_the_kth_place(ctx, k):
+    """Small-integer rows: hundreds of index rows at exactly the same distance -- the radix selection of the exact kernels' first level
+    (k >= 24: kz_exact_chunk_radix_kernel) must keep, of the rows tied at the k-th place, those with the smallest index."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.default_rng(k)
+    q = rng.integers(0, 3, (150, 8)).astype(np.float32)
+    y = rng.integers(0, 3, (21_000, 8)).astype(np.float32)      # (six chunks of 4 096: the two-level selection)
+    qm, ym = N.DeviceMatrix(ctx, q, "sqeuclidean"), N.DeviceMatrix(ctx, y, "sqeuclidean")
+    ctx.set_option("eps_scale", 1e30)
+    out = {}
+    for rows in (0, 1):
+        ctx.set_option("exact_rows", rows)
+        dd, ii, st = N.knn(ctx, qm, ym, k)
+        assert st["n_fallback_rows"] == 150, st
+        out[rows] = (dd.numpy(), ii.numpy())
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    od, oi = O.knn_exact(q, y, k, "sqeuclidean")
+    np.testing.assert_array_equal(out[1][1], oi)
+    np.testing.assert_array_equal(out[1][0], od)
