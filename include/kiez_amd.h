@@ -53,7 +53,8 @@ typedef struct kz_knn_stats {
     double main_kernel_ms;   /* HIP-event time of the fused distance+top-k kernel (the dominant kernel)   */
     double finalize_ms;      /* merge + certify + float64 re-rank kernel                                   */
     double fallback_ms;      /* exact float64 brute-force for uncertified rows (0 if none)                 */
-    int64_t n_fallback_rows; /* query rows whose candidate set could not be certified                      */
+    int64_t n_fallback_rows; /* query rows answered by the exact float64 kernels: no approximate tier could certify their
+                                candidate set (or, a handful left by the split-bf16 tier, sent there directly)        */
     int32_t list_len;        /* K' = per-list candidate count kept by the fused kernel                     */
     int32_t n_splits;        /* index range splits (grid.y)                                                */
     int32_t n_blocks;        /* workgroups launched                                                        */
