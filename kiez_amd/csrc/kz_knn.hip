@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(256) void kz_exact_dist_rows_kernel(const int* __re
 static bool kz_launch_exact_rows(kz_ctx* ctx, const int* fl, int b0, int nb, int64_t cq_begin, const kz_matrix* query, const kz_matrix* index,
                                  int metric, double* vals) {
     const int d = (int)index->d;
-    if (index->dtype != KZ_F32 || (d & 3) != 0 || d > 256 || metric > KZ_COSINE) return false;
+    if (index->dtype != KZ_F32 || (d & 3) != 0 || d > 256 || metric > KZ_COSINE || (((uintptr_t)query->raw | (uintptr_t)index->raw) & 15u) != 0) return false;
     const bool norm = metric == KZ_COSINE && index->norm64 != nullptr;
     const int rows_per_wave = 256;
     const dim3 grid((unsigned)((index->n + 4 * rows_per_wave - 1) / (4 * rows_per_wave)), (unsigned)((nb + 3) / 4));
@@ -2001,7 +2001,12 @@ static int kz_escalate_ladder(kz_ctx* ctx, kz_matrix* query, int64_t cq_begin, c
             kz_pool_free(ctx, plist, 0);
             return rc;
         }
-        KZ_HIP(hipMemcpyAsync(keep, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        if (hipMemcpyAsync(keep, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+            kz_pool_free(ctx, plist, 0);
+            kz_pool_free(ctx, keep, 0);
+            kz_set_error("kz_knn: copying the list of uncertified rows failed");
+            return KZ_ERR_HIP;
+        }
         hipLaunchKernelGGL(kz_strided_pick_kernel, dim3((n_probe + 255) / 256), dim3(256), 0, ctx->stream, keep, n_probe, (int64_t)(n_fail / n_probe), plist);
         kz_knn_stats stw;
         memset(&stw, 0, sizeof(stw));
