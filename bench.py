@@ -73,6 +73,92 @@ TIER_KERNEL = {
     0: "kz_knn_cand_kernel (fp32 MFMA 32x32x2 fused distance+top-k)"}
 
 
+LINE_LIMIT = 4096     # bytes of the ONE stdout line (the driver keeps a bounded tail of stdout: round 5's 20 KB line did not parse)
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms",
+                 "algorithmic_flop_per_launch", "effective_clock_ghz", "mfma_pipe_busy", "shared_sweeps")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "fit_seconds_extrapolated", "kneighbors_seconds_extrapolated")
+CHECK_KEYS = ("rows", "ranks", "fit_state_rows", "fit_state_max_rel_err", "fit_state_rows_identical", "index_rows_identical",
+              "knife_edge_rows", "knife_edge_rows_identical", "rows_not_knife_edge", "recall_at_k", "max_rel_dist_err",
+              "hits_reference_formula")
+CONFIG_DROP = ("inputs", "parallelism", "engine")
+
+
+def _r(x, digits=6):
+    """Floats of the compact line at 6 significant digits (the detail file keeps full precision)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def compact_line(line, detail_path):
+    """The ONE stdout line: exactly what the contract reads (metric, value, unit, n_gpus, steps, warmup, ms_per_step, scaling,
+    dtype, data, config, roofline, cpu_baseline) + check, recall_at_k, the per-workload `summary` rows and the name of the side
+    file that holds everything else.  Never longer than LINE_LIMIT bytes: the optional parts are dropped, last first, until it fits."""
+    c = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                  "vs_baseline", "dtype", "data")}
+    if line.get("launch_check"):
+        c["launch_check"] = True
+    cfg = dict(line.get("config") or {})
+    par = cfg.get("parallelism")
+    for k in CONFIG_DROP:
+        cfg.pop(k, None)
+    if par:
+        cfg["parallelism"] = par.split(" (")[0]
+    c["config"] = cfg
+    if "roofline" in line:
+        roof = {k: line["roofline"].get(k) for k in ROOFLINE_KEYS}
+        roof["kernel"] = (roof.get("kernel") or "").split(" (")[0]
+        c["roofline"] = roof
+    if "cpu_baseline" in line:
+        c["cpu_baseline"] = {k: line["cpu_baseline"][k] for k in CPU_KEYS if k in line["cpu_baseline"]}
+    if "check" in line:
+        c["check"] = {k: line["check"][k] for k in CHECK_KEYS if k in line["check"]}
+    c["recall_at_k"] = line.get("recall_at_k")
+    optional = []          # dropped from the END of this list first when the line is too long
+    for k in ("summary", "host_api", "collective_ms_per_step", "hits", "certification_fallback_rows", "escalated_rows"):
+        if line.get(k) is not None:
+            v = line[k]
+            if k == "host_api":
+                v = {"value": v["value"], "unit": v["unit"], "ms": v["ms"]}
+            c[k] = v
+            optional.append(k)
+    c["detail"] = detail_path
+    c = _r(c)
+    text = json.dumps(c, separators=(",", ":"))
+    while len(text) > LINE_LIMIT and optional:
+        c.pop(optional.pop())
+        text = json.dumps(c, separators=(",", ":"))
+    if len(text) > LINE_LIMIT and "sample" in c.get("cpu_baseline", {}):
+        c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"][:160]
+        text = json.dumps(c, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:      # (cannot happen with the fields above; the contract fields alone are < 2 KB)
+        raise RuntimeError(f"bench.py: the result line is {len(text)} bytes (> {LINE_LIMIT})")
+    return text
+
+
+def emit(line, json_fd, args):
+    """Full record -> bench_detail.json next to this script (and gpurun_out/ when that exists) and stderr; compact record ->
+    the ONE stdout line."""
+    full = json.dumps(line)
+    name = getattr(args, "detail", None) or "bench_detail.json"
+    written = None
+    targets = [Path(name)] if Path(name).is_absolute() else [ROOT / name, ROOT / "gpurun_out" / name]
+    for t in targets:
+        try:
+            if t.parent.is_dir():
+                t.write_text(full + "\n")
+                written = written or name
+        except OSError:
+            pass
+    sys.stderr.write("bench.py full record: " + full + "\n")
+    sys.stderr.flush()
+    os.write(json_fd, (compact_line(line, written) + "\n").encode())
+
+
 def _median(xs):
     xs = sorted(xs)
     return xs[len(xs) // 2]
@@ -558,6 +644,7 @@ def parse_args(argv=None):
                     help="weak: every rank owns the workload's source rows (default); strong: the workload's source rows are split "
                          "over the ranks (default workload: BASELINE.json configuration 4 at its stated size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail", default="bench_detail.json", help="file name of the full record (written next to bench.py and into gpurun_out/; an absolute path: only there)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle sample check")
     ap.add_argument("--no-others", action="store_true", help="do not run the other BASELINE configurations after the main workload")
     ap.add_argument("--opt", action="append", default=[], help="context option name=value (tuning experiments)")
@@ -643,7 +730,7 @@ def main():
                 line["check"] = s["check"]
             if cpu is not None:
                 line["cpu_baseline"] = cpu
-            os.write(json_fd, (json.dumps(line) + "\n").encode())
+            emit(line, json_fd, args)
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
@@ -658,7 +745,7 @@ def main():
             raise SystemExit("--openea runs on one GPU")
         line = run_openea(args)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        emit(line, json_fd, args)
         return
 
     from kiez_amd.distributed import Comm, HipEngine
@@ -788,10 +875,8 @@ def main():
             except Exception as e:  # pragma: no cover
                 line["cosine_f32_probe"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
-        if "summary" in line:    # first in the line: a truncated tail of the driver's record still shows every workload
-            line = {"metric": line["metric"], "summary": line.pop("summary"), **line}
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        emit(line, json_fd, args)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -11,13 +11,25 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def test_default_bench_line_has_what_the_driver_reads():
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--no-others"], capture_output=True, text=True,
+def test_default_bench_line_has_what_the_driver_reads(tmp_path):
+    """The DRIVER'S command shape (`python3 bench.py --gpus 1 --steps K --warmup W`, the other workloads ON -- one step each here):
+    one stdout line, short enough for the driver's bounded tail, that parses and carries `roofline` and `cpu_baseline`."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--other-steps", "1",
+                        "--other-warmup", "1", "--detail", str(tmp_path / "detail.json")], capture_output=True, text=True,
                        timeout=1500, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 4096 and len(r.stdout) < 4200
     line = json.loads(lines[0])
+    full = json.loads((tmp_path / "detail.json").read_text())
+    assert set(full["other_workloads"]) >= {"c1", "c2", "c3", "c4s", "c4", "ea15k"} and not [o for o in full["other_workloads"].values() if "error" in o]
+    rows = line["summary"]
+    assert set(rows) >= {"columns", "ns", "c1", "c2", "c3", "c4s", "c4", "c1g", "hard", "gmm", "ea15k"}
+    for name, row in rows.items():
+        if name != "columns":
+            got, of = row[4].split("/")
+            assert got == of, (name, row)                                  # every workload's oracle check: all rows identical
     base = json.loads((ROOT / "BASELINE.json").read_text())
     assert line["metric"] == base["metric"] and line["unit"] == "queries/s" and line["higher_is_better"] is True
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["vs_baseline"] is None
@@ -34,4 +46,4 @@ def test_default_bench_line_has_what_the_driver_reads():
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "queries/s"
     chk = line["check"]
     assert chk["rows"] == 1024 and chk["index_rows_identical"] == 1024 and chk["recall_at_k"] == 1.0
-    assert line["certification_fallback_rows"] == 0 and line["rounding_bound_self_check"]["max_err_over_eps"] < 1.0
+    assert line["certification_fallback_rows"] == 0 and full["rounding_bound_self_check"]["max_err_over_eps"] < 1.0
