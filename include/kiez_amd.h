@@ -54,7 +54,7 @@ typedef struct kz_knn_stats {
     double finalize_ms;      /* merge + certify + float64 re-rank kernel                                   */
     double fallback_ms;      /* exact float64 brute-force for uncertified rows (0 if none)                 */
     int64_t n_fallback_rows; /* query rows answered by the exact float64 kernels: no approximate tier could certify their
-                                candidate set (or, a handful left by the split-bf16 tier, sent there directly)        */
+                                candidate set (or, a handful left by a pass, sent there directly: n_spec_rows)         */
     int32_t list_len;        /* K' = per-list candidate count kept by the fused kernel                     */
     int32_t n_splits;        /* index range splits (grid.y)                                                */
     int32_t n_blocks;        /* workgroups launched                                                        */
@@ -72,7 +72,8 @@ typedef struct kz_knn_stats {
     int64_t n_logged_groups; /* kz_knn_dual, reverse direction: groups of four keys the sweep logged (>= n_events / 4)   */
     int32_t wide_lists;      /* > 0: the call ran the fp16 tier's WIDE route -- that many lists of 16 per query (data whose keys
                                 are dense around the k-th neighbour: margin in ranks instead of better operands)           */
-    int32_t reserved_;
+    int32_t n_spec_rows;     /* of n_fallback_rows: a handful of rows the first pass left uncertified, answered by the exact kernels
+                                launched speculatively behind the finalize kernel (no re-search, no extra synchronisation)        */
     double probe_ms;         /* tier / floor probe of a large search (a strided sample of the query rows searched first), incl. the
                                 ladder's second rung; not part of fallback_ms                                                 */
 } kz_knn_stats;

@@ -63,7 +63,7 @@ class KnnStats(C.Structure):
         ("n_overflow_rows", C.c_int64),
         ("n_logged_groups", C.c_int64),
         ("wide_lists", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("n_spec_rows", C.c_int32),
         ("probe_ms", C.c_double),
     ]
 

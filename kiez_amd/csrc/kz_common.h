@@ -61,6 +61,8 @@ struct kz_ctx {
     int esc_ladder;   // 1 (default): kz_knn.hip "LADDER AFTER THE FACT"
     int exact_rows;   // 1 (default): the exact distance kernel that keeps four query rows in registers and takes 64 / LPR index rows per step
     int exact_direct_rows;   // a split-bf16 pass that leaves at most this many rows (default 32) hands them to the exact kernels directly (kz_knn_impl)
+    int spec_rows;    // exact kernels launched speculatively behind every finalize kernel for up to this many uncertified rows (default 64; kz_knn.hip "SPECULATIVE RESCUE")
+    double spec_elems; // ... at most spec_elems / (n d) of them (default 1.6e9: 8 rows of a 1 M x 200 index)
     int range_boot;   // 1 (default): short-list routes of the ordinary kernel sweep index range 0 first and start the other ranges' lists at the floor read off it (kz_knn.hip "RANGE-0 BOOTSTRAP")
     int wide_lists;   // fp16 tier's WIDE route (kz_knn_impl): lists of 16 per query when the tier probe finds the keys dense around the k-th neighbour (default 32; 0 = off)
     int wide_sel;     // ... entries of those lists the finalize kernel selects (default 256)

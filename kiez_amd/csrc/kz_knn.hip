@@ -986,19 +986,31 @@ __global__ __launch_bounds__(256, MINW) void kz_knn_finalize_kernel(KnnFinParams
 // ---------------------------------------------------------------------------------------------------
 // Stage 3: exact float64 brute force for uncertified rows (rare; correctness backstop)
 // ---------------------------------------------------------------------------------------------------
+// SPECULATIVE launches of the exact kernels (kz_spec_rescue below): the grid is sized for `cap` rows BEFORE the host knows how
+// many rows the finalize kernel left uncertified; the count is read from device memory, row b of the grid lives when
+// b < count <= cap (count > cap: nothing runs here, the host takes the ordinary re-search).
+__device__ __forceinline__ bool kz_spec_row_live(const int* __restrict__ dyn_n, int b, int cap) {
+    const int n = *dyn_n;
+    return n <= cap && b < n;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void kz_exact_dist_kernel(const int* __restrict__ fail_list, int batch0, int64_t q_begin,
                                                             const T* __restrict__ qraw, const T* __restrict__ yraw,
                                                             const double* __restrict__ qsqn, const double* __restrict__ ysqn,
-                                                            int64_t n_i, int d, int metric, double p, double* __restrict__ vals) {
+                                                            int64_t n_i, int d, int metric, double p, double* __restrict__ vals,
+                                                            const int* __restrict__ dyn_n = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
-    if (i >= n_i) return;
     const int b = blockIdx.y;
+    if (dyn_n && !kz_spec_row_live(dyn_n, b, (int)gridDim.y)) return;
     const int64_t qrow = q_begin + fail_list[batch0 + b];
-    const double v = kz_exact_value<T>(qraw + qrow * (int64_t)d, yraw + i * (int64_t)d, qsqn[qrow], ysqn[i], d, metric, lane, p);
-    if (lane == 0) vals[(int64_t)b * n_i + i] = v;
+    // (grid-stride over the index rows: the ordinary callers launch one wave per pair, a speculative launch a bounded grid --
+    //  workgroups of a dead row cost their dispatch, and n_i / 4 x R of them would be milliseconds on a 1 M-row index)
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n_i; i += (int64_t)gridDim.x * 4) {
+        const double v = kz_exact_value<T>(qraw + qrow * (int64_t)d, yraw + i * (int64_t)d, qsqn[qrow], ysqn[i], d, metric, lane, p);
+        if (lane == 0) vals[(int64_t)b * n_i + i] = v;
+    }
 }
 
 // The same values for float32 rows of d <= 256 (d a multiple of 4), many pairs per wave step (round 5).  kz_exact_dist_kernel spends
@@ -1016,8 +1028,13 @@ __global__ __launch_bounds__(256) void kz_exact_dist_rows_kernel(const int* __re
                                                                  const float* __restrict__ qraw, const float* __restrict__ yraw,
                                                                  const double* __restrict__ ynorm64, const double* __restrict__ qsqn,
                                                                  const double* __restrict__ ysqn, int64_t n_i, int d, int metric,
-                                                                 int rows_per_wave, double* __restrict__ vals) {
+                                                                 int rows_per_wave, double* __restrict__ vals,
+                                                                 const int* __restrict__ dyn_n = nullptr) {
     constexpr int G = 64 / LPR, Q = 4;
+    if (dyn_n) {   // (speculative launch: nb was the grid's capacity)
+        if (!kz_spec_row_live(dyn_n, blockIdx.y * Q, nb)) return;
+        nb = *dyn_n;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPR, sl = lane & (LPR - 1);
     const int k0 = 4 * sl;
@@ -1107,7 +1124,7 @@ __global__ __launch_bounds__(256) void kz_exact_dist_rows_kernel(const int* __re
 }
 // -> true when the kernel above took the batch
 static bool kz_launch_exact_rows(kz_ctx* ctx, const int* fl, int b0, int nb, int64_t cq_begin, const kz_matrix* query, const kz_matrix* index,
-                                 int metric, double* vals) {
+                                 int metric, double* vals, const int* dyn_n = nullptr) {
     const int d = (int)index->d;
     if (index->dtype != KZ_F32 || (d & 3) != 0 || d > 256 || metric > KZ_COSINE || (((uintptr_t)query->raw | (uintptr_t)index->raw) & 15u) != 0) return false;
     const bool norm = metric == KZ_COSINE && index->norm64 != nullptr;
@@ -1119,11 +1136,11 @@ static bool kz_launch_exact_rows(kz_ctx* ctx, const int* fl, int b0, int nb, int
         if (norm)                                                                                                                       \
             hipLaunchKernelGGL((kz_exact_dist_rows_kernel<L, true>), grid, dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin,          \
                                (const float*)query->raw, (const float*)index->raw, index->norm64, query->sqn, index->sqn, index->n, d, \
-                               metric, rows_per_wave, vals);                                                                            \
+                               metric, rows_per_wave, vals, dyn_n);                                                                     \
         else                                                                                                                            \
             hipLaunchKernelGGL((kz_exact_dist_rows_kernel<L, false>), grid, dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin,         \
                                (const float*)query->raw, (const float*)index->raw, (const double*)nullptr, query->sqn, index->sqn,      \
-                               index->n, d, metric, rows_per_wave, vals);                                                               \
+                               index->n, d, metric, rows_per_wave, vals, dyn_n);                                                        \
     } while (0)
     if (lanes <= 8)
         KZ_EXACT_ROWS(8);
@@ -1233,11 +1250,13 @@ static void kz_launch_family_dist(kz_ctx* ctx, const int* fl, int b0, int nb, in
 // per query row before, the distance kernel's time now).  One workgroup per (chunk, query row); a thread holds 16 values.
 constexpr int KZ_EXACT_CHUNK = 4096;
 __global__ __launch_bounds__(256) void kz_exact_chunk_kernel(const double* __restrict__ vals, int64_t n_i, int k_eff, int n_chunks,
-                                                             double* __restrict__ cand_v, int* __restrict__ cand_i) {
+                                                             double* __restrict__ cand_v, int* __restrict__ cand_i,
+                                                             const int* __restrict__ dyn_n = nullptr) {
     __shared__ double s_v[4];
     __shared__ int s_i[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x, b = blockIdx.y;
+    if (dyn_n && !kz_spec_row_live(dyn_n, b, (int)gridDim.y)) return;
     const double* v = vals + (int64_t)b * n_i;
     const int64_t i0 = (int64_t)c * KZ_EXACT_CHUNK;
     constexpr int PER = KZ_EXACT_CHUNK / 256;
@@ -1302,12 +1321,14 @@ __global__ __launch_bounds__(256) void kz_exact_chunk_kernel(const double* __res
 // of a workgroup-wide arg-min: k = 50: 0.96 -> see r05_notes), then everything below it and, of the entries equal to it, those with
 // the smallest index rows.  The survivors come out in no particular order: kz_exact_select_kernel orders by (value, index row).
 __global__ __launch_bounds__(256) void kz_exact_chunk_radix_kernel(const double* __restrict__ vals, int64_t n_i, int k_eff, int n_chunks,
-                                                                   double* __restrict__ cand_v, int* __restrict__ cand_i) {
+                                                                   double* __restrict__ cand_v, int* __restrict__ cand_i,
+                                                                   const int* __restrict__ dyn_n = nullptr) {
     __shared__ unsigned long long s_or[4], s_and[4];
     __shared__ int s_cnt[4];
     __shared__ int s_pos;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x, b = blockIdx.y;
+    if (dyn_n && !kz_spec_row_live(dyn_n, b, (int)gridDim.y)) return;
     const double* v = vals + (int64_t)b * n_i;
     const int64_t i0 = (int64_t)c * KZ_EXACT_CHUNK;
     constexpr int PER = KZ_EXACT_CHUNK / 256;
@@ -1427,12 +1448,13 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
                                                               int64_t n_entries, int64_t n_i, int k,
                                                               int exclude_self, const int64_t* __restrict__ self_ids,
                                                               int metric, double p, double* __restrict__ out_dist,
-                                                              int64_t* __restrict__ out_ind) {
+                                                              int64_t* __restrict__ out_ind, const int* __restrict__ dyn_n = nullptr) {
     __shared__ double s_v[4];
     __shared__ int s_i[4];
     extern __shared__ __attribute__((aligned(16))) char sel_sm[];   // k_eff doubles + k_eff ints (any k the host admits)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
+    if (dyn_n && !kz_spec_row_live(dyn_n, b, (int)gridDim.x)) return;
     const int q = fail_list[batch0 + b];
     // the row's values: all n_i of them (cand_idx == nullptr: entry i is index row i), or the survivors of kz_exact_chunk_kernel
     // (n_entries (value, index row) pairs; unused places hold (+inf, INT_MAX) and are never reached: k_eff <= n_i real entries exist)
@@ -1906,6 +1928,84 @@ struct KzDualPass {
 static inline int64_t kz_rows_per_chunk(const kz_ctx* ctx, int KP_mem, bool wide_route) {
     return ctx->chunk_rows > 0 ? ctx->chunk_rows : (int64_t)128 * 4096 * (wide_route ? 1 : (KP_mem <= 16 ? 4 : (KP_mem <= 32 ? 2 : 1)));
 }
+// SPECULATIVE RESCUE (round 6).  A pass on data that is fine still leaves a HANDFUL of rows uncertified (near-ties around the k-th
+// place, a crowded index range: 2 - 20 rows of a 15 k .. 1 M row search), and what they cost was never the arithmetic: the host had to
+// learn the count (read-back + stream synchronisation), gather the rows into a sub-matrix, pack it, sweep the whole index for one
+// query tile (a latency-bound launch: 108 us on a 15 k-row index), finalize, scatter, synchronise again -- 0.25 ms per search of a
+// 15 k x 15 k step that takes 1.7 ms (bench.py "ea15k"), 1.3 ms per step on a 1 M-row index.  The exact float64 kernels answer a row
+// for n d multiply-adds whatever the data: they are launched BEHIND the finalize kernel, before the host knows anything, for up to R
+// rows -- grid sized for R, the count read from device memory (kz_spec_row_live), every workgroup of a dead row returns at once.  R is
+// 4 .. "spec_rows" (64), as many as "spec_elems" / (n d) allows (a row of a 1 M x 200 index is 0.2 G multiply-adds: R = 8).  The
+// read-back that follows tells the host whether that was all (count <= R: the results are in place -- the exact float64 order, what
+// every route returns) or whether the ordinary re-search has to run (count > R: the speculative launches did nothing).
+struct KzSpec {
+    int R = 0;            // rows the speculative launches cover (0: not launched)
+    double* vals = nullptr;
+    double* cand_v = nullptr;
+    int* cand_i = nullptr;
+};
+static void kz_spec_release(kz_ctx* ctx, KzSpec& sp) {
+    kz_pool_free(ctx, sp.vals, 0);
+    kz_pool_free(ctx, sp.cand_v, 0);
+    kz_pool_free(ctx, sp.cand_i, 0);
+    sp = KzSpec();
+}
+static int kz_spec_rows(const kz_ctx* ctx, const kz_matrix* index, int k_eff) {
+    if (ctx->spec_rows <= 0 || index->metric >= KZ_MANHATTAN || k_eff > 64) return 0;
+    const double nd = (double)index->n * (double)index->d;
+    int R = (int)(ctx->spec_elems / (nd > 1.0 ? nd : 1.0)) & ~3;
+    if (R > ctx->spec_rows) R = ctx->spec_rows & ~3;
+    return R < 4 ? 0 : R;
+}
+// fail_list / fail_count: the finalize kernel's device-side list and counter (fail_list holds rows relative to q0)
+static int kz_spec_rescue(kz_ctx* ctx, KzSpec& sp, int R, const kz_matrix* query, int64_t q0, const int* fail_list, const int* fail_count,
+                          const kz_matrix* index, int k, int exclude_self, const int64_t* d_self_ids, double* out_dist, int64_t* out_ind) {
+    const int metric = index->metric;
+    const int k_eff = k + (exclude_self ? 1 : 0);
+    const int k_sel = (int)(k_eff < index->n ? k_eff : index->n);
+    const size_t sel_lds = (size_t)k_sel * 12 + 16;
+    const int n_chunks = (int)((index->n + KZ_EXACT_CHUNK - 1) / KZ_EXACT_CHUNK);
+    const bool two_level = n_chunks > 4 && k_sel <= KZ_EXACT_CHUNK;
+    int rc = kz_pool_alloc(ctx, (size_t)R * (size_t)index->n * 8, (void**)&sp.vals);
+    if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 8, (void**)&sp.cand_v);
+    if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 4, (void**)&sp.cand_i);
+    if (rc != KZ_OK) {   // (no memory for a speculation: the ordinary re-search will do)
+        kz_spec_release(ctx, sp);
+        return rc == KZ_ERR_NOMEM ? KZ_OK : rc;
+    }
+    const int dist_blocks = (int)((index->n + 3) / 4 < 128 ? (index->n + 3) / 4 : 128);   // (grid-stride; dead rows cost their dispatch)
+    const double* sel_v = two_level ? (const double*)sp.cand_v : (const double*)sp.vals;
+    const int* sel_i = two_level ? (const int*)sp.cand_i : (const int*)nullptr;
+    const int64_t n_entries = two_level ? (int64_t)n_chunks * k_sel : index->n;
+    if (index->dtype == KZ_F32) {
+        if (!(ctx->exact_rows && kz_launch_exact_rows(ctx, fail_list, 0, R, q0, query, index, metric, sp.vals, fail_count)))
+            hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3(dist_blocks, R), dim3(256), 0, ctx->stream, fail_list, 0, q0,
+                               (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn, index->n, (int)index->d, metric,
+                               index->mink_p, sp.vals, fail_count);
+    } else {
+        hipLaunchKernelGGL(kz_exact_dist_kernel<double>, dim3(dist_blocks, R), dim3(256), 0, ctx->stream, fail_list, 0, q0,
+                           (const double*)query->raw, (const double*)index->raw, query->sqn, index->sqn, index->n, (int)index->d, metric,
+                           index->mink_p, sp.vals, fail_count);
+    }
+    if (two_level)
+        hipLaunchKernelGGL(k_sel >= 24 && ctx->exact_rows ? kz_exact_chunk_radix_kernel : kz_exact_chunk_kernel, dim3(n_chunks, R), dim3(256), 0,
+                           ctx->stream, (const double*)sp.vals, index->n, k_sel, n_chunks, sp.cand_v, sp.cand_i, fail_count);
+    if (index->dtype == KZ_F32)
+        hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(R), dim3(256), sel_lds, ctx->stream, fail_list, 0, q0, sel_v, sel_i, n_entries,
+                           index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p, out_dist, out_ind, fail_count);
+    else
+        hipLaunchKernelGGL(kz_exact_select_kernel<double>, dim3(R), dim3(256), sel_lds, ctx->stream, fail_list, 0, q0, sel_v, sel_i, n_entries,
+                           index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p, out_dist, out_ind, fail_count);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        kz_spec_release(ctx, sp);
+        kz_set_error("kz_knn: speculative exact re-search failed to launch: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    sp.R = R;
+    return KZ_OK;
+}
+
 static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q_count, kz_matrix* index, int k,
                        int exclude_self, const int64_t* d_self_ids, int precision_override, int kp_min, double* d_dist,
                        int64_t* d_ind, kz_knn_stats* stats, KzDualPass* dual);
@@ -2327,7 +2427,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         return KZ_ERR_INVALID;
     }
     double main_ms = 0, fin_ms = 0, fb_ms = 0;   // (the tier probe's time is reported under its own field, kz_knn_stats.probe_ms)
-    int64_t n_fail_total = 0, n_escalated = 0, n_first_fail = 0;
+    int64_t n_fail_total = 0, n_escalated = 0, n_first_fail = 0, n_spec = 0;
     double max_err_ratio = 0.0;
     int last_splits = 1, last_blocks = 0, first_tier = tier;
     for (int64_t c0 = 0; c0 < q_count;) {
@@ -2523,6 +2623,17 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (boot_floor) kz_pool_free(ctx, const_cast<float*>(boot_floor), 0);   // (stream-ordered: the launches above have it)
         KZ_HIP(hipGetLastError());
         KZ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        // SPECULATIVE RESCUE (above kz_escalate_rows): the exact kernels for up to R uncertified rows, before the count is known
+        KzSpec spec;
+        if (!exact_only && !(dual && dual->raw_lists) && tier != KZ_TIER_F32) {
+            const int R = kz_spec_rows(ctx, index, k_eff);
+            if (R > 0) {
+                rc = kz_spec_rescue(ctx, spec, R, query, fp.row_map ? 0 : cq_begin, fail_list, fail_count, index, k, exclude_self, d_self_ids,
+                                    fp.out_dist, fp.out_ind);
+                if (rc != KZ_OK) return rc;
+                if (spec.R > 0) KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+            }
+        }
         KZ_HIP(hipMemcpyAsync(ctx->h_counters + 8, fail_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         // matrices created from device rows have not had their finiteness verdict read yet (kz_matrix_create waits for
         // nothing): it rides on this call's read-back
@@ -2530,7 +2641,13 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         for (int u = 0; u < 2; ++u)
             if (unchecked[u])
                 KZ_HIP(hipMemcpyAsync(ctx->h_counters + 44 + 10 * u, unchecked[u]->d_stats, 40, hipMemcpyDeviceToHost, ctx->stream));
-        KZ_HIP(hipStreamSynchronize(ctx->stream));
+        {
+            const hipError_t es = hipStreamSynchronize(ctx->stream);
+            const int spec_R = spec.R;
+            kz_spec_release(ctx, spec);   // (stream-ordered pool: the launches that used the buffers are on the stream)
+            spec.R = spec_R;
+            KZ_HIP(es);
+        }
         for (int u = 0; u < 2; ++u) {
             if (!unchecked[u]) continue;
             if (ctx->h_counters[44 + 10 * u + 8] != 0) {
@@ -2566,7 +2683,14 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         // one query tile in at most eight pieces -- 2.2 ms on 300 k rows of d = 64 whatever the row count -- while the exact kernels
         // cost ~35 us a row there (both scale with n d): bench.py "hard", ~20 rows per direction and step: 60.6 -> see r05_notes.
         const bool exact_direct = tier == KZ_TIER_BF && !dual && n_fail > 0 && n_fail <= ctx->exact_direct_rows;
-        if (tier != KZ_TIER_F32 && n_fail > 0 && !exact_direct) {
+        // (the speculative launches behind the finalize kernel have answered them all)
+        const bool rescued = spec.R > 0 && n_fail > 0 && n_fail <= spec.R;
+        if (rescued) {
+            KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+            fb_ms += ms;
+            n_spec += n_fail;
+        }
+        if (tier != KZ_TIER_F32 && n_fail > 0 && !exact_direct && !rescued) {
             // Escalate only the uncertified rows: gather them into a dense query block and search it again -- fp16 tier
             // with lists shorter than 128: same operands, lists four times as long (no new image of the index: 14 rows
             // of a 1M-row index cost 0.4 ms this way against 7 ms for packing its float32 image); otherwise the split-bf16
@@ -2632,7 +2756,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         }
         n_fail_total += n_fail;
 
-        if (n_fail > 0) {
+        if (n_fail > 0 && !rescued) {
             // exact brute force in batches; the fail list lives at the end of the scratch block, the value matrix
             // goes to a separate allocation so that the list is not overwritten by a scratch regrow.
             KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -2688,7 +2812,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                                            index->n, (int)index->d, metric, index->mink_p, (double*)vals);
                     if (two_level)
                         hipLaunchKernelGGL(k_sel >= 24 && ctx->exact_rows ? kz_exact_chunk_radix_kernel : kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0,
-                                           ctx->stream, (const double*)vals, index->n, k_sel, n_chunks, cand_v, cand_i);
+                                           ctx->stream, (const double*)vals, index->n, k_sel, n_chunks, cand_v, cand_i, (const int*)nullptr);
                     hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
                                        two_level ? (const double*)cand_v : (const double*)vals, two_level ? (const int*)cand_i : (const int*)nullptr,
                                        two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p,
@@ -2702,7 +2826,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                                            index->n, (int)index->d, metric, index->mink_p, (double*)vals);
                     if (two_level)
                         hipLaunchKernelGGL(k_sel >= 24 && ctx->exact_rows ? kz_exact_chunk_radix_kernel : kz_exact_chunk_kernel, dim3(n_chunks, nb), dim3(256), 0,
-                                           ctx->stream, (const double*)vals, index->n, k_sel, n_chunks, cand_v, cand_i);
+                                           ctx->stream, (const double*)vals, index->n, k_sel, n_chunks, cand_v, cand_i, (const int*)nullptr);
                     hipLaunchKernelGGL(kz_exact_select_kernel<double>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, cq_begin,
                                        two_level ? (const double*)cand_v : (const double*)vals, two_level ? (const int*)cand_i : (const int*)nullptr,
                                        two_level ? (int64_t)n_chunks * k_sel : index->n, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p,
@@ -2738,6 +2862,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         stats->max_err_ratio = max_err_ratio;
         stats->n_first_pass_fail = n_first_fail > 0x7fffffff ? 0x7fffffff : (int32_t)n_first_fail;
         stats->wide_lists = wide_route ? long_pieces : 0;
+        stats->n_spec_rows = n_spec > 0x7fffffff ? 0x7fffffff : (int32_t)n_spec;
     }
     return KZ_OK;
 }

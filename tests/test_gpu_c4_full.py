@@ -54,7 +54,7 @@ def test_c4_full_size_against_the_oracle(c4_single):
     # one sweep served both directions; nothing fell back to the exact kernels, the rounding bound held
     assert st_f["dual"] == 1 and st_r.get("dual") == 1, (st_f, st_r)
     assert st_f["max_err_ratio"] < 1.0 and st_r["max_err_ratio"] < 1.0
-    assert st_f["n_fallback_rows"] == 0 and st_r["n_fallback_rows"] == 0
+    assert st_f["n_fallback_rows"] == st_f["n_spec_rows"] and st_r["n_fallback_rows"] == st_r["n_spec_rows"]   # (no row beyond the handful the speculative exact launches answer)
     fd, fi, rd, ri, dist, ind = r["fd"], r["fi"], r["rd"], r["ri"], r["dist"], r["ind"]
     assert r["k_fwd"] == K and fd.shape == (D.N_SOURCE, K) and rd.shape == (D.N_TARGET, K) and dist.shape == (D.N_SOURCE, K)
     assert ind.dtype == np.int64 and dist.dtype == np.float64

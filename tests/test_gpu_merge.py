@@ -131,7 +131,7 @@ def test_more_than_128_candidates_through_the_api(K):
     from oracle import kiez_oracle as O
     from tests.golden_util import knife_edge_rows, knife_edge_topk_ok
     rng = np.random.RandomState(K)
-    s, t = rng.rand(700, 24), rng.rand(900, 24)
+    s, t = (rng.rand(700, 24), rng.rand(900, 24)) if K <= 150 else (rng.rand(360, 24), rng.rand(440, 24))   # (the oracle's MP-empiric loop is O(rows K^2))
     for hub, kw, metric in ((None, {}, "euclidean"), ("CSLS", {}, "euclidean"), ("LocalScaling", {"method": "standard"}, "euclidean"),
                             ("LocalScaling", {"method": "nicdm"}, "cosine"), ("MutualProximity", {"method": "normal"}, "euclidean"),
                             ("MutualProximity", {"method": "empiric"}, "euclidean"), ("DisSimLocal", {}, "sqeuclidean")):

@@ -81,7 +81,7 @@ def test_sharded_kiez_hip_engine_over_rccl_single_rank():
     assert r.returncode == 0 and "SHARDED_RCCL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
 
 
-def test_bench_line_of_a_launched_run_carries_check_and_cpu_baseline():
+def test_bench_line_of_a_launched_run_carries_check_and_cpu_baseline(tmp_path):
     """`bench.py` as torch.distributed.run starts it (RANK / WORLD_SIZE / MASTER_* in the environment, RCCL process group), one
     rank, every collective forced: the line of a launched run -- the code path of `--gpus 8` -- carries the oracle check
     (fit state + rows of every rank's shard), recall@k and the CPU baseline, for both ways of getting the target onto the ranks."""
@@ -91,9 +91,12 @@ def test_bench_line_of_a_launched_run_carries_check_and_cpu_baseline():
         env = {**os.environ, "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port,
                "KIEZ_AMD_FORCE_COLLECTIVES": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
         r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--workload", "c2", "--steps", "2", "--warmup", "1",
-                            "--no-others", "--target-upload", upload], capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+                            "--no-others", "--target-upload", upload, "--detail", str(tmp_path / "detail.json")],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
         assert r.returncode == 0, r.stderr[-6000:]
-        line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
+        short = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1]
+        assert len(short) < 4096 and json.loads(short)["check"]["index_rows_identical"] == 1024 and json.loads(short)["cpu_baseline"]["value"] > 0
+        line = json.loads((tmp_path / "detail.json").read_text())     # (the full record the compact stdout line points to)
         chk = line["check"]
         assert line["recall_at_k"] == chk["recall_at_k"] == 1.0
         assert chk["index_rows_identical"] == chk["rows"] == 1024 and chk["index_rows_identical_per_rank"] == [1024]

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export O=gpurun_out/hostgaps; mkdir -p $O
 for w in ${WL:-ns}; do
-  timeout 400 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/kt_$w -- python3 bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-others --no-check > $O/$w.json 2> $O/$w.err
+  timeout 400 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/kt_$w -- python3 bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-others --detail bench_detail_$w.json --no-check > $O/$w.json 2> $O/$w.err
   ls $O/kt_$w/*/ | head
   k=$(find $O/kt_$w -name "*kernel_trace.csv" | head -1); h=$(find $O/kt_$w -name "*hip_api_trace.csv" | head -1)
   python3 - "$k" "$h" ${MIN:-40} <<'PY' | tee $O/${w}_host.txt | tail -${TAIL:-70}
