@@ -511,7 +511,11 @@ __device__ __forceinline__ int kz_rank_select(const float* ekey, const int* eidx
 }
 
 // One query, one wave (only wave-level synchronisation inside).
-template <typename T, int FROWS>
+// NV (round 6): 16-byte loads per lane and candidate row in the pipelined re-rank -- 1: float32 rows of up to 256 elements, 2: up to
+// 512 (the second 256-element chunk's four fma continue the first chunk's chain: kz_wave_dot's order).  d = 300 -- the dimension
+// of the entity-alignment embeddings kiez is used on, and of BASELINE configuration 4 -- used to take the generic loop below: no
+// load in flight under the sums, the query row re-read per candidate (250 k x 1 M x 300: 7.3 ms per launch against 4.3 at d = 200).
+template <typename T, int FROWS, int NV = 1>
 __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const int64_t q, const int lane, char* wbase) {
     const int KS = p.KSEL > 0 ? p.KSEL : p.KP;   // candidates selected and re-ranked
     double* cv = reinterpret_cast<double*>(wbase);
@@ -740,23 +744,31 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 #ifdef KZ_NO_FIN_PIPE
     if (false) {
 #else
-    if (sizeof(T) == 4 && vec && p.d <= 256 && Vr > 0) {
+    if (sizeof(T) == 4 && vec && p.d <= 256 * NV && Vr > 0) {
 #endif   // (Vr == 0: a reverse-direction row without a single event)
-        // float32 rows of up to 256 elements (one 16-byte load per lane and row): the loads of the NEXT group of FROWS
+        // float32 rows of up to 256 NV elements (NV 16-byte loads per lane and row): the loads of the NEXT group of FROWS
         // candidates are issued before the current group's fma chains and butterfly sums -- same arithmetic in the same order
         // as the generic loop below (and as kz_wave_dot), only the memory latency of group g+1 hides under the sums of group g
         const int k0 = 4 * lane;
-        const bool act = k0 < p.d;
-        const int k0r = act ? k0 : 0;
-        double qk[4] = {0.0, 0.0, 0.0, 0.0};
-        if (act) {
-            kz_row4(qptr, k0, p.d, true, qk);
-            if (p.metric == KZ_COSINE) {
+        bool act[NV];
+        int k0r[NV];
+        double qk[4 * NV];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qk[e] = qk[e] / qs;
+        for (int c = 0; c < NV; ++c) {
+            act[c] = k0 + 256 * c < p.d;
+            k0r[c] = act[c] ? k0 + 256 * c : 0;
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            if (act[c]) {
+                kz_row4(qptr, k0r[c], p.d, true, t);
+                if (p.metric == KZ_COSINE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = t[e] / qs;
+                }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qk[4 * c + e] = t[e];
         }
-        auto issue = [&](int c0, float4 (&buf)[FROWS], double (&ysb)[FROWS]) {
+        auto issue = [&](int c0, float4 (&buf)[FROWS][NV], double (&ysb)[FROWS]) {
 #pragma unroll
             for (int u = 0; u < FROWS; ++u) {
                 // (no branch around a load, and no load under a condition: with loads on some paths only the compiler waits for
@@ -766,33 +778,44 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
                 //  candidate again.)
                 const int yi = ci[min(c0 + u, Vr - 1)];
                 ysb[u] = p.ysqn[yi];
-                buf[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(yraw) + (int64_t)yi * p.d + k0r);
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+                    buf[u][c] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(yraw) + (int64_t)yi * p.d + k0r[c]);
             }
         };
-        auto reduce = [&](int c0, const float4 (&buf)[FROWS], const double (&ysb)[FROWS]) {
+        auto reduce = [&](int c0, const float4 (&buf)[FROWS][NV], const double (&ysb)[FROWS]) {
 #pragma unroll
             for (int u = 0; u < FROWS; ++u) {
-                const double yk[4] = {(double)buf[u].x, (double)buf[u].y, (double)buf[u].z, (double)buf[u].w};
                 double a = 0.0;
-                if (act) {
-                    if (p.metric == KZ_COSINE) {
-                        bool done = false;
-                        if (p.fast_div) {
-                            const double rcp = 1.0 / ysb[u];   // (wave-uniform: every lane holds the same row norm)
-                            const int rcp_hi = __builtin_amdgcn_readfirstlane((int)((unsigned long long)__double_as_longlong(rcp) >> 32));
-                            if ((rcp_hi & 0x7ff00000) != 0x7ff00000) {
+                bool done = false;
+                if (p.metric == KZ_COSINE && p.fast_div) {
+                    const double rcp = 1.0 / ysb[u];   // (wave-uniform: every lane holds the same row norm)
+                    const int rcp_hi = __builtin_amdgcn_readfirstlane((int)((unsigned long long)__double_as_longlong(rcp) >> 32));
+                    if ((rcp_hi & 0x7ff00000) != 0x7ff00000) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) a = fma(qk[e], kz_div_shared(yk[e], ysb[u], rcp), a);
-                                done = true;
+                        for (int c = 0; c < NV; ++c) {
+                            const double yk[4] = {(double)buf[u][c].x, (double)buf[u][c].y, (double)buf[u][c].z, (double)buf[u][c].w};
+                            if (act[c]) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a = fma(qk[4 * c + e], kz_div_shared(yk[e], ysb[u], rcp), a);
                             }
                         }
-                        if (!done) {
+                        done = true;
+                    }
+                }
+                if (!done) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e] / ysb[u], a);
+                    for (int c = 0; c < NV; ++c) {
+                        const double yk[4] = {(double)buf[u][c].x, (double)buf[u][c].y, (double)buf[u][c].z, (double)buf[u][c].w};
+                        if (act[c]) {
+                            if (p.metric == KZ_COSINE) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a = fma(qk[4 * c + e], yk[e] / ysb[u], a);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a = fma(qk[4 * c + e], yk[e], a);
+                            }
                         }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) a = fma(qk[e], yk[e], a);
                     }
                 }
                 const double dot = kz_wave_sum(a);
@@ -809,7 +832,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         // three groups in flight (a rotating set of three register buffers, the loop unrolled by three: no copies): the gathers
         // of groups g + 1 and g + 2 are under way while group g is reduced
         constexpr int R = FROWS;
-        float4 b0[R], b1[R], b2[R];
+        float4 b0[R][NV], b1[R][NV], b2[R][NV];
         double y0[R], y1[R], y2[R];
         issue(0, b0, y0);
         issue(R, b1, y1);
@@ -825,7 +848,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
             if ((c0 += R) >= Vr) break;
         }
 #else
-        float4 cur[FROWS], nxt[FROWS];
+        float4 cur[FROWS][NV], nxt[FROWS][NV];
         double ys_c[FROWS], ys_n[FROWS];
         issue(0, cur, ys_c);
         for (int c0 = 0; c0 < Vr; c0 += 2 * FROWS) {   // (unrolled by two: the buffers swap roles, no copies)
@@ -958,6 +981,9 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
 // A workgroup finalizes KZ_FIN_QPB consecutive queries (wave w takes queries w, w+4, ...).  32 per workgroup (sharing the list
 // cache lines of one wave-interleaved block) measured 2x SLOWER than 4: finalize is latency-bound and wants many workgroups.
 constexpr int KZ_FIN_QPB = 4;
+#ifndef KZ_FIN_WAVES_2
+#define KZ_FIN_WAVES_2 5  // ... of the two-loads-per-row build (NV = 2: 24 more registers of gather buffers and query elements)
+#endif
 #ifndef KZ_FIN_WAVES
 #define KZ_FIN_WAVES 7  // minimum waves per SIMD the finalize kernel is compiled for (see KZ_FIN_ROWS_N above)
 #endif
@@ -965,7 +991,7 @@ constexpr int KZ_FIN_QPB = 4;
 // ordinary pass (a dozen to ~50 gathered rows per query: waves in flight beat rows in flight per wave); <8, 2> serves the long-k
 // route (hundreds of gathered rows per query, one workgroup per CU for its LDS anyway: the gathers of a query were a chain of
 // ~k / 2 round trips).
-template <typename T, int FROWS, int MINW>
+template <typename T, int FROWS, int MINW, int NV = 1>
 __global__ __launch_bounds__(256, MINW) void kz_knn_finalize_kernel(KnnFinParams p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int lane = threadIdx.x & 63;
@@ -976,7 +1002,7 @@ __global__ __launch_bounds__(256, MINW) void kz_knn_finalize_kernel(KnnFinParams
     for (int rep = 0; rep < KZ_FIN_QPB / 4; ++rep) {
         const int64_t q = p.q_first + (int64_t)blockIdx.x * KZ_FIN_QPB + rep * 4 + wave;
         if (q >= p.q_last) break;  // whole wave leaves; only wave-level sync inside
-        kz_finalize_query<T, FROWS>(p, q, lane, wbase);
+        kz_finalize_query<T, FROWS, NV>(p, q, lane, wbase);
         kz_wave_sync();
     }
 }
@@ -1023,13 +1049,16 @@ __global__ __launch_bounds__(256) void kz_exact_dist_kernel(const int* __restric
 // skips add the exact zeros of lanes past the row) -- as in the finalize kernel for many candidates (kz_knn_fin_wide.h), so the
 // values are bit for bit those of kz_exact_value, kz_pair_values and the re-rank.  Cosine: the index rows normalised once in
 // float64 (kz_matrix_norm64) where that image exists, else the shared-reciprocal division.
-template <int LPR, bool NORM>
+template <int LPR, bool NORM, int NV = 1>
 __global__ __launch_bounds__(256) void kz_exact_dist_rows_kernel(const int* __restrict__ fail_list, int batch0, int nb, int64_t q_begin,
                                                                  const float* __restrict__ qraw, const float* __restrict__ yraw,
                                                                  const double* __restrict__ ynorm64, const double* __restrict__ qsqn,
                                                                  const double* __restrict__ ysqn, int64_t n_i, int d, int metric,
                                                                  int rows_per_wave, double* __restrict__ vals,
                                                                  const int* __restrict__ dyn_n = nullptr) {
+    // NV = 2 (round 6): rows of 260 .. 512 elements -- a lane owns elements 4 sl .. 4 sl + 3 of BOTH 256-element chunks of the row
+    // (LPR = 64, one index row per wave step), the second chunk's four fma continue the first's chain: kz_wave_dot's order for d > 256.
+    static_assert(NV == 1 || LPR == 64, "two chunks per lane: the whole wave owns one row");
     constexpr int G = 64 / LPR, Q = 4;
     if (dyn_n) {   // (speculative launch: nb was the grid's capacity)
         if (!kz_spec_row_live(dyn_n, blockIdx.y * Q, nb)) return;
@@ -1038,67 +1067,89 @@ __global__ __launch_bounds__(256) void kz_exact_dist_rows_kernel(const int* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPR, sl = lane & (LPR - 1);
     const int k0 = 4 * sl;
-    const bool act = k0 < d;
-    const int k0r = act ? k0 : 0;
+    bool act[NV];
+    int k0r[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        act[c] = k0 + 256 * c < d;
+        k0r[c] = act[c] ? k0 + 256 * c : 0;
+    }
     const int b0 = blockIdx.y * Q;
-    double qk[Q][4], qs[Q];
+    double qk[Q][4 * NV], qs[Q];
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
         const int bq = b0 + j < nb ? b0 + j : nb - 1;
         const int64_t qrow = q_begin + fail_list[batch0 + bq];
         qs[j] = qsqn[qrow];
-        qk[j][0] = qk[j][1] = qk[j][2] = qk[j][3] = 0.0;
-        if (act) {
-            kz_row4(qraw + qrow * (int64_t)d, k0, d, true, qk[j]);
-            if (metric == KZ_COSINE) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qk[j][e] = qk[j][e] / qs[j];
+        for (int c = 0; c < NV; ++c) {
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            if (act[c]) {
+                kz_row4(qraw + qrow * (int64_t)d, k0r[c], d, true, t);
+                if (metric == KZ_COSINE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = t[e] / qs[j];
+                }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qk[j][4 * c + e] = t[e];
         }
     }
     const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
     const int64_t i1 = i0 + rows_per_wave < n_i ? i0 + rows_per_wave : n_i;
     if (i0 >= i1) return;
     struct Buf {
-        float4 f;
+        float4 f[NV];
         double ys;
-        double2 n0, n1;
+        double2 n0[NV], n1[NV];
     };
     auto issue = [&](int64_t i, Buf& b) {   // (rows past the end: the last row again, nothing is written for them)
         const int64_t yi = i + grp < i1 ? i + grp : i1 - 1;
         if (NORM) {
-            const double* row = ynorm64 + yi * (int64_t)d + k0r;
-            b.n0 = *reinterpret_cast<const double2*>(row);
-            b.n1 = *reinterpret_cast<const double2*>(row + 2);
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const double* row = ynorm64 + yi * (int64_t)d + k0r[c];
+                b.n0[c] = *reinterpret_cast<const double2*>(row);
+                b.n1[c] = *reinterpret_cast<const double2*>(row + 2);
+            }
         } else {
             b.ys = ysqn[yi];
-            b.f = *reinterpret_cast<const float4*>(yraw + yi * (int64_t)d + k0r);
+#pragma unroll
+            for (int c = 0; c < NV; ++c) b.f[c] = *reinterpret_cast<const float4*>(yraw + yi * (int64_t)d + k0r[c]);
         }
     };
     auto reduce = [&](int64_t i, const Buf& b) {
-        double yv[4] = {0.0, 0.0, 0.0, 0.0};
-        if (act) {
-            if (NORM) {
-                yv[0] = b.n0.x, yv[1] = b.n0.y, yv[2] = b.n1.x, yv[3] = b.n1.y;
-            } else {
-                const double yk[4] = {(double)b.f.x, (double)b.f.y, (double)b.f.z, (double)b.f.w};
-                if (metric == KZ_COSINE) {
-                    const double rcp = 1.0 / b.ys;
-                    const bool fin = (((unsigned long long)__double_as_longlong(rcp) >> 52) & 0x7ff) != 0x7ff;
+        double yv[4 * NV];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) yv[e] = fin ? kz_div_shared(yk[e], b.ys, rcp) : yk[e] / b.ys;
+        for (int c = 0; c < NV; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[4 * c + e] = 0.0;
+            if (act[c]) {
+                if (NORM) {
+                    yv[4 * c] = b.n0[c].x, yv[4 * c + 1] = b.n0[c].y, yv[4 * c + 2] = b.n1[c].x, yv[4 * c + 3] = b.n1[c].y;
                 } else {
+                    const double yk[4] = {(double)b.f[c].x, (double)b.f[c].y, (double)b.f[c].z, (double)b.f[c].w};
+                    if (metric == KZ_COSINE) {
+                        const double rcp = 1.0 / b.ys;
+                        const bool fin = (((unsigned long long)__double_as_longlong(rcp) >> 52) & 0x7ff) != 0x7ff;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) yv[e] = yk[e];
+                        for (int e = 0; e < 4; ++e) yv[4 * c + e] = fin ? kz_div_shared(yk[e], b.ys, rcp) : yk[e] / b.ys;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) yv[4 * c + e] = yk[e];
+                    }
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             double a = 0.0;
-            if (act) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a = fma(qk[j][e], yv[e], a);
+            for (int c = 0; c < NV; ++c) {
+                if (act[c]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = fma(qk[j][4 * c + e], yv[4 * c + e], a);
+                }
             }
 #pragma unroll
             for (int off = LPR >> 1; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
@@ -1124,11 +1175,10 @@ __global__ __launch_bounds__(256) void kz_exact_dist_rows_kernel(const int* __re
 }
 // -> true when the kernel above took the batch
 static bool kz_launch_exact_rows(kz_ctx* ctx, const int* fl, int b0, int nb, int64_t cq_begin, const kz_matrix* query, const kz_matrix* index,
-                                 int metric, double* vals, const int* dyn_n = nullptr) {
+                                 int metric, double* vals, const int* dyn_n = nullptr, int rows_per_wave = 256) {
     const int d = (int)index->d;
-    if (index->dtype != KZ_F32 || (d & 3) != 0 || d > 256 || metric > KZ_COSINE || (((uintptr_t)query->raw | (uintptr_t)index->raw) & 15u) != 0) return false;
+    if (index->dtype != KZ_F32 || (d & 3) != 0 || d > 512 || metric > KZ_COSINE || (((uintptr_t)query->raw | (uintptr_t)index->raw) & 15u) != 0) return false;
     const bool norm = metric == KZ_COSINE && index->norm64 != nullptr;
-    const int rows_per_wave = 256;
     const dim3 grid((unsigned)((index->n + 4 * rows_per_wave - 1) / (4 * rows_per_wave)), (unsigned)((nb + 3) / 4));
     const int lanes = (d + 3) >> 2;
 #define KZ_EXACT_ROWS(L)                                                                                                                \
@@ -1148,8 +1198,14 @@ static bool kz_launch_exact_rows(kz_ctx* ctx, const int* fl, int b0, int nb, int
         KZ_EXACT_ROWS(16);
     else if (lanes <= 32)
         KZ_EXACT_ROWS(32);
-    else
+    else if (lanes <= 64)
         KZ_EXACT_ROWS(64);
+    else if (norm)   // (260 .. 512 elements: two chunks per lane)
+        hipLaunchKernelGGL((kz_exact_dist_rows_kernel<64, true, 2>), grid, dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin, (const float*)query->raw,
+                           (const float*)index->raw, index->norm64, query->sqn, index->sqn, index->n, d, metric, rows_per_wave, vals, dyn_n);
+    else
+        hipLaunchKernelGGL((kz_exact_dist_rows_kernel<64, false, 2>), grid, dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin, (const float*)query->raw,
+                           (const float*)index->raw, (const double*)nullptr, query->sqn, index->sqn, index->n, d, metric, rows_per_wave, vals, dyn_n);
 #undef KZ_EXACT_ROWS
     return true;
 }
@@ -1690,7 +1746,10 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
             // ("fin_wide" = 2: every launch that selects from several lists, KSEL > 0 -- the short-list routes -- takes it too)
             const bool rows_vec = fp.d <= 256 && (fp.d & 3) == 0 && (((uintptr_t)fp.qraw | (uintptr_t)fp.yraw) & 15u) == 0;
             const bool wide2 = (wide || (ctx->fin_wide >= 2 && fp.KSEL > 0)) && dtype == KZ_F32 && fp.tier_h && !fp.excl_floor && ctx->fin_wide && rows_vec;
-            const void* fk = dtype == KZ_F32 ? (wide2 ? (const void*)kz_knn_finalize_wide_kernel<float, 4> : (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>))
+            // (float32 rows of 260 .. 512 elements, 16-byte aligned: the build whose pipelined re-rank takes two loads per lane and row)
+            const bool two_chunks = !wide && !wide2 && dtype == KZ_F32 && fp.d > 256 && fp.d <= 512 && (fp.d & 3) == 0 &&
+                                    (((uintptr_t)fp.qraw | (uintptr_t)fp.yraw) & 15u) == 0;
+            const void* fk = two_chunks ? (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES_2, 2> : dtype == KZ_F32 ? (wide2 ? (const void*)kz_knn_finalize_wide_kernel<float, 4> : (wide ? (const void*)kz_knn_finalize_kernel<float, 8, 2> : (const void*)kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>))
                                              : (wide ? (const void*)kz_knn_finalize_kernel<double, 4, 2> : (const void*)kz_knn_finalize_kernel<double, KZ_FIN_ROWS, KZ_FIN_WAVES>);
             if (wide2) fin_lds = (size_t)4 * kz_fin_wide_wave_bytes(fp.max_m, fp.KSEL);
             if (fin_lds > 65536) KZ_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
@@ -1698,6 +1757,8 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
                 hipLaunchKernelGGL((kz_knn_finalize_wide_kernel<float, 4>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
             else if (dtype == KZ_F32 && wide)
                 hipLaunchKernelGGL((kz_knn_finalize_kernel<float, 8, 2>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
+            else if (dtype == KZ_F32 && two_chunks)
+                hipLaunchKernelGGL((kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES_2, 2>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
             else if (dtype == KZ_F32)
                 hipLaunchKernelGGL((kz_knn_finalize_kernel<float, KZ_FIN_ROWS, KZ_FIN_WAVES>), dim3(fin_blocks), dim3(256), fin_lds, st, fp);
             else if (wide)
@@ -1965,7 +2026,9 @@ static int kz_spec_rescue(kz_ctx* ctx, KzSpec& sp, int R, const kz_matrix* query
     const int k_sel = (int)(k_eff < index->n ? k_eff : index->n);
     const size_t sel_lds = (size_t)k_sel * 12 + 16;
     const int n_chunks = (int)((index->n + KZ_EXACT_CHUNK - 1) / KZ_EXACT_CHUNK);
-    const bool two_level = n_chunks > 4 && k_sel <= KZ_EXACT_CHUNK;
+    // (two selection levels from two chunks on: the single-level kernel passes k_eff times over the whole row with ONE workgroup --
+    //  135 us for 15 k values, k = 10; the chunk kernel selects from registers)
+    const bool two_level = n_chunks >= 2 && k_sel <= KZ_EXACT_CHUNK;
     int rc = kz_pool_alloc(ctx, (size_t)R * (size_t)index->n * 8, (void**)&sp.vals);
     if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 8, (void**)&sp.cand_v);
     if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 4, (void**)&sp.cand_i);
@@ -1973,12 +2036,15 @@ static int kz_spec_rescue(kz_ctx* ctx, KzSpec& sp, int R, const kz_matrix* query
         kz_spec_release(ctx, sp);
         return rc == KZ_ERR_NOMEM ? KZ_OK : rc;
     }
-    const int dist_blocks = (int)((index->n + 3) / 4 < 128 ? (index->n + 3) / 4 : 128);   // (grid-stride; dead rows cost their dispatch)
+    const int dist_blocks = (int)((index->n + 3) / 4 < 256 ? (index->n + 3) / 4 : 256);   // (grid-stride; dead rows cost their dispatch)
     const double* sel_v = two_level ? (const double*)sp.cand_v : (const double*)sp.vals;
     const int* sel_i = two_level ? (const int*)sp.cand_i : (const int*)nullptr;
     const int64_t n_entries = two_level ? (int64_t)n_chunks * k_sel : index->n;
     if (index->dtype == KZ_F32) {
-        if (!(ctx->exact_rows && kz_launch_exact_rows(ctx, fail_list, 0, R, q0, query, index, metric, sp.vals, fail_count)))
+        // (a handful of rows: short stretches of index rows per wave, so that the launch is wide -- 15 k rows: 235 x R / 4 workgroups)
+        int rpw = (int)(index->n / 1024);
+        rpw = rpw < 16 ? 16 : (rpw > 256 ? 256 : rpw);
+        if (!(ctx->exact_rows && kz_launch_exact_rows(ctx, fail_list, 0, R, q0, query, index, metric, sp.vals, fail_count, rpw)))
             hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3(dist_blocks, R), dim3(256), 0, ctx->stream, fail_list, 0, q0,
                                (const float*)query->raw, (const float*)index->raw, query->sqn, index->sqn, index->n, (int)index->d, metric,
                                index->mink_p, sp.vals, fail_count);

@@ -1,5 +1,5 @@
 """The exact float64 distance kernel that takes many pairs per wave step (kz_exact_dist_rows_kernel: four query rows in registers,
-64 / LPR consecutive index rows per step) against the one-pair-per-wave kernel it replaces for float32 rows of d <= 256: the same
+64 / LPR consecutive index rows per step) against the one-pair-per-wave kernel it replaces for float32 rows of d <= 512: the same
 values bit for bit (both reproduce kz_wave_dot's order of operations), on every metric, ragged sizes, with and without the
 normalised float64 rows of a cosine index.  The exact kernels are the backstop below every approximate tier (the reference has no
 tiers: scikit-learn's brute force, sklearn_nearest_neighbors.py:96-101).  `pytest -m gpu`."""
@@ -19,7 +19,7 @@ def ctx():
 
 
 @pytest.mark.parametrize("metric", ["euclidean", "sqeuclidean", "cosine"])
-@pytest.mark.parametrize("d", [4, 20, 32, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("d", [4, 20, 32, 64, 100, 128, 200, 256, 260, 300, 384, 512])      # (> 256: two chunks per lane, round 6)
 def test_same_bits_as_the_one_pair_kernel(ctx, metric, d):
     from kiez_amd import _native as N
     from oracle import kiez_oracle as O
