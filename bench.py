@@ -277,7 +277,7 @@ def sample_check(res, sk, eng, comm, source_dev, target_h, K, k, metric, hub, hu
     g_d = comm.all_gather_rows(res[0][sel_t].contiguous(), sel_counts)
     g_i = comm.all_gather_rows(res[1][sel_t].contiguous(), sel_counts)
     g_src = comm.all_gather_rows(source_dev[sel_t].contiguous(), sel_counts)
-    src_full = comm.all_gather_rows(source_dev, counts) if hub is not None else None     # (the reverse pass' index: every shard)
+    src_full = comm.gather_rows_to0(source_dev, counts) if hub is not None else None     # (the reverse pass' index: every shard, on rank 0 only)
     if rank != 0:
         return None
     begins = np.concatenate([[0], np.cumsum(counts)])[:-1]
@@ -625,7 +625,7 @@ def job_cpu_baseline(args, comm, eng, s, source_dev, source_h, target_h):
     n_s, n_t, d, metric, K, k, hub, hub_kw, _ = WORKLOADS[s["name"]]
     held = source_h
     if comm.world > 1 and hub is not None:
-        full = comm.all_gather_rows(source_dev, [row for row in s["shard_rows"]])
+        full = comm.gather_rows_to0(source_dev, [row for row in s["shard_rows"]])      # (rank 0 only holds the gathered shards)
         held = eng.to_numpy(full) if comm.rank == 0 else None
         del full
     if comm.rank != 0:
@@ -740,7 +740,11 @@ def main():
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # (rank 0 runs the oracle check and the CPU baseline between collectives, tens of seconds during which the other ranks
+        #  wait inside the next one: a generous watchdog timeout)
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(minutes=30))
 
     if args.openea is not None:
         if world != 1:

@@ -61,6 +61,8 @@ struct kz_ctx {
     int esc_ladder;   // 1 (default): kz_knn.hip "LADDER AFTER THE FACT"
     int exact_rows;   // 1 (default): the exact distance kernel that keeps four query rows in registers and takes 64 / LPR index rows per step
     int exact_direct_rows;   // a split-bf16 pass that leaves at most this many rows (default 32) hands them to the exact kernels directly (kz_knn_impl)
+    int abl_stamp;    // diagnostic: kz_knn.hip "abl_stamp"
+    int abl_refloor;  // diagnostic: kz_knn.hip "abl_refloor"
     int spec_rows;    // exact kernels launched speculatively behind every finalize kernel for up to this many uncertified rows (default 64; kz_knn.hip "SPECULATIVE RESCUE")
     double spec_elems; // ... at most spec_elems / (n d) of them (default 1.6e9: 8 rows of a 1 M x 200 index)
     int range_boot;   // 1 (default): short-list routes of the ordinary kernel sweep index range 0 first and start the other ranges' lists at the floor read off it (kz_knn.hip "RANGE-0 BOOTSTRAP")
@@ -285,29 +287,26 @@ __device__ __forceinline__ double kz_wave_dot_normalized(const T* __restrict__ a
 // sum |.|^p -- rounded to the input dtype.  Every kernel that evaluates the family (the tiled distance kernel of kz_knn.hip,
 // kz_pair_values) adds the terms of a pair in this order, one thread per pair: manhattan and chebyshev values are scikit-learn's
 // bit for bit, minkowski's to the last bit of pow().
-// One term.  p_int > 0: p is a small integer, the power is a product chain (float32 inputs, p <= 4: one rounding, as a
-// correctly rounded pow); else pow().
-// CHAIN: -1 = decide at run time (p_int > 0: chain, else pow); 0 = a chain of run-time length p_int; 3 / 4 = that chain, unrolled
+// One term.  p_int = 3 or 4 (float32 inputs only, kz_family_p_int): the power as a product with ONE rounding -- a is a float32
+// value, so a a is exact in float64 (48 bits) and (a a) a, (a a)(a a) round the exact product once: the correctly rounded a^p, what
+// a correctly rounded pow() returns.  Anything else -- float64 inputs, p >= 5, fractional p -- calls pow() as scikit-learn's
+// MinkowskiDistance does (a longer chain, or a chain on float64 values, rounds more than once: 1 ulp off in a quarter of the terms).
+// CHAIN: -1 = decide at run time from p_int; 3 / 4 = that product, unrolled
 template <typename T, int METRIC, int CHAIN = -1>
 __device__ __forceinline__ double kz_family_term(T x, T y, double p, int p_int) {
     const T df = x - y;
     const double a = fabs((double)df);
     if (METRIC != KZ_MINKOWSKI) return a;
-    if (CHAIN == 3) return (a * a) * a;            // (the order of the run-time chain: ((a a) a) a ...)
-    if (CHAIN == 4) return ((a * a) * a) * a;
-    if (CHAIN == 0 || p_int > 0) {
-        double r = a;
-        for (int i = 1; i < p_int; ++i) r *= a;
-        return r;
-    }
+    if (CHAIN == 3 || (CHAIN < 0 && p_int == 3)) return (a * a) * a;
+    if (CHAIN == 4 || (CHAIN < 0 && p_int == 4)) return (a * a) * (a * a);
     return pow(a, p);
 }
 template <int METRIC>
 __device__ __forceinline__ double kz_family_add(double acc, double term) {
     return METRIC == KZ_CHEBYSHEV ? fmax(acc, term) : acc + term;
 }
-__host__ __device__ __forceinline__ int kz_family_p_int(int metric, double p) {
-    return (metric == KZ_MINKOWSKI && p >= 2.0 && p <= 8.0 && p == (double)(int)p) ? (int)p : 0;
+__host__ __device__ __forceinline__ int kz_family_p_int(int metric, double p, bool f32_inputs) {
+    return (metric == KZ_MINKOWSKI && f32_inputs && (p == 3.0 || p == 4.0)) ? (int)p : 0;
 }
 template <typename T, int METRIC>
 __device__ __forceinline__ double kz_family_value_seq_m(const T* __restrict__ a, const T* __restrict__ b, int d, double p, int p_int) {
@@ -318,7 +317,7 @@ __device__ __forceinline__ double kz_family_value_seq_m(const T* __restrict__ a,
 // (one thread, one pair)
 template <typename T>
 __device__ __forceinline__ double kz_family_value_seq(const T* __restrict__ a, const T* __restrict__ b, int d, int metric, double p) {
-    const int p_int = kz_family_p_int(metric, p);
+    const int p_int = kz_family_p_int(metric, p, sizeof(T) == 4);
     if (metric == KZ_MANHATTAN) return kz_family_value_seq_m<T, KZ_MANHATTAN>(a, b, d, p, p_int);
     if (metric == KZ_CHEBYSHEV) return kz_family_value_seq_m<T, KZ_CHEBYSHEV>(a, b, d, p, p_int);
     return kz_family_value_seq_m<T, KZ_MINKOWSKI>(a, b, d, p, p_int);

@@ -1281,7 +1281,7 @@ static void kz_launch_family_dist(kz_ctx* ctx, const int* fl, int b0, int nb, in
                                   double* vals) {
     constexpr int DK = sizeof(T) == 4 ? 32 : 16;
     const dim3 grid((unsigned)((index->n + 63) / 64), (unsigned)((nb + 63) / 64));
-    const int p_int = kz_family_p_int(index->metric, index->mink_p);
+    const int p_int = kz_family_p_int(index->metric, index->mink_p, sizeof(T) == 4);
 #define KZ_FAMILY_LAUNCH(M, C)                                                                                                          \
     hipLaunchKernelGGL((kz_family_dist_kernel<T, M, DK, C>), grid, dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin, (const T*)query->raw, \
                        (const T*)index->raw, index->n, (int)index->d, index->mink_p, p_int, vals)
@@ -1290,11 +1290,9 @@ static void kz_launch_family_dist(kz_ctx* ctx, const int* fl, int b0, int nb, in
     else if (index->metric == KZ_CHEBYSHEV)
         KZ_FAMILY_LAUNCH(KZ_CHEBYSHEV, -1);
     else if (p_int == 3)
-        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, 3);     // (integer exponent 2 .. 8: a product chain, no pow() in the kernel; 3 and 4 unrolled)
+        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, 3);     // (float32 inputs, p = 3 or 4: a product with one rounding, no pow() in the kernel)
     else if (p_int == 4)
         KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, 4);
-    else if (p_int > 0)
-        KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, 0);
     else
         KZ_FAMILY_LAUNCH(KZ_MINKOWSKI, -1);
 #undef KZ_FAMILY_LAUNCH
@@ -1945,6 +1943,11 @@ __global__ void kz_boot_floor_kernel(const float* __restrict__ in_key, const int
     out[q_begin + q] = f;
 }
 
+__global__ void kz_floor_nudge_kernel(float* __restrict__ f, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && f[i] > -INFINITY) f[i] = nextafterf(f[i], -INFINITY);
+}
+
 // Escalation of uncertified rows: gather rows cq_begin + fail_list[0 .. n_fail) of `query` into a dense block, search it
 // again (kz_knn_impl with the given precision / minimum list length; that call sends ITS uncertified rows further down)
 // and scatter the results into out_dist / out_ind at the rows' positions.  Ends with a stream synchronisation.
@@ -2487,7 +2490,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // re-search of the uncertified rows)
     const int KP_mem = KP_class > KP ? KP_class : KP;   // (short-list route: several lists of 16 -- the chunk of the replaced list length)
     // (the wide route keeps 32 lists of 16 per query -- 4 KiB: 524288 rows)
-    const int64_t max_rows_per_chunk = kz_rows_per_chunk(ctx, KP_mem, wide_route);
+    int64_t max_rows_per_chunk = kz_rows_per_chunk(ctx, KP_mem, wide_route);   // (halved below where a chunk's lists would pass 2^32 entries)
     if (dual && dual->raw_lists && q_count > max_rows_per_chunk) {
         kz_set_error("kz_knn: internal: a raw-list pass must be one launch");
         return KZ_ERR_INVALID;
@@ -2509,8 +2512,13 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         if (tier == KZ_TIER_H && short_ord && long_pieces >= 2) {
             // (a re-search of the previous chunk's uncertified rows may have selected -- or packed -- the index dealt over another
             //  number of ranges: this route's own image again; cached, two are kept)
+            // (any failure ends the call: launching on whatever image the last sub-search selected would certify against the wrong
+            //  range layout; unreachable while a slot exists once the route is chosen)
             const int rcd = kz_himage_dealt(index, wide_route || forced_lists > 0 ? long_pieces : route_P);
-            if (rcd != KZ_OK && rcd != KZ_ERR_NOMEM) return rcd;
+            if (rcd != KZ_OK) {
+                if (rcd == KZ_ERR_NOMEM) kz_set_error("kz_knn: out of device memory for the row-dealt image of the index");
+                return rcd;
+            }
         }
         int slots = 0;
         {
@@ -2518,27 +2526,38 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             if (rcs != KZ_OK) return rcs;
         }
         const int64_t cq_begin = q_begin + c0;
-        const int64_t cq_count = (q_count - c0 < max_rows_per_chunk) ? (q_count - c0) : max_rows_per_chunk;
         const int qt0 = (int)(cq_begin / KZ_TILE);
-        const int qt1 = (int)((cq_begin + cq_count - 1) / KZ_TILE);
-        const int n_qtiles = qt1 - qt0 + 1;
+        int64_t cq_count = 0;
+        int n_qtiles = 0, force_pieces = 0, max_pieces = 0;
         // ---- schedule: which workgroup sweeps which (query tile, index-tile range): kz_prepare_pass above --------------
-        KzPass ps;
-        // (long-k route: exactly long_pieces index ranges per query tile, one round)
-        int force_pieces = (tier == KZ_TIER_F32 && long_pieces > 8) ? 8 : long_pieces;
-        if (tier == KZ_TIER_H && short_ord && force_pieces > 0) {
-            // a SMALL launch on the short-list route (a re-search of a few hundred uncertified rows, a probe): P ranges per query
-            // tile leave most of the chip idle (216 rows x 10 ranges: 20 workgroups sweeping 390 tiles each, 1.98 ms) -- every
-            // range is cut further, s P lists of 16 per query (the finalize kernel selects from any number of lists), as long as
-            // a piece keeps at least 8 tiles and a query at most KZ_MAX_PIECES (128) lists
-            const int units = (n_qtiles + tpw_h - 1) / tpw_h;
-            int sub = slots / (units * force_pieces);
-            if (sub > KZ_MAX_PIECES / force_pieces) sub = KZ_MAX_PIECES / force_pieces;
-            if (sub > n_ytiles / (8 * force_pieces)) sub = n_ytiles / (8 * force_pieces);
-            if (sub > 1 && 4 * kz_fin_wave_bytes(force_pieces * sub * 16, KSEL) <= 160 * 1024) force_pieces *= sub;
+        for (;;) {
+            cq_count = (q_count - c0 < max_rows_per_chunk) ? (q_count - c0) : max_rows_per_chunk;
+            n_qtiles = (int)((cq_begin + cq_count - 1) / KZ_TILE) - qt0 + 1;
+            // (long-k route: exactly long_pieces index ranges per query tile, one round)
+            force_pieces = (tier == KZ_TIER_F32 && long_pieces > 8) ? 8 : long_pieces;
+            if (tier == KZ_TIER_H && short_ord && force_pieces > 0) {
+                // a SMALL launch on the short-list route (a re-search of a few hundred uncertified rows, a probe): P ranges per query
+                // tile leave most of the chip idle (216 rows x 10 ranges: 20 workgroups sweeping 390 tiles each, 1.98 ms) -- every
+                // range is cut further, s P lists of 16 per query (the finalize kernel selects from any number of lists), as long as
+                // a piece keeps at least 8 tiles and a query at most KZ_MAX_PIECES (128) lists
+                const int units = (n_qtiles + tpw_h - 1) / tpw_h;
+                int sub = slots / (units * force_pieces);
+                if (sub > KZ_MAX_PIECES / force_pieces) sub = KZ_MAX_PIECES / force_pieces;
+                if (sub > n_ytiles / (8 * force_pieces)) sub = n_ytiles / (8 * force_pieces);
+                if (sub > 1 && 4 * kz_fin_wave_bytes(force_pieces * sub * 16, KSEL) <= 160 * 1024) force_pieces *= sub;
+            }
+            max_pieces = kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1);
+            if (dual && dual->max_entries > 0 && max_pieces > dual->max_entries / KP) max_pieces = dual->max_entries / KP;
+            // The kernels address a launch's lists with 32-bit element offsets: a chunk whose plan would pass 2^32 entries (K' = 16,
+            // 2 M rows over 128 ranges) is halved -- the plan is host arithmetic, made here once more than kz_prepare_pass makes it.
+            KzPlan pl;
+            kz_plan_pass(n_qtiles, n_ytiles, slots, max_pieces, (tier == KZ_TIER_H ? 1 : 2) * KP, tier == KZ_TIER_F32 ? 2 : 1, tier == KZ_TIER_H ? 1 : 0,
+                         tier == KZ_TIER_H ? tpw_h : 1, force_pieces > 0 ? force_pieces : ctx->force_splits,
+                         min_pieces_call > ctx->min_splits ? min_pieces_call : ctx->min_splits, &pl);
+            if (pl.list_elems < ((size_t)1 << 32) || cq_count <= 8 * KZ_TILE || (dual && dual->raw_lists)) break;
+            max_rows_per_chunk = ((cq_count / 2 + KZ_TILE - 1) / KZ_TILE) * KZ_TILE;
         }
-        int max_pieces = kz_max_pieces(KP, tier == KZ_TIER_F32 ? 2 : 1);
-        if (dual && dual->max_entries > 0 && max_pieces > dual->max_entries / KP) max_pieces = dual->max_entries / KP;
+        KzPass ps;
         // (range-0 bootstrap: the short-list routes of the ordinary 32-query kernel, from four ranges on)
         const bool boot = tier == KZ_TIER_H && short_ord && !dual && !q64 && ctx->range_boot && force_pieces >= 4;
         int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, max_pieces, KP, tier, cq_count, &ps,
@@ -2553,6 +2572,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         int* fail_count = ctx->d_counters + 8;
         KZ_HIP(hipMemsetAsync(fail_count, 0, 4 * sizeof(int), ctx->stream));  // fail counter, (unused), error-ratio bits
         const float* boot_floor = nullptr;   // (this chunk's range-0 floor, if any: the finalize kernel must know it)
+        unsigned long long* stamp_buf = nullptr;   // (diagnostic "abl_stamp")
         KnnCandParams cp;
         memset(&cp, 0, sizeof(cp));
         if (tier == KZ_TIER_H) {
@@ -2611,9 +2631,36 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W - ps.W0, ctx->h_wps, ctx->h_wide));
             cp.work = d_work;
             boot_floor = bfloor;
-        } else if (tier == KZ_TIER_H)
+        } else if (tier == KZ_TIER_H) {
+            if (ctx->abl_stamp && getenv("KZ_STAMP_FILE")) {   // (diagnostic: a -DKZ_ABL_STAMP build of the fp16 units fills it)
+                rc = kz_pool_alloc(ctx, (size_t)W * (16 + 1024), (void**)&stamp_buf);
+                if (rc != KZ_OK) return rc;
+                KZ_HIP(hipMemsetAsync(stamp_buf, 0, (size_t)W * (16 + 1024), ctx->stream));
+                cp.log_meta = stamp_buf;
+                cp.log_keys = stamp_buf + 2 * (size_t)W;
+            }
             KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
-        else if (tier == KZ_TIER_BF)
+            cp.log_meta = nullptr;
+            cp.log_keys = nullptr;
+            if (rc == KZ_OK && ctx->abl_refloor && !short_ord && ps.lay.n_regions == 1 && ps.lay.pieces[0] == 1) {
+                // DIAGNOSTIC ("abl_refloor", profiles/r06_event_ablation.md): the same sweep AGAIN with every list starting at the
+                // threshold it ENDED on (the K'-th best key of the first sweep's list): K' insertions per query instead of
+                // K' (1 + ln(n / K')) -- the time any seeding of the lists could at best reach.  The second sweep is the one timed.
+                float* bfloor = nullptr;
+                const int64_t n_pad = (int64_t)query->n_tiles * KZ_TILE;
+                rc = kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&bfloor);
+                if (rc != KZ_OK) return rc;
+                hipLaunchKernelGGL(kz_boot_floor_kernel, dim3((unsigned)((cq_count + 255) / 256)), dim3(256), 0, ctx->stream, out_key, out_idx, lay, KP,
+                                   cq_begin - (int64_t)qt0 * KZ_TILE, cq_begin, cq_count, cp.qfloor, bfloor);
+                // (one ulp below: entries equal to the threshold must get in again)
+                hipLaunchKernelGGL(kz_floor_nudge_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, bfloor, n_pad);
+                KZ_HIP(hipGetLastError());
+                cp.qfloor = bfloor;
+                KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+                KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
+                boot_floor = bfloor;
+            }
+        } else if (tier == KZ_TIER_BF)
             KZ_DISPATCH_KP(rc, kz_bf_launch, (n_slices, ctx, cp, W));
         else
             KZ_DISPATCH_CAND(rc, kz_launch_cand, (ctx, cp, W));
@@ -2713,6 +2760,21 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             kz_spec_release(ctx, spec);   // (stream-ordered pool: the launches that used the buffers are on the stream)
             spec.R = spec_R;
             KZ_HIP(es);
+        }
+        if (stamp_buf) {   // (diagnostic: start / end of every workgroup of the sweep, in work-table order, appended to the file)
+            std::vector<unsigned long long> hs((size_t)W * 130);
+            KZ_HIP(hipMemcpy(hs.data(), stamp_buf, (size_t)W * (16 + 1024), hipMemcpyDeviceToHost));
+            kz_pool_free(ctx, stamp_buf, 0);
+            if (FILE* f = fopen(getenv("KZ_STAMP_FILE"), "a")) {
+                fprintf(f, "# launch W=%d n_qtiles=%d n_ytiles=%d slices=%d\n", W, n_qtiles, n_ytiles, n_slices);
+                for (int w = 0; w < W; ++w) {
+                    fprintf(f, "%d %llu %llu", w, hs[2 * (size_t)w], hs[2 * (size_t)w + 1]);
+                    if (w < 8 || w % 97 == 0)   // (per-tile stamps of a few workgroups: the first 64 tiles, then every 16th)
+                        for (int t = 0; t < 128; ++t) fprintf(f, " %llu", hs[2 * (size_t)W + (size_t)w * 128 + t]);
+                    fprintf(f, "\n");
+                }
+                fclose(f);
+            }
         }
         for (int u = 0; u < 2; ++u) {
             if (!unchecked[u]) continue;

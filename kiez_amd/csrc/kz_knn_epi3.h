@@ -361,7 +361,11 @@ __device__ __forceinline__ void kz_tile_epilogue3(f32x16 (&acc)[4], KzCandState3
     for (int mt = 0; mt < 4; ++mt) bmx[mt] = fmaxf(fmaxf(gm[4 * mt], gm[4 * mt + 1]), fmaxf(gm[4 * mt + 2], gm[4 * mt + 3]));
     const float m = fmaxf(fmaxf(bmx[0], bmx[1]), fmaxf(bmx[2], bmx[3]));
     float tau_a = st.tau;
+#ifdef KZ_ABL_NO_EVENTS   // (diagnostic build, tools/ab_build.sh: no list event is ever logged -- WRONG results, the sweep's time without events)
+    const unsigned long long anym = 0ull;
+#else
     const unsigned long long anym = __builtin_amdgcn_ballot_w64(m > tau_a);
+#endif
     // Dual pass: the index rows of a tile are sorted by their event threshold, so ONE per-tile value (the tile's smallest
     // theta, plus this query's own offset: cthr) tested against the same maxima finds the groups that may hold an event of
     // an index row -- a second compare on the tile maximum, nothing per key.  Which of the four keys of such a group

@@ -99,6 +99,9 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     const int j = lane & 31;
     const int h = lane >> 5;
     const int4 wd = p.work[blockIdx.x];
+#ifdef KZ_ABL_STAMP   // (diagnostic build, tools/ab_build.sh + option "abl_stamp": when every workgroup started and ended, 100 MHz clock)
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int t_begin = wd.y, t_end = wd.z, s = wd.w;
     const int total = (t_end - t_begin) * NSR;
     // WIDE: waves 4 b .. 4 b + 3 take query tile wd.x + b; a workgroup at the end of the launch may reach past its last
@@ -322,9 +325,24 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
     };
 
     int tile = t_begin;
+#ifdef KZ_ABL_STAMP
+    // (per-tile stamps of this workgroup's first 64 tiles, then of every 16th: [W][128] in log_keys)
+    auto tile_stamp = [&](int t) {
+        if constexpr (!DUAL) {
+            const int rel = t - t_begin;
+            const int slot = rel < 64 ? rel : 64 + ((rel - 64) >> 4);
+            if (p.log_keys && threadIdx.x == 0 && slot < 128 && (rel < 64 || ((rel - 64) & 15) == 0))
+                ((unsigned long long*)p.log_keys)[(size_t)blockIdx.x * 128 + slot] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+#else
+    auto tile_stamp = [](int) {};
+#endif
     for (;;) {
+        tile_stamp(tile);
         run_tile(tile, std::integral_constant<int, 0>{});
         if (++tile >= t_end) break;
+        tile_stamp(tile);
         run_tile(tile, std::integral_constant<int, (NSR & 1)>{});
         if (++tile >= t_end) break;
     }
@@ -342,4 +360,13 @@ __global__ __launch_bounds__(WIDE ? 256 * WPS : 256, WIDE ? 1 : WPS) void kz_knn
             }
         }
     }
+#ifdef KZ_ABL_STAMP
+    if constexpr (!DUAL) {
+        if (p.log_meta && threadIdx.x == 0) {
+            unsigned long long* o = (unsigned long long*)p.log_meta + 2 * (size_t)blockIdx.x;
+            o[0] = stamp0;
+            o[1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }

@@ -59,6 +59,8 @@ static const KzOption KZ_OPTIONS[] = {
     {"esc_ladder", KZ_OPT_BOOL, KZ_O(esc_ladder), 0, 1, 1, 0, {}, 0, "a pass without a probe that leaves more than half of its rows uncertified tries the wide route on a sample of them before the split-bf16 tier"},
     {"exact_rows", KZ_OPT_BOOL, KZ_O(exact_rows), 0, 1, 1, 0, {}, 0, "exact float64 kernels: many pairs per wave step for float32 rows of d <= 256 (kz_exact_dist_rows_kernel)"},
     {"exact_direct_rows", KZ_OPT_INT, KZ_O(exact_direct_rows), 0, 4096, 32, 0, {}, 0, "at most this many rows left by the split-bf16 tier skip the float32-operand kernel and go to the exact kernels"},
+    {"abl_refloor", KZ_OPT_BOOL, KZ_O(abl_refloor), 0, 1, 0, 0, {}, 0, "diagnostic: an ordinary one-range fp16 sweep runs twice, the second (timed) one from the first one's final thresholds"},
+    {"abl_stamp", KZ_OPT_BOOL, KZ_O(abl_stamp), 0, 1, 0, 0, {}, 0, "diagnostic: with a -DKZ_ABL_STAMP build and KZ_STAMP_FILE set, start / end of every workgroup of an ordinary fp16 sweep"},
     {"spec_rows", KZ_OPT_INT, KZ_O(spec_rows), 0, 64, 64, 0, {}, 0, "exact kernels launched speculatively behind every finalize for at most this many uncertified rows (0 = off)"},
     {"spec_elems", KZ_OPT_F64, KZ_O(spec_elems), 0, 1e300, 1.6e9, 0, {}, 0, "... and at most this / (index rows x d) of them"},
     {"wide_lists", KZ_OPT_INT, KZ_O(wide_lists), 2, 32, 32, KZ_OPT_SET, {0}, -1, "fp16 tier's wide route: lists of 16 per query (0 = off)"},

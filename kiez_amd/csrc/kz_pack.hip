@@ -405,6 +405,12 @@ int kz_matrix_norm64(kz_matrix* m) {
     const size_t bytes = (size_t)m->n * (size_t)m->d * 8;
     if (bytes > ((size_t)8 << 30)) return KZ_OK;   // (of 288 GB; beyond, the per-pair divisions stay)
     kz_ctx* ctx = m->ctx;
+    // (the image lives as long as the matrix and is in no footprint gate of the searches: a large one is only built while it is a
+    //  small part of what the device has FREE -- a process that shares the GPU with another allocator keeps the per-pair divisions)
+    if (bytes > ((size_t)256 << 20)) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 8 < bytes) return KZ_OK;
+    }
     if (kz_pool_alloc(ctx, bytes, (void**)&m->norm64) != KZ_OK) {
         m->norm64 = nullptr;
         return KZ_OK;   // (an optimisation only)

@@ -320,6 +320,22 @@ class Comm:
         self._timed("all_gather", pad, lambda: self.dist.all_gather(parts, pad, group=self.group))
         return torch.cat([parts[r][: counts[r]] for r in range(self.world)], dim=0)
 
+    def gather_rows_to0(self, t, counts):
+        """Ragged row blocks of all ranks concatenated in rank order ON RANK 0 ONLY (None elsewhere): for evidence that one rank
+        evaluates (bench.py's oracle check and CPU baseline gather the source shards) -- an all_gather would put world x shard on
+        every GPU."""
+        torch = _torch()
+        if self.world == 1 and not self.always:
+            return t
+        mx = max(counts)
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        parts = [torch.empty_like(pad) for _ in range(self.world)] if self.rank == 0 else None
+        self._timed("gather", pad, lambda: self.dist.gather(pad, gather_list=parts, dst=0, group=self.group))
+        if self.rank != 0:
+            return None
+        return torch.cat([parts[r][: counts[r]] for r in range(self.world)], dim=0)
+
     def all_to_all_rows(self, t, counts):
         """Row blocks of `t` (block r = counts[r] rows, in rank order) go to rank r; returns what this rank received, stacked
         in rank order: [world, counts[rank], ...].  The exchange step of the shared sweep: every rank holds, for ALL

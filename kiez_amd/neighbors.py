@@ -167,6 +167,8 @@ def canonical_metric(metric: str, p=2) -> str:
             return "manhattan"
         if np.isinf(p):
             return "chebyshev"
+        if p >= 1e6:    # (kz_matrix_set_minkowski_p's limit: said here, in the constructor, like every other metric error)
+            raise ValueError(f"metric='minkowski' with p={p!r}: the MI355X exact backend takes 1 <= p < 1e6 (or p = inf: chebyshev)")
         return f"minkowski[{float(p)!r}]"
     if metric in ("l2", "euclidean"):
         return "euclidean"

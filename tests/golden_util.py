@@ -19,6 +19,7 @@ PIPELINE_CASES = [
     "conftest_two_source", "conftest_single_source", "c0_two_source", "c0_single_source",
     "f32_euclidean", "f32_sqeuclidean", "f32_gauss_single", "cosine_k50", "cosine_single",
     "f64_manhattan", "f32_chebyshev_single", "f32_minkowski_p3", "f64_minkowski_p1_5_single", "f32_cityblock",
+    "f64_minkowski_p3", "f64_minkowski_p4", "f32_minkowski_p4",
 ]
 
 

@@ -126,6 +126,11 @@ def main():
     run_case("f64_minkowski_p1_5_single", s, None, 6, [6, 1], "minkowski", p=1.5, hubs={"none", "mp_normal"},
              sk_algorithm="brute")
     run_case("f32_cityblock", s32, t32, 5, [5], "cityblock", hubs={"none", "csls"})
+    # 5c. integer exponents where a product chain and pow() part ways (round-5 advisor finding): float64 inputs with p = 3 / 4 (the
+    #     device calls pow() there, as scikit-learn does) and float32 inputs with p = 4 (the one-rounding product (a a)(a a))
+    run_case("f64_minkowski_p3", s, t, 8, [8, 2], "minkowski", p=3, hubs={"none", "csls"}, sk_algorithm="brute")
+    run_case("f64_minkowski_p4", s, t, 8, [8], "minkowski", p=4, hubs={"none", "ls"}, sk_algorithm="brute")
+    run_case("f32_minkowski_p4", s32, t32, 10, [10, 3], "minkowski", p=4, hubs={"none", "csls", "mp_normal"}, sk_algorithm="brute")
     if ONLY:
         return
     # 6. HubnessReduction._sort (kiez/hubness_reduction/base.py:72-87): the reference's own test input
