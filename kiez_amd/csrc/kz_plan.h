@@ -12,7 +12,8 @@
 #define KZ_TILE 128
 #endif
 constexpr int KZ_MAX_REGIONS = 8;
-constexpr int KZ_QGROUP = 24;   // query tiles sharing an XCD at a time (x splits ~= resident workgroups)
+constexpr int KZ_QGROUP = 24;
+constexpr int KZ_PLAN_START_TILES = 24;   // what the start of an item costs, in tiles of steady sweep (kz_plan_rounds)   // query tiles sharing an XCD at a time (x splits ~= resident workgroups)
 
 // Candidate-list storage.  The host schedule cuts the query tiles of a launch into a few REGIONS; every query of region r owns
 // pieces[r] lists (one per index-range piece; two per piece -- one per lane half -- for the float32 kernels).
@@ -51,6 +52,35 @@ static inline void kz_plan_rounds(int n_qtiles, int n_ytiles, int slots, int max
     auto split_len = [&](int sp) { return (n_ytiles + sp - 1) / sp; };
     auto split_cnt = [&](int sp) { return (n_ytiles + split_len(sp) - 1) / split_len(sp); };
     int R = n_qtiles, n = 0;
+    // ONE ROUND where that is shorter (round 6).  Every item pays the start of a sweep -- its lists fill from -inf: the first tile of an
+    // item takes ~35 us, the second ~18, ... ~0.1 ms in all before the steady 2.3 - 4.3 us per tile (per-tile clock stamps, tools/
+    // stamp_show.py) -- about KZ_PLAN_START_TILES tiles' worth.  The greedy rounds below cut a SMALL launch (fewer query tiles than
+    // slots) into ceil(slots / R) ranges, which leaves a few query tiles for a second round of short items that pay that start
+    // again behind the first (15 k x 15 k x 300: 510 items of 24 tiles, then 224 of 9: 336 us, the second round 100 of them);
+    // floor(slots / R) ranges put every query tile into one round (472 items of 30 tiles).  Both plans are priced -- start + length
+    // per round -- and the cheaper one is taken.
+    if (force_splits <= 0 && n_qtiles < slots) {
+        const int sp1 = clamp_s(slots / n_qtiles > min_splits ? slots / n_qtiles : min_splits);
+        if (split_cnt(sp1) * n_qtiles <= slots) {
+            int cost_rounds = 0, Rg = n_qtiles, ng = 0;
+            while (Rg > 0) {   // (the greedy rounds, priced only)
+                int spg = clamp_s((slots + Rg - 1) / Rg);
+                if (ng == 0 && spg < min_splits) spg = clamp_s(min_splits);
+                int Ag = slots / split_cnt(spg);
+                if (Ag < 1) Ag = 1;
+                if (Ag > Rg || ng == KZ_MAX_REGIONS - 1) Ag = Rg;
+                cost_rounds += KZ_PLAN_START_TILES + split_len(spg);
+                Rg -= Ag;
+                ++ng;
+            }
+            if (KZ_PLAN_START_TILES + split_len(sp1) <= cost_rounds) {
+                round_qtiles[0] = n_qtiles;
+                round_splits[0] = sp1;
+                *n_rounds = 1;
+                return;
+            }
+        }
+    }
     while (R > 0) {
         int sp, A;
         if (force_splits > 0) {

@@ -60,6 +60,14 @@ def test_c1_schedule_is_the_documented_one():
     assert _plan(100_000, 100_000, 10, 768) == [(768, 1, 782), (14, 53, 15)]
 
 
+def test_a_small_launch_takes_one_round_where_that_is_shorter():
+    """Every item pays the start of a sweep (~24 tiles' worth): fewer query tiles than slots -> floor(slots / tiles) ranges, ONE round,
+    when start + length beats the greedy rounds' sum (kz_plan.h; measured with per-workgroup clock stamps on the 15 k x 15 k shape)."""
+    assert _plan(15_000, 15_000, 10, 512) == [(118, 4, 30)]                  # (greedy: [(102, 5, 24), (16, 14, 9)])
+    assert _plan(500 * 128, 100_000, 10, 768) == [(384, 2, 391), (109, 7, 112), (7, 87, 9)]   # two thirds of the slots: the rounds stay
+    assert _plan(1000, 1300, 10, 512) == [(8, 1, 11)]                        # an index of 11 tiles is not cut below 8
+
+
 def test_knobs():
     assert _plan(5000, 50_000, 10, 512, force_splits=5) == [(40, 5, 79)]
     r = _plan(100_000, 100_000, 10, 512, min_splits=4)
