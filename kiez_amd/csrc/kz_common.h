@@ -14,6 +14,25 @@
 #define KZ_LIVE_MAX 1024
 #define KZ_POOL_SLOTS 256   // cached released buffers (a shared-sweep fit + kneighbors releases ~90: 64 slots evicted ~28 a step -- hipFree, a device-wide sync each)
 
+// Former context options that no tool or test set (round 6: one table of <= 30 options): the values every build ran with.
+constexpr int KZ_K_LDS_PAD = 0;   // extra dynamic LDS per workgroup (lowers occupancy; diagnostic)
+constexpr int KZ_K_LONG_K = 1;   // 111 .. ~540 neighbours on the fused kernels (0: exact kernels)
+constexpr int KZ_K_FIN_WIDE = 1;   // finalize of > 160 selected candidates without O(n^2) sorts, several rows per gather step
+constexpr int KZ_K_RANGE_BOOT = 1;   // short-list routes: index range 0 first, the other ranges' lists start at the floor read off it
+constexpr double KZ_K_NESTED_MIN_MS = 2.0;   // the nested sample of the shared sweep is taken when it saves at least this many model-ms (sweep / stride)
+constexpr int KZ_K_DUAL_SHORT_DIV = 5;   // 
+constexpr int KZ_K_DUAL_SHORT_KP = 16;   // 
+constexpr int KZ_K_MIN_SPLITS = 1;   // minimum index splits per query tile in the large-item region
+constexpr int KZ_K_QGROUP = 0;   // query tiles per group of the work table (0 = automatic)
+constexpr int KZ_K_H_WIDE = 0;   // fp16 kernel: wide workgroups on one ring (kz_knn_h16.h "WIDE": measured slower on every shared sweep, round 6: 250 k x 1 M x 300 149.2 -> 151.4 ms)
+constexpr int KZ_K_H_WPS = 0;   // fp16 kernel: workgroups per CU (0 = automatic)
+constexpr double KZ_K_PROBE_MIN_MS = 12.0;   // ... unless the sweep is at least this many model-ms (2 n_q n_i d / 1e12) long
+constexpr int KZ_K_EXACT_DIRECT_ROWS = 32;   // at most this many rows left by the split-bf16 tier skip the float32-operand kernel and go to the exact kernels
+constexpr double KZ_K_SPEC_ELEMS = 1.6e9;   // ... and at most this / (index rows x d) of them
+constexpr int KZ_K_FLOOR_PROBE = 1024;   // ... rows of the probe in kz_knn_dual
+constexpr int KZ_K_DUAL_DEAL = 1;   // query rows dealt into load-balanced tiles
+constexpr int KZ_K_ESC_SHORT = 1;   // rows a K' = 16 pass cannot certify: more lists of 16 instead of lists of 64
+
 struct kz_ctx {
     int device;
     hipStream_t stream;
@@ -22,25 +41,16 @@ struct kz_ctx {
     int stream2_busy;    // kz_knn_dual: the reverse chain is (or is about to be) on stream2 -- nobody else may queue behind it
     hipStream_t stream2; // second stream: kz_knn_dual runs the reverse direction's event chain beside the forward direction's finalize
     double eps_scale;
-    int qgroup;            // query tiles per group of the work table (0 = automatic: 24, an XCD's worth of workgroups for the fp16 kernel)
     int force_splits;
-    int h_wps;        // tuning knob: 2 = run the fp16 kernel's two-workgroups-per-CU build also where three would fit
-    int long_k;       // 1 (default): 111 .. ~540 neighbours per query on the fused kernels (kz_knn_impl "long-k route"); 0: exact kernels
-    int h_wide;       // 1: the fp16 kernel's WIDE builds (one workgroup per CU, its query tiles share one ring; kz_knn_h16.h); 0 (default): narrow
     int chunk_rows;   // test knob: query rows per chunk (0 = default 524288)
-    int min_splits;   // tuning knob: minimum index splits per query tile in the large-item region
     int precision;    // 0: fp16 first pass where eligible (default), 2: split-bf16 first pass, 1: float32 operands only
     int dual_stride;  // kz_knn_dual: every dual_stride-th tile of the query side is in the threshold sample (0: no dual pass, 1: automatic)
-    int dual_deal;    // tuning knob: 1 (default) = the dual pass deals the query rows into load-balanced tiles, 0 = natural order
     int esc_bf;            // 1 (default): rows the fp16 tier cannot certify with its longest lists go to the split-bf16 operands before the float32 ones
-    int esc_short;         // 1 (default): uncertified rows of a K' = 16 pass are searched again with lists of 16 over >= 4 index ranges; 0: with lists of 64
     int short_ord_min_tiles;   // ... when an index range has at least this many tiles (default 48)
     int short_ord;         // 1 (default): the ordinary fp16 kernel takes the short-list route too (a dealt second image of the index)
     int dual_short_main;   // 1 (default): the main sweep of kz_knn_dual keeps k / dual_short_div lists of 16 per query instead of one of 32 / 64; 0: one list of K'
-    int dual_short_div;    // (default 5)
     int dual_rev_long;     // 1 (default): the reverse direction of kz_knn_dual keeps lists of 2 K'
     int dual_short_extra;  // ... of whose entries the finalize kernel selects k + this many (default 48)
-    int dual_short_kp;     // list length of that route: 16 (default) or 32
     int dual_short_min_tiles;   // ... taken when an index range has at least this many tiles (default 128; test knob)
     int dual_sample_short; // 1 (default): the sample sweep of kz_knn_dual uses lists of 16 (32) over several index ranges whatever K' is; 0: lists of K'
     int dual_overlap; // 1 (default): kz_knn_dual runs the reverse direction's chain on the second stream beside the forward finalize; 0: behind it
@@ -49,26 +59,17 @@ struct kz_ctx {
     int h_q64;        // 64-queries-per-wave kernel (kz_knn_h64.h) for K' = 16 sweeps of 4 .. 13 slices: 2 (default) = where it pays (kz_knn_impl), 1 = always, 0 = never
     int fin_fast_div; // finalize kernel, cosine: shared-reciprocal division (kz_div_shared)
     double probe_min_pairs;  // ordinary searches below this many distance pairs take neither the tier probe nor a floor (5e10)
-    double probe_min_ms;     // ... unless the sweep is this long (2 n_q n_i d / 1e12 model-ms; 12): a probe is ~0.45 ms
     int list_floor;   // kz_knn_dual: 1 = the forward lists of the shared sweep start at a population floor (kz_knn_dual.h "POPULATION FLOOR")
-    int floor_probe;  // ... rows of the probe behind it
-    double floor_margin;  // ... the largest shortfall of the probe below the model, times this
-    int dual_rank;    // kz_knn_dual: rank of the sample key that becomes a row's event threshold (0 = automatic, -1 = k + 1, > 0 = that rank; kz_knn_dual.h)
     int tier_probe;   // rows of the strided sample a large ordinary search sends through the fp16 pass first (0 = off; default 1024): more than half uncertified -> the call starts at split-bf16
     int dual_nested;  // kz_knn_dual: 1 (default) = the sample is the first tiles of the dealt image and is swept ONLY by the sample sweep (kz_knn_dual.h "NESTED")
-    int fin_wide;     // 1 (default): finalize launches with more than 160 selected candidates run kz_knn_fin_wide.h (no O(n^2) sorts, several rows per gather step)
-    double nested_min_ms;   // kz_knn_dual: the nested sample is taken from this saving on (model-ms of sweep / stride; 2)
     int esc_ladder;   // 1 (default): kz_knn.hip "LADDER AFTER THE FACT"
     int exact_rows;   // 1 (default): the exact distance kernel that keeps four query rows in registers and takes 64 / LPR index rows per step
-    int exact_direct_rows;   // a split-bf16 pass that leaves at most this many rows (default 32) hands them to the exact kernels directly (kz_knn_impl)
-    int abl_stamp;    // diagnostic: kz_knn.hip "abl_stamp"
-    int abl_refloor;  // diagnostic: kz_knn.hip "abl_refloor"
+    int abl;          // diagnostics (bit mask): 1 = kz_knn.hip "abl_refloor", 2 = "abl_stamp"
+    double floor_margin;  // seeded lists: the largest shortfall of the probe below the model, times this (default 1.3; 0 = the model itself: a test knob)
+    int dual_rank;    // kz_knn_dual: rank of the sample key that becomes a row's event threshold (0 = automatic, -1 = k + 1, > 0 = that rank; kz_knn_dual.h)
     int spec_rows;    // exact kernels launched speculatively behind every finalize kernel for up to this many uncertified rows (default 64; kz_knn.hip "SPECULATIVE RESCUE")
-    double spec_elems; // ... at most spec_elems / (n d) of them (default 1.6e9: 8 rows of a 1 M x 200 index)
-    int range_boot;   // 1 (default): short-list routes of the ordinary kernel sweep index range 0 first and start the other ranges' lists at the floor read off it (kz_knn.hip "RANGE-0 BOOTSTRAP")
     int wide_lists;   // fp16 tier's WIDE route (kz_knn_impl): lists of 16 per query when the tier probe finds the keys dense around the k-th neighbour (default 32; 0 = off)
     int wide_sel;     // ... entries of those lists the finalize kernel selects (default 256)
-    int lds_pad;      // diagnostic knob: extra dynamic LDS bytes per workgroup of the bf16 kernel (lowers occupancy)
     // scratch (grown on demand, reused across calls)
     void* scratch;
     size_t scratch_bytes;

@@ -1743,7 +1743,7 @@ static int kz_launch_finalize(kz_ctx* ctx, KnnFinParams& fp, const KzListLayout&
             // (many selected candidates + float32 rows on the fp16 tier, ordinary direction: kz_knn_fin_wide.h -- option "fin_wide")
             // ("fin_wide" = 2: every launch that selects from several lists, KSEL > 0 -- the short-list routes -- takes it too)
             const bool rows_vec = fp.d <= 256 && (fp.d & 3) == 0 && (((uintptr_t)fp.qraw | (uintptr_t)fp.yraw) & 15u) == 0;
-            const bool wide2 = (wide || (ctx->fin_wide >= 2 && fp.KSEL > 0)) && dtype == KZ_F32 && fp.tier_h && !fp.excl_floor && ctx->fin_wide && rows_vec;
+            const bool wide2 = (wide || (KZ_K_FIN_WIDE >= 2 && fp.KSEL > 0)) && dtype == KZ_F32 && fp.tier_h && !fp.excl_floor && KZ_K_FIN_WIDE && rows_vec;
             // (float32 rows of 260 .. 512 elements, 16-byte aligned: the build whose pipelined re-rank takes two loads per lane and row)
             const bool two_chunks = !wide && !wide2 && dtype == KZ_F32 && fp.d > 256 && fp.d <= 512 && (fp.d & 3) == 0 &&
                                     (((uintptr_t)fp.qraw | (uintptr_t)fp.yraw) & 15u) == 0;
@@ -1793,7 +1793,7 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
                            KzPass* out, int tpw = 1, int force_pieces = 0, int min_pieces = 0, bool boot_first = false) {
     KzPlan pl;
     kz_plan_pass(n_qtiles, n_ytiles, slots, max_pieces, (tier == KZ_TIER_H ? 1 : 2) * KP, tier == KZ_TIER_F32 ? 2 : 1,
-                 tier == KZ_TIER_H ? 1 : 0, tpw, force_pieces > 0 ? force_pieces : ctx->force_splits, min_pieces > ctx->min_splits ? min_pieces : ctx->min_splits, &pl);
+                 tier == KZ_TIER_H ? 1 : 0, tpw, force_pieces > 0 ? force_pieces : ctx->force_splits, min_pieces > KZ_K_MIN_SPLITS ? min_pieces : KZ_K_MIN_SPLITS, &pl);
     const KzListLayout& lay = pl.lay;
     const int W = pl.W;
     const size_t list_elems = pl.list_elems;
@@ -1833,7 +1833,7 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
         // (fp16 kernel: query groups of four times what an XCD holds, see kz_plan_fill_work; "qgroup" overrides.  500k x 500k,
         //  ten ranges per query tile, main kernel: 24: 109.3 ms, 96: 107.6, 384: 102.5, 768 .. 4096: 101.9 .. 103.2)
         const int per_xcd = (slots + 7) / 8;
-        const int qgroup = ctx->qgroup > 0 ? ctx->qgroup : (tier == KZ_TIER_H && 4 * per_xcd > KZ_QGROUP ? 4 * per_xcd : KZ_QGROUP);
+        const int qgroup = KZ_K_QGROUP > 0 ? KZ_K_QGROUP : (tier == KZ_TIER_H && 4 * per_xcd > KZ_QGROUP ? 4 * per_xcd : KZ_QGROUP);
         kz_plan_fill_work(pl, n_ytiles, tpw, (KzWorkItem*)hw, qgroup);
         out->W0 = 0;
         if (boot_first) {
@@ -2017,7 +2017,7 @@ static void kz_spec_release(kz_ctx* ctx, KzSpec& sp) {
 static int kz_spec_rows(const kz_ctx* ctx, const kz_matrix* index, int k_eff) {
     if (ctx->spec_rows <= 0 || index->metric >= KZ_MANHATTAN || k_eff > 64) return 0;
     const double nd = (double)index->n * (double)index->d;
-    int R = (int)(ctx->spec_elems / (nd > 1.0 ? nd : 1.0)) & ~3;
+    int R = (int)(KZ_K_SPEC_ELEMS / (nd > 1.0 ? nd : 1.0)) & ~3;
     if (R > ctx->spec_rows) R = ctx->spec_rows & ~3;
     return R < 4 ? 0 : R;
 }
@@ -2238,7 +2238,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     const bool no_gemm_form = index->metric >= KZ_MANHATTAN;
     int KP = no_gemm_form ? 0 : kz_pick_list_len(k_eff);
     int KSEL = 0, long_pieces = 0;
-    if (KP == 0 && !dual && ctx->long_k && !no_gemm_form) {
+    if (KP == 0 && !dual && KZ_K_LONG_K && !no_gemm_form) {
         const int S = k_eff / 24 + 1 > 4 ? k_eff / 24 + 1 : 4;
         const int sel = k_eff + (k_eff / 8 > 16 ? k_eff / 8 : 16);
         // (finalize: 4 waves x (S 128 entries x 8 B + KSEL x 28 B) of LDS per workgroup)
@@ -2320,7 +2320,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     //  kernel: k = 128 32.4 -> 12.5 ms, k = 160 35.4 -> 13.3; beyond 32 lists the finalize kernel selects by repeated arg-max)
     const bool longk_lists = KSEL > 0 && long_pieces > 0 && KP == 128 && kp_min <= 0 && k_eff <= 320;
     if (!dual && !no_short && tier == KZ_TIER_H && ctx->short_ord && KP > 16 && (KSEL == 0 || longk_lists) && !exact_only) {
-        int P = (k_eff + ctx->dual_short_div - 1) / ctx->dual_short_div;
+        int P = (k_eff + KZ_K_DUAL_SHORT_DIV - 1) / KZ_K_DUAL_SHORT_DIV;
         if (P < KP / 16) P = KP / 16;
         if (kp_min >= 128) P = 16;   // (a re-search that asks for lists of 128: all the ranges the finalize kernel's fast selection takes)
         const int sel = k_eff + (KP >= 128 ? 80 : 48) < P * 16 ? k_eff + (KP >= 128 ? 80 : 48) : P * 16;
@@ -2382,7 +2382,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     if (tier == KZ_TIER_H && !dual && precision_override < 0 && kp_min == 0 && forced_lists == 0 && !exact_only && ctx->tier_probe > 0 && ctx->esc_bf &&
         q_count >= (int64_t)16 * ctx->tier_probe && ctx->chunk_rows == 0 &&
         ((double)q_count * (double)index->n >= ctx->probe_min_pairs ||
-         2.0 * (double)q_count * (double)index->n * (double)(index->kg * 4) / 1e12 >= ctx->probe_min_ms)) {
+         2.0 * (double)q_count * (double)index->n * (double)(index->kg * 4) / 1e12 >= KZ_K_PROBE_MIN_MS)) {
         const int n_probe = ctx->tier_probe;
         int* plist = nullptr;
         int rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);
@@ -2469,14 +2469,14 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             int blocks_per_cu = 1;
             int rc0;
             if (t == KZ_TIER_H && q64) {
-                rc0 = kz_h64_occupancy(n_slices, dual ? 1 : 0, &blocks_per_cu, ctx->lds_pad);
+                rc0 = kz_h64_occupancy(n_slices, dual ? 1 : 0, &blocks_per_cu, KZ_K_LDS_PAD);
                 tpw_h = 2;
             } else if (t == KZ_TIER_H && dual)
-                KZ_DISPATCH_KP(rc0, kz_hd_occupancy, (n_slices, &blocks_per_cu, &tpw_h, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
+                KZ_DISPATCH_KP(rc0, kz_hd_occupancy, (n_slices, &blocks_per_cu, &tpw_h, KZ_K_H_WPS, KZ_K_H_WIDE, KZ_K_LDS_PAD));
             else if (t == KZ_TIER_H)
-                KZ_DISPATCH_KP(rc0, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw_h, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
+                KZ_DISPATCH_KP(rc0, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw_h, KZ_K_H_WPS, KZ_K_H_WIDE, KZ_K_LDS_PAD));
             else if (t == KZ_TIER_BF)
-                KZ_DISPATCH_KP(rc0, kz_bf_occupancy, (n_slices, &blocks_per_cu, ctx->lds_pad));
+                KZ_DISPATCH_KP(rc0, kz_bf_occupancy, (n_slices, &blocks_per_cu, KZ_K_LDS_PAD));
             else
                 KZ_DISPATCH_CAND(rc0, kz_cand_occupancy, (&blocks_per_cu));
             if (rc0 != KZ_OK) return rc0;
@@ -2553,13 +2553,13 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             KzPlan pl;
             kz_plan_pass(n_qtiles, n_ytiles, slots, max_pieces, (tier == KZ_TIER_H ? 1 : 2) * KP, tier == KZ_TIER_F32 ? 2 : 1, tier == KZ_TIER_H ? 1 : 0,
                          tier == KZ_TIER_H ? tpw_h : 1, force_pieces > 0 ? force_pieces : ctx->force_splits,
-                         min_pieces_call > ctx->min_splits ? min_pieces_call : ctx->min_splits, &pl);
+                         min_pieces_call > KZ_K_MIN_SPLITS ? min_pieces_call : KZ_K_MIN_SPLITS, &pl);
             if (pl.list_elems < ((size_t)1 << 32) || cq_count <= 8 * KZ_TILE || (dual && dual->raw_lists)) break;
             max_rows_per_chunk = ((cq_count / 2 + KZ_TILE - 1) / KZ_TILE) * KZ_TILE;
         }
         KzPass ps;
         // (range-0 bootstrap: the short-list routes of the ordinary 32-query kernel, from four ranges on)
-        const bool boot = tier == KZ_TIER_H && short_ord && !dual && !q64 && ctx->range_boot && force_pieces >= 4;
+        const bool boot = tier == KZ_TIER_H && short_ord && !dual && !q64 && KZ_K_RANGE_BOOT && force_pieces >= 4;
         int rc = kz_prepare_pass(ctx, n_qtiles, n_ytiles, slots, max_pieces, KP, tier, cq_count, &ps,
                                  tier == KZ_TIER_H ? tpw_h : 1, force_pieces, min_pieces_call, boot);
         if (rc != KZ_OK) return rc;
@@ -2612,12 +2612,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             if (q64)
                 rc = kz_h64_launch(n_slices, 1, ctx, cp, W);
             else
-                KZ_DISPATCH_KP(rc, kz_hd_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
+                KZ_DISPATCH_KP(rc, kz_hd_launch, (n_slices, ctx, cp, W, KZ_K_H_WPS, KZ_K_H_WIDE));
         } else if (tier == KZ_TIER_H && q64)
             rc = kz_h64_launch(n_slices, 0, ctx, cp, W);
         else if (tier == KZ_TIER_H && boot && ps.W0 > 0 && ps.W0 < W) {
             // range 0 of every query tile, the floor off its lists, then the other ranges
-            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W0, ctx->h_wps, ctx->h_wide));
+            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W0, KZ_K_H_WPS, KZ_K_H_WIDE));
             if (rc != KZ_OK) return rc;
             float* bfloor = nullptr;
             const int64_t n_pad = (int64_t)query->n_tiles * KZ_TILE;
@@ -2628,21 +2628,21 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             KZ_HIP(hipGetLastError());
             cp.qfloor = bfloor;
             cp.work = d_work + ps.W0;
-            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W - ps.W0, ctx->h_wps, ctx->h_wide));
+            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W - ps.W0, KZ_K_H_WPS, KZ_K_H_WIDE));
             cp.work = d_work;
             boot_floor = bfloor;
         } else if (tier == KZ_TIER_H) {
-            if (ctx->abl_stamp && getenv("KZ_STAMP_FILE")) {   // (diagnostic: a -DKZ_ABL_STAMP build of the fp16 units fills it)
+            if ((ctx->abl & 2) && getenv("KZ_STAMP_FILE")) {   // (diagnostic: a -DKZ_ABL_STAMP build of the fp16 units fills it)
                 rc = kz_pool_alloc(ctx, (size_t)W * (16 + 1024), (void**)&stamp_buf);
                 if (rc != KZ_OK) return rc;
                 KZ_HIP(hipMemsetAsync(stamp_buf, 0, (size_t)W * (16 + 1024), ctx->stream));
                 cp.log_meta = stamp_buf;
                 cp.log_keys = stamp_buf + 2 * (size_t)W;
             }
-            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
+            KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, KZ_K_H_WPS, KZ_K_H_WIDE));
             cp.log_meta = nullptr;
             cp.log_keys = nullptr;
-            if (rc == KZ_OK && ctx->abl_refloor && !short_ord && ps.lay.n_regions == 1 && ps.lay.pieces[0] == 1) {
+            if (rc == KZ_OK && (ctx->abl & 1) && !short_ord && ps.lay.n_regions == 1 && ps.lay.pieces[0] == 1) {
                 // DIAGNOSTIC ("abl_refloor", profiles/r06_event_ablation.md): the same sweep AGAIN with every list starting at the
                 // threshold it ENDED on (the K'-th best key of the first sweep's list): K' insertions per query instead of
                 // K' (1 + ln(n / K')) -- the time any seeding of the lists could at best reach.  The second sweep is the one timed.
@@ -2657,7 +2657,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 KZ_HIP(hipGetLastError());
                 cp.qfloor = bfloor;
                 KZ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-                KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, ctx->h_wps, ctx->h_wide));
+                KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, W, KZ_K_H_WPS, KZ_K_H_WIDE));
                 boot_floor = bfloor;
             }
         } else if (tier == KZ_TIER_BF)
@@ -2723,7 +2723,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         fp.fail_count = fail_count;
         fp.fail_list = fail_list;
         fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
-        if (fp.tier_h && metric == KZ_COSINE && (fp.KSEL > 0 ? fp.KSEL : KP) > 160 && ctx->fin_wide && !(dual && dual->raw_lists)) {
+        if (fp.tier_h && metric == KZ_COSINE && (fp.KSEL > 0 ? fp.KSEL : KP) > 160 && KZ_K_FIN_WIDE && !(dual && dual->raw_lists)) {
             // (hundreds of re-ranked candidates per query: the normalised float64 rows of the index, built once -- kz_pack.hip)
             rc = kz_matrix_norm64(index);
             if (rc != KZ_OK) return rc;
@@ -2810,7 +2810,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         // A HANDFUL of rows left by the split-bf16 operands skips the float32-operand kernel: that kernel sweeps the whole index for
         // one query tile in at most eight pieces -- 2.2 ms on 300 k rows of d = 64 whatever the row count -- while the exact kernels
         // cost ~35 us a row there (both scale with n d): bench.py "hard", ~20 rows per direction and step: 60.6 -> see r05_notes.
-        const bool exact_direct = tier == KZ_TIER_BF && !dual && n_fail > 0 && n_fail <= ctx->exact_direct_rows;
+        const bool exact_direct = tier == KZ_TIER_BF && !dual && n_fail > 0 && n_fail <= KZ_K_EXACT_DIRECT_ROWS;
         // (the speculative launches behind the finalize kernel have answered them all)
         const bool rescued = spec.R > 0 && n_fail > 0 && n_fail <= spec.R;
         if (rescued) {
@@ -2847,7 +2847,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 //  300k x 300k x 96, clusters of very different spread: 9 968 rows to the exact kernels and 726 ms per call before, none and
                 //  169 ms now; lists of 128 for every call: bench.py "hard", k = 50, 118 -> 225 ms -- its lists of 64 were long enough)
                 next_kp = ((next_prec == 1 || wide_route) && KP_class < 64) ? 64 : 0;
-            } else if (KP == 16 && KSEL == 0 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS) {
+            } else if (KP == 16 && KSEL == 0 && KZ_K_ESC_SHORT && n_fail <= KZ_ESC_SHORT_MAX_ROWS) {
                 next_prec = 0;
                 next_kp = -1;   // a handful of rows of a K' = 16 pass: more lists of 16
             } else {

@@ -28,10 +28,10 @@ static int kz_bf_occupancy(int* blocks_per_cu, int lds_pad) {
 template <int KP, int NSR>
 static int kz_launch_bf(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
     if (NSR <= KZ_TWM)
-        hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, (NSR <= KZ_TWM ? NSR : KZ_TWM), 2>), dim3(n_blocks), dim3(256), KZ_BF_LDS + ctx->lds_pad,
+        hipLaunchKernelGGL((kz_knn_cand_bf_kernel<KP, (NSR <= KZ_TWM ? NSR : KZ_TWM), 2>), dim3(n_blocks), dim3(256), KZ_BF_LDS + KZ_K_LDS_PAD,
                            ctx->stream, p);
     else
-        hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<KP, (NSR > KZ_TWM ? NSR : KZ_TWM + 1)>), dim3(n_blocks), dim3(256), KZ_OV_LDS + ctx->lds_pad,
+        hipLaunchKernelGGL((kz_knn_cand_bf_ov_kernel<KP, (NSR > KZ_TWM ? NSR : KZ_TWM + 1)>), dim3(n_blocks), dim3(256), KZ_OV_LDS + KZ_K_LDS_PAD,
                            ctx->stream, p);
     KZ_HIP(hipGetLastError());
     return KZ_OK;

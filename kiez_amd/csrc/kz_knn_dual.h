@@ -645,7 +645,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         // Same box, rank 8, ms per step: ns stride 9 / 10 / 11 / 12 / 13 / 14 / 16 / 18 / 23 (the old choice) -> 98.5 / 98.4 / 98.0 /
         // 97.5 / 98.1 / 97.8 / 98.6 / 99.6 / 99.8; C4's share 10 / 12 / 14 / 16 / 28 -> 147.3 / 146.1 / 148.2 / 147.5 / 149.7; gmm
         // (200k x 200k x 300) 6 / 8 / 10 / 12 -> 34.0 / 34.7 / 34.9 / 35.7; C3 (rank 12) 8 / 10 / 13 / 16 -> 127.7 / 124.9 / 125.8 / 126.8.
-        if (ctx->dual_nested && ctx->dual_deal && !small_sweep && b->n <= kz_rows_per_chunk(ctx, KP, false) && t_ms / stride >= ctx->nested_min_ms) {
+        if (ctx->dual_nested && !small_sweep && b->n <= kz_rows_per_chunk(ctx, KP, false) && t_ms / stride >= KZ_K_NESTED_MIN_MS) {
             int half = (int)(0.5 * (s_opt > 32.0 ? 32.0 : s_opt) + 0.5);
             if (half < 4) half = 4;
             while (half < stride && kz_dual_p_fail(k, rank, (double)half) > 1e-3) ++half;
@@ -820,18 +820,18 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     bool tier_probed = false;   // the tier probe below has looked at the data
     // (the floor takes ~2 % off a sweep with one list of 16 per query, ~4.5 % with ten; its probe costs 0.4 - 1 ms: sweeps from
     //  T ~ 25 model-ms on -- C2's shared sweep, T = 2.6: 5.94 ms per step with the floor, 5.58 without)
-    bool want_floor = ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe &&
+    bool want_floor = ctx->list_floor && KZ_K_FLOOR_PROBE > 0 && a->n >= (int64_t)16 * KZ_K_FLOOR_PROBE &&
                       (ctx->dual_force || t_sweep_ms >= (KP > 16 ? 12.0 : 25.0));   // ("dual_force", the test knob, skips this gate too)
     // The same probe is this call's TIER PROBE (kz_knn_impl): a shared sweep of a size at which an ordinary search would first
     // look whether the data is hard for fp16 as a whole looks too -- more than half of the probe rows uncertified: two ordinary
     // searches instead, each of which starts at the split-bf16 tier (bench.py "hard", 300k x 301k clustered rows: 127 ms per step
     // that way, 201 ms through a shared fp16 sweep whose rows nearly all go down the tiers afterwards).
     const bool want_tier = !ctx->dual_force && ctx->tier_probe > 0 && ctx->esc_bf && a->n >= (int64_t)16 * ctx->tier_probe &&
-                           ((double)a->n * (double)b->n >= ctx->probe_min_pairs || t_sweep_ms >= ctx->probe_min_ms);
+                           ((double)a->n * (double)b->n >= ctx->probe_min_pairs || t_sweep_ms >= KZ_K_PROBE_MIN_MS);
     // (a tier probe that runs anyway gives the floor for nothing: sweeps of 12 .. 25 model-ms with lists of 16)
-    if (want_tier && ctx->list_floor && ctx->floor_probe > 0 && a->n >= (int64_t)16 * ctx->floor_probe) want_floor = true;
+    if (want_tier && ctx->list_floor && KZ_K_FLOOR_PROBE > 0 && a->n >= (int64_t)16 * KZ_K_FLOOR_PROBE) want_floor = true;
     if (want_floor || want_tier) {
-        const int n_probe = want_floor ? ctx->floor_probe : (ctx->tier_probe < 1024 ? ctx->tier_probe : 1024);
+        const int n_probe = want_floor ? KZ_K_FLOOR_PROBE : (ctx->tier_probe < 1024 ? ctx->tier_probe : 1024);
         const int64_t pstride = a->n / n_probe;
         int* plist = nullptr;
         rc = kz_pool_alloc(ctx, (size_t)n_probe * sizeof(int), (void**)&plist);
@@ -911,7 +911,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     hipLaunchKernelGGL(kz_dual_c2key_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, ctx->stream, ia->rowq, a->n, q_key);
     hipLaunchKernelGGL(kz_iota_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_iota, (int)a_pad);
     KZ_DUAL_HIP(hipGetLastError());
-    if (ctx->dual_deal) {
+    if (KZ_K_DUAL_DEAL) {
         KZ_DUAL_RC(kz_sort_pairs_f32_i32(ctx, q_key, q_key_s, q_iota, q_sorted, (int)a->n, 0));
         hipLaunchKernelGGL(kz_dual_deal_kernel, dim3((unsigned)((a_pad + 255) / 256)), dim3(256), 0, ctx->stream, q_sorted, a->n, a_pad, row_map);
     } else {   // tuning knob "dual_deal" = 0: the query rows in their natural order
@@ -937,8 +937,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     const int64_t s_img_rows = s_tiles * KZ_TILE;   // rows of S: image rows [0, s_img_rows) of the dealt image
     // (it saves t_sweep / stride and costs ~1 ms of extra launches, sorts and a host synchronisation: C2's shared sweep, 2.6 model-ms at
     //  stride 4, went from 5.7 to 6.7 ms per step with it -- taken from 2 model-ms of saving on; "dual_force" keeps it for the tests)
-    bool nested = ctx->dual_nested && ctx->dual_deal && s_tiles >= 8 && s_tiles < a->n / KZ_TILE && s_img_rows >= (int64_t)8 * KP &&
-                  b->n <= kz_rows_per_chunk(ctx, KP, false) && (ctx->dual_force || t_sweep_ms / stride >= ctx->nested_min_ms);
+    bool nested = ctx->dual_nested && s_tiles >= 8 && s_tiles < a->n / KZ_TILE && s_img_rows >= (int64_t)8 * KP &&
+                  b->n <= kz_rows_per_chunk(ctx, KP, false) && (ctx->dual_force || t_sweep_ms / stride >= KZ_K_NESTED_MIN_MS);
     if (nested) {
         const double t2_ms = 2.0 * (double)b->n * (double)s_img_rows * (double)(a->kg * 4) / 1e12;
         const int rank3_safe = k + 1 < KP ? k + 1 : KP;
@@ -1023,7 +1023,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         {
             const int KP = KPs3;   // (KZ_DISPATCH_KP switches on `KP`)
             int blocks_per_cu = 1, tpw = 1;
-            KZ_DISPATCH_KP(rc, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
+            KZ_DISPATCH_KP(rc, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw, KZ_K_H_WPS, KZ_K_H_WIDE, KZ_K_LDS_PAD));
             if (rc != KZ_OK) {
                 release();
                 return rc;
@@ -1044,7 +1044,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
                 cp.kg = b->kg;
                 cp.out_key = ps.out_key;
                 cp.out_idx = ps.out_idx;
-                KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W, ctx->h_wps, ctx->h_wide));
+                KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W, KZ_K_H_WPS, KZ_K_H_WIDE));
             }
             if (rc != KZ_OK) {
                 release();
@@ -1162,7 +1162,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         // ---- sample sweep: B x sample(A) with the ordinary kernel, lists of at most 256 entries per row -----------------------
         const int KP = KPs;   // (KZ_DISPATCH_KP switches on `KP`)
         int blocks_per_cu = 1, tpw = 1;
-        KZ_DISPATCH_KP(rc, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw, ctx->h_wps, ctx->h_wide, ctx->lds_pad));
+        KZ_DISPATCH_KP(rc, kz_h_occupancy, (n_slices, &blocks_per_cu, &tpw, KZ_K_H_WPS, KZ_K_H_WIDE, KZ_K_LDS_PAD));
         if (rc != KZ_OK) {
             release();
             return rc;
@@ -1182,7 +1182,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         cp.kg = b->kg;
         cp.out_key = ps.out_key;
         cp.out_idx = ps.out_idx;
-        KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W, ctx->h_wps, ctx->h_wide));
+        KZ_DISPATCH_KP(rc, kz_h_launch, (n_slices, ctx, cp, ps.W, KZ_K_H_WPS, KZ_K_H_WIDE));
         if (rc != KZ_OK) {
             release();
             return rc;
@@ -1205,9 +1205,9 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     int main_pieces = 0;
     if (ctx->dual_short_main && KP > 16) {
         // (a range of at least 64 tiles: the k nearest rows of a query must be spread over many more tiles than there are ranges)
-        const int per = ctx->dual_short_div * (ctx->dual_short_kp / 16);
+        const int per = KZ_K_DUAL_SHORT_DIV * (KZ_K_DUAL_SHORT_KP / 16);
         const int P = (k + per - 1) / per;
-        if (P >= 2 && P * ctx->dual_short_kp <= 512 && KP > ctx->dual_short_kp && b_tiles - 1 >= (int64_t)ctx->dual_short_min_tiles * P) main_pieces = P;
+        if (P >= 2 && P * KZ_K_DUAL_SHORT_KP <= 512 && KP > KZ_K_DUAL_SHORT_KP && b_tiles - 1 >= (int64_t)ctx->dual_short_min_tiles * P) main_pieces = P;
     }
     if (main_pieces > 0) {
         // (iota and theta -- the sort's inputs -- are free now: they take the dealt order)
@@ -1254,8 +1254,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     dp.log_cnt = d_cnt;
     dp.log_cap = log_cap;
     dp.short_pieces = main_pieces;
-    dp.short_ksel = k + ctx->dual_short_extra < main_pieces * ctx->dual_short_kp ? k + ctx->dual_short_extra : main_pieces * ctx->dual_short_kp;
-    dp.short_kp = ctx->dual_short_kp;
+    dp.short_ksel = k + ctx->dual_short_extra < main_pieces * KZ_K_DUAL_SHORT_KP ? k + ctx->dual_short_extra : main_pieces * KZ_K_DUAL_SHORT_KP;
+    dp.short_kp = KZ_K_DUAL_SHORT_KP;
     // ---- the reverse direction's chain: events -> lists -> ordinary finalize with B as the query side.  Enqueued on the
     // context's SECOND stream from inside kz_knn_impl, right behind the sweep (KzDualPass::post_sweep): it shares no buffer
     // with what the first stream does meanwhile (finalize of A's lists, fail-counter read-back, re-search of uncertified rows)
@@ -1310,7 +1310,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             list3 = rm3;   // (the matrix rows of S)
         }
         if (n_fail3 > 0) {
-            const int kp_min3 = ((int64_t)n_fail3 * 8 > s_img_rows || KPr >= 128) ? 0 : (KPr == 16 && ctx->esc_short && n_fail3 <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
+            const int kp_min3 = ((int64_t)n_fail3 * 8 > s_img_rows || KPr >= 128) ? 0 : (KPr == 16 && KZ_K_ESC_SHORT && n_fail3 <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
             kz_knn_stats st3;
             float ms3 = 0;
             const int prec3 = ((int64_t)n_fail3 * 2 > s_img_rows && ctx->esc_bf) ? 2 : -1;
@@ -1352,7 +1352,7 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         } else if (n_fail > 0) {
             // rows of B with an overflowing buffer or an uncertified list: the ordinary search, longer lists when they are few
             // (K' = 16: more lists instead of longer ones, kz_knn_impl kp_min = -1)
-            const int kp_min = ((int64_t)n_fail * 8 > b->n || KPr >= 128) ? 0 : (KPr == 16 && ctx->esc_short && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
+            const int kp_min = ((int64_t)n_fail * 8 > b->n || KPr >= 128) ? 0 : (KPr == 16 && KZ_K_ESC_SHORT && n_fail <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
             kz_knn_stats st2;
             // (more than half of B's rows: fp16 is the wrong tier for this data -- the split-bf16 operands at once)
             const int prec = ((int64_t)n_fail * 2 > b->n && ctx->esc_bf) ? 2 : -1;

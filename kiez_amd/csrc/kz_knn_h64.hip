@@ -19,7 +19,7 @@ static int kz_h64_run(kz_ctx* ctx, const KnnCandParams& p, int n_blocks) {
     KnnCandParams pc = p;
     void* args[] = {&pc};
     KZ_HIP(hipLaunchKernel((const void*)kz_knn_cand_h64_kernel<NSR, DUAL>, dim3(n_blocks), dim3(256), args,
-                           (size_t)(KzH64Cfg<NSR, DUAL>::LDS_BYTES + ctx->lds_pad), ctx->stream));
+                           (size_t)(KzH64Cfg<NSR, DUAL>::LDS_BYTES + KZ_K_LDS_PAD), ctx->stream));
     return KZ_OK;
 }
 

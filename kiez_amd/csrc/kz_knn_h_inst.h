@@ -33,7 +33,7 @@ constexpr int KZ_H_WPS3_MAX_KP16 = 13;  // d <= 208: K' = 16 only
 template <int KP, int NSR>
 static const void* kz_h_kernel(int wps, int wide_opt, int* lds, int* tpw) {
     constexpr bool three = NSR <= KZ_H_WPS3_MAX || (KP == 16 && NSR <= KZ_H_WPS3_MAX_KP16);
-    constexpr bool WIDE_OK = KP == 16 && NSR > 8;
+    constexpr bool WIDE_OK = false;   // (round 6: the wide builds are no longer instantiated -- KZ_K_H_WIDE; was KP == 16 && NSR > 8)
     const int wide = WIDE_OK ? wide_opt : 0;
     if (three && wps != 2) {
         constexpr int N3 = three ? NSR : 2;
@@ -78,7 +78,7 @@ static int kz_launch_h(kz_ctx* ctx, const KnnCandParams& p, int n_blocks, int wp
     const void* kern = kz_h_kernel<KP, NSR>(wps, wide, &lds, &tpw);
     KnnCandParams pc = p;
     void* args[] = {&pc};
-    KZ_HIP(hipLaunchKernel(kern, dim3(n_blocks), dim3(256 * tpw), args, (size_t)(lds + ctx->lds_pad), ctx->stream));
+    KZ_HIP(hipLaunchKernel(kern, dim3(n_blocks), dim3(256 * tpw), args, (size_t)(lds + KZ_K_LDS_PAD), ctx->stream));
     return KZ_OK;
 }
 

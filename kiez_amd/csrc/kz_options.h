@@ -37,49 +37,31 @@ static const KzOption KZ_OPTIONS[] = {
      "multiplies the certification bound (test knob: a huge value sends every row to the exact float64 kernels)"},
     // ---- internal: scheduling / occupancy ---------------------------------------------------------------------------------------
     {"force_splits", KZ_OPT_INT, KZ_O(force_splits), 0, 64, 0, 0, {}, 0, "fixed index split count (0 = automatic)"},
-    {"min_splits", KZ_OPT_INT, KZ_O(min_splits), 1, 32, 1, 0, {}, 0, "minimum index splits per query tile in the large-item region"},
     {"chunk_rows", KZ_OPT_INT, KZ_O(chunk_rows), 0, 1e9, 0, 0, {}, 0, "query rows per chunk (0 = by list length)"},
-    {"qgroup", KZ_OPT_INT, KZ_O(qgroup), 0, 4096, 0, 0, {}, 0, "query tiles per group of the work table (0 = automatic)"},
-    {"h_wps", KZ_OPT_INT, KZ_O(h_wps), 0, 3, 0, KZ_OPT_SET, {0, 2, 3}, 3, "fp16 kernel: workgroups per CU (0 = automatic)"},
-    {"h_wide", KZ_OPT_INT, KZ_O(h_wide), 0, 1, 0, 0, {}, 0, "fp16 kernel: wide workgroups on one ring"},
     {"h_q64", KZ_OPT_INT, KZ_O(h_q64), 0, 2, 2, 0, {}, 0, "64-queries-per-wave build: 2 where it pays, 1 wherever built, 0 never"},
-    {"lds_pad", KZ_OPT_INT, KZ_O(lds_pad), 0, 90000, 0, 0, {}, 0, "extra dynamic LDS per workgroup (lowers occupancy; diagnostic)"},
     // ---- internal: list routes ---------------------------------------------------------------------------------------------------
-    {"long_k", KZ_OPT_BOOL, KZ_O(long_k), 0, 1, 1, 0, {}, 0, "111 .. ~540 neighbours on the fused kernels (0: exact kernels)"},
     {"short_ord", KZ_OPT_BOOL, KZ_O(short_ord), 0, 1, 1, 0, {}, 0, "ordinary search: k / 5 lists of 16 on a row-dealt image (13 .. 320 neighbours)"},
     {"short_ord_min_tiles", KZ_OPT_INT, KZ_O(short_ord_min_tiles), 1, 1e9, 48, 0, {}, 0, "... when an index range has at least this many tiles"},
-    {"esc_short", KZ_OPT_BOOL, KZ_O(esc_short), 0, 1, 1, 0, {}, 0, "rows a K' = 16 pass cannot certify: more lists of 16 instead of lists of 64"},
     {"esc_bf", KZ_OPT_BOOL, KZ_O(esc_bf), 0, 1, 1, 0, {}, 0, "split-bf16 operands before the float32 ones for rows the fp16 tier cannot certify"},
     {"tier_probe", KZ_OPT_INT, KZ_O(tier_probe), 0, 65536, 1024, 0, {}, 0, "rows of the strided sample a large search sends through the fp16 pass first (0 = off)"},
     {"probe_min_pairs", KZ_OPT_F64, KZ_O(probe_min_pairs), 0, 1e300, 5e10, 0, {}, 0, "searches of fewer distance pairs take neither the tier probe nor a floor"},
-    {"probe_min_ms", KZ_OPT_F64, KZ_O(probe_min_ms), 0, 1e300, 12.0, 0, {}, 0, "... unless the sweep is at least this many model-ms (2 n_q n_i d / 1e12) long"},
-    {"fin_wide", KZ_OPT_INT, KZ_O(fin_wide), 0, 2, 1, 0, {}, 0, "finalize of > 160 selected candidates without O(n^2) sorts, several rows per gather step"},
-    {"range_boot", KZ_OPT_BOOL, KZ_O(range_boot), 0, 1, 1, 0, {}, 0, "short-list routes: index range 0 first, the other ranges' lists start at the floor read off it"},
-    {"nested_min_ms", KZ_OPT_F64, KZ_O(nested_min_ms), 0, 1e300, 2.0, 0, {}, 0, "the nested sample of the shared sweep is taken when it saves at least this many model-ms (sweep / stride)"},
     {"esc_ladder", KZ_OPT_BOOL, KZ_O(esc_ladder), 0, 1, 1, 0, {}, 0, "a pass without a probe that leaves more than half of its rows uncertified tries the wide route on a sample of them before the split-bf16 tier"},
     {"exact_rows", KZ_OPT_BOOL, KZ_O(exact_rows), 0, 1, 1, 0, {}, 0, "exact float64 kernels: many pairs per wave step for float32 rows of d <= 256 (kz_exact_dist_rows_kernel)"},
-    {"exact_direct_rows", KZ_OPT_INT, KZ_O(exact_direct_rows), 0, 4096, 32, 0, {}, 0, "at most this many rows left by the split-bf16 tier skip the float32-operand kernel and go to the exact kernels"},
-    {"abl_refloor", KZ_OPT_BOOL, KZ_O(abl_refloor), 0, 1, 0, 0, {}, 0, "diagnostic: an ordinary one-range fp16 sweep runs twice, the second (timed) one from the first one's final thresholds"},
-    {"abl_stamp", KZ_OPT_BOOL, KZ_O(abl_stamp), 0, 1, 0, 0, {}, 0, "diagnostic: with a -DKZ_ABL_STAMP build and KZ_STAMP_FILE set, start / end of every workgroup of an ordinary fp16 sweep"},
+    {"abl", KZ_OPT_INT, KZ_O(abl), 0, 3, 0, 0, {}, 0, "diagnostics, bit mask: 1 = an ordinary one-range fp16 sweep runs twice, the second (timed) one from the first one's final thresholds; 2 = with a -DKZ_ABL_STAMP build and KZ_STAMP_FILE set, clock stamps of every workgroup of an ordinary fp16 sweep"},
     {"spec_rows", KZ_OPT_INT, KZ_O(spec_rows), 0, 64, 64, 0, {}, 0, "exact kernels launched speculatively behind every finalize for at most this many uncertified rows (0 = off)"},
-    {"spec_elems", KZ_OPT_F64, KZ_O(spec_elems), 0, 1e300, 1.6e9, 0, {}, 0, "... and at most this / (index rows x d) of them"},
     {"wide_lists", KZ_OPT_INT, KZ_O(wide_lists), 2, 32, 32, KZ_OPT_SET, {0}, -1, "fp16 tier's wide route: lists of 16 per query (0 = off)"},
     {"wide_sel", KZ_OPT_INT, KZ_O(wide_sel), 16, 512, 256, 0, {}, 0, "... entries of those lists the finalize kernel selects"},
+    {"floor_margin", KZ_OPT_F64, KZ_O(floor_margin), 0, 1e6, 1.3, 0, {}, 0, "seeded lists: the largest shortfall of the probe below the model, times this (0: the model itself -- half of the rows are searched again; test knob)"},
+    {"dual_rank", KZ_OPT_INT, KZ_O(dual_rank), -1, 128, 0, 0, {}, 0, "rank of the sample key that becomes a row's event threshold (0 automatic, -1 = k + 1; 1: many rows short of events, test knob)"},
     {"list_floor", KZ_OPT_INT, KZ_O(list_floor), 0, 1, 1, 0, {}, 0, "seeded candidate lists (population floor from a probe)"},
-    {"floor_probe", KZ_OPT_INT, KZ_O(floor_probe), 0, 65536, 1024, 0, {}, 0, "... rows of the probe in kz_knn_dual"},
-    {"floor_margin", KZ_OPT_F64, KZ_O(floor_margin), 0, 1e6, 1.3, 0, {}, 0, "... the largest shortfall of the probe below the model, times this"},
     {"fin_fast_div", KZ_OPT_INT, KZ_O(fin_fast_div), 0, 1, 1, 0, {}, 0, "cosine re-rank through one reciprocal per candidate row (bit-identical)"},
     // ---- internal: shared sweep ----------------------------------------------------------------------------------------------------
     {"dual_force", KZ_OPT_BOOL, KZ_O(dual_force), 0, 1, 0, 0, {}, 0, "run the shared sweep also where its cost model says it does not pay (tests)"},
-    {"dual_deal", KZ_OPT_BOOL, KZ_O(dual_deal), 0, 1, 1, 0, {}, 0, "query rows dealt into load-balanced tiles"},
     {"dual_overlap", KZ_OPT_BOOL, KZ_O(dual_overlap), 0, 1, 1, 0, {}, 0, "reverse direction's chain on the second stream"},
     {"dual_nested", KZ_OPT_BOOL, KZ_O(dual_nested), 0, 1, 1, 0, {}, 0, "sampled rows are swept by the sample sweep only (itself a shared sweep)"},
-    {"dual_rank", KZ_OPT_INT, KZ_O(dual_rank), -1, 128, 0, 0, {}, 0, "rank of the sample key that becomes a row's event threshold (0 automatic, -1 = k + 1)"},
     {"dual_rev_long", KZ_OPT_BOOL, KZ_O(dual_rev_long), 0, 1, 1, 0, {}, 0, "reverse lists of twice the list length"},
     {"dual_sample_short", KZ_OPT_BOOL, KZ_O(dual_sample_short), 0, 1, 1, 0, {}, 0, "sample sweep keeps lists of 16 (32) over several ranges"},
     {"dual_short_main", KZ_OPT_BOOL, KZ_O(dual_short_main), 0, 1, 1, 0, {}, 0, "main sweep keeps k / dual_short_div lists of 16 (13 .. 110 neighbours)"},
-    {"dual_short_div", KZ_OPT_INT, KZ_O(dual_short_div), 1, 16, 5, 0, {}, 0, ""},
-    {"dual_short_kp", KZ_OPT_INT, KZ_O(dual_short_kp), 16, 32, 16, KZ_OPT_SET, {16, 32}, 2, ""},
     {"dual_short_extra", KZ_OPT_INT, KZ_O(dual_short_extra), 1, 200, 48, 0, {}, 0, "entries selected beyond k on that route"},
     {"dual_short_min_tiles", KZ_OPT_INT, KZ_O(dual_short_min_tiles), 1, 1e9, 128, 0, {}, 0, "... taken when an index range has at least this many tiles"},
 };

@@ -20,8 +20,8 @@ def ctx():
     c.set_option("dual_force", 1)   # the test shapes are far below the size at which the shared sweep pays
     yield c
     for name, value in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("eps_scale", 1.0), ("precision", 0), ("dual_max_gb", 0),
-                        ("dual_overlap", 1), ("dual_sample_short", 1), ("dual_short_main", 1), ("dual_short_min_tiles", 128), ("esc_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1),
-                        ("qgroup", 0)):
+                        ("dual_overlap", 1), ("dual_sample_short", 1), ("dual_short_main", 1), ("dual_short_min_tiles", 128), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1),
+                        ("dual_rank", 0)):
         c.set_option(name, value)
 
 

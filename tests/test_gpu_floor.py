@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-_RESET = (("list_floor", 1), ("floor_probe", 1024), ("floor_margin", 1.3), ("dual_force", 0), ("tier_probe", 1024), ("h_q64", 2))
+_RESET = (("list_floor", 1), ("floor_margin", 1.3), ("dual_force", 0), ("tier_probe", 1024), ("h_q64", 2))
 
 
 @pytest.fixture()
@@ -45,7 +45,6 @@ def test_shared_sweep_results_do_not_depend_on_the_floor(ctx, kind, metric, k, d
     a, b = _data(kind, 20_000, d, 1), _data(kind, 33_000, d, 2)
     ctx.set_option("dual_force", 1)
     ctx.set_option("h_q64", q64)
-    ctx.set_option("floor_probe", 512)
     outs, stats = [], []
     for floor, margin in ((0, 1.3), (1, 1.3), (1, 0.0), (1, 50.0)):
         ctx.set_option("list_floor", floor)

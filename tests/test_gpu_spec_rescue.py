@@ -16,7 +16,7 @@ def ctx():
     from kiez_amd import _native as N
     c = N.Context.get()
     yield c
-    for name, value in (("spec_rows", 64), ("spec_elems", 1.6e9), ("eps_scale", 1.0), ("dual_force", 0)):
+    for name, value in (("spec_rows", 64), ("eps_scale", 1.0), ("dual_force", 0)):
         c.set_option(name, value)
 
 

@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 OPTS = (("tier_probe", 1024), ("probe_min_pairs", 5e10), ("wide_lists", 32), ("wide_sel", 256), ("dual_force", 0), ("eps_scale", 1.0), ("esc_ladder", 1),
-        ("probe_min_ms", 12.0))
+        ("probe_min_pairs", 5e10))
 
 
 @pytest.fixture()

@@ -27,8 +27,6 @@ def run(name):
     ctx = N.Context.get()
     ctx.set_option("dual_force", 1)
     import os
-    if os.environ.get("DUAL_DEAL"):
-        ctx.set_option("dual_deal", int(os.environ["DUAL_DEAL"]))
     if os.environ.get("DUAL_STRIDE"):
         ctx.set_option("dual_stride", int(os.environ["DUAL_STRIDE"]))
     am, bm = N.DeviceMatrix(ctx, a, metric), N.DeviceMatrix(ctx, b, metric)

@@ -53,7 +53,6 @@ for case in range(n_cases):
     print(f"case {case}: na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} stride/chunk/deal/wide/overlap/short-min/short-sample/rev-long/extra/bf {opt}", flush=True)
     ctx.set_option("dual_stride", opt[0])
     ctx.set_option("chunk_rows", opt[1])
-    ctx.set_option("dual_deal", opt[2])
     am, bm = N.DeviceMatrix(ctx, a, metric), N.DeviceMatrix(ctx, b, metric)
     ctx.set_option("dual_force", 0)
     ctx.set_option("list_floor", 0)
@@ -63,7 +62,6 @@ for case in range(n_cases):
     r2 = N.knn(ctx, bm, am, k); ctx.sync()
     if only >= 0: print("  b->a done", r2[2]["n_escalated_rows"], r2[2]["n_fallback_rows"], flush=True)
     ctx.set_option("dual_force", 1)
-    ctx.set_option("h_wide", opt[3])          # (the two reference searches above ran the narrow builds)
     ctx.set_option("dual_overlap", opt[4])
     ctx.set_option("dual_short_min_tiles", opt[5])
     ctx.set_option("short_ord_min_tiles", min(opt[5], 48))
@@ -73,13 +71,11 @@ for case in range(n_cases):
     ctx.set_option("esc_bf", opt[9])
     ctx.set_option("h_q64", 1 if q64 == 2 else 0)
     ctx.set_option("list_floor", fl[0])
-    ctx.set_option("floor_probe", fl[1])
     ctx.set_option("floor_margin", fl[2])
     ctx.set_option("dual_nested", nested)
     (xd, xi, sa), (yd, yi, sb) = N.knn_dual(ctx, am, bm, k)
     ctx.set_option("dual_nested", 1)
     ctx.set_option("list_floor", 0)
-    ctx.set_option("h_wide", 0)
     ctx.set_option("h_q64", 2)
     ok = (np.array_equal(r1[1].numpy(), xi.numpy()) and np.array_equal(r1[0].numpy(), xd.numpy())
           and np.array_equal(r2[1].numpy(), yi.numpy()) and np.array_equal(r2[0].numpy(), yd.numpy()))
@@ -108,8 +104,8 @@ for case in range(n_cases):
         bad += 1
     print(("ok " if ok else "BAD"), f"na={na} nb={nb} d={d} k={k} {metric} {dtype.__name__} {kind} dual {sa['dual']}/{sb['dual']} "
           f"q64 {q64} floor {fl} nested {nested} ev/row {sb['n_events'] / nb:.1f} esc {sa['n_escalated_rows']}/{sb['n_escalated_rows']} splits {sa['n_splits']} ovf {sb['n_overflow_rows']} ratio {ratio:.3f}", flush=True)
-for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_deal", 1), ("h_wide", 0), ("dual_overlap", 1),
-                ("dual_short_min_tiles", 128), ("short_ord_min_tiles", 48), ("dual_sample_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1), ("list_floor", 1), ("floor_probe", 1024), ("floor_margin", 1.3)):
+for name, v in (("dual_force", 0), ("dual_stride", 1), ("chunk_rows", 0), ("dual_overlap", 1),
+                ("dual_short_min_tiles", 128), ("short_ord_min_tiles", 48), ("dual_sample_short", 1), ("dual_rev_long", 1), ("dual_short_extra", 48), ("esc_bf", 1), ("list_floor", 1), ("floor_margin", 1.3)):
     ctx.set_option(name, v)
 print("cases", n_cases, "bad", bad)
 sys.exit(1 if bad else 0)

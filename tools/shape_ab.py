@@ -1,14 +1,14 @@
 """Diagnostic: main-kernel time of kz_knn for one shape with the library named by KIEZ_AMD_LIB (ablation builds give WRONG
-results -- timing only).  python tools/shape_ab.py n_q n_i d k [h_wps]"""
+results -- timing only).  python tools/shape_ab.py n_q n_i d k [option=value ...]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from kiez_amd import _native as N
 n_q, n_i, d, k = (int(x) for x in sys.argv[1:5])
 ctx = N.Context.get()
-for o in sys.argv[5:]:      # context options name=value (a bare number: h_wps)
+for o in sys.argv[5:]:      # context options name=value
     name, _, val = o.partition("=")
-    ctx.set_option(name if val else "h_wps", float(val or name))
+    ctx.set_option(name, float(val))
 rng = np.random.RandomState(0)
 q = rng.rand(n_q, d).astype(np.float32)
 y = rng.rand(n_i, d).astype(np.float32)

@@ -1,4 +1,4 @@
-"""Workgroup start / end times of the fp16 sweep (KZ_STAMP_FILE of a -DKZ_ABL_STAMP build, option abl_stamp): for the LAST launch in
+"""Workgroup start / end times of the fp16 sweep (KZ_STAMP_FILE of a -DKZ_ABL_STAMP build, option abl = 2): for the LAST launch in
 the file -- when the first and the last workgroup started, how long a workgroup runs, when the first and the last one ended; and a
 coarse timeline of how many workgroups are running.   python3 tools/stamp_show.py <file>"""
 import sys
