@@ -83,8 +83,8 @@ CHECK_KEYS = ("rows", "ranks", "fit_state_rows", "fit_state_max_rel_err", "fit_s
 CONFIG_DROP = ("inputs", "parallelism", "engine")
 
 
-def _r(x, digits=6):
-    """Floats of the compact line at 6 significant digits (the detail file keeps full precision)."""
+def _r(x, digits=9):
+    """Floats of the compact line at 9 significant digits (the detail file keeps full precision)."""
     if isinstance(x, float):
         return float(f"{x:.{digits}g}")
     if isinstance(x, dict):
@@ -128,6 +128,8 @@ def compact_line(line, detail_path):
             optional.append(k)
     c["detail"] = detail_path
     c = _r(c)
+    if c.get("roofline") and c["roofline"].get("achieved") is not None and c["roofline"].get("peak"):
+        c["roofline"]["frac"] = c["roofline"]["achieved"] / c["roofline"]["peak"]     # (exactly the quotient of the two numbers printed)
     text = json.dumps(c, separators=(",", ":"))
     while len(text) > LINE_LIMIT and optional:
         c.pop(optional.pop())
@@ -396,7 +398,7 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
     target = eng.to_engine(target_h) if target_h is not None else None
     eng.sync()
     sk = ShardedKiez(n_candidates=K, algorithm_kwargs={"metric": metric}, hubness=hub, hubness_kwargs=hub_kw,
-                     engine=eng, comm=comm)
+                     engine=eng, comm=comm, cache_target=target_upload == "cached")
     knn_log = []
     orig_knn = eng.knn
 
@@ -657,10 +659,12 @@ def parse_args(argv=None):
     ap.add_argument("--openea-hubness", default="CSLS")
     ap.add_argument("--openea-metric", default="euclidean")
     ap.add_argument("--openea-k", type=int, default=10)
-    ap.add_argument("--target-upload", default="broadcast", choices=("broadcast", "local"),
+    ap.add_argument("--target-upload", default="broadcast", choices=("broadcast", "local", "cached"),
                     help="N > 1: broadcast = the target lives on rank 0 and is RCCL-broadcast over xGMI inside every fit (default, "
                          "north_star's partitioning); local = every rank uploads the target itself before the timed region and fit "
-                         "runs no broadcast (ShardedKiez.fit(target_from_rank0=False)) -- the A/B of the 0.8-1.2 GB transfer per step")
+                         "runs no broadcast (ShardedKiez.fit(target_from_rank0=False)) -- the A/B of the 0.8-1.2 GB transfer per step; "
+                         "cached = broadcast by the first fit only (ShardedKiez(cache_target=True): the same target tensor in later fits "
+                         "reuses every rank's replica -- the serving pattern: one index, many query batches)")
     ap.add_argument("--launch-check", action="store_true",
                     help="NOT a measurement: run the launch / rendezvous / sharding / collective / reporting path of this script on "
                          "the CPU test engine (tests/cpu_engine.py) over gloo with a tiny shape; `value` is null.  For machines "
@@ -792,6 +796,7 @@ def main():
                        "target_upload": s["target_upload"],
                        "parallelism": f"source row-sharded x{world}, target replicated"
                                       + ((" (per step: " + ("1 RCCL broadcast of the target, " if s["target_upload"] == "broadcast" else
+                                                            "target broadcast by the first fit only, replica reused while the tensor is unchanged; " if s["target_upload"] == "cached" else
                                                             "target uploaded by every rank before the timed region, no broadcast; ")
                                           + "1 all-to-all of the per-shard reverse lists, 1 all-gather"
                                           " of the per-target fit state; measured times and bytes: collective_ms_per_step, collective_traffic_per_step)")

@@ -67,6 +67,15 @@ def test_every_rank_can_upload_the_target_itself(tmp_path):
     assert line["check"]["index_rows_identical"] == line["check"]["rows"] and line["recall_at_k"] == 1.0
 
 
+def test_target_broadcast_once_then_cached(tmp_path):
+    """`--target-upload cached`: the broadcast runs in the first fit only (1 warm-up + 2 timed steps: none inside the timed region)."""
+    r = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--launch-check", "--target-upload", "cached", "--detail", str(tmp_path / "d.json"))
+    assert r.returncode == 0, r.stderr[-4000:]
+    line, full = _lines(r, tmp_path / "d.json")
+    assert line["config"]["target_upload"] == "cached" and "broadcast" not in full["collective_traffic_per_step"]
+    assert line["check"]["index_rows_identical"] == line["check"]["rows"] and line["recall_at_k"] == 1.0
+
+
 def test_a_failing_rank_fails_the_launch():
     r = _run("--gpus", "2", "--launch-check", "--steps", "0")     # zero timed steps: every rank divides by zero
     assert r.returncode != 0
@@ -100,6 +109,8 @@ def test_the_stdout_line_stays_small_whatever_the_record_holds():
     assert line["config"]["workload"] == full["config"]["workload"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in line["roofline"]
+    assert line["roofline"]["frac"] == line["roofline"]["achieved"] / line["roofline"]["peak"]
+    assert abs(line["value"] - full["config"]["n_source_total"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-7
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in line["cpu_baseline"]
     assert line["check"]["index_rows_identical"] == 1024 and set(line["summary"]) >= {"ns", "c1", "c2", "c3", "c4s", "c4", "ea15k"}

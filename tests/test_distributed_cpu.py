@@ -202,3 +202,71 @@ def test_single_process_pipeline_with_and_without_the_shared_sweep(shared):
         assert sk.shared == (shared and hub is not None and not single), (name, sk.shared)
         np.testing.assert_array_equal(i.numpy(), oi, err_msg=name)
         np.testing.assert_allclose(d.numpy(), od, rtol=1e-9, atol=1e-9, err_msg=name)
+
+
+def _cache_worker(rank, world, port, q):
+    """`ShardedKiez(cache_target=True)`: the same target tensor in consecutive fits is broadcast once; a new tensor or an in-place
+    write (torch's version counter) is broadcast again; results always those of the target as it is NOW."""
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import warnings
+
+        import torch
+        import torch.distributed as dist
+        from kiez_amd.distributed import Comm, ShardedKiez, row_slice
+        from oracle import kiez_oracle as O
+        from tests.cpu_engine import OracleEngine
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        warnings.simplefilter("ignore")
+        rng = np.random.RandomState(5)
+        source, source2, target = rng.rand(90, 8), rng.rand(70, 8), rng.rand(60, 8)
+        tgt = torch.from_numpy(target.copy())       # the caller's tensor on the engine's device (CPU engine: host memory)
+        comm = Comm()
+        sk = ShardedKiez(n_candidates=6, algorithm_kwargs={"metric": "euclidean"}, hubness="CSLS", engine=OracleEngine(), comm=comm,
+                         cache_target=True)
+        log = []
+
+        def step(src, t_arg, want_bcast, t_now):
+            comm.reset_timers()
+            b, c = row_slice(len(src), rank, world)
+            sk.fit(src[b:b + c], t_arg if rank == 0 else None)
+            d, i = sk.kneighbors(4)
+            od, oi = O.kiez_pipeline(src, t_now, 6, 4, "euclidean", 2, "CSLS", {})
+            calls = comm.traffic().get("broadcast", {"calls": 0})["calls"]
+            log.append((calls == (1 if want_bcast else 0), bool(np.array_equal(i.numpy(), oi[b:b + c])),
+                        bool(np.allclose(d.numpy(), od[b:b + c], rtol=1e-9, atol=1e-9))))
+        step(source, tgt, True, target)            # first fit: broadcast
+        step(source2, tgt, False, target)          # another source batch, the SAME target tensor: no broadcast
+        step(source, tgt, False, target)
+        if rank == 0:
+            tgt.mul_(0.5)                          # in-place write on rank 0: the version counter moves -> broadcast again
+        step(source, tgt, True, target * 0.5)
+        step(source2, tgt, False, target * 0.5)
+        other = rng.rand(60, 8)
+        step(source, other, True, other)           # a host array: copied into a new tensor by every fit -> never cached
+        step(source, other, True, other)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, log, None))
+    except Exception:  # pragma: no cover
+        q.put((rank, None, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_target_replica_is_reused_while_the_target_tensor_is_unchanged(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cache_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, log, err in out:
+        assert err is None, f"rank {rank} failed:\n{err}"
+        assert len(log) == 7 and all(all(t) for t in log), (rank, log)
