@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 5
+#define KZ_ABI_VERSION 6
 /* candidates per query the rescaling / sort kernels take (kz_knn itself returns up to 4096 neighbours) */
 #define KZ_MAX_CANDIDATES 4096
 /* entries per row kz_merge_topk merges (segments x segment length) */
@@ -207,6 +207,30 @@ int kz_pair_values(kz_ctx* ctx, const kz_matrix* query, int64_t q_begin, int64_t
  * (0 when d_ind is NULL: kinds that only need the merged distances).  segs * seg_len <= KZ_MERGE_MAX_ENTRIES. */
 int kz_merge_topk(kz_ctx* ctx, const double* d_key, const int64_t* d_ind, const double* d_dist, int64_t n, int segs, int seg_len,
                   int k, double* d_odist, int64_t* d_oind);
+
+/* ---- multi-GPU: the collectives of the sharded path (kz_comm.hip), over RCCL -- ABI v6 ------------------------------------------
+ * One process per GPU.  What the reference's only multi-device call hands to a library (kiez/neighbors/approximate/faiss.py:138,
+ * faiss.index_cpu_to_all_gpus) a host in ANY language binds here, without torch: rank 0 draws a 128-byte id (kz_comm_unique_id)
+ * and distributes it by whatever the host has (MPI, a file, a socket); every rank calls kz_comm_create with its context.  The
+ * collectives are enqueued on the context's stream -- ordered with its kernels, no host synchronisation.  librccl.so is loaded by
+ * the first of these calls (dlopen; a copy the process already holds is taken first) and is not a link-time dependency: without
+ * RCCL they return KZ_ERR_UNSUPPORTED.  Buffers are device pointers, sizes are bytes.
+ *   kz_comm_broadcast           d_buf of rank `root` to every rank, in place                  (the replicated target)
+ *   kz_comm_all_gather          d_recv [world][bytes_per_rank] = every rank's d_send          (fit state, shard sizes, source shards)
+ *   kz_comm_all_to_all          block r of d_send (send_offset[r], send_bytes[r]) to rank r; d_recv [world][recv_bytes] = the blocks
+ *                               received, in rank order                                       (per-shard reverse lists -> kz_merge_topk)
+ *   kz_comm_all_reduce_min_f64  element-wise minimum over the ranks, in place                 (DisSimLocal's global shift) */
+#define KZ_COMM_ID_BYTES 128
+typedef struct kz_comm kz_comm;
+int kz_comm_unique_id(void* id128);
+int kz_comm_create(kz_ctx* ctx, const void* id128, int rank, int world, kz_comm** out);
+int kz_comm_destroy(kz_comm* comm);
+int kz_comm_rank(const kz_comm* comm, int* rank, int* world);
+int kz_comm_broadcast(kz_comm* comm, void* d_buf, size_t bytes, int root);
+int kz_comm_all_gather(kz_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);
+int kz_comm_all_to_all(kz_comm* comm, const void* d_send, const size_t* send_offset, const size_t* send_bytes, void* d_recv,
+                       size_t recv_bytes);
+int kz_comm_all_reduce_min_f64(kz_comm* comm, double* d_buf, size_t count);
 
 /* Single-source mode (fit(source) only): d_dist / d_ind = [n, K1] result of ONE kz_knn of the matrix against itself for
  * K1 = K + 1 neighbours WITHOUT exclude_self, rows row0 .. row0 + n.  Writes both views the reference computes with two

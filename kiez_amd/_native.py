@@ -40,7 +40,7 @@ MAX_FUSED_NEIGHBORS = 110   # neighbours per query ONE fused list keeps (list le
 MAX_NEIGHBORS = 4096
 MAX_HUBNESS_CANDIDATES = 4096  # n_candidates the device hubness kernels (transform, final sort) handle (KZ_MAX_CANDIDATES)
 MERGE_MAX_ENTRIES = 8192       # entries per row kz_merge_topk merges (KZ_MERGE_MAX_ENTRIES)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _ERR_TYPES = {1: ValueError, 2: RuntimeError, 3: NotImplementedError, 4: MemoryError, 5: ValueError}
 
@@ -116,6 +116,14 @@ SYMBOLS = [
     ("kz_kocc_stats", C.c_int, [_P, _P, _I64, C.c_double, C.c_int, C.POINTER(C.c_double)]),
     ("kz_kocc_select", C.c_int, [_P, _P, _I64, C.c_int, C.c_double, _P, C.POINTER(_I64)]),
     ("kz_hit_positions", C.c_int, [_P, _P, _P, _I64, C.c_int, _P]),
+    ("kz_comm_unique_id", C.c_int, [_P]),
+    ("kz_comm_create", C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("kz_comm_destroy", C.c_int, [_P]),
+    ("kz_comm_rank", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("kz_comm_broadcast", C.c_int, [_P, _P, C.c_size_t, C.c_int]),
+    ("kz_comm_all_gather", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("kz_comm_all_to_all", C.c_int, [_P, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _P, C.c_size_t]),
+    ("kz_comm_all_reduce_min_f64", C.c_int, [_P, _P, C.c_size_t]),
 ]
 
 

@@ -378,6 +378,149 @@ class Comm:
         return t
 
 
+class RcclComm(Comm):
+    """The same exchange steps through the C ABI's own collectives (`kz_comm_*`, kiez_amd/csrc/kz_comm.hip: RCCL on the context's
+    stream) instead of `torch.distributed`: what a host WITHOUT torch binds (INTEGRATION.md "multi-GPU").  Here the buffers are still
+    the engine's tensors -- only their device pointers cross the ABI -- so the sharded pipeline above runs unchanged on it.
+
+    The 128-byte unique id is the host's to distribute: `RcclComm.unique_id()` on rank 0, then any channel (a file, MPI, a socket);
+    `RcclComm.from_file(engine, rank, world, path)` is the file rendezvous (rank 0 writes, the others poll)."""
+
+    def __init__(self, engine, rank: int, world: int, unique_id: bytes, always: bool = False, time_collectives: bool = False):
+        from . import _native as N
+        if len(unique_id) != 128:
+            raise ValueError("unique_id: the 128 bytes of RcclComm.unique_id() on rank 0")
+        self.N = N
+        self.engine = engine
+        self.lib = engine.ctx.lib
+        self.rank, self.world = int(rank), int(world)
+        self.always = bool(always) or os.environ.get("KIEZ_AMD_FORCE_COLLECTIVES") == "1"
+        self.group = None
+        self.timed = bool(time_collectives)
+        self._events, self._wall, self._bytes = [], {}, {}
+        h = _P()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        N._check(self.lib.kz_comm_create(engine.ctx.handle, buf, self.rank, self.world, C.byref(h)), "kz_comm_create")
+        self.handle = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _native as N
+        buf = C.create_string_buffer(128)
+        N._check(N.load().kz_comm_unique_id(buf), "kz_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_file(cls, engine, rank: int, world: int, path: str, timeout_s: float = 120.0, **kw):
+        import time
+        if rank == 0:
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as fh:
+                fh.write(cls.unique_id())
+            os.replace(tmp, path)     # (atomic: a reader never sees a partial id)
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"RcclComm.from_file: {path} did not appear within {timeout_s} s")
+            time.sleep(0.01)
+        with open(path, "rb") as fh:
+            uid = fh.read()
+        return cls(engine, rank, world, uid, **kw)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.kz_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):   # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _p(t):
+        assert t.is_cuda and t.is_contiguous()
+        return _P(t.data_ptr())
+
+    @staticmethod
+    def _nbytes(t):
+        return t.numel() * t.element_size()
+
+    # -- the collectives (same contracts as Comm's) -------------------------------------------------------------------------
+    def broadcast(self, t, src=0):
+        if self.world > 1 or self.always:
+            self._timed("broadcast", t, lambda: self.N._check(self.lib.kz_comm_broadcast(self.handle, self._p(t), self._nbytes(t), int(src)),
+                                                               "kz_comm_broadcast"))
+        return t
+
+    def broadcast_begin(self, t, src=0):
+        # (kz_comm_* enqueue on the context's stream: the transfer is ordered like a kernel, there is nothing to overlap with on
+        #  that stream -- begin runs it, end is a no-op; "broadcast_exposed" = the whole transfer)
+        if not (self.world > 1 or self.always):
+            return None
+        self._timed("broadcast_exposed", t, lambda: self.N._check(self.lib.kz_comm_broadcast(self.handle, self._p(t), self._nbytes(t), int(src)),
+                                                                   "kz_comm_broadcast"))
+        rec = self._bytes.pop("broadcast_exposed")
+        tot = self._bytes.setdefault("broadcast", [0, 0])
+        tot[0] += rec[0]
+        tot[1] += rec[1]
+        return ("done",)
+
+    def broadcast_end(self, token):
+        return None
+
+    def all_gather_rows(self, t, counts):
+        torch = _torch()
+        if self.world == 1 and not self.always:
+            return t
+        mx = max(counts)
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        out = torch.empty((self.world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self._timed("all_gather", pad, lambda: self.N._check(self.lib.kz_comm_all_gather(self.handle, self._p(pad), self._p(out), self._nbytes(pad)),
+                                                              "kz_comm_all_gather"))
+        if all(c == mx for c in counts):
+            return out
+        return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(self.world)], dim=0)
+
+    def gather_rows_to0(self, t, counts):
+        out = self.all_gather_rows(t, counts)     # (no gather primitive in the ABI: evidence paths only)
+        return out if self.rank == 0 else None
+
+    def all_to_all_rows(self, t, counts):
+        torch = _torch()
+        mine = counts[self.rank]
+        if self.world == 1 and not self.always:
+            return t.reshape((1,) + tuple(t.shape))
+        t = t.contiguous()
+        row_bytes = self._nbytes(t) // max(t.shape[0], 1)
+        out = torch.empty((self.world * mine,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        offs = (C.c_size_t * self.world)(*[sum(counts[:r]) * row_bytes for r in range(self.world)])
+        lens = (C.c_size_t * self.world)(*[counts[r] * row_bytes for r in range(self.world)])
+        self._timed("all_to_all", t, lambda: self.N._check(self.lib.kz_comm_all_to_all(self.handle, self._p(t), offs, lens, self._p(out), mine * row_bytes),
+                                                            "kz_comm_all_to_all"))
+        return out.reshape((self.world, mine) + tuple(t.shape[1:]))
+
+    def all_gather_vec(self, values, device):
+        torch = _torch()
+        values = [int(v) for v in values]
+        if self.world == 1 and not self.always:
+            return [values]
+        mine = torch.tensor(values, dtype=torch.int64, device=device)
+        out = torch.empty((self.world, len(values)), dtype=torch.int64, device=device)
+        self.N._check(self.lib.kz_comm_all_gather(self.handle, self._p(mine), self._p(out), self._nbytes(mine)), "kz_comm_all_gather")
+        return out.cpu().tolist()
+
+    def all_reduce_min(self, t):
+        if self.world > 1 or self.always:
+            torch = _torch()
+            assert t.dtype == torch.float64
+            self._timed("all_reduce", t, lambda: self.N._check(self.lib.kz_comm_all_reduce_min_f64(self.handle, self._p(t), t.numel()),
+                                                                "kz_comm_all_reduce_min_f64"))
+        return t
+
+
 def row_slice(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous balanced partition of n rows: (begin, count) of `rank`."""
     base, rem = divmod(n, world)
