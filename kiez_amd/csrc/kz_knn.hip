@@ -1210,6 +1210,66 @@ static bool kz_launch_exact_rows(kz_ctx* ctx, const int* fl, int b0, int nb, int
     return true;
 }
 
+#include "kz_exact_lanes.h"
+// -> true when the one-pair-per-lane kernel (kz_exact_lanes.h) took the batch: float32 rows of up to 512 elements (a multiple of 4,
+// 16-byte aligned), the euclidean family on the raw rows, cosine on the normalised float64 rows where that image exists, and a
+// batch of at least KZ_XL_MIN_ROWS query rows (a handful is the cooperative kernel's: it needs no staging and no pre-pass).
+constexpr int KZ_XL_MIN_ROWS = 32;
+static int kz_launch_exact_lanes(kz_ctx* ctx, const int* fl, int b0, int nb, int64_t cq_begin, const kz_matrix* query, const kz_matrix* index,
+                                 int metric, double* vals, bool* took) {
+    *took = false;
+    const int d = (int)index->d;
+    if (ctx->exact_rows < 2 || nb < KZ_XL_MIN_ROWS || index->dtype != KZ_F32 || (d & 3) != 0 || d > 512 || metric > KZ_COSINE ||
+        (((uintptr_t)query->raw | (uintptr_t)index->raw) & 15u) != 0)
+        return KZ_OK;
+    const bool cosine = metric == KZ_COSINE;
+    if (cosine && (index->norm64 == nullptr || d > 256)) return KZ_OK;
+    const int d_pad = d;   // (a multiple of 4: whole leaves)
+    const int nb_pad = (nb + 4 * KZ_XL_Q - 1) / (4 * KZ_XL_Q) * (4 * KZ_XL_Q);   // (whole blocks of 4 waves x KZ_XL_Q rows)
+    double* qd = nullptr;
+    int rc = kz_pool_alloc(ctx, ((size_t)nb_pad * d_pad + nb_pad) * 8, (void**)&qd);
+    if (rc != KZ_OK) return rc == KZ_ERR_NOMEM ? KZ_OK : rc;   // (no memory for the operand rows: the cooperative kernel)
+    double* qsq = qd + (size_t)nb_pad * d_pad;
+    hipLaunchKernelGGL(kz_exact_qprep_kernel, dim3(nb_pad), dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin, (const float*)query->raw, query->sqn, d,
+                       d_pad, metric, qd, qsq);
+    const dim3 grid((unsigned)((index->n + KZ_XL_ROWS - 1) / KZ_XL_ROWS));
+    const size_t lds = (size_t)(d_pad / 4) * (KZ_XL_ROWS + 1) * (cosine ? 32 : 16);   // (<= 133 KiB: 512 float32 / 256 float64 elements)
+    hipError_t e = hipSuccess;
+#define KZ_XL_LAUNCH(NL, NVV, ELT, rows)                                                                                                       \
+    do {                                                                                                                                        \
+        if (lds > 65536) e = hipFuncSetAttribute((const void*)kz_exact_dist_lanes_kernel<NL, NVV, ELT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess)                                                                                                                     \
+            hipLaunchKernelGGL((kz_exact_dist_lanes_kernel<NL, NVV, ELT>), grid, dim3(256), lds, ctx->stream, nb, (const double*)qd, (const double*)qsq, \
+                               (const ELT*)(rows), index->sqn, index->n, d, d_pad, metric, vals);                                               \
+    } while (0)
+    if (cosine) {
+        if (d <= 64)
+            KZ_XL_LAUNCH(16, 1, double, index->norm64);
+        else if (d <= 128)
+            KZ_XL_LAUNCH(32, 1, double, index->norm64);
+        else
+            KZ_XL_LAUNCH(64, 1, double, index->norm64);
+    } else {
+        if (d <= 64)
+            KZ_XL_LAUNCH(16, 1, float, index->raw);
+        else if (d <= 128)
+            KZ_XL_LAUNCH(32, 1, float, index->raw);
+        else if (d <= 256)
+            KZ_XL_LAUNCH(64, 1, float, index->raw);
+        else
+            KZ_XL_LAUNCH(64, 2, float, index->raw);
+    }
+#undef KZ_XL_LAUNCH
+    if (e == hipSuccess) e = hipGetLastError();
+    kz_pool_free(ctx, qd, 0);   // (stream-ordered pool)
+    if (e != hipSuccess) {
+        kz_set_error("kz_knn: exact distance kernel (one pair per lane) failed: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    *took = true;
+    return KZ_OK;
+}
+
 // The Minkowski family beyond p = 2 (KZ_MANHATTAN, KZ_CHEBYSHEV, KZ_MINKOWSKI): no inner-product form, hence no MFMA -- a
 // register-tiled VALU kernel.  A workgroup of 256 threads owns 64 queries x 64 index rows, a thread 4 x 4 pairs; the rows are
 // staged through LDS DK features at a time, transposed ([feature][row]: a thread reads its four query values and its four index
@@ -2931,7 +2991,18 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             for (int b0 = 0; b0 < n_fail; b0 += (int)batch) {
                 const int nb = (n_fail - b0 < batch) ? (n_fail - b0) : (int)batch;
                 if (index->dtype == KZ_F32) {
-                    if (no_gemm_form)
+                    bool lanes = false;
+                    if (!no_gemm_form) {
+                        rc = kz_launch_exact_lanes(ctx, fl, b0, nb, cq_begin, query, index, metric, (double*)vals, &lanes);
+                        if (rc != KZ_OK) {
+                            kz_pool_free(ctx, fl, 0);
+                            kz_pool_free(ctx, cand_v, 0);
+                            kz_pool_free(ctx, cand_i, 0);
+                            return rc;
+                        }
+                    }
+                    if (lanes) {
+                    } else if (no_gemm_form)
                         kz_launch_family_dist<float>(ctx, fl, b0, nb, cq_begin, query, index, (double*)vals);
                     else if (ctx->exact_rows && kz_launch_exact_rows(ctx, fl, b0, nb, cq_begin, query, index, metric, (double*)vals)) {
                     } else

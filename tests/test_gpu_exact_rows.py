@@ -1,4 +1,4 @@
-"""The exact float64 distance kernel that takes many pairs per wave step (kz_exact_dist_rows_kernel: four query rows in registers,
+"""The exact float64 distance kernels: the one that takes many pairs per wave step (kz_exact_dist_rows_kernel: four query rows in registers,
 64 / LPR consecutive index rows per step) against the one-pair-per-wave kernel it replaces for float32 rows of d <= 512: the same
 values bit for bit (both reproduce kz_wave_dot's order of operations), on every metric, ragged sizes, with and without the
 normalised float64 rows of a cosine index.  The exact kernels are the backstop below every approximate tier (the reference has no
@@ -15,7 +15,7 @@ def ctx():
     c = N.Context.get()
     yield c
     c.set_option("eps_scale", 1.0)
-    c.set_option("exact_rows", 1)
+    c.set_option("exact_rows", 2)
 
 
 @pytest.mark.parametrize("metric", ["euclidean", "sqeuclidean", "cosine"])
@@ -32,13 +32,14 @@ def test_same_bits_as_the_one_pair_kernel(ctx, metric, d):
     qm, ym = N.DeviceMatrix(ctx, q, metric), N.DeviceMatrix(ctx, y, metric)
     ctx.set_option("eps_scale", 1e30)      # every row fails every certification: the exact kernels answer
     out = {}
-    for rows in (0, 1):
+    for rows in (0, 1, 2):      # one pair per wave / many pairs per wave step / one pair per LANE (kz_exact_lanes.h, round 6)
         ctx.set_option("exact_rows", rows)
         dd, ii, st = N.knn(ctx, qm, ym, k)
         assert st["n_fallback_rows"] == n_q, st
         out[rows] = (dd.numpy(), ii.numpy())
-    np.testing.assert_array_equal(out[0][1], out[1][1])
-    np.testing.assert_array_equal(out[0][0], out[1][0])
+    for rows in (1, 2):
+        np.testing.assert_array_equal(out[0][1], out[rows][1], err_msg=f"exact_rows {rows}")
+        np.testing.assert_array_equal(out[0][0], out[rows][0], err_msg=f"exact_rows {rows}")
     q64, y64 = (q.astype(np.float64), y.astype(np.float64)) if metric == "cosine" else (q, y)
     od, oi = O.knn_exact(q64, y64, k, metric)
     np.testing.assert_array_equal(out[1][1], oi)
@@ -72,12 +73,14 @@ def test_many_exact_ties_at_the_kth_place(ctx, k):
     qm, ym = N.DeviceMatrix(ctx, q, "sqeuclidean"), N.DeviceMatrix(ctx, y, "sqeuclidean")
     ctx.set_option("eps_scale", 1e30)
     out = {}
-    for rows in (0, 1):
+    for rows in (0, 1, 2):
         ctx.set_option("exact_rows", rows)
         dd, ii, st = N.knn(ctx, qm, ym, k)
         assert st["n_fallback_rows"] == 150, st
         out[rows] = (dd.numpy(), ii.numpy())
     np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][1], out[2][1])
+    np.testing.assert_array_equal(out[0][0], out[2][0])
     np.testing.assert_array_equal(out[0][0], out[1][0])
     od, oi = O.knn_exact(q, y, k, "sqeuclidean")
     np.testing.assert_array_equal(out[1][1], oi)

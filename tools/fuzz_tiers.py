@@ -47,7 +47,7 @@ def main():
         ctx.set_option("wide_sel", ws)
         # the bottom of the ladder: the exact kernels' two distance kernels, the shortcut to them, the ladder after the fact
         er, ed, el = int(rng.randint(0, 2)), int(rng.choice([0, 32, 4096])), int(rng.randint(0, 2))
-        ctx.set_option("exact_rows", er)
+        ctx.set_option("exact_rows", 2 if (er and ed == 32) else er)      # (2: + the one-pair-per-lane kernel for batches of >= 32 rows)
         ctx.set_option("esc_ladder", el)
         res = {}
         for prec in (0, 2, 1):   # fp16 first pass (default), split-bf16, float32 operands only
@@ -62,7 +62,7 @@ def main():
         ctx.set_option("short_ord_min_tiles", 48)
         ctx.set_option("eps_scale", 1.0)
         ctx.set_option("h_q64", 2)
-        for name, v in (("tier_probe", 1024), ("probe_min_pairs", 5e10), ("wide_lists", 32), ("wide_sel", 256), ("exact_rows", 1),
+        for name, v in (("tier_probe", 1024), ("probe_min_pairs", 5e10), ("wide_lists", 32), ("wide_sel", 256), ("exact_rows", 2),
                         ("esc_ladder", 1)):
             ctx.set_option(name, v)
         ok = all(np.array_equal(res[0][1], res[p][1]) and np.array_equal(res[0][0], res[p][0]) for p in (1, 2))
