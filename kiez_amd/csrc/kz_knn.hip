@@ -2081,6 +2081,22 @@ static int kz_spec_rows(const kz_ctx* ctx, const kz_matrix* index, int k_eff) {
     if (R > ctx->spec_rows) R = ctx->spec_rows & ~3;
     return R < 4 ? 0 : R;
 }
+// The buffers of a speculation for R rows (ahead of the launches where those run on another stream than the pool's: the reverse
+// chains of kz_knn_dual -- a buffer handed out here may have been released by work that is still in flight on the context's stream).
+// No memory: sp stays empty and nothing is speculated (the ordinary re-search will do).
+static int kz_spec_alloc(kz_ctx* ctx, KzSpec& sp, int R, const kz_matrix* index, int k_eff) {
+    const int k_sel = (int)(k_eff < index->n ? k_eff : index->n);
+    const int n_chunks = (int)((index->n + KZ_EXACT_CHUNK - 1) / KZ_EXACT_CHUNK);
+    const bool two_level = n_chunks >= 2 && k_sel <= KZ_EXACT_CHUNK;
+    int rc = kz_pool_alloc(ctx, (size_t)R * (size_t)index->n * 8, (void**)&sp.vals);
+    if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 8, (void**)&sp.cand_v);
+    if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 4, (void**)&sp.cand_i);
+    if (rc != KZ_OK) {
+        kz_spec_release(ctx, sp);
+        return rc == KZ_ERR_NOMEM ? KZ_OK : rc;
+    }
+    return KZ_OK;
+}
 // fail_list / fail_count: the finalize kernel's device-side list and counter (fail_list holds rows relative to q0)
 static int kz_spec_rescue(kz_ctx* ctx, KzSpec& sp, int R, const kz_matrix* query, int64_t q0, const int* fail_list, const int* fail_count,
                           const kz_matrix* index, int k, int exclude_self, const int64_t* d_self_ids, double* out_dist, int64_t* out_ind) {
@@ -2092,12 +2108,9 @@ static int kz_spec_rescue(kz_ctx* ctx, KzSpec& sp, int R, const kz_matrix* query
     // (two selection levels from two chunks on: the single-level kernel passes k_eff times over the whole row with ONE workgroup --
     //  135 us for 15 k values, k = 10; the chunk kernel selects from registers)
     const bool two_level = n_chunks >= 2 && k_sel <= KZ_EXACT_CHUNK;
-    int rc = kz_pool_alloc(ctx, (size_t)R * (size_t)index->n * 8, (void**)&sp.vals);
-    if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 8, (void**)&sp.cand_v);
-    if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 4, (void**)&sp.cand_i);
-    if (rc != KZ_OK) {   // (no memory for a speculation: the ordinary re-search will do)
-        kz_spec_release(ctx, sp);
-        return rc == KZ_ERR_NOMEM ? KZ_OK : rc;
+    if (!sp.vals) {   // (not allocated ahead by the caller: kz_spec_alloc)
+        const int rc = kz_spec_alloc(ctx, sp, R, index, k_eff);
+        if (rc != KZ_OK || !sp.vals) return rc;
     }
     const int dist_blocks = (int)((index->n + 3) / 4 < 256 ? (index->n + 3) / 4 : 256);   // (grid-stride; dead rows cost their dispatch)
     const double* sel_v = two_level ? (const double*)sp.cand_v : (const double*)sp.vals;

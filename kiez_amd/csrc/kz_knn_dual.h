@@ -506,6 +506,7 @@ struct KzRevChain {
     double* d_dist;
     int64_t* d_ind;
     int timed, h_fail, h_cnt, second_stream;
+    KzSpec* spec;   // speculative exact re-search behind this chain's finalize (kz_knn.hip "SPECULATIVE RESCUE"); buffers owned by the caller
 };
 static int kz_dual_enqueue_chain(KzRevChain& r) {
     kz_ctx* ctx = r.ctx;
@@ -573,6 +574,15 @@ static int kz_dual_enqueue_chain(KzRevChain& r) {
         const int rc2 = kz_launch_finalize(ctx, fp, lay, r.KP, r.n_rows, r.im->dtype);
         if (rc2 != KZ_OK) return rc2;
         if (r.timed) KZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
+        if (r.spec) {
+            // (the handful of rows this chain leaves uncertified -- short of events, an overflowing buffer, a near-tie -- answered by the
+            //  exact kernels on this chain's stream before the host knows the count; fail_list holds matrix rows)
+            const int R = kz_spec_rows(ctx, r.im, r.k);
+            if (R > 0 && r.spec->vals) {   // (the buffers were allocated ahead: kz_knn_dual)
+                const int rc3 = kz_spec_rescue(ctx, *r.spec, R, r.qm, 0, r.fail_list, r.fail_count, r.im, r.k, 0, nullptr, r.d_dist, r.d_ind);
+                if (rc3 != KZ_OK) return rc3;
+            }
+        }
         KZ_HIP(hipMemcpyAsync(ctx->h_counters + r.h_fail, r.fail_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         KZ_HIP(hipMemcpyAsync(ctx->h_counters + r.h_cnt, r.d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
         return KZ_OK;
@@ -732,8 +742,11 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         s3_packed = ss_packed = nullptr; s3_bias = ss_bias = theta3 = theta3_s = theta3_min = floor3 = floor3m = qnb_b = col3_key = nullptr;
         iota3 = perm3 = rm3 = row_map_b = ev3_cnt = col3_idx = fail3 = sev_cnt = nullptr; ev3 = sev = nullptr; log3_keys = log3_meta = nullptr; d_cnt3 = nullptr;
     };
+    KzSpec spec_ba, spec_s3;   // (buffers of the two chains' speculative exact launches: released with everything else, behind the second stream's sync)
     auto release = [&]() {
         release_nested();
+        kz_spec_release(ctx, spec_ba);
+        kz_spec_release(ctx, spec_s3);
         kz_pool_free(ctx, s_packed, 0);
         kz_pool_free(ctx, s_bias, 0);
         kz_pool_free(ctx, p_packed, 0);
@@ -1105,6 +1118,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         rv3.ev = ev3; rv3.ev_cap = ev_cap3; rv3.KP = ctx->dual_rev_long ? (2 * KP < 128 ? 2 * KP : 128) : KP; rv3.k = k;
         rv3.n_rows = s_img_rows; rv3.n_tiles = s_tiles; rv3.d_dist = d_dist_ab; rv3.d_ind = d_ind_ab;
         rv3.timed = 0; rv3.h_fail = 24; rv3.h_cnt = 28; rv3.second_stream = ctx->dual_overlap ? 1 : 0;
+        if (kz_spec_rows(ctx, b, k) > 0) KZ_DUAL_RC(kz_spec_alloc(ctx, spec_s3, kz_spec_rows(ctx, b, k), b, k));   // (ahead of the chain: see kz_spec_alloc)
+        rv3.spec = &spec_s3;
         dp2.qpack = (const float*)ib->packed;
         dp2.row_map = row_map_b;
         dp2.ypack = (const float*)ss_packed;
@@ -1268,6 +1283,8 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
     rv.row_map = row_map; rv.ev_cnt = ev_cnt; rv.perm = perm; rv.col_idx = col_idx; rv.fail_list = fail_list; rv.fail_count = fail_count_b;
     rv.ev = ev; rv.ev_cap = ev_cap; rv.KP = KPr; rv.k = k; rv.n_rows = b->n; rv.n_tiles = b_tiles; rv.d_dist = d_dist_ba; rv.d_ind = d_ind_ba;
     rv.timed = 1; rv.h_fail = 12; rv.h_cnt = 16; rv.second_stream = 1;
+    if (kz_spec_rows(ctx, a, k) > 0) KZ_DUAL_RC(kz_spec_alloc(ctx, spec_ba, kz_spec_rows(ctx, a, k), a, k));   // (ahead of the chain: see kz_spec_alloc)
+    rv.spec = &spec_ba;
     auto enqueue_reverse = [](void* user) -> int { return kz_dual_enqueue_chain(*(KzRevChain*)user); };
     if (ctx->dual_overlap) {
         dp.post_sweep = +enqueue_reverse;
@@ -1309,7 +1326,11 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
             n_fail3 = (int)s_img_rows;
             list3 = rm3;   // (the matrix rows of S)
         }
-        if (n_fail3 > 0) {
+        const bool rescued3 = hc3[0] <= (unsigned long long)log_cap3 && spec_s3.R > 0 && n_fail3 > 0 && n_fail3 <= spec_s3.R;
+        if (rescued3) {   // (the speculative exact launches behind the chain's finalize have answered them)
+            st_ab.n_fallback_rows += n_fail3;
+            st_ab.n_spec_rows += n_fail3;
+        } else if (n_fail3 > 0) {
             const int kp_min3 = ((int64_t)n_fail3 * 8 > s_img_rows || KPr >= 128) ? 0 : (KPr == 16 && KZ_K_ESC_SHORT && n_fail3 <= KZ_ESC_SHORT_MAX_ROWS ? -1 : (KPr * 4 < 128 ? KPr * 4 : 128));
             kz_knn_stats st3;
             float ms3 = 0;
@@ -1349,6 +1370,9 @@ extern "C" int kz_knn_dual(kz_ctx* ctx, const kz_matrix* a_c, const kz_matrix* b
         st_ba.n_logged_groups = (int64_t)(hc[0] & ((1ull << 62) - 1));
         if (hc[0] > (unsigned long long)log_cap) {
             dp.broken = 1;   // the log itself overflowed: events are missing for unknown rows
+        } else if (spec_ba.R > 0 && n_fail > 0 && n_fail <= spec_ba.R) {
+            st_ba.n_fallback_rows = n_fail;   // (answered by the speculative exact launches behind the chain's finalize)
+            st_ba.n_spec_rows = n_fail;
         } else if (n_fail > 0) {
             // rows of B with an overflowing buffer or an uncertified list: the ordinary search, longer lists when they are few
             // (K' = 16: more lists instead of longer ones, kz_knn_impl kp_min = -1)
