@@ -20,8 +20,14 @@
 // d_pad = leaves x 4 elements per row, zero filled.
 __global__ __launch_bounds__(256) void kz_exact_qprep_kernel(const int* __restrict__ fail_list, int batch0, int nb, int64_t q_begin,
                                                              const float* __restrict__ qraw, const double* __restrict__ qsqn, int d, int d_pad,
-                                                             int metric, double* __restrict__ qd, double* __restrict__ qsq) {
-    const int b = blockIdx.x;   // (the grid covers the batch rounded up to whole quads of rows: the rows past it are zeros)
+                                                             int metric, double* __restrict__ qd, double* __restrict__ qsq,
+                                                             const int* __restrict__ dyn_n = nullptr) {
+    const int b = blockIdx.x;   // (the grid covers the batch rounded up to whole blocks of rows: the rows past it are zeros)
+    if (dyn_n) {   // (speculative launch, kz_spec_rescue: nb is the capacity, the row count is on the device)
+        const int n = *dyn_n;
+        if (n > nb || n <= 0) return;
+        nb = n;
+    }
     const bool live = b < nb;
     const int64_t qrow = live ? q_begin + fail_list[batch0 + b] : 0;
     const double qs = live ? qsqn[qrow] : 1.0;
@@ -81,11 +87,20 @@ __host__ __device__ constexpr int kz_bitrev(int i) {
 
 // NLEAF = 16 / 32 / 64 leaves of the first chunk (d <= 64 / 128 / 256; beyond: 64 and NV = 2).  vals[b][i] as kz_exact_dist_kernel.
 // LDS: the index tile [leaf entries][KZ_XL_ROWS + 1] x ENTRY bytes, then the query block [4 waves x KZ_XL_Q rows][d_pad] float64.
-template <int NLEAF, int NV, typename ELT>
+// COS_RAW: cosine on the RAW float32 rows (no normalised float64 image of the index): the lane divides its row's elements by the
+// row's norm as the cooperative kernel does (one reciprocal per row, kz_div_shared: the IEEE quotient) -- per leaf, shared by the
+// wave's four query rows.
+template <int NLEAF, int NV, typename ELT, bool COS_RAW = false>
 __global__ __launch_bounds__(256) void kz_exact_dist_lanes_kernel(int nb, const double* __restrict__ qd, const double* __restrict__ qsq,
                                                                   const ELT* __restrict__ yrows, const double* __restrict__ ysqn, int64_t n_i, int d,
-                                                                  int d_pad, int metric, double* __restrict__ vals) {
+                                                                  int d_pad, int metric, double* __restrict__ vals,
+                                                                  const int* __restrict__ dyn_n = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char xl_sm[];
+    if (dyn_n) {   // (speculative launch: nb is the capacity; nothing to do -- or too much -- returns before the tile is staged)
+        const int n = *dyn_n;
+        if (n > nb || n <= 0) return;
+        nb = n;
+    }
     constexpr int ENTRY = 4 * (int)sizeof(ELT);
     constexpr int LOG = NLEAF == 64 ? 6 : (NLEAF == 32 ? 5 : 4);
     constexpr int QB = 4 * KZ_XL_Q;   // query rows of the workgroup's block
@@ -110,7 +125,9 @@ __global__ __launch_bounds__(256) void kz_exact_dist_lanes_kernel(int nb, const 
     }
     __syncthreads();   // (the tile is staged)
     const int64_t i = i0 + lane;
-    const double ys = (metric != KZ_COSINE && i < n_i) ? ysqn[i] : 0.0;
+    const double ys = i < n_i ? ysqn[i] : 1.0;   // (euclidean family: |y|^2; cosine: the row's norm, used by COS_RAW only)
+    const double ys_rcp = 1.0 / ys;
+    const bool ys_fin = (((unsigned long long)__double_as_longlong(ys_rcp) >> 52) & 0x7ff) != 0x7ff;
     kz_xl_lds* ylane = (kz_xl_lds*)(ytile + (size_t)lane * ENTRY);
     // A leaf's operands: the lane's index entry from LDS; the four elements of each of the wave's query rows from the float64 operand
     // rows in global memory -- the address is the same in every lane, so they come through the SCALAR cache into scalar registers and
@@ -158,6 +175,9 @@ __global__ __launch_bounds__(256) void kz_exact_dist_lanes_kernel(int nb, const 
             if (leaf_of(it_) + 64 * c < n_groups) { /* (uniform; a leaf past the row is an exact zero) */          \
                 double y[4];                                                                                       \
                 (O).y[c].get(y);                                                                                   \
+                if (COS_RAW) {                                                                                     \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) y[e] = ys_fin ? kz_div_shared(y[e], ys, ys_rcp) : y[e] / ys; \
+                }                                                                                                  \
                 _Pragma("unroll") for (int j = 0; j < KZ_XL_Q; ++j) {                                              \
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) x[j] = fma((O).q[c][j][e], y[e], x[j]);          \
                 }                                                                                                  \

@@ -1215,23 +1215,30 @@ static bool kz_launch_exact_rows(kz_ctx* ctx, const int* fl, int b0, int nb, int
 // 16-byte aligned), the euclidean family on the raw rows, cosine on the normalised float64 rows where that image exists, and a
 // batch of at least KZ_XL_MIN_ROWS query rows (a handful is the cooperative kernel's: it needs no staging and no pre-pass).
 constexpr int KZ_XL_MIN_ROWS = 32;
+static inline size_t kz_exact_lanes_qd_bytes(int nb, int d) {   // float64 operand rows + squared norms of whole blocks of query rows
+    const size_t nb_pad = (size_t)(nb + 4 * KZ_XL_Q - 1) / (4 * KZ_XL_Q) * (4 * KZ_XL_Q);
+    return (nb_pad * (size_t)d + nb_pad) * 8;
+}
+// dyn_n (speculative launch): nb is the capacity of the launch, the row count is read on the device
 static int kz_launch_exact_lanes(kz_ctx* ctx, const int* fl, int b0, int nb, int64_t cq_begin, const kz_matrix* query, const kz_matrix* index,
-                                 int metric, double* vals, bool* took) {
+                                 int metric, double* vals, bool* took, const int* dyn_n = nullptr, double* qd_buf = nullptr) {
     *took = false;
     const int d = (int)index->d;
-    if (ctx->exact_rows < 2 || nb < KZ_XL_MIN_ROWS || index->dtype != KZ_F32 || (d & 3) != 0 || d > 512 || metric > KZ_COSINE ||
+    if (ctx->exact_rows < 2 || (nb < KZ_XL_MIN_ROWS && !dyn_n) || index->dtype != KZ_F32 || (d & 3) != 0 || d > 512 || metric > KZ_COSINE ||
         (((uintptr_t)query->raw | (uintptr_t)index->raw) & 15u) != 0)
         return KZ_OK;
-    const bool cosine = metric == KZ_COSINE;
-    if (cosine && (index->norm64 == nullptr || d > 256)) return KZ_OK;
+    const bool cosine = metric == KZ_COSINE && index->norm64 != nullptr && d <= 256;   // (the normalised float64 rows, staged as they are)
+    const bool cos_raw = metric == KZ_COSINE && !cosine;                               // (the raw rows, divided by the lane)
     const int d_pad = d;   // (a multiple of 4: whole leaves)
     const int nb_pad = (nb + 4 * KZ_XL_Q - 1) / (4 * KZ_XL_Q) * (4 * KZ_XL_Q);   // (whole blocks of 4 waves x KZ_XL_Q rows)
-    double* qd = nullptr;
-    int rc = kz_pool_alloc(ctx, ((size_t)nb_pad * d_pad + nb_pad) * 8, (void**)&qd);
-    if (rc != KZ_OK) return rc == KZ_ERR_NOMEM ? KZ_OK : rc;   // (no memory for the operand rows: the cooperative kernel)
+    double* qd = qd_buf;   // (a caller that runs these launches on another stream than the pool's brings the buffer: kz_spec_alloc)
+    if (!qd) {
+        const int rc = kz_pool_alloc(ctx, kz_exact_lanes_qd_bytes(nb, d), (void**)&qd);
+        if (rc != KZ_OK) return rc == KZ_ERR_NOMEM ? KZ_OK : rc;   // (no memory for the operand rows: the cooperative kernel)
+    }
     double* qsq = qd + (size_t)nb_pad * d_pad;
     hipLaunchKernelGGL(kz_exact_qprep_kernel, dim3(nb_pad), dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin, (const float*)query->raw, query->sqn, d,
-                       d_pad, metric, qd, qsq);
+                       d_pad, metric, qd, qsq, dyn_n);
     const dim3 grid((unsigned)((index->n + KZ_XL_ROWS - 1) / KZ_XL_ROWS));
     const size_t lds = (size_t)(d_pad / 4) * (KZ_XL_ROWS + 1) * (cosine ? 32 : 16);   // (<= 133 KiB: 512 float32 / 256 float64 elements)
     hipError_t e = hipSuccess;
@@ -1240,9 +1247,26 @@ static int kz_launch_exact_lanes(kz_ctx* ctx, const int* fl, int b0, int nb, int
         if (lds > 65536) e = hipFuncSetAttribute((const void*)kz_exact_dist_lanes_kernel<NL, NVV, ELT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e == hipSuccess)                                                                                                                     \
             hipLaunchKernelGGL((kz_exact_dist_lanes_kernel<NL, NVV, ELT>), grid, dim3(256), lds, ctx->stream, nb, (const double*)qd, (const double*)qsq, \
-                               (const ELT*)(rows), index->sqn, index->n, d, d_pad, metric, vals);                                               \
+                               (const ELT*)(rows), index->sqn, index->n, d, d_pad, metric, vals, dyn_n);                                        \
     } while (0)
-    if (cosine) {
+    if (cos_raw) {
+#define KZ_XL_LAUNCH_COS(NL, NVV)                                                                                                              \
+    do {                                                                                                                                        \
+        if (lds > 65536) e = hipFuncSetAttribute((const void*)kz_exact_dist_lanes_kernel<NL, NVV, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess)                                                                                                                     \
+            hipLaunchKernelGGL((kz_exact_dist_lanes_kernel<NL, NVV, float, true>), grid, dim3(256), lds, ctx->stream, nb, (const double*)qd, (const double*)qsq, \
+                               (const float*)index->raw, index->sqn, index->n, d, d_pad, metric, vals, dyn_n);                                  \
+    } while (0)
+        if (d <= 64)
+            KZ_XL_LAUNCH_COS(16, 1);
+        else if (d <= 128)
+            KZ_XL_LAUNCH_COS(32, 1);
+        else if (d <= 256)
+            KZ_XL_LAUNCH_COS(64, 1);
+        else
+            KZ_XL_LAUNCH_COS(64, 2);
+#undef KZ_XL_LAUNCH_COS
+    } else if (cosine) {
         if (d <= 64)
             KZ_XL_LAUNCH(16, 1, double, index->norm64);
         else if (d <= 128)
@@ -1261,7 +1285,7 @@ static int kz_launch_exact_lanes(kz_ctx* ctx, const int* fl, int b0, int nb, int
     }
 #undef KZ_XL_LAUNCH
     if (e == hipSuccess) e = hipGetLastError();
-    kz_pool_free(ctx, qd, 0);   // (stream-ordered pool)
+    if (!qd_buf) kz_pool_free(ctx, qd, 0);   // (stream-ordered pool)
     if (e != hipSuccess) {
         kz_set_error("kz_knn: exact distance kernel (one pair per lane) failed: %s", hipGetErrorString(e));
         return KZ_ERR_HIP;
@@ -2067,8 +2091,10 @@ struct KzSpec {
     double* vals = nullptr;
     double* cand_v = nullptr;
     int* cand_i = nullptr;
+    double* qd = nullptr;   // float64 operand rows of the (up to R) query rows: kz_exact_lanes.h
 };
 static void kz_spec_release(kz_ctx* ctx, KzSpec& sp) {
+    kz_pool_free(ctx, sp.qd, 0);
     kz_pool_free(ctx, sp.vals, 0);
     kz_pool_free(ctx, sp.cand_v, 0);
     kz_pool_free(ctx, sp.cand_i, 0);
@@ -2091,6 +2117,7 @@ static int kz_spec_alloc(kz_ctx* ctx, KzSpec& sp, int R, const kz_matrix* index,
     int rc = kz_pool_alloc(ctx, (size_t)R * (size_t)index->n * 8, (void**)&sp.vals);
     if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 8, (void**)&sp.cand_v);
     if (rc == KZ_OK && two_level) rc = kz_pool_alloc(ctx, (size_t)R * n_chunks * k_sel * 4, (void**)&sp.cand_i);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, kz_exact_lanes_qd_bytes(R, (int)index->d), (void**)&sp.qd);
     if (rc != KZ_OK) {
         kz_spec_release(ctx, sp);
         return rc == KZ_ERR_NOMEM ? KZ_OK : rc;
@@ -2116,7 +2143,20 @@ static int kz_spec_rescue(kz_ctx* ctx, KzSpec& sp, int R, const kz_matrix* query
     const double* sel_v = two_level ? (const double*)sp.cand_v : (const double*)sp.vals;
     const int* sel_i = two_level ? (const int*)sp.cand_i : (const int*)nullptr;
     const int64_t n_entries = two_level ? (int64_t)n_chunks * k_sel : index->n;
-    if (index->dtype == KZ_F32) {
+    bool lanes = false;
+    // (... from ~4 workgroups of 64 index rows per CU on: on a 15 k-row index its 235 workgroups run one per CU, all latency -- 73 us
+    //  against the cooperative kernel's 60)
+    if (index->dtype == KZ_F32 && index->n >= (int64_t)4 * KZ_XL_ROWS * ctx->n_cus) {
+        // (one pair per lane where that kernel applies: a pass over a 500 k x 200 index per FOUR rows made the cooperative kernel 2 ms
+        //  for 16 rows -- on the critical path behind the forward finalize; 0.3 ms)
+        const int rcl = kz_launch_exact_lanes(ctx, fail_list, 0, R, q0, query, index, metric, sp.vals, &lanes, fail_count, sp.qd);
+        if (rcl != KZ_OK) {
+            kz_spec_release(ctx, sp);
+            return rcl;
+        }
+    }
+    if (lanes) {
+    } else if (index->dtype == KZ_F32) {
         // (a handful of rows: short stretches of index rows per wave, so that the launch is wide -- 15 k rows: 235 x R / 4 workgroups)
         int rpw = (int)(index->n / 1024);
         rpw = rpw < 16 ? 16 : (rpw > 256 ? 256 : rpw);

@@ -45,6 +45,35 @@ def test_same_bits_as_the_one_pair_kernel(ctx, metric, d):
     np.testing.assert_array_equal(out[1][1], oi)
 
 
+@pytest.mark.parametrize("d", [64, 200, 300])
+def test_cosine_on_raw_rows_in_the_one_pair_per_lane_kernel(ctx, d):
+    """Fewer than 64 uncertified rows: the normalised float64 image of a cosine index is not built, and the one-pair-per-lane kernel
+    divides the raw rows itself (COS_RAW) -- the same bits as the other two kernels."""
+    from kiez_amd import _native as N
+    from oracle import kiez_oracle as O
+    rng = np.random.default_rng(100 + d)
+    q = rng.standard_normal((40, d)).astype(np.float32)
+    y = rng.standard_normal((5003, d)).astype(np.float32)
+    y[7] = 0.0
+    y[11] = y[3]
+    ctx.set_option("eps_scale", 1e30)
+    ctx.set_option("spec_rows", 0)         # (the ordinary exact path: 40 rows >= the lane kernel's 32, < the image's 64)
+    try:
+        out = {}
+        for rows in (0, 1, 2):
+            ctx.set_option("exact_rows", rows)
+            qm, ym = N.DeviceMatrix(ctx, q, "cosine"), N.DeviceMatrix(ctx, y, "cosine")     # (fresh matrices: no image from an earlier batch)
+            dd, ii, st = N.knn(ctx, qm, ym, 9)
+            assert st["n_fallback_rows"] == 40, st
+            out[rows] = (dd.numpy(), ii.numpy())
+    finally:
+        ctx.set_option("spec_rows", 64)
+    for rows in (1, 2):
+        np.testing.assert_array_equal(out[0][1], out[rows][1])
+        np.testing.assert_array_equal(out[0][0], out[rows][0])
+    np.testing.assert_array_equal(out[2][1], O.knn_exact(q.astype(np.float64), y.astype(np.float64), 9, "cosine")[1])
+
+
 def test_values_are_those_of_kz_pair_values(ctx):
     """... and bit for bit the values kz_pair_values gives for the same pairs (the ordering values that travel between GPUs)."""
     from kiez_amd import _native as N
