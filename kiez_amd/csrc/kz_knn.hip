@@ -2104,6 +2104,11 @@ static int kz_spec_rows(const kz_ctx* ctx, const kz_matrix* index, int k_eff) {
     if (ctx->spec_rows <= 0 || index->metric >= KZ_MANHATTAN || k_eff > 64) return 0;
     const double nd = (double)index->n * (double)index->d;
     int R = (int)(KZ_K_SPEC_ELEMS / (nd > 1.0 ? nd : 1.0)) & ~3;
+    // (where the one-pair-per-lane kernel takes the launch -- kz_spec_rescue -- the index is staged once per block of 16 query rows
+    //  whatever their number: 32 rows cost little more than 4; 1 M x 200: 0.53 ms for 4 rows, the re-search of 16 took 3.5 ms)
+    if (R < 32 && ctx->exact_rows >= 2 && index->dtype == KZ_F32 && (index->d & 3) == 0 && index->d <= 512 &&
+        index->n >= (int64_t)4 * 64 * ctx->n_cus && ((uintptr_t)index->raw & 15u) == 0)
+        R = 32;
     if (R > ctx->spec_rows) R = ctx->spec_rows & ~3;
     return R < 4 ? 0 : R;
 }
