@@ -2106,7 +2106,7 @@ static int kz_spec_rows(const kz_ctx* ctx, const kz_matrix* index, int k_eff) {
     int R = (int)(KZ_K_SPEC_ELEMS / (nd > 1.0 ? nd : 1.0)) & ~3;
     // (where the one-pair-per-lane kernel takes the launch -- kz_spec_rescue -- the index is staged once per block of 16 query rows
     //  whatever their number: 32 rows cost little more than 4; 1 M x 200: 0.53 ms for 4 rows, the re-search of 16 took 3.5 ms)
-    if (R < 32 && ctx->exact_rows >= 2 && index->dtype == KZ_F32 && (index->d & 3) == 0 && index->d <= 512 &&
+    if (R < 32 && nd <= 1.0e9 && ctx->exact_rows >= 2 && index->dtype == KZ_F32 && (index->d & 3) == 0 && index->d <= 512 &&   // (<= 4 GB of rows staged, 1.3 GB of values)
         index->n >= (int64_t)4 * 64 * ctx->n_cus && ((uintptr_t)index->raw & 15u) == 0)
         R = 32;
     if (R > ctx->spec_rows) R = ctx->spec_rows & ~3;

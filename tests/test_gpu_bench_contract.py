@@ -15,7 +15,7 @@ def test_default_bench_line_has_what_the_driver_reads(tmp_path):
     """The DRIVER'S command shape (`python3 bench.py --gpus 1 --steps K --warmup W`, the other workloads ON -- one step each here):
     one stdout line, short enough for the driver's bounded tail, that parses and carries `roofline` and `cpu_baseline`."""
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--other-steps", "1",
-                        "--other-warmup", "1", "--detail", str(tmp_path / "detail.json")], capture_output=True, text=True,
+                        "--other-warmup", "0", "--detail", str(tmp_path / "detail.json")], capture_output=True, text=True,
                        timeout=1500, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
