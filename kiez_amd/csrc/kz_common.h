@@ -20,16 +20,16 @@ constexpr int KZ_K_LONG_K = 1;   // 111 .. ~540 neighbours on the fused kernels 
 constexpr int KZ_K_FIN_WIDE = 1;   // finalize of > 160 selected candidates without O(n^2) sorts, several rows per gather step
 constexpr int KZ_K_RANGE_BOOT = 1;   // short-list routes: index range 0 first, the other ranges' lists start at the floor read off it
 constexpr double KZ_K_NESTED_MIN_MS = 2.0;   // the nested sample of the shared sweep is taken when it saves at least this many model-ms (sweep / stride)
-constexpr int KZ_K_DUAL_SHORT_DIV = 5;   // 
-constexpr int KZ_K_DUAL_SHORT_KP = 16;   // 
+constexpr int KZ_K_DUAL_SHORT_DIV = 5;   // short-list routes: one list of 16 per this many neighbours (k / 5 lists)
+constexpr int KZ_K_DUAL_SHORT_KP = 16;   // ... of this length
 constexpr int KZ_K_MIN_SPLITS = 1;   // minimum index splits per query tile in the large-item region
 constexpr int KZ_K_QGROUP = 0;   // query tiles per group of the work table (0 = automatic)
 constexpr int KZ_K_H_WIDE = 0;   // fp16 kernel: wide workgroups on one ring (kz_knn_h16.h "WIDE": measured slower on every shared sweep, round 6: 250 k x 1 M x 300 149.2 -> 151.4 ms)
 constexpr int KZ_K_H_WPS = 0;   // fp16 kernel: workgroups per CU (0 = automatic)
-constexpr double KZ_K_PROBE_MIN_MS = 12.0;   // ... unless the sweep is at least this many model-ms (2 n_q n_i d / 1e12) long
+constexpr double KZ_K_PROBE_MIN_MS = 12.0;   // searches below "probe_min_pairs" distance pairs take neither the tier probe nor a floor -- unless the sweep is at least this many model-ms (2 n_q n_i d / 1e12) long
 constexpr int KZ_K_EXACT_DIRECT_ROWS = 32;   // at most this many rows left by the split-bf16 tier skip the float32-operand kernel and go to the exact kernels
-constexpr double KZ_K_SPEC_ELEMS = 1.6e9;   // ... and at most this / (index rows x d) of them
-constexpr int KZ_K_FLOOR_PROBE = 1024;   // ... rows of the probe in kz_knn_dual
+constexpr double KZ_K_SPEC_ELEMS = 1.6e9;   // speculative rescue: at most this / (index rows x d) rows (and at most "spec_rows")
+constexpr int KZ_K_FLOOR_PROBE = 1024;   // seeded lists: rows of the probe in kz_knn_dual
 constexpr int KZ_K_DUAL_DEAL = 1;   // query rows dealt into load-balanced tiles
 constexpr int KZ_K_ESC_SHORT = 1;   // rows a K' = 16 pass cannot certify: more lists of 16 instead of lists of 64
 
