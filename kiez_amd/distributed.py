@@ -413,16 +413,25 @@ class RcclComm(Comm):
     @classmethod
     def from_file(cls, engine, rank: int, world: int, path: str, timeout_s: float = 120.0, **kw):
         import time
+        t0 = time.time()
         if rank == 0:
             tmp = path + ".tmp"
             with open(tmp, "wb") as fh:
                 fh.write(cls.unique_id())
             os.replace(tmp, path)     # (atomic: a reader never sees a partial id)
-        t0 = time.time()
-        while not os.path.exists(path):
+
+        def fresh():
+            # (a file left behind by an EARLIER job at the same path is older than this process' call: never taken for this job's id;
+            #  the ranks of one job call this within `stale_s` of each other)
+            try:
+                return os.path.getmtime(path) >= t0 - float(kw.get("stale_s", 30.0))
+            except OSError:
+                return False
+        while not fresh():
             if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"RcclComm.from_file: {path} did not appear within {timeout_s} s")
+                raise TimeoutError(f"RcclComm.from_file: no fresh {path} within {timeout_s} s")
             time.sleep(0.01)
+        kw.pop("stale_s", None)
         with open(path, "rb") as fh:
             uid = fh.read()
         return cls(engine, rank, world, uid, **kw)
