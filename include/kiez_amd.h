@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 6
+#define KZ_ABI_VERSION 7
 /* candidates per query the rescaling / sort kernels take (kz_knn itself returns up to 4096 neighbours) */
 #define KZ_MAX_CANDIDATES 4096
 /* entries per row kz_merge_topk merges (segments x segment length) */
@@ -76,6 +76,9 @@ typedef struct kz_knn_stats {
                                 launched speculatively behind the finalize kernel (no re-search, no extra synchronisation)        */
     double probe_ms;         /* tier / floor probe of a large search (a strided sample of the query rows searched first), incl. the
                                 ladder's second rung; not part of fallback_ms                                                 */
+    int64_t n_range_rows;    /* of n_fallback_rows: rows answered by the RANGE re-search -- the exact kernels on the index rows whose
+                                approximate key lies within the rounding bound of the row's k-th candidate, not on the whole index */
+    int64_t n_range_pairs;   /* (query row, index row) pairs the range re-search evaluated in float64                            */
 } kz_knn_stats;
 
 /* ---- library / context -------------------------------------------------------------------------------- */

@@ -40,7 +40,7 @@ MAX_FUSED_NEIGHBORS = 110   # neighbours per query ONE fused list keeps (list le
 MAX_NEIGHBORS = 4096
 MAX_HUBNESS_CANDIDATES = 4096  # n_candidates the device hubness kernels (transform, final sort) handle (KZ_MAX_CANDIDATES)
 MERGE_MAX_ENTRIES = 8192       # entries per row kz_merge_topk merges (KZ_MERGE_MAX_ENTRIES)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _ERR_TYPES = {1: ValueError, 2: RuntimeError, 3: NotImplementedError, 4: MemoryError, 5: ValueError}
 
@@ -65,6 +65,8 @@ class KnnStats(C.Structure):
         ("wide_lists", C.c_int32),
         ("n_spec_rows", C.c_int32),
         ("probe_ms", C.c_double),
+        ("n_range_rows", C.c_int64),
+        ("n_range_pairs", C.c_int64),
     ]
 
     def as_dict(self):

@@ -243,6 +243,8 @@ struct KnnFinParams {
     int64_t* out_ind;
     int* fail_count;
     int* fail_list;
+    double* fail_tau;     // optional, beside fail_list: the exact value of the row's k-th best CANDIDATE (+inf: fewer than k candidates) -- an
+                          // upper bound of its k-th neighbour's value whatever the tier: what the range re-search starts from (kz_range.h)
     unsigned long long* err_ratio_bits;  // max over certified candidates of |key~ - key| / eps (bits of a non-negative double)
 };
 
@@ -971,6 +973,7 @@ __device__ __forceinline__ void kz_finalize_query(const KnnFinParams& p, const i
         if (lane == 0) {
             const int pos = atomicAdd(p.fail_count, 1);
             p.fail_list[pos] = (int)qout;
+            if (p.fail_tau) p.fail_tau[pos] = Vr >= k_eff ? sv[k_eff - 1] : (double)INFINITY;
         }
         return;
     }
@@ -1586,7 +1589,9 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
                                                               int64_t n_entries, int64_t n_i, int k,
                                                               int exclude_self, const int64_t* __restrict__ self_ids,
                                                               int metric, double p, double* __restrict__ out_dist,
-                                                              int64_t* __restrict__ out_ind, const int* __restrict__ dyn_n = nullptr) {
+                                                              int64_t* __restrict__ out_ind, const int* __restrict__ dyn_n = nullptr,
+                                                              const long long* __restrict__ seg_off = nullptr, int* __restrict__ left = nullptr,
+                                                              int* __restrict__ left_cnt = nullptr) {
     __shared__ double s_v[4];
     __shared__ int s_i[4];
     extern __shared__ __attribute__((aligned(16))) char sel_sm[];   // k_eff doubles + k_eff ints (any k the host admits)
@@ -1599,6 +1604,18 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
     const double* v = vals + (int64_t)b * n_entries;
     const int* vid = cand_idx ? cand_idx + (int64_t)b * n_entries : nullptr;
     const int k_eff = (int)min((int64_t)(k + (exclude_self ? 1 : 0)), n_i);
+    if (seg_off) {
+        // range re-search (kz_range.h): row b's entries are the segment [seg_off[b], seg_off[b + 1]) of vals / cand_idx; a segment
+        // with fewer than k entries cannot answer its row -- the row is handed back (left)
+        const long long s0 = seg_off[b];
+        n_entries = seg_off[b + 1] - s0;
+        if (n_entries < k_eff) {
+            if (tid == 0) left[atomicAdd(left_cnt, 1)] = q;
+            return;
+        }
+        v = vals + s0;
+        vid = cand_idx + s0;
+    }
     double* s_sv = reinterpret_cast<double*>(sel_sm);
     int* s_si = reinterpret_cast<int*>(s_sv + k_eff);
     double pv = -1.0;  // values are >= 0
@@ -1865,6 +1882,7 @@ struct KzPass {
     float* out_key;   // candidate lists (scratch)
     int* out_idx;
     int* fail_list;   // [fail_rows] (scratch)
+    double* fail_tau; // [fail_rows] (scratch; KnnFinParams::fail_tau)
     int4* d_work;     // [W] (scratch)
 };
 
@@ -1886,16 +1904,18 @@ static int kz_prepare_pass(kz_ctx* ctx, int n_qtiles, int n_ytiles, int slots, i
     KZ_REQUIRE(list_elems < ((size_t)1 << 32), "kz_knn: the candidate lists of one launch exceed 2^32 entries (%zu): fewer rows per chunk (option chunk_rows)", list_elems);
     const size_t key_bytes = (list_elems * 4 + 255) & ~(size_t)255;
     const size_t fail_bytes = ((size_t)fail_rows * 4 + 255) & ~(size_t)255;
+    const size_t tau_bytes = ((size_t)fail_rows * 8 + 255) & ~(size_t)255;
     const size_t work_bytes = ((size_t)W * sizeof(int4) + 255) & ~(size_t)255;
     void* scratch = nullptr;
-    int rc = kz_scratch(ctx, key_bytes * 2 + fail_bytes + work_bytes, &scratch);
+    int rc = kz_scratch(ctx, key_bytes * 2 + fail_bytes + tau_bytes + work_bytes, &scratch);
     if (rc != KZ_OK) return rc;
     out->lay = lay;
     out->W = W;
     out->out_key = (float*)scratch;
     out->out_idx = (int*)((char*)scratch + key_bytes);
     out->fail_list = (int*)((char*)scratch + 2 * key_bytes);
-    out->d_work = (int4*)((char*)scratch + 2 * key_bytes + fail_bytes);
+    out->fail_tau = (double*)((char*)scratch + 2 * key_bytes + fail_bytes);
+    out->d_work = (int4*)((char*)scratch + 2 * key_bytes + fail_bytes + tau_bytes);
     {
         // host-side table (pinned staging grows on demand)
         const size_t need = work_bytes;
@@ -2067,6 +2087,7 @@ struct KzDualPass {
     int n_ytiles;
     int raw_lists;
     int max_entries;
+    int no_q64;                    // the 32-queries-per-wave build whatever "h_q64" says (kz_range.h reads that build's log format)
     const float* lists_key;
     const int* lists_idx;
     KzListLayout lists_lay;
@@ -2314,6 +2335,8 @@ static int kz_escalate_ladder(kz_ctx* ctx, kz_matrix* query, int64_t cq_begin, c
     if (ms_out) *ms_out += ms_probe;
     return rc;
 }
+
+#include "kz_range.h"
 
 static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q_count, kz_matrix* index, int k,
                        int exclude_self, const int64_t* d_self_ids, int precision_override, int kp_min, double* d_dist,
@@ -2578,7 +2601,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // chip (100k x 100k: +30 %).  Option "h_q64": 2 (default) = the shared sweep from 9 slices on over >= 4 rounds of units,
     // 1 = wherever the kernel is built for (tests), 0 = never.
     const bool q64_ok = tier == KZ_TIER_H && KP == 16 && kz_h64_supports(n_slices) && !exact_only;
-    const bool q64 = q64_ok && (ctx->h_q64 == 1 || (ctx->h_q64 == 2 && dual && n_slices >= 9 &&
+    const bool q64 = q64_ok && !(dual && dual->no_q64) && (ctx->h_q64 == 1 || (ctx->h_q64 == 2 && dual && n_slices >= 9 &&
                                                      (q_count + 2 * KZ_TILE - 1) / (2 * KZ_TILE) >= (int64_t)4 * 2 * ctx->n_cus));
     int slots_cache[3] = {0, 0, 0};
     int tpw_h = 1;   // query tiles per workgroup of the fp16 kernel this call runs (wide builds: 2 or 3)
@@ -2614,7 +2637,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         return KZ_ERR_INVALID;
     }
     double main_ms = 0, fin_ms = 0, fb_ms = 0;   // (the tier probe's time is reported under its own field, kz_knn_stats.probe_ms)
-    int64_t n_fail_total = 0, n_escalated = 0, n_first_fail = 0, n_spec = 0;
+    int64_t n_fail_total = 0, n_escalated = 0, n_first_fail = 0, n_spec = 0, n_range = 0, n_range_pairs = 0;
     double max_err_ratio = 0.0;
     int last_splits = 1, last_blocks = 0, first_tier = tier;
     for (int64_t c0 = 0; c0 < q_count;) {
@@ -2840,6 +2863,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         }
         fp.fail_count = fail_count;
         fp.fail_list = fail_list;
+        fp.fail_tau = ps.fail_tau;
         fp.err_ratio_bits = (unsigned long long*)(ctx->d_counters + 10);
         if (fp.tier_h && metric == KZ_COSINE && (fp.KSEL > 0 ? fp.KSEL : KP) > 160 && KZ_K_FIN_WIDE && !(dual && dual->raw_lists)) {
             // (hundreds of re-ranked candidates per query: the normalised float64 rows of the index, built once -- kz_pack.hip)
@@ -2903,7 +2927,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             memcpy(&unchecked[u]->max_norm, ctx->h_counters + 44 + 10 * u, 8);
             unchecked[u]->checked = true;
         }
-        const int n_fail = exact_only ? (int)cq_count : ctx->h_counters[8];
+        int n_fail = exact_only ? (int)cq_count : ctx->h_counters[8];
         n_first_fail += n_fail;
         {
             double ratio;
@@ -2989,6 +3013,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             fb_ms += ms;
             n_escalated += n_fail + st2.n_escalated_rows;
             n_fail_total += st2.n_fallback_rows;
+            n_range += st2.n_range_rows;
+            n_range_pairs += st2.n_range_pairs;
             if (st2.max_err_ratio > max_err_ratio) max_err_ratio = st2.max_err_ratio;
             c0 += max_rows_per_chunk;
             if (tier_next != tier && short_ord) {   // (the other tiers' kernels keep one list of K' per query)
@@ -3010,6 +3036,43 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&fl);  // stream-ordered pool: no device sync
             if (rc != KZ_OK) return rc;
             KZ_HIP(hipMemcpyAsync(fl, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+            // RANGE RE-SEARCH (kz_range.h): the exact kernels on the pairs that can matter; the rows it hands back -- and every
+            // row where it does not apply -- go on against the whole index below
+            int n_dense = n_fail;
+            if (!exact_only && n_fail >= KZ_RANGE_MIN_ROWS && kz_range_shapes_ok(ctx, query, index)) {
+                double* tau = nullptr;
+                int* left = nullptr;
+                rc = kz_pool_alloc(ctx, (size_t)n_fail * 8, (void**)&tau);
+                if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&left);
+                if (rc == KZ_OK && hipMemcpyAsync(tau, ps.fail_tau, (size_t)n_fail * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                    kz_set_error("kz_knn: copying the bounds of the uncertified rows failed");
+                    rc = KZ_ERR_HIP;
+                }
+                long long pairs = 0;
+                if (rc == KZ_OK)
+                    rc = kz_range_rescue(ctx, query, cq_begin, fl, tau, n_fail, index, k, exclude_self, d_self_ids, fp.out_dist, fp.out_ind, left,
+                                         &n_dense, &pairs);
+                kz_pool_free(ctx, tau, 0);
+                if (rc != KZ_OK) {
+                    kz_pool_free(ctx, left, 0);
+                    kz_pool_free(ctx, fl, 0);
+                    return rc;
+                }
+                n_range += n_fail - n_dense;
+                n_range_pairs += pairs;
+                kz_pool_free(ctx, fl, 0);   // (the rows handed back take the list's place)
+                fl = left;
+            }
+            n_fail = n_dense;
+            if (n_fail == 0) {
+                kz_pool_free(ctx, fl, 0);
+                KZ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+                KZ_HIP(hipStreamSynchronize(ctx->stream));
+                KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+                fb_ms += ms;
+                c0 += max_rows_per_chunk;
+                continue;
+            }
             if (metric == KZ_COSINE && n_fail >= 64 && ctx->exact_rows) {   // (many rows: the normalised float64 index rows, once)
                 rc = kz_matrix_norm64(index);
                 if (rc != KZ_OK) return rc;
@@ -3120,6 +3183,8 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         stats->n_first_pass_fail = n_first_fail > 0x7fffffff ? 0x7fffffff : (int32_t)n_first_fail;
         stats->wide_lists = wide_route ? long_pieces : 0;
         stats->n_spec_rows = n_spec > 0x7fffffff ? 0x7fffffff : (int32_t)n_spec;
+        stats->n_range_rows = n_range;
+        stats->n_range_pairs = n_range_pairs;
     }
     return KZ_OK;
 }

@@ -40,10 +40,11 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
     const int k_eff = p.k + (p.exclude_self ? 1 : 0);
     const int64_t qout = p.row_map ? qrow : q;
     const double qs = p.qsqn[qrow];
-    auto fail = [&]() {
+    auto fail = [&](const double tau = (double)INFINITY) {   // (tau: KnnFinParams::fail_tau)
         if (lane == 0) {
             const int pos = atomicAdd(p.fail_count, 1);
             p.fail_list[pos] = (int)qout;
+            if (p.fail_tau) p.fail_tau[pos] = tau;
         }
     };
     const int64_t lrow = p.list_row0 + q;
@@ -395,7 +396,7 @@ __device__ __forceinline__ void kz_finalize_query_wide(const KnnFinParams& p, co
         certified = Vr >= k_eff && (double)bound * key_scale + eps_q < exact_key(out_v[k_eff - 1]);
     if (bound_violated) certified = false;
     if (!certified) {
-        fail();
+        fail(Vr >= k_eff ? out_v[k_eff - 1] : (double)INFINITY);
         return;
     }
     kz_emit_sorted<T>(out_v, out_i, ns, p.k, p.exclude_self, p.self_ids ? p.self_ids[q] : qrow, p.metric,

@@ -1,0 +1,496 @@
+// RANGE RE-SEARCH (round 6): the exact float64 kernels on the PAIRS that can matter instead of on every pair.
+//
+// A row that no tier could certify used to end on the exact kernels against the WHOLE index -- n d multiply-adds per row: on
+// data whose clusters are orders of magnitude tighter than its extent (tools/cliff_probe.py, last kind) a tenth of the rows, 265 of
+// a 609 ms call on 200 k x 200 k x 200.  But the pass that failed the row has re-ranked its candidates in float64: the value tau of
+// its k-th best CANDIDATE bounds the value of its k-th NEIGHBOUR from above (any k exact values do), so a neighbour y has
+//     value(x, y) <= tau   =>   key(x, y) >= key(tau)   =>   key~(x, y) >= key(tau) - eps(x)
+// for the approximate keys key~ of ANY tier with its rounding bound eps (kz_finalize_query).  The rows at or above that threshold
+// are a few thousand rows of the row's own cluster, not the index.  So:
+//   1. kz_range_thr_kernel: thr(x) = (key(tau) - eps) / scale in the fp16 tier's key units, rounded down;
+//   2. the fp16 sweep kernel in its dual-pass build (kz_knn_h16.h, DUAL) over the failed rows: that build already logs, besides
+//      its lists, every group of four keys whose maximum reaches a per-(query, index tile) threshold qnbias(q) + theta(tile) -- the
+//      events of the shared sweep.  With theta = 0 and qnbias = thr it logs the range { y : key~(x, y) >= thr(x) }; its lists start
+//      at +inf and stay empty.  No new sweep kernel;
+//   3. kz_range_count_kernel / kz_range_scan_kernel / kz_range_fill_kernel: the log (unordered, groups of four) into one segment of
+//      index rows per failed row;
+//   4. kz_exact_pairs_kernel: the exact values of those pairs -- kz_exact_dist_rows_kernel's arithmetic operation for operation
+//      (bit-identical values), the index rows gathered through the segment;
+//   5. kz_exact_select_kernel over the segment: the k smallest by (value, row), written like every other route writes them.
+// A row whose segment holds fewer than k entries (tau = +inf: it never had k candidates), a batch whose log overflows its buffer
+// even at the smallest batch size: those rows go to the exact kernels against the whole index as before (`left`).  Correct for any
+// data; what the data decides is how many pairs are left -- uniform noise inside eps of everything keeps them all.
+// Reference: the brute-force search it replaces row by row, kiez/neighbors/exact/sklearn_nearest_neighbors.py:96-101.
+#pragma once
+
+constexpr int KZ_RANGE_MIN_ROWS = 128;      // fewer rows: the whole-index kernels (a sweep for a handful of rows costs more than it saves)
+constexpr int KZ_RANGE_BATCH = 32768;       // failed rows per sweep
+constexpr int KZ_RANGE_MIN_BATCH = 1024;    // a log that overflows at this batch size: the batch goes to `left`
+constexpr int KZ_RANGE_PPW = 256;           // pairs per wave of kz_exact_pairs_kernel
+
+// thr [n_pad]: the threshold of batch row i in the fp16 tier's key units (+inf: nothing is logged -- pad rows, tau = +inf);
+// inf_floor [n_pad] = +inf: the floor the sweep's lists start from (they stay empty).  The bound is kz_finalize_query's, term by term.
+__global__ void kz_range_thr_kernel(const double* __restrict__ tau, int nb, int64_t n_pad, const double* __restrict__ rowq,
+                                    const double* __restrict__ qsqn, const double* __restrict__ y_hmax, const double* __restrict__ hscale,
+                                    const double* __restrict__ ystats, int metric, double eps_mult, double gamma_acc,
+                                    float* __restrict__ thr, float* __restrict__ inf_floor) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    inf_floor[i] = INFINITY;
+    float t = INFINITY;
+    if (i < nb) {
+        const double tv = tau[i];
+        if (tv < (double)INFINITY) {
+            const double qc2 = rowq[i * 3 + 0], qh = rowq[i * 3 + 1], qr = rowq[i * 3 + 2];
+            const double Yh = y_hmax[0], Ry = y_hmax[1], Yc2 = y_hmax[2];
+            const double qc = sqrt(qc2), yc = sqrt(Yc2);
+            const double ymax = ystats[0];
+            const double raw2 = metric == KZ_COSINE ? 2.0 : qsqn[i] + ymax * ymax;
+            const double eps = eps_mult * (qr * Yh + qh * Ry + qr * Ry + gamma_acc * (0.5 * Yc2 + qh * Yh) +
+                                           1.1920928955078125e-07 * (qc + yc) * (qc + yc) + 1e-12 * (0.5 * Yc2 + qc2) + 1e-14 * raw2);
+            const double key = 0.5 * (qc2 - (metric == KZ_COSINE ? 2.0 * tv : tv));
+            const double want = (key - eps) / hscale[1];
+            float f = (float)want;
+            if ((double)f > want) f = nextafterf(f, -INFINITY);
+            t = nextafterf(f, -INFINITY);   // (one more: the threshold errs towards MORE pairs)
+            if (!(t == t)) t = -INFINITY;   // (never expected; a NaN threshold would log nothing)
+        }
+    }
+    thr[i] = t;
+}
+
+// Keys of a logged group that really are in the range of their row (the kernel logs a group when its MAXIMUM is): index rows
+// row0 .. row0 + 3 of the image = of the matrix (the sweep runs on the undealt image), query = batch row mt.y.
+__device__ __forceinline__ int kz_range_group(const f32x4e kv, const i32x2e mt, const float* __restrict__ thr, int64_t n_i, int* row0_out) {
+    const int ql = mt.x & 63, tg = mt.x >> 6;
+    const int row0 = (tg >> 4) * KZ_TILE + ((tg >> 2) & 3) * 32 + (tg & 3) * 8 + 4 * (ql >> 5);
+    const float t = thr[mt.y];
+    int m = 0;
+    m |= (kv.x >= t && row0 + 0 < n_i) ? 1 : 0;
+    m |= (kv.y >= t && row0 + 1 < n_i) ? 2 : 0;
+    m |= (kv.z >= t && row0 + 2 < n_i) ? 4 : 0;
+    m |= (kv.w >= t && row0 + 3 < n_i) ? 8 : 0;
+    *row0_out = row0;
+    return m;
+}
+__global__ __launch_bounds__(256) void kz_range_count_kernel(const f32x4e* __restrict__ log_keys, const i32x2e* __restrict__ log_meta,
+                                                             long long n_groups, const float* __restrict__ thr, int64_t n_i,
+                                                             int* __restrict__ cnt) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += (long long)gridDim.x * blockDim.x) {
+        const i32x2e mt = log_meta[i];
+        int row0;
+        const int m = kz_range_group(log_keys[i], mt, thr, n_i, &row0);
+        if (m) atomicAdd(cnt + mt.y, __popc(m));
+    }
+}
+// seg_off [nb + 1]: exclusive prefix sums of cnt [nb] (one workgroup of 1024 threads; nb <= KZ_RANGE_BATCH)
+__global__ __launch_bounds__(1024) void kz_range_scan_kernel(const int* __restrict__ cnt, int nb, long long* __restrict__ seg_off) {
+    __shared__ long long part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+    long long s = 0;
+    for (int i = lo; i < hi; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    long long run = part[tid] - s;
+    for (int i = lo; i < hi; ++i) {
+        seg_off[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 1023) seg_off[nb] = part[1023];
+}
+__global__ __launch_bounds__(256) void kz_range_fill_kernel(const f32x4e* __restrict__ log_keys, const i32x2e* __restrict__ log_meta,
+                                                            long long n_groups, const float* __restrict__ thr, int64_t n_i,
+                                                            const long long* __restrict__ seg_off, int* __restrict__ cur,
+                                                            int* __restrict__ pair_idx) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += (long long)gridDim.x * blockDim.x) {
+        const i32x2e mt = log_meta[i];
+        int row0;
+        const int m = kz_range_group(log_keys[i], mt, thr, n_i, &row0);
+        if (!m) continue;
+        long long o = seg_off[mt.y] + atomicAdd(cur + mt.y, __popc(m));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (m & (1 << u)) pair_idx[o++] = row0 + u;
+    }
+}
+
+// The exact values of the pairs (batch row r, index row pair_idx[p]) for p in [seg_off[r], seg_off[r + 1]): a wave takes
+// pairs_per_wave consecutive pairs of the flat array -- finds the row of its first pair by bisection, keeps that row's elements in
+// registers, and moves on to the next row where the segment ends.  A pair's arithmetic is kz_exact_dist_rows_kernel's (above):
+// the lane's four fma per 256-element chunk in element order, the butterfly inside the lane group, the same last line.
+template <int LPR, bool NORM, int NV = 1>
+__global__ __launch_bounds__(256) void kz_exact_pairs_kernel(const long long* __restrict__ seg_off, int n_rows, const int* __restrict__ fail_list,
+                                                             int batch0, int64_t q_begin, const float* __restrict__ qraw,
+                                                             const float* __restrict__ yraw, const double* __restrict__ ynorm64,
+                                                             const double* __restrict__ qsqn, const double* __restrict__ ysqn, int d, int metric,
+                                                             const int* __restrict__ pair_idx, double* __restrict__ pair_val, int pairs_per_wave) {
+    static_assert(NV == 1 || LPR == 64, "two chunks per lane: the whole wave owns one row");
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPR, sl = lane & (LPR - 1);
+    const int k0 = 4 * sl;
+    bool act[NV];
+    int k0r[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        act[c] = k0 + 256 * c < d;
+        k0r[c] = act[c] ? k0 + 256 * c : 0;
+    }
+    const long long total = seg_off[n_rows];
+    long long p0 = ((long long)blockIdx.x * 4 + wave) * pairs_per_wave;
+    if (p0 >= total) return;
+    const long long p1 = p0 + pairs_per_wave < total ? p0 + pairs_per_wave : total;
+    int r;
+    {   // the row of pair p0: seg_off[r] <= p0 < seg_off[r + 1]  (seg_off[0] = 0 <= p0 < total = seg_off[n_rows])
+        int lo = 0, hi = n_rows;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_off[mid] <= p0) lo = mid; else hi = mid;
+        }
+        r = lo;
+    }
+    struct Buf {
+        float4 f[NV];
+        double ys;
+        double2 n0[NV], n1[NV];
+    };
+    while (p0 < p1) {
+        while (seg_off[r + 1] <= p0) ++r;   // (empty segments)
+        const long long seg_end = seg_off[r + 1];
+        const long long rend = seg_end < p1 ? seg_end : p1;
+        const int64_t qrow = q_begin + fail_list[batch0 + r];
+        const double qs = qsqn[qrow];
+        double qk[4 * NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            if (act[c]) {
+                kz_row4(qraw + qrow * (int64_t)d, k0r[c], d, true, t);
+                if (metric == KZ_COSINE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = t[e] / qs;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qk[4 * c + e] = t[e];
+        }
+        auto issue = [&](long long i, Buf& b) {   // (pairs past the end: the last pair again, nothing is written for them)
+            const int64_t yi = pair_idx[i + grp < rend ? i + grp : rend - 1];
+            if (NORM) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    const double* row = ynorm64 + yi * (int64_t)d + k0r[c];
+                    b.n0[c] = *reinterpret_cast<const double2*>(row);
+                    b.n1[c] = *reinterpret_cast<const double2*>(row + 2);
+                }
+            } else {
+                b.ys = ysqn[yi];
+#pragma unroll
+                for (int c = 0; c < NV; ++c) b.f[c] = *reinterpret_cast<const float4*>(yraw + yi * (int64_t)d + k0r[c]);
+            }
+        };
+        auto reduce = [&](long long i, const Buf& b) {
+            double yv[4 * NV];
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[4 * c + e] = 0.0;
+                if (act[c]) {
+                    if (NORM) {
+                        yv[4 * c] = b.n0[c].x, yv[4 * c + 1] = b.n0[c].y, yv[4 * c + 2] = b.n1[c].x, yv[4 * c + 3] = b.n1[c].y;
+                    } else {
+                        const double yk[4] = {(double)b.f[c].x, (double)b.f[c].y, (double)b.f[c].z, (double)b.f[c].w};
+                        if (metric == KZ_COSINE) {
+                            const double rcp = 1.0 / b.ys;
+                            const bool fin = (((unsigned long long)__double_as_longlong(rcp) >> 52) & 0x7ff) != 0x7ff;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) yv[4 * c + e] = fin ? kz_div_shared(yk[e], b.ys, rcp) : yk[e] / b.ys;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) yv[4 * c + e] = yk[e];
+                        }
+                    }
+                }
+            }
+            double a = 0.0;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                if (act[c]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = fma(qk[4 * c + e], yv[4 * c + e], a);
+                }
+            }
+#pragma unroll
+            for (int off = LPR >> 1; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+            double v;
+            if (metric == KZ_COSINE)
+                v = fmin(fmax(1.0 - a, 0.0), 2.0);
+            else
+                v = fmax((qs + b.ys) - 2.0 * a, 0.0);
+            if (sl == 0 && i + grp < rend) pair_val[i + grp] = v;
+        };
+        Buf ba, bb;
+        issue(p0, ba);
+        for (long long i = p0; i < rend;) {   // (two steps in flight; the conditions are wave-uniform)
+            issue(i + G, bb);
+            reduce(i, ba);
+            i += G;
+            if (i >= rend) break;
+            issue(i + G, ba);
+            reduce(i, bb);
+            i += G;
+        }
+        p0 = rend;
+    }
+}
+static bool kz_range_shapes_ok(const kz_ctx* ctx, const kz_matrix* query, const kz_matrix* index) {
+    const int d = (int)index->d;
+    const int n_slices = index->kg / 4;
+    return ctx->exact_rows >= 3 && ctx->precision != 1 && index->dtype == KZ_F32 && (d & 3) == 0 && d <= 512 && index->metric <= KZ_COSINE &&
+           (((uintptr_t)query->raw | (uintptr_t)index->raw) & 15u) == 0 && n_slices >= 2 && n_slices <= 24 && query->kg == index->kg;
+}
+static void kz_launch_exact_pairs(kz_ctx* ctx, const long long* seg_off, int nb, const int* fl, int b0, int64_t q_begin, const kz_matrix* query,
+                                  const kz_matrix* index, long long total, const int* pair_idx, double* pair_val) {
+    const int d = (int)index->d, metric = index->metric;
+    const bool norm = metric == KZ_COSINE && index->norm64 != nullptr;
+    const long long waves = (total + KZ_RANGE_PPW - 1) / KZ_RANGE_PPW;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    const int lanes = (d + 3) >> 2;
+#define KZ_EXACT_PAIRS(L, NVV)                                                                                                               \
+    do {                                                                                                                                     \
+        if (norm)                                                                                                                            \
+            hipLaunchKernelGGL((kz_exact_pairs_kernel<L, true, NVV>), grid, dim3(256), 0, ctx->stream, seg_off, nb, fl, b0, q_begin,         \
+                               (const float*)query->raw, (const float*)index->raw, index->norm64, query->sqn, index->sqn, d, metric,         \
+                               pair_idx, pair_val, KZ_RANGE_PPW);                                                                            \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((kz_exact_pairs_kernel<L, false, NVV>), grid, dim3(256), 0, ctx->stream, seg_off, nb, fl, b0, q_begin,        \
+                               (const float*)query->raw, (const float*)index->raw, (const double*)nullptr, query->sqn, index->sqn, d, metric, \
+                               pair_idx, pair_val, KZ_RANGE_PPW);                                                                            \
+    } while (0)
+    if (lanes <= 8)
+        KZ_EXACT_PAIRS(8, 1);
+    else if (lanes <= 16)
+        KZ_EXACT_PAIRS(16, 1);
+    else if (lanes <= 32)
+        KZ_EXACT_PAIRS(32, 1);
+    else if (lanes <= 64)
+        KZ_EXACT_PAIRS(64, 1);
+    else
+        KZ_EXACT_PAIRS(64, 2);
+#undef KZ_EXACT_PAIRS
+}
+
+// fl / tau [n_fail] (device; the caller's copies -- not in the context's scratch block, which the sweep below re-carves): rows
+// q0 + fl[i] of `query`.  Results of the rows it answers go to out_dist / out_ind at row fl[i]; the others are appended to
+// left [n_fail] (device), *n_left = their number.  Ends synchronised with the stream.  n_pairs_out: pairs evaluated (statistics).
+static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int* fl, const double* tau, int n_fail, kz_matrix* index, int k,
+                           int exclude_self, const int64_t* d_self_ids, double* out_dist, int64_t* out_ind, int* left, int* n_left,
+                           long long* n_pairs_out) {
+    *n_left = 0;
+    if (n_pairs_out) *n_pairs_out = 0;
+    const int metric = index->metric;
+    const int k_eff = k + (exclude_self ? 1 : 0);
+    const int k_sel = (int)(k_eff < index->n ? k_eff : index->n);
+    const size_t sel_lds = (size_t)k_sel * 12 + 16;
+    const size_t row_bytes = (size_t)query->d * 4;
+    const int64_t y_pad = index->n_tiles * KZ_TILE;
+    // the log: 24 bytes per group of four keys -- at most a quarter of the free memory, at most 2^28 groups (6 GiB)
+    size_t mem_free = 0, mem_total = 0;
+    KZ_HIP(hipMemGetInfo(&mem_free, &mem_total));
+    long long log_cap = (long long)(mem_free / 4 / 24);
+    if (log_cap > (1ll << 28)) log_cap = 1ll << 28;
+    if (log_cap < (1ll << 16)) {   // (no room for a log worth sweeping for: everything stays with the caller)
+        KZ_HIP(hipMemcpyAsync(left, fl, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        KZ_HIP(hipStreamSynchronize(ctx->stream));
+        *n_left = n_fail;
+        return KZ_OK;
+    }
+    if (metric == KZ_COSINE) {   // (the normalised float64 rows of the index, once -- as the whole-index kernels take them)
+        const int rc = kz_matrix_norm64(index);
+        if (rc != KZ_OK) return rc;
+    }
+    float* theta0 = nullptr;
+    void *log_keys = nullptr, *log_meta = nullptr;
+    unsigned long long* counters = nullptr;   // [0] the log's group counter, [1] rows appended to `left`
+    int rc = kz_pool_alloc(ctx, (size_t)y_pad * 4, (void**)&theta0);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 16, &log_keys);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 8, &log_meta);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, 64, (void**)&counters);
+    auto release_all = [&]() {
+        kz_pool_free(ctx, theta0, 0);
+        kz_pool_free(ctx, log_keys, 0);
+        kz_pool_free(ctx, log_meta, 0);
+        kz_pool_free(ctx, counters, 0);
+    };
+    if (rc != KZ_OK) {
+        release_all();
+        if (rc != KZ_ERR_NOMEM) return rc;
+        KZ_HIP(hipMemcpyAsync(left, fl, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        KZ_HIP(hipStreamSynchronize(ctx->stream));
+        *n_left = n_fail;
+        return KZ_OK;
+    }
+    hipError_t e = hipMemsetAsync(theta0, 0, (size_t)y_pad * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 64, ctx->stream);
+    if (e != hipSuccess) {
+        release_all();
+        kz_set_error("kz_knn: range re-search: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    int* left_cnt = (int*)(counters + 1);
+    long long pairs_total = 0;
+    auto read_back = [&](void* dst, const void* src, size_t bytes) -> hipError_t {   // (behind everything queued on the context's stream)
+        const hipError_t e1 = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        return e1 != hipSuccess ? e1 : hipStreamSynchronize(ctx->stream);
+    };
+    int batch = n_fail < KZ_RANGE_BATCH ? n_fail : KZ_RANGE_BATCH;
+    for (int b0 = 0; b0 < n_fail;) {
+        const int nb = n_fail - b0 < batch ? n_fail - b0 : batch;
+        // ---- the batch's rows as a matrix of their own, their thresholds, the sweep ------------------------------------
+        void* sub_raw = nullptr;
+        kz_matrix* qsub = nullptr;
+        float *thr = nullptr, *inff = nullptr;
+        int* cnt = nullptr;   // [nb] pairs per row, then [nb] fill cursors
+        long long* seg_off = nullptr;
+        int* pair_idx = nullptr;
+        double* pair_val = nullptr;
+        auto release = [&]() {
+            if (qsub) kz_matrix_destroy(qsub);
+            kz_pool_free(ctx, sub_raw, 0);
+            kz_pool_free(ctx, thr, 0);
+            kz_pool_free(ctx, inff, 0);
+            kz_pool_free(ctx, cnt, 0);
+            kz_pool_free(ctx, seg_off, 0);
+            kz_pool_free(ctx, pair_idx, 0);
+            kz_pool_free(ctx, pair_val, 0);
+        };
+        auto fail = [&](int code) {
+            release();
+            release_all();
+            return code;
+        };
+        const int64_t n_pad = (int64_t)((nb + KZ_TILE - 1) / KZ_TILE) * KZ_TILE;
+        rc = kz_pool_alloc(ctx, (size_t)nb * row_bytes, &sub_raw);
+        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&thr);
+        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_pad * 4, (void**)&inff);
+        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)nb * 2 * sizeof(int), (void**)&cnt);
+        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)(nb + 1) * sizeof(long long), (void**)&seg_off);
+        if (rc != KZ_OK) return fail(rc);
+        hipLaunchKernelGGL(kz_gather_rows_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const char*)query->raw, fl + b0, q0, nb, (int64_t)row_bytes,
+                           (char*)sub_raw, (int64_t*)nullptr, (const int64_t*)nullptr);
+        rc = kz_matrix_create(ctx, sub_raw, 2, nb, query->d, query->dtype, query->metric, &qsub);
+        if (rc == KZ_OK) rc = kz_himage_ensure(qsub, index);
+        if (rc != KZ_OK) return fail(rc);
+        hipLaunchKernelGGL(kz_range_thr_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, tau + b0, nb, n_pad,
+                           qsub->himg->rowq, qsub->sqn, index->himg->d_max, index->himg->center->d_scale, index->d_stats, metric, ctx->eps_scale,
+                           kz_gamma_acc_h(index->kg), thr, inff);
+        e = hipMemsetAsync(counters, 0, 8, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, (size_t)nb * 2 * sizeof(int), ctx->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            kz_set_error("kz_knn: range re-search: %s", hipGetErrorString(e));
+            return fail(KZ_ERR_HIP);
+        }
+        KzDualPass dp;
+        memset(&dp, 0, sizeof(dp));
+        dp.probed = 1;
+        dp.qpack = (const float*)qsub->himg->packed;
+        dp.ypack = (const float*)index->himg->packed;
+        dp.ybias = index->himg->bias;
+        dp.theta = theta0;
+        dp.qnbias = thr;
+        dp.qfloor = inff;
+        dp.log_keys = log_keys;
+        dp.log_meta = log_meta;
+        dp.log_cnt = counters;
+        dp.log_cap = log_cap;
+        dp.raw_lists = 1;
+        dp.no_q64 = 1;
+        kz_knn_stats st;
+        // (k = 1: lists of 16 -- the build with the most workgroups per CU; nothing is finalized, out_dist / out_ind are not written)
+        rc = kz_knn_impl(ctx, qsub, 0, nb, index, 1, 0, nullptr, 0, 0, out_dist, out_ind, &st, &dp);
+        if (rc != KZ_OK) return fail(rc);
+        unsigned long long n_groups = 0;
+        if (read_back(&n_groups, counters, 8) != hipSuccess) {
+            kz_set_error("kz_knn: range re-search: reading the log counter failed");
+            return fail(KZ_ERR_HIP);
+        }
+        bool over = dp.broken || st.first_pass != KZ_TIER_H || n_groups > (unsigned long long)log_cap;
+        long long total = 0;
+        if (!over && n_groups > 0) {
+            const int gb = (int)((n_groups + 255) / 256 < 8192 ? (n_groups + 255) / 256 : 8192);
+            hipLaunchKernelGGL(kz_range_count_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const f32x4e*)log_keys, (const i32x2e*)log_meta,
+                               (long long)n_groups, thr, index->n, cnt);
+        }
+        if (!over) {
+            hipLaunchKernelGGL(kz_range_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, nb, seg_off);
+            if (hipGetLastError() != hipSuccess || read_back(&total, seg_off + nb, 8) != hipSuccess) {
+                kz_set_error("kz_knn: range re-search: counting the pairs failed");
+                return fail(KZ_ERR_HIP);
+            }
+            // (idx + value: 12 bytes a pair, at most a quarter of what is free now)
+            size_t f2 = 0, t2 = 0;
+            KZ_HIP(hipMemGetInfo(&f2, &t2));
+            if ((size_t)total * 12 > f2 / 4) over = true;
+        }
+        if (over) {
+            release();
+            if (batch > KZ_RANGE_MIN_BATCH && nb > KZ_RANGE_MIN_BATCH) {   // the same rows again, fewer per sweep
+                batch = batch / 4 > KZ_RANGE_MIN_BATCH ? batch / 4 : KZ_RANGE_MIN_BATCH;
+                continue;
+            }
+            // (its rows stay with the caller: appended to `left` by a copy -- left_cnt is only read by this stream)
+            int have = 0;
+            hipError_t e2 = read_back(&have, left_cnt, sizeof(int));
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(left + have, fl + b0, (size_t)nb * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
+            have += nb;
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(left_cnt, &have, sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+            if (e2 != hipSuccess) {
+                release_all();
+                kz_set_error("kz_knn: range re-search: %s", hipGetErrorString(e2));
+                return KZ_ERR_HIP;
+            }
+            b0 += nb;
+            continue;
+        }
+        if (total > 0) {
+            rc = kz_pool_alloc(ctx, (size_t)total * 4, (void**)&pair_idx);
+            if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)total * 8, (void**)&pair_val);
+            if (rc != KZ_OK) return fail(rc);
+            const int gb = (int)((n_groups + 255) / 256 < 8192 ? (n_groups + 255) / 256 : 8192);
+            hipLaunchKernelGGL(kz_range_fill_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const f32x4e*)log_keys, (const i32x2e*)log_meta,
+                               (long long)n_groups, thr, index->n, seg_off, cnt + nb, pair_idx);
+            kz_launch_exact_pairs(ctx, seg_off, nb, fl, b0, q0, query, index, total, pair_idx, pair_val);
+        }
+        hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(nb), dim3(256), sel_lds, ctx->stream, fl, b0, q0, (const double*)pair_val,
+                           (const int*)pair_idx, (int64_t)0, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p, out_dist, out_ind,
+                           (const int*)nullptr, (const long long*)seg_off, left, left_cnt);
+        e = hipGetLastError();
+        if (e != hipSuccess) {
+            kz_set_error("kz_knn: range re-search: %s", hipGetErrorString(e));
+            return fail(KZ_ERR_HIP);
+        }
+        pairs_total += total;
+        release();   // (stream-ordered pool: the launches above have the buffers)
+        b0 += nb;
+    }
+    int have = 0;
+    e = read_back(&have, left_cnt, sizeof(int));
+    release_all();
+    if (e != hipSuccess) {
+        kz_set_error("kz_knn: range re-search failed: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    *n_left = have;
+    if (n_pairs_out) *n_pairs_out = pairs_total;
+    return KZ_OK;
+}
