@@ -64,7 +64,7 @@ struct kz_ctx {
     int dual_nested;  // kz_knn_dual: 1 (default) = the sample is the first tiles of the dealt image and is swept ONLY by the sample sweep (kz_knn_dual.h "NESTED")
     int esc_ladder;   // 1 (default): kz_knn.hip "LADDER AFTER THE FACT"
     int exact_rows;   // 1 (default): the exact distance kernel that keeps four query rows in registers and takes 64 / LPR index rows per step
-    int abl;          // diagnostics (bit mask): 1 = kz_knn.hip "abl_refloor", 2 = "abl_stamp"
+    int abl;          // diagnostics (bit mask): 1 = kz_knn.hip "abl_refloor", 2 = "abl_stamp", 4 / 8 = kz_range.h (overflow / hand-back paths)
     double floor_margin;  // seeded lists: the largest shortfall of the probe below the model, times this (default 1.3; 0 = the model itself: a test knob)
     int dual_rank;    // kz_knn_dual: rank of the sample key that becomes a row's event threshold (0 = automatic, -1 = k + 1, > 0 = that rank; kz_knn_dual.h)
     int spec_rows;    // exact kernels launched speculatively behind every finalize kernel for up to this many uncertified rows (default 64; kz_knn.hip "SPECULATIVE RESCUE")

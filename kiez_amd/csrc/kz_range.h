@@ -28,7 +28,8 @@ constexpr int KZ_RANGE_BATCH = 32768;       // failed rows per sweep
 constexpr int KZ_RANGE_MIN_BATCH = 1024;    // a log that overflows at this batch size: the batch goes to `left`
 constexpr int KZ_RANGE_PPW = 256;           // pairs per wave of kz_exact_pairs_kernel
 
-// thr [n_pad]: the threshold of batch row i in the fp16 tier's key units (+inf: nothing is logged -- pad rows, tau = +inf);
+// thr [n_pad]: the threshold of batch row i in the fp16 tier's key units (+inf: nothing is logged -- pad rows, tau = +inf; diagnostic
+// "abl" bit 8: every row, as if no row had k candidates);
 // inf_floor [n_pad] = +inf: the floor the sweep's lists start from (they stay empty).  The bound is kz_finalize_query's, term by term.
 __global__ void kz_range_thr_kernel(const double* __restrict__ tau, int nb, int64_t n_pad, const double* __restrict__ rowq,
                                     const double* __restrict__ qsqn, const double* __restrict__ y_hmax, const double* __restrict__ hscale,
@@ -157,10 +158,16 @@ __global__ __launch_bounds__(256) void kz_exact_pairs_kernel(const long long* __
         }
         r = lo;
     }
+    // U pairs per lane group and step, two steps in flight, the index rows of the step after those already read (a pair is two
+    // dependent loads: its index row's number, then the row).  Measured at d = 200, 4.1e7 pairs: 5.65 ms = 5.8 TB/s of gathered rows
+    // -- what the memory side delivers for 800-byte rows in random order; one pair per step: 5.82 ms; the segments ordered so that
+    // rows with the same range run together (their index rows then fit the memory-side cache, not an XCD's L2): no change.
+    constexpr int U = NV == 1 ? 4 : 2;
+    constexpr int STEP = U * G;
     struct Buf {
-        float4 f[NV];
-        double ys;
-        double2 n0[NV], n1[NV];
+        float4 f[U][NV];
+        double ys[U];
+        double2 n0[U][NV], n1[U][NV];
     };
     while (p0 < p1) {
         while (seg_off[r + 1] <= p0) ++r;   // (empty segments)
@@ -182,71 +189,90 @@ __global__ __launch_bounds__(256) void kz_exact_pairs_kernel(const long long* __
 #pragma unroll
             for (int e = 0; e < 4; ++e) qk[4 * c + e] = t[e];
         }
-        auto issue = [&](long long i, Buf& b) {   // (pairs past the end: the last pair again, nothing is written for them)
-            const int64_t yi = pair_idx[i + grp < rend ? i + grp : rend - 1];
-            if (NORM) {
+        auto load_idx = [&](long long i, int (&ix)[U]) {   // (pairs past the end: the last pair again, nothing is written for them)
 #pragma unroll
-                for (int c = 0; c < NV; ++c) {
-                    const double* row = ynorm64 + yi * (int64_t)d + k0r[c];
-                    b.n0[c] = *reinterpret_cast<const double2*>(row);
-                    b.n1[c] = *reinterpret_cast<const double2*>(row + 2);
+            for (int u = 0; u < U; ++u) {
+                const long long p = i + u * G + grp;
+                ix[u] = pair_idx[p < rend ? p : rend - 1];
+            }
+        };
+        auto issue = [&](const int (&ix)[U], Buf& b) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t yi = ix[u];
+                if (NORM) {
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) {
+                        const double* row = ynorm64 + yi * (int64_t)d + k0r[c];
+                        b.n0[u][c] = *reinterpret_cast<const double2*>(row);
+                        b.n1[u][c] = *reinterpret_cast<const double2*>(row + 2);
+                    }
+                } else {
+                    b.ys[u] = ysqn[yi];
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) b.f[u][c] = *reinterpret_cast<const float4*>(yraw + yi * (int64_t)d + k0r[c]);
                 }
-            } else {
-                b.ys = ysqn[yi];
-#pragma unroll
-                for (int c = 0; c < NV; ++c) b.f[c] = *reinterpret_cast<const float4*>(yraw + yi * (int64_t)d + k0r[c]);
             }
         };
         auto reduce = [&](long long i, const Buf& b) {
-            double yv[4 * NV];
 #pragma unroll
-            for (int c = 0; c < NV; ++c) {
+            for (int u = 0; u < U; ++u) {
+                double yv[4 * NV];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) yv[4 * c + e] = 0.0;
-                if (act[c]) {
-                    if (NORM) {
-                        yv[4 * c] = b.n0[c].x, yv[4 * c + 1] = b.n0[c].y, yv[4 * c + 2] = b.n1[c].x, yv[4 * c + 3] = b.n1[c].y;
-                    } else {
-                        const double yk[4] = {(double)b.f[c].x, (double)b.f[c].y, (double)b.f[c].z, (double)b.f[c].w};
-                        if (metric == KZ_COSINE) {
-                            const double rcp = 1.0 / b.ys;
-                            const bool fin = (((unsigned long long)__double_as_longlong(rcp) >> 52) & 0x7ff) != 0x7ff;
+                for (int c = 0; c < NV; ++c) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) yv[4 * c + e] = fin ? kz_div_shared(yk[e], b.ys, rcp) : yk[e] / b.ys;
+                    for (int e = 0; e < 4; ++e) yv[4 * c + e] = 0.0;
+                    if (act[c]) {
+                        if (NORM) {
+                            yv[4 * c] = b.n0[u][c].x, yv[4 * c + 1] = b.n0[u][c].y, yv[4 * c + 2] = b.n1[u][c].x, yv[4 * c + 3] = b.n1[u][c].y;
                         } else {
+                            const double yk[4] = {(double)b.f[u][c].x, (double)b.f[u][c].y, (double)b.f[u][c].z, (double)b.f[u][c].w};
+                            if (metric == KZ_COSINE) {
+                                const double rcp = 1.0 / b.ys[u];
+                                const bool fin = (((unsigned long long)__double_as_longlong(rcp) >> 52) & 0x7ff) != 0x7ff;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) yv[4 * c + e] = yk[e];
+                                for (int e = 0; e < 4; ++e) yv[4 * c + e] = fin ? kz_div_shared(yk[e], b.ys[u], rcp) : yk[e] / b.ys[u];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) yv[4 * c + e] = yk[e];
+                            }
                         }
                     }
                 }
-            }
-            double a = 0.0;
+                double a = 0.0;
 #pragma unroll
-            for (int c = 0; c < NV; ++c) {
-                if (act[c]) {
+                for (int c = 0; c < NV; ++c) {
+                    if (act[c]) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a = fma(qk[4 * c + e], yv[4 * c + e], a);
+                        for (int e = 0; e < 4; ++e) a = fma(qk[4 * c + e], yv[4 * c + e], a);
+                    }
                 }
-            }
 #pragma unroll
-            for (int off = LPR >> 1; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
-            double v;
-            if (metric == KZ_COSINE)
-                v = fmin(fmax(1.0 - a, 0.0), 2.0);
-            else
-                v = fmax((qs + b.ys) - 2.0 * a, 0.0);
-            if (sl == 0 && i + grp < rend) pair_val[i + grp] = v;
+                for (int off = LPR >> 1; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+                double v;
+                if (metric == KZ_COSINE)
+                    v = fmin(fmax(1.0 - a, 0.0), 2.0);
+                else
+                    v = fmax((qs + b.ys[u]) - 2.0 * a, 0.0);
+                const long long p = i + u * G + grp;
+                if (sl == 0 && p < rend) pair_val[p] = v;
+            }
         };
         Buf ba, bb;
-        issue(p0, ba);
-        for (long long i = p0; i < rend;) {   // (two steps in flight; the conditions are wave-uniform)
-            issue(i + G, bb);
+        int ia[U], ib[U];
+        load_idx(p0, ia);
+        issue(ia, ba);
+        load_idx(p0 + STEP, ib);
+        for (long long i = p0; i < rend;) {   // (two steps in flight, the rows of a third known; the conditions are wave-uniform)
+            issue(ib, bb);
+            load_idx(i + 2 * STEP, ia);
             reduce(i, ba);
-            i += G;
+            i += STEP;
             if (i >= rend) break;
-            issue(i + G, ba);
+            issue(ia, ba);
+            load_idx(i + 2 * STEP, ib);
             reduce(i, bb);
-            i += G;
+            i += STEP;
         }
         p0 = rend;
     }
@@ -307,7 +333,8 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
     KZ_HIP(hipMemGetInfo(&mem_free, &mem_total));
     long long log_cap = (long long)(mem_free / 4 / 24);
     if (log_cap > (1ll << 28)) log_cap = 1ll << 28;
-    if (log_cap < (1ll << 16)) {   // (no room for a log worth sweeping for: everything stays with the caller)
+    if ((ctx->abl & 4) && log_cap > 4096) log_cap = 4096;   // (diagnostic: a log that overflows -- every batch is handed back)
+    if (log_cap < (1ll << 16) && !(ctx->abl & 4)) {   // (no room for a log worth sweeping for: everything stays with the caller)
         KZ_HIP(hipMemcpyAsync(left, fl, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
         KZ_HIP(hipStreamSynchronize(ctx->stream));
         *n_left = n_fail;
@@ -389,7 +416,7 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
         rc = kz_matrix_create(ctx, sub_raw, 2, nb, query->d, query->dtype, query->metric, &qsub);
         if (rc == KZ_OK) rc = kz_himage_ensure(qsub, index);
         if (rc != KZ_OK) return fail(rc);
-        hipLaunchKernelGGL(kz_range_thr_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, tau + b0, nb, n_pad,
+        hipLaunchKernelGGL(kz_range_thr_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, tau + b0, (ctx->abl & 8) ? 0 : nb, n_pad,
                            qsub->himg->rowq, qsub->sqn, index->himg->d_max, index->himg->center->d_scale, index->d_stats, metric, ctx->eps_scale,
                            kz_gamma_acc_h(index->kg), thr, inff);
         e = hipMemsetAsync(counters, 0, 8, ctx->stream);

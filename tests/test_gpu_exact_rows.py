@@ -15,7 +15,7 @@ def ctx():
     c = N.Context.get()
     yield c
     c.set_option("eps_scale", 1.0)
-    c.set_option("exact_rows", 2)
+    c.set_option("exact_rows", 3)
 
 
 @pytest.mark.parametrize("metric", ["euclidean", "sqeuclidean", "cosine"])

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libkiez_amd.so does not export {name}"
     bound = {s[0] for s in N.SYMBOLS}
     assert set(declared) == bound, f"ctypes prototypes out of sync with the header: {set(declared) ^ bound}"
-    assert lib.kz_abi_version() == N.ABI_VERSION == 6
+    assert lib.kz_abi_version() == N.ABI_VERSION == 7
 
 
 def test_code_object_is_gfx950_only():
