@@ -79,6 +79,8 @@ typedef struct kz_knn_stats {
     int64_t n_range_rows;    /* of n_fallback_rows: rows answered by the RANGE re-search -- the exact kernels on the index rows whose
                                 approximate key lies within the rounding bound of the row's k-th candidate, not on the whole index */
     int64_t n_range_pairs;   /* (query row, index row) pairs the range re-search evaluated in float64                            */
+    int64_t n_range_group_rows; /* of n_range_rows: rows answered as part of a GROUP -- rows of one tight cluster share the range of a
+                                representative row: a dense block of pairs instead of one range per row                        */
 } kz_knn_stats;
 
 /* ---- library / context -------------------------------------------------------------------------------- */

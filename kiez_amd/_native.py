@@ -67,6 +67,7 @@ class KnnStats(C.Structure):
         ("probe_ms", C.c_double),
         ("n_range_rows", C.c_int64),
         ("n_range_pairs", C.c_int64),
+        ("n_range_group_rows", C.c_int64),
     ]
 
     def as_dict(self):

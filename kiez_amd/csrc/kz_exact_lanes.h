@@ -42,6 +42,27 @@ __global__ __launch_bounds__(256) void kz_exact_qprep_kernel(const int* __restri
     }
 }
 
+// The same for the rows of MANY blocks at once (kz_range.h, grouped ranges): rows [n_slots] holds the query row of every operand row
+// (relative to q_begin), -1 = a padding row of a block (zeros).
+__global__ __launch_bounds__(256) void kz_exact_qprep_slots_kernel(const int* __restrict__ rows, int64_t q_begin, const float* __restrict__ qraw,
+                                                                   const double* __restrict__ qsqn, int d, int d_pad, int metric,
+                                                                   double* __restrict__ qd, double* __restrict__ qsq) {
+    const int b = blockIdx.x;
+    const int r = rows[b];
+    const bool live = r >= 0;
+    const int64_t qrow = live ? q_begin + r : 0;
+    const double qs = live ? qsqn[qrow] : 1.0;
+    if (threadIdx.x == 0) qsq[b] = live ? qs : 0.0;
+    for (int e = threadIdx.x; e < d_pad; e += 256) {
+        double v = 0.0;
+        if (live && e < d) {
+            v = (double)qraw[qrow * (int64_t)d + e];
+            if (metric == KZ_COSINE) v = v / qs;
+        }
+        qd[(int64_t)b * d_pad + e] = v;
+    }
+}
+
 constexpr int KZ_XL_ROWS = 64;   // index rows per workgroup tile = lanes of a wave
 constexpr int KZ_XL_Q = 4;       // query rows a wave carries through the tree at once (a workgroup: 4 waves x 4 rows per block)
 
@@ -90,12 +111,31 @@ __host__ __device__ constexpr int kz_bitrev(int i) {
 // COS_RAW: cosine on the RAW float32 rows (no normalised float64 image of the index): the lane divides its row's elements by the
 // row's norm as the cooperative kernel does (one reciprocal per row, kz_div_shared: the IEEE quotient) -- per leaf, shared by the
 // wave's four query rows.
-template <int NLEAF, int NV, typename ELT, bool COS_RAW = false>
+// GATHER (kz_range.h, grouped ranges): ONE launch for many dense blocks.  Block g = blockIdx.z has its own query rows (nb of them,
+// operand rows from qd_off on) and its own "index": the list gather [gather_off .. + n_rows) of index rows -- row i of the block is
+// row gather[i] of yrows / ysqn; its values go to vals [val_off + b n_rows + i].  blockIdx.y takes `q_chunk` query rows of the block
+// (a multiple of the workgroup's 16): a block of a few hundred query rows x a few thousand index rows fills the chip.
+struct KzXlGroup {
+    int nb, n_rows;
+    long long qd_off, gather_off, val_off;   // operand rows (in rows), list entries, values
+};
+template <int NLEAF, int NV, typename ELT, bool COS_RAW = false, bool GATHER = false>
 __global__ __launch_bounds__(256) void kz_exact_dist_lanes_kernel(int nb, const double* __restrict__ qd, const double* __restrict__ qsq,
                                                                   const ELT* __restrict__ yrows, const double* __restrict__ ysqn, int64_t n_i, int d,
                                                                   int d_pad, int metric, double* __restrict__ vals,
-                                                                  const int* __restrict__ dyn_n = nullptr) {
+                                                                  const int* __restrict__ dyn_n = nullptr, const int* __restrict__ gather = nullptr,
+                                                                  const KzXlGroup* __restrict__ groups = nullptr, int q_chunk = 0) {
     extern __shared__ __attribute__((aligned(16))) char xl_sm[];
+    if constexpr (GATHER) {
+        const KzXlGroup g = groups[blockIdx.z];
+        nb = g.nb;
+        n_i = g.n_rows;
+        qd += (size_t)g.qd_off * d_pad;
+        qsq += g.qd_off;
+        gather += g.gather_off;
+        vals += g.val_off;
+        if ((int64_t)blockIdx.x * KZ_XL_ROWS >= n_i || (int)blockIdx.y * q_chunk >= nb) return;   // (uniform: before anything is staged)
+    }
     if (dyn_n) {   // (speculative launch: nb is the capacity; nothing to do -- or too much -- returns before the tile is staged)
         const int n = *dyn_n;
         if (n > nb || n <= 0) return;
@@ -113,7 +153,8 @@ __global__ __launch_bounds__(256) void kz_exact_dist_lanes_kernel(int nb, const 
     //      16- / 32-byte global loads), the padding entry per leaf spreads their stores over the banks ----
     for (int idx = threadIdx.x; idx < KZ_XL_ROWS * n_groups; idx += 256) {
         const int r = idx / n_groups, g = idx - r * n_groups;
-        const int64_t yi = i0 + r < n_i ? i0 + r : n_i - 1;
+        int64_t yi = i0 + r < n_i ? i0 + r : n_i - 1;
+        if constexpr (GATHER) yi = gather[yi];
         char* dst = ytile + ((size_t)g * (KZ_XL_ROWS + 1) + r) * ENTRY;
         const ELT* src = yrows + yi * (int64_t)d + 4 * g;
         if constexpr (sizeof(ELT) == 4) {
@@ -125,7 +166,7 @@ __global__ __launch_bounds__(256) void kz_exact_dist_lanes_kernel(int nb, const 
     }
     __syncthreads();   // (the tile is staged)
     const int64_t i = i0 + lane;
-    const double ys = i < n_i ? ysqn[i] : 1.0;   // (euclidean family: |y|^2; cosine: the row's norm, used by COS_RAW only)
+    const double ys = i < n_i ? ysqn[GATHER ? (int64_t)gather[i] : i] : 1.0;   // (euclidean family: |y|^2; cosine: the row's norm, used by COS_RAW only)
     const double ys_rcp = 1.0 / ys;
     const bool ys_fin = (((unsigned long long)__double_as_longlong(ys_rcp) >> 52) & 0x7ff) != 0x7ff;
     kz_xl_lds* ylane = (kz_xl_lds*)(ytile + (size_t)lane * ENTRY);
@@ -150,7 +191,9 @@ __global__ __launch_bounds__(256) void kz_exact_dist_lanes_kernel(int nb, const 
         }
     };
     const int nb_pad = (nb + QB - 1) / QB * QB;   // (qd / qsq hold whole blocks of rows, zero filled)
-    for (int bb = 0; bb < nb_pad; bb += QB) {   // (uniform)
+    const int bb_first = GATHER ? (int)blockIdx.y * q_chunk : 0;
+    const int bb_last = GATHER ? (bb_first + q_chunk < nb_pad ? bb_first + q_chunk : nb_pad) : nb_pad;
+    for (int bb = bb_first; bb < bb_last; bb += QB) {   // (uniform)
         qrow = qd + ((size_t)bb + (size_t)wave * KZ_XL_Q) * d_pad;
         // ---- the tree, depth first: leaves in bit-reversed order; the partial sums of the completed subtrees sit in lev[0 .. LOG),
         //      one per level, like the digits of a binary counter: leaf `it` is added in at level 0 and carried upward through every

@@ -1223,8 +1223,13 @@ static inline size_t kz_exact_lanes_qd_bytes(int nb, int d) {   // float64 opera
     return (nb_pad * (size_t)d + nb_pad) * 8;
 }
 // dyn_n (speculative launch): nb is the capacity of the launch, the row count is read on the device
+// groups != nullptr (kz_range.h, grouped ranges): ONE launch for n_groups dense blocks (KzXlGroup) -- fl [n_slots] then holds the
+// query row of every operand row of every block (-1: padding), gather the blocks' lists of index rows; nb = n_slots, rows_max /
+// q_max = the largest block's index rows / query rows; vals as the blocks' val_off say.
 static int kz_launch_exact_lanes(kz_ctx* ctx, const int* fl, int b0, int nb, int64_t cq_begin, const kz_matrix* query, const kz_matrix* index,
-                                 int metric, double* vals, bool* took, const int* dyn_n = nullptr, double* qd_buf = nullptr) {
+                                 int metric, double* vals, bool* took, const int* dyn_n = nullptr, double* qd_buf = nullptr,
+                                 const int* gather = nullptr, const KzXlGroup* groups = nullptr, int n_groups = 0, int rows_max = 0,
+                                 int q_max = 0) {
     *took = false;
     const int d = (int)index->d;
     if (ctx->exact_rows < 2 || (nb < KZ_XL_MIN_ROWS && !dyn_n) || index->dtype != KZ_F32 || (d & 3) != 0 || d > 512 || metric > KZ_COSINE ||
@@ -1233,32 +1238,47 @@ static int kz_launch_exact_lanes(kz_ctx* ctx, const int* fl, int b0, int nb, int
     const bool cosine = metric == KZ_COSINE && index->norm64 != nullptr && d <= 256;   // (the normalised float64 rows, staged as they are)
     const bool cos_raw = metric == KZ_COSINE && !cosine;                               // (the raw rows, divided by the lane)
     const int d_pad = d;   // (a multiple of 4: whole leaves)
-    const int nb_pad = (nb + 4 * KZ_XL_Q - 1) / (4 * KZ_XL_Q) * (4 * KZ_XL_Q);   // (whole blocks of 4 waves x KZ_XL_Q rows)
+    const int nb_pad = groups ? nb : (nb + 4 * KZ_XL_Q - 1) / (4 * KZ_XL_Q) * (4 * KZ_XL_Q);   // (whole blocks of 4 waves x KZ_XL_Q rows; groups: the slots are padded per block)
     double* qd = qd_buf;   // (a caller that runs these launches on another stream than the pool's brings the buffer: kz_spec_alloc)
     if (!qd) {
         const int rc = kz_pool_alloc(ctx, kz_exact_lanes_qd_bytes(nb, d), (void**)&qd);
         if (rc != KZ_OK) return rc == KZ_ERR_NOMEM ? KZ_OK : rc;   // (no memory for the operand rows: the cooperative kernel)
     }
     double* qsq = qd + (size_t)nb_pad * d_pad;
-    hipLaunchKernelGGL(kz_exact_qprep_kernel, dim3(nb_pad), dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin, (const float*)query->raw, query->sqn, d,
-                       d_pad, metric, qd, qsq, dyn_n);
-    const dim3 grid((unsigned)((index->n + KZ_XL_ROWS - 1) / KZ_XL_ROWS));
+    if (groups)
+        hipLaunchKernelGGL(kz_exact_qprep_slots_kernel, dim3(nb_pad), dim3(256), 0, ctx->stream, fl, cq_begin, (const float*)query->raw, query->sqn, d,
+                           d_pad, metric, qd, qsq);
+    else
+        hipLaunchKernelGGL(kz_exact_qprep_kernel, dim3(nb_pad), dim3(256), 0, ctx->stream, fl, b0, nb, cq_begin, (const float*)query->raw, query->sqn, d,
+                           d_pad, metric, qd, qsq, dyn_n);
+    const int64_t n_rows = groups ? rows_max : index->n;
+    // (groups: a workgroup takes q_chunk = 64 query rows of its block -- four rounds of its 16 -- for one tile of 64 index rows)
+    const int q_chunk = 16 * KZ_XL_Q;
+    const dim3 grid((unsigned)((n_rows + KZ_XL_ROWS - 1) / KZ_XL_ROWS), groups ? (unsigned)((q_max + q_chunk - 1) / q_chunk) : 1u,
+                    groups ? (unsigned)n_groups : 1u);
     const size_t lds = (size_t)(d_pad / 4) * (KZ_XL_ROWS + 1) * (cosine ? 32 : 16);   // (<= 133 KiB: 512 float32 / 256 float64 elements)
     hipError_t e = hipSuccess;
-#define KZ_XL_LAUNCH(NL, NVV, ELT, rows)                                                                                                       \
+#define KZ_XL_LAUNCH_G(NL, NVV, ELT, CR, GA, rows)                                                                                             \
     do {                                                                                                                                        \
-        if (lds > 65536) e = hipFuncSetAttribute((const void*)kz_exact_dist_lanes_kernel<NL, NVV, ELT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 65536) e = hipFuncSetAttribute((const void*)kz_exact_dist_lanes_kernel<NL, NVV, ELT, CR, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e == hipSuccess)                                                                                                                     \
-            hipLaunchKernelGGL((kz_exact_dist_lanes_kernel<NL, NVV, ELT>), grid, dim3(256), lds, ctx->stream, nb, (const double*)qd, (const double*)qsq, \
-                               (const ELT*)(rows), index->sqn, index->n, d, d_pad, metric, vals, dyn_n);                                        \
+            hipLaunchKernelGGL((kz_exact_dist_lanes_kernel<NL, NVV, ELT, CR, GA>), grid, dim3(256), lds, ctx->stream, nb, (const double*)qd, (const double*)qsq, \
+                               (const ELT*)(rows), index->sqn, n_rows, d, d_pad, metric, vals, dyn_n, gather, groups, q_chunk);                 \
+    } while (0)
+#define KZ_XL_LAUNCH(NL, NVV, ELT, rows)                          \
+    do {                                                           \
+        if (groups)                                                \
+            KZ_XL_LAUNCH_G(NL, NVV, ELT, false, true, rows);       \
+        else                                                       \
+            KZ_XL_LAUNCH_G(NL, NVV, ELT, false, false, rows);      \
     } while (0)
     if (cos_raw) {
-#define KZ_XL_LAUNCH_COS(NL, NVV)                                                                                                              \
-    do {                                                                                                                                        \
-        if (lds > 65536) e = hipFuncSetAttribute((const void*)kz_exact_dist_lanes_kernel<NL, NVV, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e == hipSuccess)                                                                                                                     \
-            hipLaunchKernelGGL((kz_exact_dist_lanes_kernel<NL, NVV, float, true>), grid, dim3(256), lds, ctx->stream, nb, (const double*)qd, (const double*)qsq, \
-                               (const float*)index->raw, index->sqn, index->n, d, d_pad, metric, vals, dyn_n);                                  \
+#define KZ_XL_LAUNCH_COS(NL, NVV)                                        \
+    do {                                                                  \
+        if (groups)                                                       \
+            KZ_XL_LAUNCH_G(NL, NVV, float, true, true, index->raw);       \
+        else                                                              \
+            KZ_XL_LAUNCH_G(NL, NVV, float, true, false, index->raw);      \
     } while (0)
         if (d <= 64)
             KZ_XL_LAUNCH_COS(16, 1);
@@ -1287,6 +1307,7 @@ static int kz_launch_exact_lanes(kz_ctx* ctx, const int* fl, int b0, int nb, int
             KZ_XL_LAUNCH(64, 2, float, index->raw);
     }
 #undef KZ_XL_LAUNCH
+#undef KZ_XL_LAUNCH_G
     if (e == hipSuccess) e = hipGetLastError();
     if (!qd_buf) kz_pool_free(ctx, qd, 0);   // (stream-ordered pool)
     if (e != hipSuccess) {
@@ -1591,7 +1612,8 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
                                                               int metric, double p, double* __restrict__ out_dist,
                                                               int64_t* __restrict__ out_ind, const int* __restrict__ dyn_n = nullptr,
                                                               const long long* __restrict__ seg_off = nullptr, int* __restrict__ left = nullptr,
-                                                              int* __restrict__ left_cnt = nullptr) {
+                                                              int* __restrict__ left_cnt = nullptr, const long long* __restrict__ idx_off = nullptr,
+                                                              const int* __restrict__ seg_len = nullptr) {
     __shared__ double s_v[4];
     __shared__ int s_i[4];
     extern __shared__ __attribute__((aligned(16))) char sel_sm[];   // k_eff doubles + k_eff ints (any k the host admits)
@@ -1599,6 +1621,7 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
     const int b = blockIdx.x;
     if (dyn_n && !kz_spec_row_live(dyn_n, b, (int)gridDim.x)) return;
     const int q = fail_list[batch0 + b];
+    if (q < 0) return;   // (grouped ranges, kz_range.h: a padding slot of a block)
     // the row's values: all n_i of them (cand_idx == nullptr: entry i is index row i), or the survivors of kz_exact_chunk_kernel
     // (n_entries (value, index row) pairs; unused places hold (+inf, INT_MAX) and are never reached: k_eff <= n_i real entries exist)
     const double* v = vals + (int64_t)b * n_entries;
@@ -1608,13 +1631,13 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
         // range re-search (kz_range.h): row b's entries are the segment [seg_off[b], seg_off[b + 1]) of vals / cand_idx; a segment
         // with fewer than k entries cannot answer its row -- the row is handed back (left)
         const long long s0 = seg_off[b];
-        n_entries = seg_off[b + 1] - s0;
+        n_entries = seg_len ? (int64_t)seg_len[b] : seg_off[b + 1] - s0;   // (seg_len: the segments are not adjacent)
         if (n_entries < k_eff) {
             if (tid == 0) left[atomicAdd(left_cnt, 1)] = q;
             return;
         }
         v = vals + s0;
-        vid = cand_idx + s0;
+        vid = cand_idx + (idx_off ? idx_off[b] : s0);   // (idx_off: the rows of a group share one list of index rows)
     }
     double* s_sv = reinterpret_cast<double*>(sel_sm);
     int* s_si = reinterpret_cast<int*>(s_sv + k_eff);
@@ -2637,7 +2660,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         return KZ_ERR_INVALID;
     }
     double main_ms = 0, fin_ms = 0, fb_ms = 0;   // (the tier probe's time is reported under its own field, kz_knn_stats.probe_ms)
-    int64_t n_fail_total = 0, n_escalated = 0, n_first_fail = 0, n_spec = 0, n_range = 0, n_range_pairs = 0;
+    int64_t n_fail_total = 0, n_escalated = 0, n_first_fail = 0, n_spec = 0, n_range = 0, n_range_pairs = 0, n_range_group = 0;
     double max_err_ratio = 0.0;
     int last_splits = 1, last_blocks = 0, first_tier = tier;
     for (int64_t c0 = 0; c0 < q_count;) {
@@ -3015,6 +3038,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             n_fail_total += st2.n_fallback_rows;
             n_range += st2.n_range_rows;
             n_range_pairs += st2.n_range_pairs;
+            n_range_group += st2.n_range_group_rows;
             if (st2.max_err_ratio > max_err_ratio) max_err_ratio = st2.max_err_ratio;
             c0 += max_rows_per_chunk;
             if (tier_next != tier && short_ord) {   // (the other tiers' kernels keep one list of K' per query)
@@ -3048,10 +3072,10 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                     kz_set_error("kz_knn: copying the bounds of the uncertified rows failed");
                     rc = KZ_ERR_HIP;
                 }
-                long long pairs = 0;
+                long long pairs = 0, grouped = 0;
                 if (rc == KZ_OK)
                     rc = kz_range_rescue(ctx, query, cq_begin, fl, tau, n_fail, index, k, exclude_self, d_self_ids, fp.out_dist, fp.out_ind, left,
-                                         &n_dense, &pairs);
+                                         &n_dense, &pairs, &grouped);
                 kz_pool_free(ctx, tau, 0);
                 if (rc != KZ_OK) {
                     kz_pool_free(ctx, left, 0);
@@ -3060,6 +3084,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 }
                 n_range += n_fail - n_dense;
                 n_range_pairs += pairs;
+                n_range_group += grouped;
                 kz_pool_free(ctx, fl, 0);   // (the rows handed back take the list's place)
                 fl = left;
             }
@@ -3185,6 +3210,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         stats->n_spec_rows = n_spec > 0x7fffffff ? 0x7fffffff : (int32_t)n_spec;
         stats->n_range_rows = n_range;
         stats->n_range_pairs = n_range_pairs;
+        stats->n_range_group_rows = n_range_group;
     }
     return KZ_OK;
 }

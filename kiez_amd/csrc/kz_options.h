@@ -47,7 +47,7 @@ static const KzOption KZ_OPTIONS[] = {
     {"probe_min_pairs", KZ_OPT_F64, KZ_O(probe_min_pairs), 0, 1e300, 5e10, 0, {}, 0, "searches of fewer distance pairs take neither the tier probe nor a floor"},
     {"esc_ladder", KZ_OPT_BOOL, KZ_O(esc_ladder), 0, 1, 1, 0, {}, 0, "a pass without a probe that leaves more than half of its rows uncertified tries the wide route on a sample of them before the split-bf16 tier"},
     {"exact_rows", KZ_OPT_INT, KZ_O(exact_rows), 0, 3, 3, 0, {}, 0, "exact float64 distance kernels: 0 one pair per wave, 1 + many pairs per wave step (float32 rows of d <= 512), 2 + one pair per LANE for batches of >= 32 rows (kz_exact_lanes.h), 3 (default) + the RANGE re-search for >= 128 rows (kz_range.h: only the index rows within the rounding bound of a row's k-th candidate); all bit-identical"},
-    {"abl", KZ_OPT_INT, KZ_O(abl), 0, 15, 0, 0, {}, 0, "diagnostics, bit mask: 1 = an ordinary one-range fp16 sweep runs twice, the second (timed) one from the first one's final thresholds; 2 = with a -DKZ_ABL_STAMP build and KZ_STAMP_FILE set, clock stamps of every workgroup of an ordinary fp16 sweep; 4 = the range re-search's log holds 4096 groups (overflow path); 8 = the range re-search treats every row as one without k candidates (hand-back path)"},
+    {"abl", KZ_OPT_INT, KZ_O(abl), 0, 31, 0, 0, {}, 0, "diagnostics, bit mask: 1 = an ordinary one-range fp16 sweep runs twice, the second (timed) one from the first one's final thresholds; 2 = with a -DKZ_ABL_STAMP build and KZ_STAMP_FILE set, clock stamps of every workgroup of an ordinary fp16 sweep; 4 = the range re-search's log holds 4096 groups (overflow path); 8 = the range re-search treats every row as one without k candidates (hand-back path); 16 = no grouped ranges (one range per row)"},
     {"spec_rows", KZ_OPT_INT, KZ_O(spec_rows), 0, 64, 64, 0, {}, 0, "exact kernels launched speculatively behind every finalize for at most this many uncertified rows (0 = off)"},
     {"wide_lists", KZ_OPT_INT, KZ_O(wide_lists), 2, 32, 32, KZ_OPT_SET, {0}, -1, "fp16 tier's wide route: lists of 16 per query (0 = off)"},
     {"wide_sel", KZ_OPT_INT, KZ_O(wide_sel), 16, 512, 256, 0, {}, 0, "... entries of those lists the finalize kernel selects"},

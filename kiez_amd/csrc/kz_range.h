@@ -314,14 +314,371 @@ static void kz_launch_exact_pairs(kz_ctx* ctx, const long long* seg_off, int nb,
 #undef KZ_EXACT_PAIRS
 }
 
+// The log of a sweep and what the sweep needs around it (allocated once per call of kz_range_rescue)
+struct KzRangeLog {
+    float* theta0 = nullptr;               // [index tiles * 128] zeros: the per-tile part of the kernel's threshold
+    void* keys = nullptr;                  // [cap] groups of four keys
+    void* meta = nullptr;                  // [cap] {lane | 16 tile + group, batch row}
+    unsigned long long* counters = nullptr;   // [0] groups logged, [1] (as int) rows handed back
+    long long cap = 0;
+};
+// The sweep of the rows of `qsub` (nb rows; tau [nb] on the device) against the whole index: thr / inff [n_pad] are filled, the log
+// holds the groups, *n_groups their number; *over: the log overflowed or the fp16 tier did not run -- nothing usable was logged.
+static int kz_range_sweep_rows(kz_ctx* ctx, kz_matrix* qsub, const double* tau, int nb, kz_matrix* index, const KzRangeLog& lg, float* thr,
+                               float* inff, double* out_dist, int64_t* out_ind, unsigned long long* n_groups, bool* over) {
+    int rc = kz_himage_ensure(qsub, index);
+    if (rc != KZ_OK) return rc;
+    const int64_t n_pad = qsub->n_tiles * KZ_TILE;
+    hipLaunchKernelGGL(kz_range_thr_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, tau, (ctx->abl & 8) ? 0 : nb, n_pad,
+                       qsub->himg->rowq, qsub->sqn, index->himg->d_max, index->himg->center->d_scale, index->d_stats, index->metric, ctx->eps_scale,
+                       kz_gamma_acc_h(index->kg), thr, inff);
+    hipError_t e = hipMemsetAsync(lg.counters, 0, 8, ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        kz_set_error("kz_knn: range re-search: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    KzDualPass dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.probed = 1;
+    dp.qpack = (const float*)qsub->himg->packed;
+    dp.ypack = (const float*)index->himg->packed;
+    dp.ybias = index->himg->bias;
+    dp.theta = lg.theta0;
+    dp.qnbias = thr;
+    dp.qfloor = inff;
+    dp.log_keys = lg.keys;
+    dp.log_meta = lg.meta;
+    dp.log_cnt = lg.counters;
+    dp.log_cap = lg.cap;
+    dp.raw_lists = 1;
+    dp.no_q64 = 1;
+    kz_knn_stats st;
+    // (k = 1: lists of 16 -- the build with the most workgroups per CU; nothing is finalized, out_dist / out_ind are not written)
+    rc = kz_knn_impl(ctx, qsub, 0, nb, index, 1, 0, nullptr, 0, 0, out_dist, out_ind, &st, &dp);
+    if (rc != KZ_OK) return rc;
+    e = hipMemcpyAsync(n_groups, lg.counters, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        kz_set_error("kz_knn: range re-search: reading the log counter failed");
+        return KZ_ERR_HIP;
+    }
+    *over = dp.broken || st.first_pass != KZ_TIER_H || *n_groups > (unsigned long long)lg.cap;
+    return KZ_OK;
+}
+
+// ---- GROUPED ranges ----------------------------------------------------------------------------------------------------------
+// Thousands of failed rows are rows of a few tight clusters, and the rows of one cluster all have the same range -- the cluster.
+// Sweeping the index once per ROW to find it (4.25 ms per 8 k rows, most of it the log's traffic) and gathering an index row per
+// PAIR (5.8 TB/s, HBM-bound) does that work hundreds of times over.  Instead:
+//   * every KZ_RG_STRIDE-th failed row is a REPRESENTATIVE; every failed row x is assigned to its nearest representative r(x)
+//     (exact float64, one search of the failed rows against the representatives on the exact kernels);
+//   * a neighbour y of x has |x - y| <= a(x) = the distance of x's k-th candidate, so |r - y| <= |r - x| + a(x): the range of r
+//     with the radius R(r) = max over its rows of that sum holds every neighbour of every row assigned to r (cosine: the same on
+//     the chords sqrt(2 dist) of the unit vectors);
+//   * the representatives -- a 64th of the rows -- are swept and logged as above; a group (r, its rows M, its range B) is then a
+//     DENSE block of |M| x |B| pairs for the one-pair-per-lane kernel (kz_exact_lanes.h, GATHER: a workgroup stages 64 rows of B
+//     once for all rows of M; 3.8e10 pairs/s against the per-pair gather's 7e9); kz_exact_select_kernel picks every row's k best
+//     of its group's block.
+// Where the data has no such structure the radius R(r) covers most of the index: groups whose range holds more than half of it, or
+// whose blocks do not fit the memory budget, are not taken -- their rows go through the per-row range above.  Values and order are
+// the exact kernels' as everywhere.
+constexpr int KZ_RG_MIN_ROWS = 2048;   // failed rows from which representatives are tried
+constexpr int KZ_RG_STRIDE = 256;      // one representative per this many failed rows (at least KZ_XL_MIN_ROWS of them) ...
+constexpr int KZ_RG_MAX_REPS = 1024;   // ... at most this many
+
+// vals [n_rep][n]: the exact values between the representatives and the failed rows.  grp [n]: the nearest representative of failed
+// row i (-1: no bound, the row is not grouped); rbits [n_rep]: the radius (bits of a positive float, rounded up) = max over the rows
+// of a representative; mcount [n_rep]: its rows
+__global__ void kz_rg_assign_kernel(const double* __restrict__ tau, const double* __restrict__ vals, int n_rep, int n, int metric,
+                                    int* __restrict__ grp, int* __restrict__ rbits, int* __restrict__ mcount) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double tv = tau[i];
+    int g = -1;
+    if (tv < (double)INFINITY) {
+        double best = INFINITY;
+        g = 0;
+        for (int j = 0; j < n_rep; ++j) {
+            const double v = vals[(size_t)j * n + i];
+            if (v < best) {
+                best = v;
+                g = j;
+            }
+        }
+        const double s = metric == KZ_COSINE ? 2.0 : 1.0;   // (values: squared distances / cosine distances; chords: sqrt(s value))
+        // (a row whose nearest representative is more than four times its own k-th candidate away -- a row of a cluster without a
+        //  representative -- would blow up the radius for every row of that group: it stays on its own)
+        if (best > 16.0 * tv) {
+            g = -1;
+        } else {
+            const double r = (sqrt(s * tv) + sqrt(s * best)) * (1.0 + 1e-9) + 1e-300;
+            float rf = (float)r;
+            if ((double)rf < r) rf = nextafterf(rf, INFINITY);
+            atomicMax(rbits + g, __float_as_int(rf));
+            atomicAdd(mcount + g, 1);
+        }
+    }
+    grp[i] = g;
+}
+// tau_rep [n_rep]: the bound of a representative's range in value units (squared distance / cosine distance), +inf: no rows
+__global__ void kz_rg_tau_kernel(const int* __restrict__ rbits, const int* __restrict__ mcount, int n_rep, int metric, double* __restrict__ tau_rep) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rep) return;
+    double t = INFINITY;
+    if (mcount[j] > 0) {
+        const double R = (double)__int_as_float(rbits[j]);
+        t = R * R * (1.0 + 1e-6) / (metric == KZ_COSINE ? 2.0 : 1.0);
+        if (metric == KZ_COSINE && t > 2.0) t = 2.0;
+    }
+    tau_rep[j] = t;
+}
+// acc_of [n_rep]: the group's ordinal among the accepted groups, or -1.  Accepted rows: slot mate_off[a] + its arrival; the others
+// are appended to rest / rest_tau.
+__global__ void kz_rg_mates_kernel(const int* __restrict__ grp, const int* __restrict__ acc_of, const int* __restrict__ mate_off, int n,
+                                   const int* __restrict__ fl, const double* __restrict__ tau, int* __restrict__ mcur, int* __restrict__ mates,
+                                   int* __restrict__ slot_grp, int* __restrict__ rest, double* __restrict__ rest_tau, int* __restrict__ rest_cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = grp[i];
+    const int a = g >= 0 ? acc_of[g] : -1;
+    if (a >= 0) {
+        const int slot = mate_off[a] + atomicAdd(mcur + a, 1);
+        mates[slot] = fl[i];
+        slot_grp[slot] = a;
+    } else {
+        const int p = atomicAdd(rest_cnt, 1);
+        rest[p] = fl[i];
+        rest_tau[p] = tau[i];
+    }
+}
+// per slot b (operand row b of the launch: the m-th row of an accepted group a, or padding behind its rows): where its values and its
+// group's range rows lie.  Slots of a group start at mate_off[a] (a multiple of 16), slot_grp was set for the real rows only.
+__global__ void kz_rg_slots_kernel(const int* __restrict__ slot_grp, const int* __restrict__ mate_off, const int* __restrict__ blen,
+                                   const long long* __restrict__ ball_off, const long long* __restrict__ val_off, int n_slots,
+                                   long long* __restrict__ seg_off, int* __restrict__ seg_len, long long* __restrict__ idx_off) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_slots) return;
+    const int a = slot_grp[b];
+    if (a < 0) {   // (padding: an empty segment; kz_exact_select_kernel skips the slot by its row number -1)
+        seg_off[b] = idx_off[b] = 0;
+        seg_len[b] = 0;
+        return;
+    }
+    seg_off[b] = val_off[a] + (long long)(b - mate_off[a]) * blen[a];
+    seg_len[b] = blen[a];
+    idx_off[b] = ball_off[a];
+}
+// The grouped path over fl / tau [n_fail]: rows it answers are written (or, a segment short of k entries, appended to `left`); the
+// others come back as rest / rest_tau [*n_rest] for the per-row path.  *pairs: pairs evaluated.
+static int kz_range_grouped(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int* fl, const double* tau, int n_fail, kz_matrix* index, int k,
+                            int exclude_self, const int64_t* d_self_ids, double* out_dist, int64_t* out_ind, const KzRangeLog& lg, int* rest,
+                            double* rest_tau, int* n_rest, int* left, int* left_cnt, long long* pairs) {
+    const int metric = index->metric, d = (int)index->d;
+    const int k_eff = k + (exclude_self ? 1 : 0);
+    const int k_sel = (int)(k_eff < index->n ? k_eff : index->n);
+    const size_t sel_lds = (size_t)k_sel * 12 + 16;
+    const size_t row_bytes = (size_t)d * 4;
+    int n_rep = (n_fail + KZ_RG_STRIDE - 1) / KZ_RG_STRIDE;
+    if (n_rep > KZ_RG_MAX_REPS) n_rep = KZ_RG_MAX_REPS;
+    if ((size_t)n_rep * n_fail > ((size_t)1 << 27)) n_rep = (int)(((size_t)1 << 27) / n_fail);   // (representatives x rows: at most 1 GiB of values)
+    *pairs = 0;
+    // every buffer of the path (released together, stream-ordered)
+    int *rep_fl = nullptr, *ibuf = nullptr, *pair_idx = nullptr, *mates = nullptr, *slot_grp = nullptr;
+    void *rep_raw = nullptr, *all_raw = nullptr;
+    kz_matrix *rm = nullptr, *fm = nullptr;
+    double *rv = nullptr, *tau_rep = nullptr, *vals = nullptr;
+    float* thr = nullptr;   // [2 n_pad]: thresholds, +inf floors
+    long long *seg_rep = nullptr, *lbuf = nullptr;
+    auto release = [&]() {
+        if (rm) kz_matrix_destroy(rm);
+        if (fm) kz_matrix_destroy(fm);
+        kz_pool_free(ctx, rep_fl, 0); kz_pool_free(ctx, ibuf, 0); kz_pool_free(ctx, pair_idx, 0); kz_pool_free(ctx, mates, 0);
+        kz_pool_free(ctx, rep_raw, 0); kz_pool_free(ctx, all_raw, 0); kz_pool_free(ctx, rv, 0);
+        kz_pool_free(ctx, tau_rep, 0); kz_pool_free(ctx, vals, 0); kz_pool_free(ctx, thr, 0);
+        kz_pool_free(ctx, seg_rep, 0); kz_pool_free(ctx, lbuf, 0);
+    };
+    // "nothing grouped": every row is the per-row path's
+    auto give_up = [&](int rc_in) -> int {
+        release();
+        if (rc_in != KZ_OK && rc_in != KZ_ERR_NOMEM) return rc_in;
+        hipError_t e0 = hipMemcpyAsync(rest, fl, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(rest_tau, tau, (size_t)n_fail * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(ctx->stream);
+        if (e0 != hipSuccess) {
+            kz_set_error("kz_knn: range re-search: %s", hipGetErrorString(e0));
+            return KZ_ERR_HIP;
+        }
+        *n_rest = n_fail;
+        return KZ_OK;
+    };
+    if (n_rep < KZ_XL_MIN_ROWS) return give_up(KZ_OK);
+    const int64_t stride = n_fail / n_rep;
+    const int64_t rep_pad = (int64_t)((n_rep + KZ_TILE - 1) / KZ_TILE) * KZ_TILE;
+    // ibuf: grp [n_fail] | rbits | mcount | cnt | cur | acc_of | mate_off | blen | mcur | iota [n_rep each] | rest_cnt [1]
+    int rc = kz_pool_alloc(ctx, (size_t)n_rep * sizeof(int), (void**)&rep_fl);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, ((size_t)n_fail + 9 * (size_t)n_rep + 4) * sizeof(int), (void**)&ibuf);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_rep * row_bytes, &rep_raw);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * row_bytes, &all_raw);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_rep * (size_t)n_fail * 8, (void**)&rv);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_rep * 8, (void**)&tau_rep);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)rep_pad * 2 * sizeof(float), (void**)&thr);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)(n_rep + 1) * sizeof(long long), (void**)&seg_rep);
+    // (slots: a group's rows, padded to whole blocks of 16 operand rows -- at most n_fail + 16 n_rep of them)
+    const size_t slots_cap = (size_t)n_fail + 16 * (size_t)n_rep;
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, slots_cap * 3 * sizeof(int), (void**)&mates);   // mates | slot_grp | seg_len
+    // lbuf: ball_off [n_rep] | val_off [n_rep] | seg_off [slots] | idx_off [slots] | group descriptors [n_rep]
+    if (rc == KZ_OK)
+        rc = kz_pool_alloc(ctx, (2 * (size_t)n_rep + 2 * slots_cap + 2) * sizeof(long long) + (size_t)n_rep * sizeof(KzXlGroup), (void**)&lbuf);
+    if (rc != KZ_OK) return give_up(rc);
+    int *grp = ibuf, *rbits = ibuf + n_fail, *mcount = rbits + n_rep, *cnt = mcount + n_rep, *cur = cnt + n_rep, *acc_of = cur + n_rep,
+        *mate_off = acc_of + n_rep, *blen = mate_off + n_rep, *mcur = blen + n_rep, *iota = mcur + n_rep, *rest_cnt = iota + n_rep;
+    long long *ball_off = lbuf, *val_off = lbuf + n_rep, *seg_off = val_off + n_rep, *idx_off = seg_off + slots_cap + 1;
+    KzXlGroup* d_groups = (KzXlGroup*)(idx_off + slots_cap + 1);
+    slot_grp = mates + slots_cap;
+    int* seg_len = slot_grp + slots_cap;
+    hipError_t e = hipMemsetAsync(rbits, 0, (9 * (size_t)n_rep + 4) * sizeof(int), ctx->stream);
+    if (e != hipSuccess) return give_up(KZ_ERR_NOMEM);
+    // ---- representatives; every failed row's nearest one (exact values representatives x failed rows, the dense kernels) --------
+    hipLaunchKernelGGL(kz_strided_pick_kernel, dim3((n_rep + 255) / 256), dim3(256), 0, ctx->stream, fl, n_rep, stride, rep_fl);
+    hipLaunchKernelGGL(kz_iota_kernel, dim3((n_rep + 255) / 256), dim3(256), 0, ctx->stream, iota, n_rep);
+    hipLaunchKernelGGL(kz_gather_rows_kernel, dim3(n_rep), dim3(256), 0, ctx->stream, (const char*)query->raw, rep_fl, q0, n_rep, (int64_t)row_bytes,
+                       (char*)rep_raw, (int64_t*)nullptr, (const int64_t*)nullptr);
+    hipLaunchKernelGGL(kz_gather_rows_kernel, dim3(n_fail), dim3(256), 0, ctx->stream, (const char*)query->raw, fl, q0, n_fail, (int64_t)row_bytes,
+                       (char*)all_raw, (int64_t*)nullptr, (const int64_t*)nullptr);
+    rc = kz_matrix_create(ctx, rep_raw, 2, n_rep, d, query->dtype, query->metric, &rm);
+    if (rc == KZ_OK) rc = kz_matrix_create(ctx, all_raw, 2, n_fail, d, query->dtype, query->metric, &fm);
+    if (rc != KZ_OK) return give_up(rc);
+    {
+        bool took = false;
+        rc = kz_launch_exact_lanes(ctx, iota, 0, n_rep, 0, rm, fm, metric, rv, &took);
+        if (rc != KZ_OK) return give_up(rc);
+        if (!took && !kz_launch_exact_rows(ctx, iota, 0, n_rep, 0, rm, fm, metric, rv))
+            hipLaunchKernelGGL(kz_exact_dist_kernel<float>, dim3((unsigned)((n_fail + 3) / 4), n_rep), dim3(256), 0, ctx->stream, iota, 0, (int64_t)0,
+                               (const float*)rm->raw, (const float*)fm->raw, rm->sqn, fm->sqn, (int64_t)n_fail, d, metric, index->mink_p, rv,
+                               (const int*)nullptr);
+    }
+    hipLaunchKernelGGL(kz_rg_assign_kernel, dim3((n_fail + 255) / 256), dim3(256), 0, ctx->stream, tau, rv, n_rep, n_fail, metric, grp, rbits, mcount);
+    hipLaunchKernelGGL(kz_rg_tau_kernel, dim3((n_rep + 255) / 256), dim3(256), 0, ctx->stream, rbits, mcount, n_rep, metric, tau_rep);
+    // ---- the representatives' ranges -----------------------------------------------------------------------------------------
+    unsigned long long n_groups = 0;
+    bool over = false;
+    rc = kz_range_sweep_rows(ctx, rm, tau_rep, n_rep, index, lg, thr, thr + rep_pad, out_dist, out_ind, &n_groups, &over);
+    if (rc != KZ_OK) return give_up(rc);
+    if (over) return give_up(KZ_OK);
+    const int gb = (int)((n_groups + 255) / 256 < 8192 ? (n_groups + 255) / 256 : 8192);
+    if (n_groups > 0)
+        hipLaunchKernelGGL(kz_range_count_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const f32x4e*)lg.keys, (const i32x2e*)lg.meta, (long long)n_groups,
+                           thr, index->n, cnt);
+    hipLaunchKernelGGL(kz_range_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, n_rep, seg_rep);
+    std::vector<int> h_cnt(n_rep), h_m(n_rep);
+    long long rep_total = 0;
+    e = hipMemcpyAsync(h_cnt.data(), cnt, (size_t)n_rep * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_m.data(), mcount, (size_t)n_rep * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&rep_total, seg_rep + n_rep, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return give_up(KZ_ERR_NOMEM);
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return give_up(KZ_ERR_NOMEM);
+    if ((size_t)rep_total * 4 > mem_free / 8) return give_up(KZ_OK);
+    // ---- which groups are taken: at least a block of rows for the dense kernel, a range of at most half the index, all blocks
+    //      within a third of the free memory (and 2^31 pairs) ------------------------------------------------------------------
+    std::vector<int> h_acc(n_rep, -1), h_moff, h_blen;
+    std::vector<long long> h_boff, h_voff;
+    std::vector<KzXlGroup> h_groups;
+    long long budget = (long long)(mem_free / 3 / 8);
+    if (budget > (1ll << 31)) budget = 1ll << 31;
+    long long tot_pairs = 0;
+    int n_slots = 0, rows_max = 0, q_max = 0;
+    {
+        long long boff = 0;
+        for (int j = 0; j < n_rep; ++j) {
+            const long long pj = (long long)h_m[j] * h_cnt[j];
+            if (h_m[j] >= KZ_XL_MIN_ROWS && h_cnt[j] >= k_sel && (int64_t)h_cnt[j] * 2 <= index->n && tot_pairs + pj <= budget) {
+                h_acc[j] = (int)h_moff.size();
+                h_moff.push_back(n_slots);
+                h_blen.push_back(h_cnt[j]);
+                h_boff.push_back(boff);
+                h_voff.push_back(tot_pairs);
+                KzXlGroup g;
+                g.nb = h_m[j];
+                g.n_rows = h_cnt[j];
+                g.qd_off = n_slots;
+                g.gather_off = boff;
+                g.val_off = tot_pairs;
+                h_groups.push_back(g);
+                n_slots += (h_m[j] + 15) / 16 * 16;
+                tot_pairs += pj;
+                if (h_cnt[j] > rows_max) rows_max = h_cnt[j];
+                if (h_m[j] > q_max) q_max = h_m[j];
+            }
+            boff += h_cnt[j];   // (the range lists of ALL representatives are filled: seg_rep)
+        }
+    }
+    const int n_acc = (int)h_moff.size();
+    if (n_acc == 0) return give_up(KZ_OK);
+    rc = kz_pool_alloc(ctx, (size_t)rep_total * 4 + 4, (void**)&pair_idx);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)tot_pairs * 8 + 8, (void**)&vals);
+    if (rc != KZ_OK) return give_up(rc);
+    // (pageable host arrays: waited for below, before the vectors go out of scope)
+    e = hipMemcpyAsync(acc_of, h_acc.data(), (size_t)n_rep * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mate_off, h_moff.data(), (size_t)n_acc * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(blen, h_blen.data(), (size_t)n_acc * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ball_off, h_boff.data(), (size_t)n_acc * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(val_off, h_voff.data(), (size_t)n_acc * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_groups, h_groups.data(), (size_t)n_acc * sizeof(KzXlGroup), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(mates, 0xff, (size_t)n_slots * sizeof(int), ctx->stream);      // (-1: padding rows)
+    if (e == hipSuccess) e = hipMemsetAsync(slot_grp, 0xff, (size_t)n_slots * sizeof(int), ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return give_up(KZ_ERR_NOMEM);
+    if (n_groups > 0)
+        hipLaunchKernelGGL(kz_range_fill_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const f32x4e*)lg.keys, (const i32x2e*)lg.meta, (long long)n_groups,
+                           thr, index->n, seg_rep, cur, pair_idx);
+    hipLaunchKernelGGL(kz_rg_mates_kernel, dim3((n_fail + 255) / 256), dim3(256), 0, ctx->stream, grp, acc_of, mate_off, n_fail, fl, tau, mcur, mates, slot_grp,
+                       rest, rest_tau, rest_cnt);
+    hipLaunchKernelGGL(kz_rg_slots_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, ctx->stream, slot_grp, mate_off, blen, ball_off, val_off, n_slots,
+                       seg_off, seg_len, idx_off);
+    // the groups = dense blocks, ONE launch: their rows against the rows of their ranges, one pair per lane (kz_exact_lanes.h, GATHER)
+    {
+        bool took = false;
+        rc = kz_launch_exact_lanes(ctx, mates, 0, n_slots, q0, query, index, metric, vals, &took, nullptr, nullptr, pair_idx, d_groups, n_acc, rows_max,
+                                   q_max);
+        if (rc == KZ_OK && !took) {
+            kz_set_error("kz_knn: internal: the dense kernel refused the groups of the range re-search");
+            rc = KZ_ERR_INVALID;
+        }
+        if (rc != KZ_OK) {
+            (void)hipStreamSynchronize(ctx->stream);
+            release();
+            return rc;
+        }
+    }
+    hipLaunchKernelGGL(kz_exact_select_kernel<float>, dim3(n_slots), dim3(256), sel_lds, ctx->stream, mates, 0, q0, (const double*)vals, (const int*)pair_idx,
+                       (int64_t)0, index->n, k, exclude_self ? 1 : 0, d_self_ids, metric, index->mink_p, out_dist, out_ind, (const int*)nullptr,
+                       (const long long*)seg_off, left, left_cnt, (const long long*)idx_off, (const int*)seg_len);
+    int h_rest = 0;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_rest, rest_cnt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release();
+    if (e != hipSuccess) {
+        kz_set_error("kz_knn: grouped range re-search failed: %s", hipGetErrorString(e));
+        return KZ_ERR_HIP;
+    }
+    *n_rest = h_rest;
+    *pairs = tot_pairs;
+    return KZ_OK;
+}
+
 // fl / tau [n_fail] (device; the caller's copies -- not in the context's scratch block, which the sweep below re-carves): rows
 // q0 + fl[i] of `query`.  Results of the rows it answers go to out_dist / out_ind at row fl[i]; the others are appended to
 // left [n_fail] (device), *n_left = their number.  Ends synchronised with the stream.  n_pairs_out: pairs evaluated (statistics).
 static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int* fl, const double* tau, int n_fail, kz_matrix* index, int k,
                            int exclude_self, const int64_t* d_self_ids, double* out_dist, int64_t* out_ind, int* left, int* n_left,
-                           long long* n_pairs_out) {
+                           long long* n_pairs_out, long long* n_grouped_out) {
     *n_left = 0;
     if (n_pairs_out) *n_pairs_out = 0;
+    if (n_grouped_out) *n_grouped_out = 0;
     const int metric = index->metric;
     const int k_eff = k + (exclude_self ? 1 : 0);
     const int k_sel = (int)(k_eff < index->n ? k_eff : index->n);
@@ -344,18 +701,21 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
         const int rc = kz_matrix_norm64(index);
         if (rc != KZ_OK) return rc;
     }
-    float* theta0 = nullptr;
-    void *log_keys = nullptr, *log_meta = nullptr;
-    unsigned long long* counters = nullptr;   // [0] the log's group counter, [1] rows appended to `left`
-    int rc = kz_pool_alloc(ctx, (size_t)y_pad * 4, (void**)&theta0);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 16, &log_keys);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 8, &log_meta);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, 64, (void**)&counters);
+    KzRangeLog lg;
+    lg.cap = log_cap;
+    int* rest = nullptr;        // the rows the grouped path leaves to the per-row path, their bounds
+    double* rest_tau = nullptr;
+    int rc = kz_pool_alloc(ctx, (size_t)y_pad * 4, (void**)&lg.theta0);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 16, &lg.keys);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 8, &lg.meta);
+    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, 64, (void**)&lg.counters);
     auto release_all = [&]() {
-        kz_pool_free(ctx, theta0, 0);
-        kz_pool_free(ctx, log_keys, 0);
-        kz_pool_free(ctx, log_meta, 0);
-        kz_pool_free(ctx, counters, 0);
+        kz_pool_free(ctx, lg.theta0, 0);
+        kz_pool_free(ctx, lg.keys, 0);
+        kz_pool_free(ctx, lg.meta, 0);
+        kz_pool_free(ctx, lg.counters, 0);
+        kz_pool_free(ctx, rest, 0);
+        kz_pool_free(ctx, rest_tau, 0);
     };
     if (rc != KZ_OK) {
         release_all();
@@ -365,19 +725,42 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
         *n_left = n_fail;
         return KZ_OK;
     }
-    hipError_t e = hipMemsetAsync(theta0, 0, (size_t)y_pad * 4, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 64, ctx->stream);
+    hipError_t e = hipMemsetAsync(lg.theta0, 0, (size_t)y_pad * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(lg.counters, 0, 64, ctx->stream);
     if (e != hipSuccess) {
         release_all();
         kz_set_error("kz_knn: range re-search: %s", hipGetErrorString(e));
         return KZ_ERR_HIP;
     }
-    int* left_cnt = (int*)(counters + 1);
+    int* left_cnt = (int*)(lg.counters + 1);
     long long pairs_total = 0;
     auto read_back = [&](void* dst, const void* src, size_t bytes) -> hipError_t {   // (behind everything queued on the context's stream)
         const hipError_t e1 = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
         return e1 != hipSuccess ? e1 : hipStreamSynchronize(ctx->stream);
     };
+    // ---- groups first: rows of one tight cluster share a representative's range ("abl" bit 16: off) ------------------------------
+    if (n_fail >= KZ_RG_MIN_ROWS && !(ctx->abl & 16)) {
+        rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&rest);
+        if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * 8, (void**)&rest_tau);
+        if (rc == KZ_OK) {
+            int n_rest = 0;
+            long long gp = 0;
+            rc = kz_range_grouped(ctx, query, q0, fl, tau, n_fail, index, k, exclude_self, d_self_ids, out_dist, out_ind, lg, rest, rest_tau, &n_rest,
+                                  left, left_cnt, &gp);
+            if (rc != KZ_OK) {
+                release_all();
+                return rc;
+            }
+            pairs_total += gp;
+            if (n_grouped_out) *n_grouped_out = n_fail - n_rest;
+            fl = rest;
+            tau = rest_tau;
+            n_fail = n_rest;
+        } else if (rc != KZ_ERR_NOMEM) {
+            release_all();
+            return rc;
+        }
+    }
     int batch = n_fail < KZ_RANGE_BATCH ? n_fail : KZ_RANGE_BATCH;
     for (int b0 = 0; b0 < n_fail;) {
         const int nb = n_fail - b0 < batch ? n_fail - b0 : batch;
@@ -414,47 +797,20 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
         hipLaunchKernelGGL(kz_gather_rows_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const char*)query->raw, fl + b0, q0, nb, (int64_t)row_bytes,
                            (char*)sub_raw, (int64_t*)nullptr, (const int64_t*)nullptr);
         rc = kz_matrix_create(ctx, sub_raw, 2, nb, query->d, query->dtype, query->metric, &qsub);
-        if (rc == KZ_OK) rc = kz_himage_ensure(qsub, index);
         if (rc != KZ_OK) return fail(rc);
-        hipLaunchKernelGGL(kz_range_thr_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, tau + b0, (ctx->abl & 8) ? 0 : nb, n_pad,
-                           qsub->himg->rowq, qsub->sqn, index->himg->d_max, index->himg->center->d_scale, index->d_stats, metric, ctx->eps_scale,
-                           kz_gamma_acc_h(index->kg), thr, inff);
-        e = hipMemsetAsync(counters, 0, 8, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, (size_t)nb * 2 * sizeof(int), ctx->stream);
-        if (e == hipSuccess) e = hipGetLastError();
+        e = hipMemsetAsync(cnt, 0, (size_t)nb * 2 * sizeof(int), ctx->stream);
         if (e != hipSuccess) {
             kz_set_error("kz_knn: range re-search: %s", hipGetErrorString(e));
             return fail(KZ_ERR_HIP);
         }
-        KzDualPass dp;
-        memset(&dp, 0, sizeof(dp));
-        dp.probed = 1;
-        dp.qpack = (const float*)qsub->himg->packed;
-        dp.ypack = (const float*)index->himg->packed;
-        dp.ybias = index->himg->bias;
-        dp.theta = theta0;
-        dp.qnbias = thr;
-        dp.qfloor = inff;
-        dp.log_keys = log_keys;
-        dp.log_meta = log_meta;
-        dp.log_cnt = counters;
-        dp.log_cap = log_cap;
-        dp.raw_lists = 1;
-        dp.no_q64 = 1;
-        kz_knn_stats st;
-        // (k = 1: lists of 16 -- the build with the most workgroups per CU; nothing is finalized, out_dist / out_ind are not written)
-        rc = kz_knn_impl(ctx, qsub, 0, nb, index, 1, 0, nullptr, 0, 0, out_dist, out_ind, &st, &dp);
-        if (rc != KZ_OK) return fail(rc);
         unsigned long long n_groups = 0;
-        if (read_back(&n_groups, counters, 8) != hipSuccess) {
-            kz_set_error("kz_knn: range re-search: reading the log counter failed");
-            return fail(KZ_ERR_HIP);
-        }
-        bool over = dp.broken || st.first_pass != KZ_TIER_H || n_groups > (unsigned long long)log_cap;
+        bool over = false;
+        rc = kz_range_sweep_rows(ctx, qsub, tau + b0, nb, index, lg, thr, inff, out_dist, out_ind, &n_groups, &over);
+        if (rc != KZ_OK) return fail(rc);
         long long total = 0;
         if (!over && n_groups > 0) {
             const int gb = (int)((n_groups + 255) / 256 < 8192 ? (n_groups + 255) / 256 : 8192);
-            hipLaunchKernelGGL(kz_range_count_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const f32x4e*)log_keys, (const i32x2e*)log_meta,
+            hipLaunchKernelGGL(kz_range_count_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const f32x4e*)lg.keys, (const i32x2e*)lg.meta,
                                (long long)n_groups, thr, index->n, cnt);
         }
         if (!over) {
@@ -494,7 +850,7 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
             if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)total * 8, (void**)&pair_val);
             if (rc != KZ_OK) return fail(rc);
             const int gb = (int)((n_groups + 255) / 256 < 8192 ? (n_groups + 255) / 256 : 8192);
-            hipLaunchKernelGGL(kz_range_fill_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const f32x4e*)log_keys, (const i32x2e*)log_meta,
+            hipLaunchKernelGGL(kz_range_fill_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const f32x4e*)lg.keys, (const i32x2e*)lg.meta,
                                (long long)n_groups, thr, index->n, seg_off, cnt + nb, pair_idx);
             kz_launch_exact_pairs(ctx, seg_off, nb, fl, b0, q0, query, index, total, pair_idx, pair_val);
         }

@@ -39,7 +39,7 @@ for n, d, k, metric in SHAPES:
             best = ms if best is None or ms < best else best
         res[er] = (dd.numpy(), ii.numpy())
         print(f"{n} x {n + 1000} x {d} k={k} {metric} exact_rows={er}: {best:8.1f} ms  fallback_ms {st['fallback_ms']:8.1f}  exact rows {st['n_fallback_rows']}"
-              f"  range rows {st['n_range_rows']}  pairs {st['n_range_pairs']}  re-searched {st['n_escalated_rows']}", flush=True)
+              f"  range rows {st['n_range_rows']} (grouped {st['n_range_group_rows']})  pairs {st['n_range_pairs']}  re-searched {st['n_escalated_rows']}", flush=True)
     if len(res) < 2:
         continue
     same_i = np.array_equal(res[3][1], res[2][1])
