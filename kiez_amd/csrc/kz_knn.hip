@@ -3022,16 +3022,62 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 next_prec = 0;
                 next_kp = (long_only ? 1000 : 0) + len;
             }
+            // EARLY RANGE RE-SEARCH (kz_range.h "grouped"): thousands of rows the split-bf16 operands could not certify are, on data
+            // with clusters far tighter than its extent, rows the float32 operands cannot certify either -- they used to cost a sweep
+            // of the whole index there (85 of 180 ms per direction, 200 k x 200 k x 200) before the exact kernels got them.  The
+            // groups are tried HERE: rows that share a representative's range are answered by the exact kernels at once; the others
+            // go on to the next tier as before.
+            int* early_left = nullptr;
+            const int* esc_list = fail_list;
+            if (tier == KZ_TIER_BF && !dual && n_fail >= KZ_RG_MIN_ROWS && kz_range_shapes_ok(ctx, query, index)) {
+                int* fl0 = nullptr;
+                double* tau0 = nullptr;
+                rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&fl0);
+                if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * 8, (void**)&tau0);
+                if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&early_left);
+                if (rc == KZ_OK && (hipMemcpyAsync(fl0, fail_list, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                                    hipMemcpyAsync(tau0, ps.fail_tau, (size_t)n_fail * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)) {
+                    kz_set_error("kz_knn: copying the uncertified rows failed");
+                    rc = KZ_ERR_HIP;
+                }
+                int n_after = n_fail;
+                long long pairs = 0, grouped = 0;
+                if (rc == KZ_OK) {
+                    KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+                    rc = kz_range_rescue(ctx, query, fp.row_map ? 0 : cq_begin, fl0, tau0, n_fail, index, k, exclude_self, d_self_ids, fp.out_dist,
+                                         fp.out_ind, early_left, &n_after, &pairs, &grouped, true);
+                }
+                kz_pool_free(ctx, fl0, 0);
+                kz_pool_free(ctx, tau0, 0);
+                if (rc != KZ_OK) {
+                    kz_pool_free(ctx, early_left, 0);
+                    return rc;
+                }
+                KZ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+                KZ_HIP(hipStreamSynchronize(ctx->stream));
+                KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+                fb_ms += ms;
+                n_range += n_fail - n_after;
+                n_range_group += n_fail - n_after;
+                n_range_pairs += pairs;
+                n_fail_total += n_fail - n_after;   // (answered by the exact kernels)
+                n_fail = n_after;
+                esc_list = early_left;
+            }
             kz_knn_stats st2;
+            memset(&st2, 0, sizeof(st2));
             // (fp16 found hard after the fact, no probe beforehand: the ladder on the failed rows -- top-level calls only)
             const bool ladder = fp16_hard && !wide_route && next_prec == 2 && !probed && kp_min == 0 && forced_lists == 0 && precision_override < 0 &&
                                 !(dual && dual->probed);
-            if (ladder)
-                rc = kz_escalate_ladder(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids, next_prec,
+            ms = 0;
+            if (n_fail == 0) {
+            } else if (ladder)
+                rc = kz_escalate_ladder(ctx, query, fp.row_map ? 0 : cq_begin, esc_list, n_fail, index, k, exclude_self, d_self_ids, next_prec,
                                         next_kp, fp.out_dist, fp.out_ind, &st2, &ms);
             else
-                rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, fail_list, n_fail, index, k, exclude_self, d_self_ids, next_prec,
+                rc = kz_escalate_rows(ctx, query, fp.row_map ? 0 : cq_begin, esc_list, n_fail, index, k, exclude_self, d_self_ids, next_prec,
                                       next_kp, fp.out_dist, fp.out_ind, &st2, &ms);
+            kz_pool_free(ctx, early_left, 0);
             if (rc != KZ_OK) return rc;
             fb_ms += ms;
             n_escalated += n_fail + st2.n_escalated_rows;

@@ -473,7 +473,7 @@ __global__ void kz_rg_slots_kernel(const int* __restrict__ slot_grp, const int* 
 // others come back as rest / rest_tau [*n_rest] for the per-row path.  *pairs: pairs evaluated.
 static int kz_range_grouped(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int* fl, const double* tau, int n_fail, kz_matrix* index, int k,
                             int exclude_self, const int64_t* d_self_ids, double* out_dist, int64_t* out_ind, const KzRangeLog& lg, int* rest,
-                            double* rest_tau, int* n_rest, int* left, int* left_cnt, long long* pairs) {
+                            double* rest_tau, int* n_rest, int* left, int* left_cnt, long long* pairs, long long pair_cap) {
     const int metric = index->metric, d = (int)index->d;
     const int k_eff = k + (exclude_self ? 1 : 0);
     const int k_sel = (int)(k_eff < index->n ? k_eff : index->n);
@@ -588,6 +588,7 @@ static int kz_range_grouped(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int
     std::vector<KzXlGroup> h_groups;
     long long budget = (long long)(mem_free / 3 / 8);
     if (budget > (1ll << 31)) budget = 1ll << 31;
+    if (pair_cap >= 0 && budget > pair_cap) budget = pair_cap;
     long long tot_pairs = 0;
     int n_slots = 0, rows_max = 0, q_max = 0;
     {
@@ -675,7 +676,7 @@ static int kz_range_grouped(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int
 // left [n_fail] (device), *n_left = their number.  Ends synchronised with the stream.  n_pairs_out: pairs evaluated (statistics).
 static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int* fl, const double* tau, int n_fail, kz_matrix* index, int k,
                            int exclude_self, const int64_t* d_self_ids, double* out_dist, int64_t* out_ind, int* left, int* n_left,
-                           long long* n_pairs_out, long long* n_grouped_out) {
+                           long long* n_pairs_out, long long* n_grouped_out, bool grouped_only = false) {
     *n_left = 0;
     if (n_pairs_out) *n_pairs_out = 0;
     if (n_grouped_out) *n_grouped_out = 0;
@@ -739,6 +740,8 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
         return e1 != hipSuccess ? e1 : hipStreamSynchronize(ctx->stream);
     };
     // ---- groups first: rows of one tight cluster share a representative's range ("abl" bit 16: off) ------------------------------
+    // (grouped_only -- the EARLY call, rows that have tiers left to try: groups only, and only while their blocks hold at most an eighth
+    //  of the pairs the whole index would; the rows that are not grouped come back in `left` for the next tier)
     if (n_fail >= KZ_RG_MIN_ROWS && !(ctx->abl & 16)) {
         rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&rest);
         if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * 8, (void**)&rest_tau);
@@ -746,7 +749,7 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
             int n_rest = 0;
             long long gp = 0;
             rc = kz_range_grouped(ctx, query, q0, fl, tau, n_fail, index, k, exclude_self, d_self_ids, out_dist, out_ind, lg, rest, rest_tau, &n_rest,
-                                  left, left_cnt, &gp);
+                                  left, left_cnt, &gp, grouped_only ? (long long)((double)n_fail * (double)index->n / 8.0) : -1);
             if (rc != KZ_OK) {
                 release_all();
                 return rc;
@@ -760,6 +763,27 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
             release_all();
             return rc;
         }
+    }
+    if (grouped_only) {   // (what the groups did not take: handed back behind the rows their selection handed back)
+        if (fl != rest) {   // (no group was tried: nothing was answered)
+            release_all();
+            KZ_HIP(hipMemcpyAsync(left, fl, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+            KZ_HIP(hipStreamSynchronize(ctx->stream));
+            *n_left = n_fail;
+            return KZ_OK;
+        }
+        int have = 0;
+        hipError_t e2 = read_back(&have, left_cnt, sizeof(int));
+        if (e2 == hipSuccess && n_fail > 0) e2 = hipMemcpyAsync(left + have, fl, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+        release_all();
+        if (e2 != hipSuccess) {
+            kz_set_error("kz_knn: range re-search: %s", hipGetErrorString(e2));
+            return KZ_ERR_HIP;
+        }
+        *n_left = have + n_fail;
+        if (n_pairs_out) *n_pairs_out = pairs_total;
+        return KZ_OK;
     }
     int batch = n_fail < KZ_RANGE_BATCH ? n_fail : KZ_RANGE_BATCH;
     for (int b0 = 0; b0 < n_fail;) {
