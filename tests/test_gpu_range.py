@@ -115,6 +115,26 @@ def test_rows_handed_back(ctx, abl):
     np.testing.assert_array_equal(dd0.numpy(), dd1.numpy())
 
 
+@pytest.mark.parametrize("metric,d,k", [("euclidean", 64, 10), ("cosine", 200, 50), ("sqeuclidean", 300, 5)])
+def test_groups_same_bits(ctx, metric, d, k):
+    """Thousands of uncertified rows: rows of one tight cluster share a representative's range (a dense block per group), tried on
+    what the split-bf16 pass leaves and again at the end of the ladder.  Three routes, the same bits: groups (default), one range per
+    row (abl 16), the whole index (exact_rows 2)."""
+    from kiez_amd import _native as N
+    q, y = _tight(14000, d, 11, n_clusters=5), _tight(20001, d, 12, n_clusters=5)
+    y[5] = y[17]
+    qm, ym = N.DeviceMatrix(ctx, q, metric), N.DeviceMatrix(ctx, y, metric)
+    dd, ii, st = _both(ctx, qm, ym, k)
+    assert st["n_range_group_rows"] >= 2048 and st["n_range_group_rows"] <= st["n_range_rows"] <= st["n_fallback_rows"], st
+    assert st["n_range_pairs"] < st["n_range_rows"] * y.shape[0] // 2, st
+    ctx.set_option("abl", 16)
+    d1, i1, s1 = N.knn(ctx, qm, ym, k)
+    ctx.set_option("abl", 0)
+    assert s1["n_range_group_rows"] == 0, s1
+    np.testing.assert_array_equal(ii, i1.numpy())
+    np.testing.assert_array_equal(dd, d1.numpy())
+
+
 def test_both_directions_of_a_fit(ctx):
     """kz_knn_dual on tight clusters: both directions' uncertified rows take the range re-search."""
     from kiez_amd import _native as N
