@@ -2541,7 +2541,6 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
     // pass writes the same values again).  Cost on data that is fine: ~0.35 % of a 300k-row sweep + ~0.3 ms (230k x 230k x 128: 13.5 -> 13.2 ms
     // with 1024 instead of 4096 rows; 200k x 400k x 200, cosine, k = 50: 32.4 -> 31.8); only top-level searches of >= 5e10 distance pairs
     // and >= 16 probe sizes of query rows take it (C1 / C2 do not).  Option "tier_probe" = 0: off.
-    bool early_h = false;          // the tier probe's verdict: offer what the fp16 pass leaves to the grouped range re-search
     float* qfloor_ord = nullptr;   // seeded lists of an ordinary search (the context's buffer: nothing to release)
     bool probed = false;           // the tier probe below has run: its verdict stands (no ladder after the fact)
     if (tier == KZ_TIER_H && !dual && precision_override < 0 && kp_min == 0 && forced_lists == 0 && !exact_only && ctx->tier_probe > 0 && ctx->esc_bf &&
@@ -2590,14 +2589,6 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             }
         }
         kz_pool_free(ctx, plist_keep, 0);
-        // Hard for fp16, the wide route does not help -- but a good part of the probe WAS certified (clusters of very different
-        // density: the loose ones are fine, the tight ones beyond any operand precision): the fp16 pass stays, and what it leaves
-        // is offered to the grouped range re-search before the split-bf16 operands see it (below, "EARLY RANGE RE-SEARCH") -- instead of
-        // three MFMA products per multiply-add for every row of the call.
-        if (hard && (int64_t)stp.n_first_pass_fail * 10 < (int64_t)n_probe * 9 && kz_range_shapes_ok(ctx, query, index) && !(ctx->abl & 16)) {
-            hard = false;
-            early_h = true;
-        }
         if (hard) {
             tier = KZ_TIER_BF;
             // (data this hard for fp16 is hard for the split-bf16 operands, too, wherever the keys are dense: lists of 64 from the
@@ -3040,8 +3031,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
             const int* esc_list = fail_list;
             // (NOT on what an fp16 pass leaves: rows that only lack margin in ranks -- 40 tight clusters, 100 k x 101 k x 128 -- are
             //  cheaper on the ladder's wide route than as 2.4e8 exact pairs: 26.5 -> 33.7 ms with the groups tried there, removed)
-            //  -- except where the tier probe has seen that the data is of that kind: early_h)
-            if ((tier == KZ_TIER_BF || (tier == KZ_TIER_H && early_h)) && !dual && n_fail >= KZ_RG_MIN_ROWS && kz_range_shapes_ok(ctx, query, index)) {
+            if (tier == KZ_TIER_BF && !dual && n_fail >= KZ_RG_MIN_ROWS && kz_range_shapes_ok(ctx, query, index)) {
                 int* fl0 = nullptr;
                 double* tau0 = nullptr;
                 rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&fl0);
