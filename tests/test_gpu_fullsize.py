@@ -20,6 +20,14 @@ def c1_data():
 THREADS = max(1, min(32, os.cpu_count() or 1))   # (oracle.knn_exact works on its row chunks with this many threads)
 
 
+@pytest.fixture(scope="module")
+def c1_oracle_forward(c1_data):
+    """The oracle's forward pass over ALL 100 000 rows -- C1's answer and the first half of C2's: computed once (22 s of host dgemm)."""
+    from oracle import kiez_oracle as O
+    s, t = c1_data
+    return O.knn_exact(s, t, 10, "euclidean", threads=THREADS)
+
+
 def _props(dist, ind, n_index, k):
     assert dist.shape == ind.shape == (dist.shape[0], k)
     assert ind.dtype == np.int64 and dist.dtype == np.float64
@@ -29,7 +37,7 @@ def _props(dist, ind, n_index, k):
     assert np.isfinite(dist).all()
 
 
-def test_c1_full_size_every_row_against_the_oracle(c1_data):
+def test_c1_full_size_every_row_against_the_oracle(c1_data, c1_oracle_forward):
     from kiez_amd import Kiez
     from oracle import kiez_oracle as O
     s, t = c1_data
@@ -42,7 +50,7 @@ def test_c1_full_size_every_row_against_the_oracle(c1_data):
     assert (np.diff(d10, axis=1) >= 0).all(), "rows must be sorted ascending"
     np.testing.assert_array_equal(i5, i10[:, :5])          # k-prefix property
     np.testing.assert_array_equal(d5, d10[:, :5])
-    od, oi = O.knn_exact(s, t, 10, "euclidean", threads=THREADS)      # ALL 100 000 rows
+    od, oi = c1_oracle_forward      # ALL 100 000 rows
     np.testing.assert_array_equal(i10, oi)
     np.testing.assert_array_equal(d10, od)                  # float32 inputs: bit-identical distances (sqrt rule)
     # exact distance recomputed in float64 for a few entries
@@ -52,7 +60,7 @@ def test_c1_full_size_every_row_against_the_oracle(c1_data):
     assert kz.algorithm.last_stats["n_fallback_rows"] < 100
 
 
-def test_c2_full_size_csls_every_row_against_the_oracle(c1_data):
+def test_c2_full_size_csls_every_row_against_the_oracle(c1_data, c1_oracle_forward):
     from kiez_amd import Kiez
     from oracle import kiez_oracle as O
     s, t = c1_data
@@ -65,7 +73,7 @@ def test_c2_full_size_csls_every_row_against_the_oracle(c1_data):
     # the whole pipeline in the oracle, ALL rows: reverse pass (fit state), forward pass, CSLS, final sort
     rd, _ = O.knn_exact(t, s, 10, "euclidean", threads=THREADS)
     np.testing.assert_array_equal(kz.hubness._r_train_dev.numpy(), rd.mean(axis=1))       # csls.py:90, bit for bit
-    fd, fi = O.knn_exact(s, t, 10, "euclidean", threads=THREADS)
+    fd, fi = c1_oracle_forward
     od, oi = O.sort_topk(O.csls_transform(fd, fi, rd), fi, 10)
     np.testing.assert_array_equal(i, oi)
     np.testing.assert_allclose(d, od, rtol=1e-9, atol=1e-12)
