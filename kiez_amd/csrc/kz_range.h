@@ -326,6 +326,11 @@ struct KzRangeLog {
 // holds the groups, *n_groups their number; *over: the log overflowed or the fp16 tier did not run -- nothing usable was logged.
 static int kz_range_sweep_rows(kz_ctx* ctx, kz_matrix* qsub, const double* tau, int nb, kz_matrix* index, const KzRangeLog& lg, float* thr,
                                float* inff, double* out_dist, int64_t* out_ind, unsigned long long* n_groups, bool* over) {
+    if (ctx->chunk_rows > 0 && nb > ctx->chunk_rows) {   // (test knob "chunk_rows": the sweep must be ONE launch -- not taken)
+        *n_groups = 0;
+        *over = true;
+        return KZ_OK;
+    }
     int rc = kz_himage_ensure(qsub, index);
     if (rc != KZ_OK) return rc;
     const int64_t n_pad = qsub->n_tiles * KZ_TILE;
@@ -786,6 +791,7 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
         return KZ_OK;
     }
     int batch = n_fail < KZ_RANGE_BATCH ? n_fail : KZ_RANGE_BATCH;
+    if (ctx->chunk_rows > 0 && batch > ctx->chunk_rows) batch = (int)ctx->chunk_rows;
     for (int b0 = 0; b0 < n_fail;) {
         const int nb = n_fail - b0 < batch ? n_fail - b0 : batch;
         // ---- the batch's rows as a matrix of their own, their thresholds, the sweep ------------------------------------

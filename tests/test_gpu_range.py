@@ -19,6 +19,7 @@ def ctx():
     c.set_option("exact_rows", 3)
     c.set_option("abl", 0)
     c.set_option("spec_rows", 64)
+    c.set_option("chunk_rows", 0)
 
 
 def _tight(n, d, seed, n_clusters=6):
@@ -133,6 +134,20 @@ def test_groups_same_bits(ctx, metric, d, k):
     assert s1["n_range_group_rows"] == 0, s1
     np.testing.assert_array_equal(ii, i1.numpy())
     np.testing.assert_array_equal(dd, d1.numpy())
+
+
+def test_small_chunks(ctx):
+    """The test knob chunk_rows (query rows per launch): the range sweeps take batches no larger than a chunk -- same results."""
+    from kiez_amd import _native as N
+    q, y = _tight(3000, 64, 1), _tight(9001, 64, 2)
+    qm, ym = N.DeviceMatrix(ctx, q, "euclidean"), N.DeviceMatrix(ctx, y, "euclidean")
+    d0, i0, st0 = N.knn(ctx, qm, ym, 10)
+    ctx.set_option("chunk_rows", 512)
+    d1, i1, st1 = N.knn(ctx, qm, ym, 10)
+    ctx.set_option("chunk_rows", 0)
+    assert st1["n_range_rows"] > 0, st1
+    np.testing.assert_array_equal(i0.numpy(), i1.numpy())
+    np.testing.assert_array_equal(d0.numpy(), d1.numpy())
 
 
 def test_both_directions_of_a_fit(ctx):
