@@ -381,7 +381,7 @@ static int kz_range_sweep_rows(kz_ctx* ctx, kz_matrix* qsub, const double* tau, 
 //   * a neighbour y of x has |x - y| <= a(x) = the distance of x's k-th candidate, so |r - y| <= |r - x| + a(x): the range of r
 //     with the radius R(r) = max over its rows of that sum holds every neighbour of every row assigned to r (cosine: the same on
 //     the chords sqrt(2 dist) of the unit vectors);
-//   * the representatives -- a 64th of the rows -- are swept and logged as above; a group (r, its rows M, its range B) is then a
+//   * the representatives -- a 256th of the rows -- are swept and logged as above; a group (r, its rows M, its range B) is then a
 //     DENSE block of |M| x |B| pairs for the one-pair-per-lane kernel (kz_exact_lanes.h, GATHER: a workgroup stages 64 rows of B
 //     once for all rows of M; 3.8e10 pairs/s against the per-pair gather's 7e9); kz_exact_select_kernel picks every row's k best
 //     of its group's block.
@@ -395,10 +395,20 @@ constexpr int KZ_RG_MAX_REPS = 1024;   // ... at most this many
 // vals [n_rep][n]: the exact values between the representatives and the failed rows.  grp [n]: the nearest representative of failed
 // row i (-1: no bound, the row is not grouped); rbits [n_rep]: the radius (bits of a positive float, rounded up) = max over the rows
 // of a representative; mcount [n_rep]: its rows
+// The values are the exact kernels' -- float64 evaluations of |x|^2 + |y|^2 - 2 x.y (cosine: 1 - x^.y^), a few 1e-13 of the squared
+// norms away from the geometry the triangle inequality speaks about: every value that enters it is taken E larger, E = 4e-11 x the
+// largest squared norm of either side (cosine: 1e-11) -- nothing next to a range's radius, ~100 x the round-off it covers.
+__device__ __forceinline__ double kz_rg_slack(const double* __restrict__ stats_a, const double* __restrict__ stats_b, int metric) {
+    if (metric == KZ_COSINE) return 1e-11;
+    const double m = fmax(stats_a[0], stats_b[0]);   // (d_stats[0]: the largest row norm of a matrix)
+    return 4e-11 * m * m;
+}
 __global__ void kz_rg_assign_kernel(const double* __restrict__ tau, const double* __restrict__ vals, int n_rep, int n, int metric,
-                                    int* __restrict__ grp, int* __restrict__ rbits, int* __restrict__ mcount) {
+                                    const double* __restrict__ stats_a, const double* __restrict__ stats_b, int* __restrict__ grp,
+                                    int* __restrict__ rbits, int* __restrict__ mcount) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const double E = kz_rg_slack(stats_a, stats_b, metric);
     const double tv = tau[i];
     int g = -1;
     if (tv < (double)INFINITY) {
@@ -417,7 +427,7 @@ __global__ void kz_rg_assign_kernel(const double* __restrict__ tau, const double
         if (best > 16.0 * tv) {
             g = -1;
         } else {
-            const double r = (sqrt(s * tv) + sqrt(s * best)) * (1.0 + 1e-9) + 1e-300;
+            const double r = (sqrt(s * (tv + E)) + sqrt(s * (best + E))) * (1.0 + 1e-9) + 1e-300;
             float rf = (float)r;
             if ((double)rf < r) rf = nextafterf(rf, INFINITY);
             atomicMax(rbits + g, __float_as_int(rf));
@@ -427,13 +437,14 @@ __global__ void kz_rg_assign_kernel(const double* __restrict__ tau, const double
     grp[i] = g;
 }
 // tau_rep [n_rep]: the bound of a representative's range in value units (squared distance / cosine distance), +inf: no rows
-__global__ void kz_rg_tau_kernel(const int* __restrict__ rbits, const int* __restrict__ mcount, int n_rep, int metric, double* __restrict__ tau_rep) {
+__global__ void kz_rg_tau_kernel(const int* __restrict__ rbits, const int* __restrict__ mcount, int n_rep, int metric,
+                                 const double* __restrict__ stats_a, const double* __restrict__ stats_b, double* __restrict__ tau_rep) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_rep) return;
     double t = INFINITY;
     if (mcount[j] > 0) {
         const double R = (double)__int_as_float(rbits[j]);
-        t = R * R * (1.0 + 1e-6) / (metric == KZ_COSINE ? 2.0 : 1.0);
+        t = R * R * (1.0 + 1e-6) / (metric == KZ_COSINE ? 2.0 : 1.0) + kz_rg_slack(stats_a, stats_b, metric);
         if (metric == KZ_COSINE && t > 2.0) t = 2.0;
     }
     tau_rep[j] = t;
@@ -563,8 +574,10 @@ static int kz_range_grouped(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int
                                (const float*)rm->raw, (const float*)fm->raw, rm->sqn, fm->sqn, (int64_t)n_fail, d, metric, index->mink_p, rv,
                                (const int*)nullptr);
     }
-    hipLaunchKernelGGL(kz_rg_assign_kernel, dim3((n_fail + 255) / 256), dim3(256), 0, ctx->stream, tau, rv, n_rep, n_fail, metric, grp, rbits, mcount);
-    hipLaunchKernelGGL(kz_rg_tau_kernel, dim3((n_rep + 255) / 256), dim3(256), 0, ctx->stream, rbits, mcount, n_rep, metric, tau_rep);
+    hipLaunchKernelGGL(kz_rg_assign_kernel, dim3((n_fail + 255) / 256), dim3(256), 0, ctx->stream, tau, rv, n_rep, n_fail, metric, fm->d_stats,
+                       index->d_stats, grp, rbits, mcount);
+    hipLaunchKernelGGL(kz_rg_tau_kernel, dim3((n_rep + 255) / 256), dim3(256), 0, ctx->stream, rbits, mcount, n_rep, metric, fm->d_stats, index->d_stats,
+                       tau_rep);
     // ---- the representatives' ranges -----------------------------------------------------------------------------------------
     unsigned long long n_groups = 0;
     bool over = false;
