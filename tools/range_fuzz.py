@@ -30,15 +30,18 @@ def data(kind, n, d, r):
     return np.full((n, d), 0.5, dtype=np.float32) + (r.random((n, d)) < 0.001).astype(np.float32)      # nearly constant
 
 
-bad = 0
+bad = n_range = n_grouped = 0
 t0 = time.time()
 for c in range(cases):
     d = int(rng.choice([16, 20, 32, 64, 100, 128, 200, 256, 260, 300, 512]))
+    kind_next = str(rng.choice(["gauss", "tight", "tight", "dups", "const"]))
     n_q = int(rng.integers(150, 9000))
+    if kind_next == "tight" and rng.random() < 0.5:
+        n_q = int(rng.integers(6000, 24000))      # (enough uncertified rows for the grouped route)
     n_i = int(rng.integers(200, 20000))
     k = int(rng.choice([1, 5, 10, 50]))
     metric = str(rng.choice(["euclidean", "sqeuclidean", "cosine"]))
-    kind = str(rng.choice(["gauss", "tight", "tight", "dups", "const"]))
+    kind = kind_next
     eps = float(rng.choice([1.0, 1.0, 30.0, 1e3, 1e30]))
     same = bool(rng.random() < 0.2)
     k = min(k, n_i - 1)
@@ -60,11 +63,13 @@ for c in range(cases):
     ctx.set_option("eps_scale", 1.0)
     ok = all(np.array_equal(out[0][0], o[0]) and np.array_equal(out[0][1], o[1]) for o in out[1:])
     st = out[0][2]
+    n_range += st["n_range_rows"] > 0
+    n_grouped += st["n_range_group_rows"] > 0
     if not ok:
         bad += 1
     if not ok or c % 20 == 0:
         print(f"case {c}: {'ok ' if ok else 'BAD'} {q.shape[0]} x {n_i} x {d} k={k} {metric} {kind} eps x{eps:g} self={same}: exact rows {st['n_fallback_rows']}"
               f" range {st['n_range_rows']} grouped {st['n_range_group_rows']} pairs {st['n_range_pairs']}; per row: range {out[1][2]['n_range_rows']}", flush=True)
     del qm, ym
-print(f"{cases} cases, {bad} bad, {time.time() - t0:.0f} s")
+print(f"{cases} cases ({n_range} with rows on the range re-search, {n_grouped} of them with groups), {bad} bad, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
