@@ -3047,7 +3047,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 if (rc == KZ_OK) {
                     KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
                     rc = kz_range_rescue(ctx, query, fp.row_map ? 0 : cq_begin, fl0, tau0, n_fail, index, k, exclude_self, d_self_ids, fp.out_dist,
-                                         fp.out_ind, early_left, &n_after, &pairs, &grouped, true);
+                                         fp.out_ind, early_left, &n_after, &pairs, &grouped, true, KZ_RANGE_EARLY_PER_ROW);
                 }
                 kz_pool_free(ctx, fl0, 0);
                 kz_pool_free(ctx, tau0, 0);
@@ -3060,7 +3060,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
                 fb_ms += ms;
                 n_range += n_fail - n_after;
-                n_range_group += n_fail - n_after;
+                n_range_group += grouped;
                 n_range_pairs += pairs;
                 n_fail_total += n_fail - n_after;   // (answered by the exact kernels)
                 n_fail = n_after;

@@ -27,6 +27,7 @@ constexpr int KZ_RANGE_MIN_ROWS = 128;      // fewer rows: the whole-index kerne
 constexpr int KZ_RANGE_BATCH = 32768;       // failed rows per sweep
 constexpr int KZ_RANGE_MIN_BATCH = 1024;    // a log that overflows at this batch size: the batch goes to `left`
 constexpr int KZ_RANGE_PPW = 256;           // pairs per wave of kz_exact_pairs_kernel
+constexpr int KZ_RANGE_EARLY_PER_ROW = 4096;   // the early call: at most this many rows outside the groups take their own ranges there
 
 // thr [n_pad]: the threshold of batch row i in the fp16 tier's key units (+inf: nothing is logged -- pad rows, tau = +inf; diagnostic
 // "abl" bit 8: every row, as if no row had k candidates);
@@ -694,7 +695,7 @@ static int kz_range_grouped(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int
 // left [n_fail] (device), *n_left = their number.  Ends synchronised with the stream.  n_pairs_out: pairs evaluated (statistics).
 static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int* fl, const double* tau, int n_fail, kz_matrix* index, int k,
                            int exclude_self, const int64_t* d_self_ids, double* out_dist, int64_t* out_ind, int* left, int* n_left,
-                           long long* n_pairs_out, long long* n_grouped_out, bool grouped_only = false) {
+                           long long* n_pairs_out, long long* n_grouped_out, bool grouped_only = false, int per_row_max = 0) {
     *n_left = 0;
     if (n_pairs_out) *n_pairs_out = 0;
     if (n_grouped_out) *n_grouped_out = 0;
@@ -782,6 +783,9 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
             return rc;
         }
     }
+    // (... unless only a few are left: the next tier would sweep the whole index for them -- 3.3 ms per launch of the float32-operand
+    //  kernel on 200 k rows whatever the row count -- where their own ranges cost a fraction of that)
+    if (grouped_only && fl == rest && n_fail <= per_row_max) grouped_only = false;
     if (grouped_only) {   // (what the groups did not take: handed back behind the rows their selection handed back)
         if (fl != rest) {   // (no group was tried: nothing was answered)
             release_all();

@@ -111,7 +111,7 @@ def test_rows_handed_back(ctx, abl):
     ctx.set_option("abl", abl)
     dd1, ii1, st1 = N.knn(ctx, qm, ym, 10)
     ctx.set_option("abl", 0)
-    assert st1["n_range_rows"] == 0 and st1["n_fallback_rows"] == st0["n_fallback_rows"], (st0, st1)
+    assert st1["n_range_rows"] == 0 and st1["n_fallback_rows"] > 0, (st0, st1)      # (the rows went on: next tier, whole-index kernels)
     np.testing.assert_array_equal(ii0.numpy(), ii1.numpy())
     np.testing.assert_array_equal(dd0.numpy(), dd1.numpy())
 
