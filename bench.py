@@ -473,6 +473,8 @@ def run_workload(name, eng, comm, dist, rank, world, steps, warmup, check=True, 
         "escalated_rows": int(sum(st.get("n_escalated_rows", 0) for _, _, st in knn_log)),
         # of fallback_rows: the handful of rows per search answered by the exact kernels launched speculatively behind the finalize
         "spec_rows": int(sum(st.get("n_spec_rows", 0) for _, _, st in knn_log)),
+        "range_rows": int(sum(st.get("n_range_rows", 0) for _, _, st in knn_log)),
+        "range_group_rows": int(sum(st.get("n_range_group_rows", 0) for _, _, st in knn_log)),
         "max_err_ratio": max((st.get("max_err_ratio", 0.0) for _, _, st in knn_log), default=0.0),
         "finalize_avg_ms": sum(st["finalize_ms"] for _, _, st in knn_log) / max(n_launch, 1),
         "fallback_total_ms": sum(st["fallback_ms"] for _, _, st in knn_log),
@@ -550,7 +552,7 @@ def short(summary):
             "main_kernel_avg_ms": s["kernel_s"] / max(s["n_launch"], 1) * 1e3, "dtype": TIER_NAME[s["tier"]],
             "roofline_frac": s["achieved"] / s["peak"], "achieved_tflops": s["achieved"],
             "finalize_avg_ms": s["finalize_avg_ms"], "certification_fallback_rows": s["fallback_rows"],
-            "escalated_rows": s["escalated_rows"], "speculative_rescue_rows": s["spec_rows"], "fallback_total_ms": s["fallback_total_ms"], "probe_ms_per_step": s["probe_ms_per_step"],
+            "escalated_rows": s["escalated_rows"], "speculative_rescue_rows": s["spec_rows"], "range_research_rows": s["range_rows"], "range_group_rows": s["range_group_rows"], "fallback_total_ms": s["fallback_total_ms"], "probe_ms_per_step": s["probe_ms_per_step"],
             "wide_lists": s["wide_lists"], "first_pass_fail_rows": s["first_pass_fail_rows"],
             "max_err_over_eps": s["max_err_ratio"], "steps": s["steps"], "shared_sweeps": s["shared_sweeps"],
             "reverse_extra_ms_per_step": s["reverse_extra_ms_per_step"], "reverse_escalated_rows": s["reverse_escalated_rows"], "check": s["check"]}
@@ -819,6 +821,8 @@ def main():
             "certification_fallback_rows": s["fallback_rows"],
             "escalated_rows": s["escalated_rows"],
             "speculative_rescue_rows": s["spec_rows"],
+            "range_research_rows": s["range_rows"],
+            "range_group_rows": s["range_group_rows"],
             "rounding_bound_self_check": {"max_err_over_eps": s["max_err_ratio"],
                                           "note": "max |approximate key - exact key| / eps over all re-ranked candidates; the certification needs < 1"},
             "other_kernels_ms": {"finalize_avg": s["finalize_avg_ms"], "fallback_total": s["fallback_total_ms"]},
