@@ -194,6 +194,9 @@ __global__ __launch_bounds__(256) void kz_exact_dist_lanes_kernel(int nb, const 
     const int bb_first = GATHER ? (int)blockIdx.y * q_chunk : 0;
     const int bb_last = GATHER ? (bb_first + q_chunk < nb_pad ? bb_first + q_chunk : nb_pad) : nb_pad;
     for (int bb = bb_first; bb < bb_last; bb += QB) {   // (uniform)
+        // (a wave whose four rows of this block all lie past the batch has nothing to compute: a speculative launch for TWO rows of a
+        //  1 M-row index ran the walk in all four waves -- four times the scalar loads the live wave waits for)
+        if (bb + wave * KZ_XL_Q >= nb) continue;
         qrow = qd + ((size_t)bb + (size_t)wave * KZ_XL_Q) * d_pad;
         // ---- the tree, depth first: leaves in bit-reversed order; the partial sums of the completed subtrees sit in lev[0 .. LOG),
         //      one per level, like the digits of a binary counter: leaf `it` is added in at level 0 and carried upward through every
