@@ -2975,7 +2975,12 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
         // A HANDFUL of rows left by the split-bf16 operands skips the float32-operand kernel: that kernel sweeps the whole index for
         // one query tile in at most eight pieces -- 2.2 ms on 300 k rows of d = 64 whatever the row count -- while the exact kernels
         // cost ~35 us a row there (both scale with n d): bench.py "hard", ~20 rows per direction and step: 60.6 -> see r05_notes.
-        const bool exact_direct = tier == KZ_TIER_BF && !dual && n_fail > 0 && n_fail <= KZ_K_EXACT_DIRECT_ROWS;
+        // (... and so do a few hundred to a few thousand rows where the range re-search applies and the index is large: that kernel's
+        //  sweep of the whole index per launch -- 3 ms on 200 k x 200 -- against one fp16 sweep of the failed rows and their pairs;
+        //  the tier probe's 1 024 rows paid 2 x 3 ms there on hard data)
+        const bool range_direct = tier == KZ_TIER_BF && !dual && !exact_only && n_fail >= KZ_RANGE_MIN_ROWS && n_fail < KZ_RG_MIN_ROWS &&
+                                  index->n >= 65536 && kz_range_shapes_ok(ctx, query, index);
+        const bool exact_direct = (tier == KZ_TIER_BF && !dual && n_fail > 0 && n_fail <= KZ_K_EXACT_DIRECT_ROWS) || range_direct;
         // (the speculative launches behind the finalize kernel have answered them all)
         const bool rescued = spec.R > 0 && n_fail > 0 && n_fail <= spec.R;
         if (rescued) {
