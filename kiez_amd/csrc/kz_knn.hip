@@ -3049,6 +3049,7 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 }
                 int n_after = n_fail;
                 long long pairs = 0, grouped = 0;
+                const bool no_mem = rc == KZ_ERR_NOMEM;   // (no room for the lists: the next tier as before -- the step is an optimisation)
                 if (rc == KZ_OK) {
                     KZ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
                     rc = kz_range_rescue(ctx, query, fp.row_map ? 0 : cq_begin, fl0, tau0, n_fail, index, k, exclude_self, d_self_ids, fp.out_dist,
@@ -3056,20 +3057,26 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                 }
                 kz_pool_free(ctx, fl0, 0);
                 kz_pool_free(ctx, tau0, 0);
-                if (rc != KZ_OK) {
+                if (no_mem) {
                     kz_pool_free(ctx, early_left, 0);
-                    return rc;
+                    early_left = nullptr;
+                    rc = KZ_OK;
+                } else {
+                    if (rc != KZ_OK) {
+                        kz_pool_free(ctx, early_left, 0);
+                        return rc;
+                    }
+                    KZ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+                    KZ_HIP(hipStreamSynchronize(ctx->stream));
+                    KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+                    fb_ms += ms;
+                    n_range += n_fail - n_after;
+                    n_range_group += grouped;
+                    n_range_pairs += pairs;
+                    n_fail_total += n_fail - n_after;   // (answered by the exact kernels)
+                    n_fail = n_after;
+                    esc_list = early_left;
                 }
-                KZ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-                KZ_HIP(hipStreamSynchronize(ctx->stream));
-                KZ_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
-                fb_ms += ms;
-                n_range += n_fail - n_after;
-                n_range_group += grouped;
-                n_range_pairs += pairs;
-                n_fail_total += n_fail - n_after;   // (answered by the exact kernels)
-                n_fail = n_after;
-                esc_list = early_left;
             }
             kz_knn_stats st2;
             memset(&st2, 0, sizeof(st2));
@@ -3126,20 +3133,26 @@ static int kz_knn_impl(kz_ctx* ctx, kz_matrix* query, int64_t q_begin, int64_t q
                     rc = KZ_ERR_HIP;
                 }
                 long long pairs = 0, grouped = 0;
+                const bool no_mem = rc == KZ_ERR_NOMEM;   // (no room for the lists: the whole-index kernels as before)
                 if (rc == KZ_OK)
                     rc = kz_range_rescue(ctx, query, cq_begin, fl, tau, n_fail, index, k, exclude_self, d_self_ids, fp.out_dist, fp.out_ind, left,
                                          &n_dense, &pairs, &grouped);
                 kz_pool_free(ctx, tau, 0);
-                if (rc != KZ_OK) {
+                if (no_mem) {
                     kz_pool_free(ctx, left, 0);
-                    kz_pool_free(ctx, fl, 0);
-                    return rc;
+                    rc = KZ_OK;
+                } else {
+                    if (rc != KZ_OK) {
+                        kz_pool_free(ctx, left, 0);
+                        kz_pool_free(ctx, fl, 0);
+                        return rc;
+                    }
+                    n_range += n_fail - n_dense;
+                    n_range_pairs += pairs;
+                    n_range_group += grouped;
+                    kz_pool_free(ctx, fl, 0);   // (the rows handed back take the list's place)
+                    fl = left;
                 }
-                n_range += n_fail - n_dense;
-                n_range_pairs += pairs;
-                n_range_group += grouped;
-                kz_pool_free(ctx, fl, 0);   // (the rows handed back take the list's place)
-                fl = left;
             }
             n_fail = n_dense;
             if (n_fail == 0) {
