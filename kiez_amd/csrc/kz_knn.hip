@@ -1639,6 +1639,48 @@ __global__ __launch_bounds__(256) void kz_exact_select_kernel(const int* __restr
         v = vals + s0;
         vid = cand_idx + (idx_off ? idx_off[b] : s0);   // (idx_off: the rows of a group share one list of index rows)
     }
+    // LONG SEGMENTS (a group's range: thousands of values per row, kz_range.h): k passes over all of them -- 82 k rows x 10 x 5 000
+    // loads, 4 ms of a 79 ms search -- become two.  Pass 1: every thread's smallest value; the k-th smallest T of those 256 minima is
+    // at or above the k-th smallest value of the segment.  Pass 2: the entries <= T (all ties included) go to a list in LDS; the k
+    // rounds below then run over that list.  The k smallest by (value, row) all lie at or below T: the same selection.  A list
+    // that would not fit (values dense at the bottom, duplicates) leaves the segment where it is.
+    constexpr int SEL_CAP = 1536;
+    __shared__ double c_v[SEL_CAP];
+    __shared__ int c_i[SEL_CAP];
+    __shared__ double s_min[256];
+    __shared__ double s_T;
+    __shared__ int s_cnt;
+    if (seg_off && n_entries >= 2048 && k_eff <= 256) {   // (uniform; every thread then owns >= 8 entries)
+        double m = INFINITY;
+        for (int64_t i = tid; i < n_entries; i += 256) m = fmin(m, v[i]);
+        s_min[tid] = m;
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        int rank = 0;
+        for (int o = 0; o < 256; ++o) {
+            const double om = s_min[o];
+            rank += (om < m || (om == m && o < tid)) ? 1 : 0;
+        }
+        if (rank == k_eff - 1) s_T = m;
+        __syncthreads();
+        const double Tv = s_T;
+        for (int64_t i = tid; i < n_entries; i += 256) {
+            const double x = v[i];
+            if (x <= Tv) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < SEL_CAP) {
+                    c_v[pos] = x;
+                    c_i[pos] = vid ? vid[i] : (int)i;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_cnt <= SEL_CAP) {   // (uniform)
+            v = c_v;
+            vid = c_i;
+            n_entries = s_cnt;
+        }
+    }
     double* s_sv = reinterpret_cast<double*>(sel_sm);
     int* s_si = reinterpret_cast<int*>(s_sv + k_eff);
     double pv = -1.0;  // values are >= 0
