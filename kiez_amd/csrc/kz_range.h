@@ -722,12 +722,29 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
         if (rc != KZ_OK) return rc;
     }
     KzRangeLog lg;
-    lg.cap = log_cap;
     int* rest = nullptr;        // the rows the grouped path leaves to the per-row path, their bounds
     double* rest_tau = nullptr;
+    // The log is sized for what is about to be swept -- 65 536 groups per representative (a range beyond that is not taken anyway),
+    // 4 096 per row of a per-row batch -- and grown when the next sweep needs more: a 6 GiB log for every call (the limit above)
+    // kept the context's buffer cache turning over gigabytes.
+    auto ensure_log = [&](long long want) -> int {
+        if (want > log_cap) want = log_cap;
+        if (want < (1ll << 16) && !(ctx->abl & 4)) want = 1ll << 16;
+        if (lg.cap >= want) return KZ_OK;
+        kz_pool_free(ctx, lg.keys, 0);
+        kz_pool_free(ctx, lg.meta, 0);
+        lg.keys = lg.meta = nullptr;
+        lg.cap = 0;
+        int rc2 = kz_pool_alloc(ctx, (size_t)want * 16, &lg.keys);
+        if (rc2 == KZ_OK) rc2 = kz_pool_alloc(ctx, (size_t)want * 8, &lg.meta);
+        if (rc2 == KZ_OK) lg.cap = want;
+        return rc2;
+    };
+    const bool try_groups = n_fail >= KZ_RG_MIN_ROWS && !(ctx->abl & 16);
     int rc = kz_pool_alloc(ctx, (size_t)y_pad * 4, (void**)&lg.theta0);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 16, &lg.keys);
-    if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)log_cap * 8, &lg.meta);
+    if (rc == KZ_OK)
+        rc = ensure_log(try_groups ? (long long)(n_fail / KZ_RG_STRIDE + 1 < KZ_RG_MAX_REPS ? n_fail / KZ_RG_STRIDE + 1 : KZ_RG_MAX_REPS) * 65536
+                                   : (long long)(n_fail < KZ_RANGE_BATCH ? n_fail : KZ_RANGE_BATCH) * 4096);
     if (rc == KZ_OK) rc = kz_pool_alloc(ctx, 64, (void**)&lg.counters);
     auto release_all = [&]() {
         kz_pool_free(ctx, lg.theta0, 0);
@@ -761,7 +778,7 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
     // ---- groups first: rows of one tight cluster share a representative's range ("abl" bit 16: off) ------------------------------
     // (grouped_only -- the EARLY call, rows that have tiers left to try: groups only, and only while their blocks hold at most an eighth
     //  of the pairs the whole index would; the rows that are not grouped come back in `left` for the next tier)
-    if (n_fail >= KZ_RG_MIN_ROWS && !(ctx->abl & 16)) {
+    if (try_groups) {
         rc = kz_pool_alloc(ctx, (size_t)n_fail * sizeof(int), (void**)&rest);
         if (rc == KZ_OK) rc = kz_pool_alloc(ctx, (size_t)n_fail * 8, (void**)&rest_tau);
         if (rc == KZ_OK) {
@@ -809,6 +826,20 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
     }
     int batch = n_fail < KZ_RANGE_BATCH ? n_fail : KZ_RANGE_BATCH;
     if (ctx->chunk_rows > 0 && batch > ctx->chunk_rows) batch = (int)ctx->chunk_rows;
+    if (n_fail > 0) {
+        rc = ensure_log((long long)batch * 4096);
+        if (rc != KZ_OK) {   // (no room for the per-row log: the rows stay with the caller)
+            int have = 0;
+            hipError_t e2 = rc == KZ_ERR_NOMEM ? read_back(&have, left_cnt, sizeof(int)) : hipErrorUnknown;
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(left + have, fl, (size_t)n_fail * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+            release_all();
+            if (e2 != hipSuccess) return rc == KZ_ERR_NOMEM ? KZ_ERR_HIP : rc;
+            *n_left = have + n_fail;
+            if (n_pairs_out) *n_pairs_out = pairs_total;
+            return KZ_OK;
+        }
+    }
     for (int b0 = 0; b0 < n_fail;) {
         const int nb = n_fail - b0 < batch ? n_fail - b0 : batch;
         // ---- the batch's rows as a matrix of their own, their thresholds, the sweep ------------------------------------
