@@ -20,6 +20,10 @@
 // A row whose segment holds fewer than k entries (tau = +inf: it never had k candidates), a batch whose log overflows its buffer
 // even at the smallest batch size: those rows go to the exact kernels against the whole index as before (`left`).  Correct for any
 // data; what the data decides is how many pairs are left -- uniform noise inside eps of everything keeps them all.
+// GROUPS (below, "GROUPED ranges"): from 2 048 failed rows on, rows of one tight cluster share the range of a representative row and
+// become one dense block for the one-pair-per-lane kernel.  WHERE (kz_knn_impl): at the end of the ladder (all of the above), and
+// early -- groups plus at most KZ_RANGE_EARLY_PER_ROW rows of their own -- on what a split-bf16 pass leaves, before the float32-operand
+// tier sweeps the index for it.
 // Reference: the brute-force search it replaces row by row, kiez/neighbors/exact/sklearn_nearest_neighbors.py:96-101.
 #pragma once
 
