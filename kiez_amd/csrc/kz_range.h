@@ -721,9 +721,9 @@ static int kz_range_rescue(kz_ctx* ctx, kz_matrix* query, int64_t q0, const int*
         *n_left = n_fail;
         return KZ_OK;
     }
-    if (metric == KZ_COSINE) {   // (the normalised float64 rows of the index, once -- as the whole-index kernels take them)
-        const int rc = kz_matrix_norm64(index);
-        if (rc != KZ_OK) return rc;
+    if (metric == KZ_COSINE && n_fail >= 1024) {   // (the normalised float64 rows of the index, once -- as the whole-index kernels take
+        const int rc = kz_matrix_norm64(index);    //  them; for a few hundred rows the image -- 800 MB for 500 k x 200 -- costs more than
+        if (rc != KZ_OK) return rc;                //  the divisions it saves: the kernels divide the raw rows, the same values)
     }
     KzRangeLog lg;
     int* rest = nullptr;        // the rows the grouped path leaves to the per-row path, their bounds
