@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: source queries/s over fit + kneighbors (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--workload ns|c1|c2|c3|c3s|c4s|c4|c1g|hard|gmm|ea15k] [--no-others]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--workload ns|c1|c2|c3|c3s|c4s|c4|c1g|hard|cliff|gmm|ea15k] [--no-others]
     python bench.py --openea EMB_DIR KG_DIR [--steps K] [--warmup W]      (real entity-alignment embeddings)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
@@ -55,6 +55,10 @@ WORKLOADS = {
     "hard": (300_000, 301_000, 64, "cosine", 50, 50, "MutualProximity", {"method": "empiric"},
              "data that is hard for the fp16 first pass (40 tight gaussian clusters far from the centre, rows stored cluster by "
              "cluster; tools/short_route_stress.py): 300k x 301k, d=64, cosine, k=50, MutualProximity empiric"),
+    "cliff": (200_000, 201_000, 200, "euclidean", 10, 10, "CSLS", {},
+              "clusters of very different density (40 gaussian clusters, spreads 0.05 .. 1.6 at centres ~42 from the origin, rows shuffled; "
+              "tools/cliff_probe.py, last kind): a third of the rows is beyond every operand precision and is answered by the range "
+              "re-search on the exact float64 kernels (csrc/kz_range.h): 200k x 201k, d=200, euclidean, k=10, CSLS"),
     "ea15k": (15_000, 15_000, 300, "euclidean", 10, 10, "CSLS", {},
               "the size the reference's users actually run (OpenEA 15K entity-alignment sets, kiez/io/data_loading.py:75-99): 15k x 15k, "
               "d=300, euclidean, k=10, CSLS, L2-normalised gaussian mixture -- a launch- and latency-bound step, not a throughput one"),
@@ -364,6 +368,14 @@ def synth_rows(name, seed, rows, d):
             m = min(100_000, rows - b)
             x = centres[rng.randint(0, 256, m)] + np.float32(0.35) * rng.standard_normal((m, d)).astype(np.float32)
             out[b:b + m] = x / np.sqrt((x * x).sum(axis=1, keepdims=True))
+        return out
+    if name == "cliff":
+        centres = (np.random.RandomState(5).standard_normal((40, d)) * 3).astype(np.float32)     # the same clusters on both sides
+        spread = (0.05 * 2.0 ** np.random.RandomState(6).randint(0, 6, 40)).astype(np.float32)
+        for b in range(0, rows, 100_000):
+            m = min(100_000, rows - b)
+            c = rng.randint(0, 40, m)
+            out[b:b + m] = centres[c] + spread[c, None] * rng.standard_normal((m, d)).astype(np.float32)
         return out
     if name == "hard":
         centres = np.random.RandomState(5).standard_normal((40, d)) * 3     # the same centres on both sides
@@ -853,7 +865,7 @@ def main():
         others = {}
         # c4 = configuration 4 at its stated size on this one GPU (the N = 1 anchor of `--scaling strong`; ~1.3 s per step: fewer
         # steps); c1g / hard = the same kernels on gaussian and on clustered data (how often the tier chain runs is data dependent)
-        for name in ("c1", "c2", "c3", "c4s", "c4", "ns", "c1g", "hard", "gmm", "ea15k"):
+        for name in ("c1", "c2", "c3", "c4s", "c4", "ns", "c1g", "hard", "cliff", "gmm", "ea15k"):
             if name == args.workload:
                 continue
             try:

@@ -25,7 +25,7 @@ def test_default_bench_line_has_what_the_driver_reads(tmp_path):
     full = json.loads((tmp_path / "detail.json").read_text())
     assert set(full["other_workloads"]) >= {"c1", "c2", "c3", "c4s", "c4", "ea15k"} and not [o for o in full["other_workloads"].values() if "error" in o]
     rows = line["summary"]
-    assert set(rows) >= {"columns", "ns", "c1", "c2", "c3", "c4s", "c4", "c1g", "hard", "gmm", "ea15k"}
+    assert set(rows) >= {"columns", "ns", "c1", "c2", "c3", "c4s", "c4", "c1g", "hard", "cliff", "gmm", "ea15k"}
     for name, row in rows.items():
         if name != "columns":
             got, of = row[4].split("/")
