@@ -118,3 +118,22 @@ def test_the_stdout_line_stays_small_whatever_the_record_holds():
     full["summary"] = {f"w{i}": [1.0] * 5 for i in range(400)}
     line = json.loads(mod.compact_line(full, "bench_detail.json"))
     assert "summary" not in line and "roofline" in line and "cpu_baseline" in line and line["value"] > 0
+
+
+def test_synthetic_rows_of_every_workload():
+    """bench.synth_rows: float32 rows of the stated shape for every workload name, the same rows for the same seed; `cliff` -- the
+    range re-search's case -- has clusters whose spreads differ by a factor of 32."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name in bench.WORKLOADS:
+        x = bench.synth_rows(name, 3, 700, 24)
+        assert x.shape == (700, 24) and x.dtype == np.float32 and np.isfinite(x).all(), name
+        np.testing.assert_array_equal(x, bench.synth_rows(name, 3, 700, 24))
+    x = bench.synth_rows("cliff", 1, 20000, 16)
+    centres = (np.random.RandomState(5).standard_normal((40, 16)) * 3).astype(np.float32)
+    c = np.argmin(((x[:, None, :] - centres[None]) ** 2).sum(-1), axis=1)
+    spread = np.array([(x[c == j] - centres[j]).std() for j in range(40) if (c == j).sum() > 50])
+    assert spread.max() / spread.min() > 8
